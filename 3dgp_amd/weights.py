@@ -1,0 +1,126 @@
+"""State-dict layout of the generator and deterministic synthetic weights.
+
+Key names and shapes are the reference's (probed in SURVEY.md section 8a):
+  synthesis.tri_plane_decoder.b{r}.{const | conv0|conv1|torgb}.{weight,bias,affine.weight,affine.bias,
+      noise_const,noise_strength,resample_filter}
+  synthesis.tri_plane_mlp.model.{0,1}.{weight,bias}
+  mapping.{embed,fc0,fc1}.{weight,bias}, mapping.w_avg
+so a state-dict exported from a reference checkpoint loads unchanged.
+
+There is no network access for checkpoints: `random_state_dict` draws every tensor from a
+numpy RandomState keyed by (seed, crc32(name)) with the reference's init distributions
+(networks_stylegan2.py:120-126,162-165; layers.py:36-38).  `exercise_all=True` additionally
+randomises biases / noise strengths / w_avg (zero at reference init) so every term of the
+forward pass is numerically live in parity tests.
+"""
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+from .config import GeneratorConfig
+
+
+def state_dict_spec(cfg: GeneratorConfig):
+    """Ordered name -> shape map of every tensor the generator forward reads."""
+    spec = OrderedDict()
+    ch = cfg.channels
+    root = 'synthesis.tri_plane_decoder'
+    img_c = cfg.plane_channels
+
+    def layer(pfx, cin, cout, res, k, noise):
+        spec[pfx + '.weight'] = (cout, cin, k, k)
+        if noise:
+            spec[pfx + '.noise_strength'] = ()
+        spec[pfx + '.bias'] = (cout,)
+        if noise:
+            spec[pfx + '.resample_filter'] = (4, 4)
+            spec[pfx + '.noise_const'] = (res, res)
+        spec[pfx + '.affine.weight'] = (cin, cfg.w_dim)
+        spec[pfx + '.affine.bias'] = (cin,)
+
+    for i, r in enumerate(cfg.block_resolutions):
+        pfx = f'{root}.b{r}'
+        cout = ch[r]
+        spec[pfx + '.resample_filter'] = (4, 4)
+        if i == 0:
+            spec[pfx + '.const'] = (cout, r, r)
+        else:
+            layer(pfx + '.conv0', ch[r // 2], cout, r, 3, cfg.use_noise)
+        layer(pfx + '.conv1', cout, cout, r, 3, cfg.use_noise)
+        layer(pfx + '.torgb', cout, img_c, r, 1, False)
+    spec['synthesis.tri_plane_mlp.model.0.weight'] = (cfg.mlp_hid, cfg.feat_dim)
+    spec['synthesis.tri_plane_mlp.model.0.bias'] = (cfg.mlp_hid,)
+    spec['synthesis.tri_plane_mlp.model.1.weight'] = (4, cfg.mlp_hid)
+    spec['synthesis.tri_plane_mlp.model.1.bias'] = (4,)
+    spec['mapping.w_avg'] = (cfg.w_dim,)
+    if cfg.c_dim > 0:
+        spec['mapping.embed.weight'] = (cfg.w_dim, cfg.c_dim)
+        spec['mapping.embed.bias'] = (cfg.w_dim,)
+    feats = [cfg.z_dim + (cfg.w_dim if cfg.c_dim > 0 else 0)] + [cfg.w_dim] * cfg.map_depth
+    for i in range(cfg.map_depth):
+        spec[f'mapping.fc{i}.weight'] = (feats[i + 1], feats[i])
+        spec[f'mapping.fc{i}.bias'] = (feats[i + 1],)
+    return spec
+
+
+def _rng(seed, name):
+    return np.random.RandomState((zlib.crc32(name.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+
+
+def resample_filter():
+    """upfirdn2d.setup_filter([1,3,3,1]) (upfirdn2d.py:70-114): outer product / 64."""
+    f = np.array([1, 3, 3, 1], dtype=np.float32)
+    f = np.outer(f, f).astype(np.float32)
+    return (f / f.sum(dtype=np.float32)).astype(np.float32)
+
+
+def random_state_dict(cfg: GeneratorConfig, seed=0, exercise_all=False):
+    sd = OrderedDict()
+    for name, shape in state_dict_spec(cfg).items():
+        g = _rng(seed, name)
+        leaf = name.rsplit('.', 1)[-1]
+        if leaf == 'resample_filter':
+            v = resample_filter()
+        elif name.startswith('mapping.fc') and leaf == 'weight':
+            v = g.randn(*shape) / 0.01                       # weight_init / lr_multiplier, layers.py:36
+        elif leaf in ('weight', 'const', 'noise_const'):
+            v = g.randn(*shape)
+        elif leaf == 'noise_strength':
+            v = np.asarray(0.1 * g.randn() if exercise_all else 0.0)
+        elif name.endswith('affine.bias'):
+            v = 1.0 + (0.1 * g.randn(*shape) if exercise_all else 0.0)
+        elif name.startswith('mapping.fc') and leaf == 'bias':
+            v = (0.1 * g.randn(*shape) / 0.01) if exercise_all else np.zeros(shape)
+        elif leaf in ('bias', 'w_avg'):
+            v = 0.1 * g.randn(*shape) if exercise_all else np.zeros(shape)
+        else:
+            raise KeyError(name)
+        sd[name] = np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float32), shape)).astype(np.float32)
+    return sd
+
+
+def synthetic_inputs(cfg: GeneratorConfig, batch, seed=0):
+    """Seeded synthetic (z, c, camera, u_coarse, u_fine) as in SURVEY.md section 8d.
+
+    RNG tensors are explicit inputs: the reference's eval forward with noise_mode='const' draws exactly
+    `rand_like [B,R,S,1]` (tri_plane_renderer.py:225) then `rand [B*R,S]` (:279); parity is defined on
+    identical values of those tensors, not on identical generator state.
+    """
+    g = np.random.RandomState(seed + 1000003)
+    z = g.randn(batch, cfg.z_dim).astype(np.float32)
+    c = np.zeros((batch, cfg.c_dim), dtype=np.float32)
+    if cfg.c_dim > 0:
+        c[np.arange(batch), (seed + np.arange(batch)) % cfg.c_dim] = 1.0
+    yaw = g.uniform(-1.57, 1.57, batch)                       # configs/camera/uniform.yaml:7
+    pitch = g.uniform(np.pi / 4, 3 * np.pi / 4, batch)        # :8
+    angles = np.stack([yaw, pitch, np.zeros(batch)], 1).astype(np.float32)
+    fov = g.uniform(10.0, 45.0, batch).astype(np.float32)     # configs/camera/base.yaml:4
+    radius = np.ones(batch, dtype=np.float32)
+    la = np.stack([g.uniform(0, 2 * np.pi, batch), g.uniform(0.1, np.pi - 0.1, batch), g.uniform(0, 0.2, batch)], 1)
+    R = cfg.img_resolution ** 2
+    S = cfg.num_ray_steps
+    u_coarse = g.rand(batch, R, S).astype(np.float32)
+    u_fine = g.rand(batch * R, S).astype(np.float32)
+    camera = dict(angles=angles, fov=fov, radius=radius, look_at=la.astype(np.float32))
+    return dict(z=z, c=c, camera=camera, u_coarse=u_coarse, u_fine=u_fine)

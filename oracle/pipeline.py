@@ -1,0 +1,183 @@
+"""Oracle glue: chains the C primitives in the reference's call order.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Plain numpy, no torch.
+
+cfg is a plain dict:
+  z_dim, w_dim, c_dim, map_depth, cbase, cmax, fmaps, use_noise,
+  tri_plane_res, feat_dim, mlp_hid, ray_marcher_type ('classical'|'mip'),
+  num_ray_steps, ray_start, ray_end, cube_scale, use_inf_depth, last_back,
+  white_back, density_bias, img_resolution
+sd is a dict name -> np.float32 array using the reference's state-dict names
+(SURVEY.md section 8a): synthesis.tri_plane_decoder.b{r}.{const|conv0|conv1|torgb}...,
+synthesis.tri_plane_mlp.model.{0,1}.{weight,bias}, mapping.{embed,fc0,fc1}.{weight,bias}, mapping.w_avg.
+"""
+import numpy as np
+
+import oracle as O
+
+
+def block_resolutions(cfg):
+    """networks_epigraf.py:94-96 with in_resolution=0."""
+    return [2 ** i for i in range(2, int(np.log2(cfg['tri_plane_res'])) + 1)]
+
+
+def channels_dict(cfg):
+    """networks_epigraf.py:98."""
+    return {r: min(int(cfg['cbase'] * cfg['fmaps']) // r, cfg['cmax']) for r in block_resolutions(cfg)}
+
+
+def num_ws(cfg):
+    """networks_epigraf.py:101-112: one w per conv, plus one torgb w for the last block."""
+    n = 0
+    for i, _ in enumerate(block_resolutions(cfg)):
+        n += 1 if i == 0 else 2
+    return n + 1
+
+
+def mapping_forward(sd, cfg, z, c, truncation_psi=1.0, truncation_cutoff=None):
+    """MappingNetwork.forward, layers.py:127-174 (no camera conditioning)."""
+    x = None
+    if cfg['z_dim'] > 0:
+        x = O.normalize_2nd_moment(z)
+    if cfg['c_dim'] > 0:
+        y = O.normalize_2nd_moment(O.fc(c, sd['mapping.embed.weight'], sd['mapping.embed.bias']))
+        x = np.concatenate([x, y], axis=1) if x is not None else y
+    for i in range(cfg['map_depth']):
+        x = O.fc(x, sd[f'mapping.fc{i}.weight'], sd[f'mapping.fc{i}.bias'], act='lrelu', lr_multiplier=0.01)
+    nws = num_ws(cfg)
+    ws = np.repeat(x[:, None, :], nws, axis=1).astype(np.float32)
+    if truncation_psi != 1:
+        w_avg = sd['mapping.w_avg'].astype(np.float32)
+        psi = np.float32(truncation_psi)
+        cut = nws if truncation_cutoff is None else truncation_cutoff
+        # torch.lerp(start, end, weight): weight < 0.5 ? start + w*(end-start) : end - (end-start)*(1-w)
+        seg = ws[:, :cut]
+        diff = seg - w_avg
+        if psi < 0.5:
+            ws[:, :cut] = w_avg + psi * diff
+        else:
+            ws[:, :cut] = seg - diff * (np.float32(1) - psi)
+    return ws
+
+
+def _layer(sd, pfx, x, w, up, noise_mode, f, use_noise):
+    """SynthesisLayer.forward, networks_stylegan2.py:128-145."""
+    styles = O.fc(w, sd[pfx + '.affine.weight'], sd[pfx + '.affine.bias'])
+    noise = None
+    if use_noise and noise_mode == 'const':
+        noise = (sd[pfx + '.noise_const'] * sd[pfx + '.noise_strength']).astype(np.float32)
+    elif use_noise and isinstance(noise_mode, dict):        # explicit 'random' noise tensors keyed by layer
+        noise = (noise_mode[pfx] * sd[pfx + '.noise_strength']).astype(np.float32)
+    x = O.modulated_conv2d(x, sd[pfx + '.weight'], styles, noise=noise, up=up, demodulate=True, resample_filter=f)
+    return O.bias_act(x, sd[pfx + '.bias'], act='lrelu')
+
+
+def _torgb(sd, pfx, x, w):
+    """ToRGBLayer.forward, networks_stylegan2.py:168-172."""
+    cin = sd[pfx + '.weight'].shape[1]
+    styles = O.fc(w, sd[pfx + '.affine.weight'], sd[pfx + '.affine.bias'])
+    styles = (styles * np.float32(1 / np.sqrt(cin))).astype(np.float32)
+    x = O.modulated_conv2d(x, sd[pfx + '.weight'], styles, demodulate=False)
+    return O.bias_act(x, sd[pfx + '.bias'])
+
+
+def synthesis_backbone(sd, cfg, ws, noise_mode='const', return_intermediates=False):
+    """SynthesisBlocksSequence.forward (networks_epigraf.py:114-129) over SynthesisBlock.forward
+    (networks_stylegan2.py:231-273), architecture 'skip', fp32."""
+    f = O.setup_filter([1, 3, 3, 1])
+    B = ws.shape[0]
+    x = img = None
+    w_idx = 0
+    inter = {}
+    root = 'synthesis.tri_plane_decoder'
+    for i, r in enumerate(block_resolutions(cfg)):
+        pfx = f'{root}.b{r}'
+        if i == 0:
+            x = np.repeat(sd[pfx + '.const'][None], B, axis=0).astype(np.float32)
+            x = _layer(sd, pfx + '.conv1', x, ws[:, w_idx], 1, noise_mode, f, cfg['use_noise'])
+            nconv = 1
+        else:
+            x = _layer(sd, pfx + '.conv0', x, ws[:, w_idx], 2, noise_mode, f, cfg['use_noise'])
+            x = _layer(sd, pfx + '.conv1', x, ws[:, w_idx + 1], 1, noise_mode, f, cfg['use_noise'])
+            nconv = 2
+        if img is not None:
+            img = O.upsample2d(img, f)
+        y = _torgb(sd, pfx + '.torgb', x, ws[:, w_idx + nconv])
+        img = img + y if img is not None else y
+        w_idx += nconv
+        if return_intermediates:
+            inter[f'x{r}'] = x
+            inter[f'img{r}'] = img
+    return (img, inter) if return_intermediates else img
+
+
+def importance_render(planes, mlp, ray_o, ray_d, opts, u_coarse, u_fine, return_intermediates=False):
+    """ImportanceRenderer.forward, tri_plane_renderer.py:126-170.
+    planes [B,3F,H,W]; mlp = (w0,b0,w1,b1); u_coarse [B,R,S]; u_fine [B*R,S]."""
+    mode = opts['ray_marcher_type']
+    B, R, _ = ray_o.shape
+    S = opts['num_proposal_steps']
+    scale = opts['box_size'] / 2
+    sdist = O.sample_stratified(u_coarse.reshape(B, R, S), mode)
+    tdist = O.s_to_t(sdist, opts['ray_start'], opts['ray_end'])
+    out = O.triplane_field(planes, O.ray_points(ray_o, ray_d, tdist), *mlp, scale=scale, mlp_mode=mode)
+    col_c = out['rgb'].reshape(B, R, S, 3)
+    den_c = out['sigma'].reshape(B, R, S, 1)
+
+    def march(c, d, z):
+        if mode == 'classical':
+            return O.march_classical(c, d, z, use_inf_depth=opts['use_inf_depth'], clamp_mode=opts.get('clamp_mode', 'softplus'),
+                                     last_back=opts.get('last_back', False))
+        return O.march_mip(c, d, z, use_inf_depth=opts['use_inf_depth'], density_bias=opts.get('density_bias', 0.0),
+                           white_back=opts.get('white_back', False))
+
+    inter = dict(sdist_coarse=sdist, colors_coarse=col_c, densities_coarse=den_c)
+    N = opts['num_fine_steps']
+    if N > 0:
+        _, _, w_c, _ = march(col_c, den_c, sdist[..., None])              # s-space depths: :152
+        sfine = O.sample_importance(sdist[..., None], w_c, u_fine, mode)   # [B,R,N,1]
+        tfine = O.s_to_t(sfine[..., 0], opts['ray_start'], opts['ray_end'])
+        out = O.triplane_field(planes, O.ray_points(ray_o, ray_d, tfine), *mlp, scale=scale, mlp_mode=mode)
+        col_f = out['rgb'].reshape(B, R, N, 3)
+        den_f = out['sigma'].reshape(B, R, N, 1)
+        d_all, c_all, s_all = O.unify_samples(tdist[..., None], col_c, den_c, tfine[..., None], col_f, den_f)
+        rgb, depth, wts, fT = march(c_all, s_all, d_all)
+        inter.update(weights_coarse=w_c, sdist_fine=sfine, colors_fine=col_f, densities_fine=den_f, all_depths=d_all)
+    else:
+        rgb, depth, wts, fT = march(col_c, den_c, sdist[..., None])
+    res = (rgb, depth, wts.sum(axis=2, dtype=np.float64).astype(np.float32), fT)
+    return (res, inter) if return_intermediates else res
+
+
+def render_options(cfg):
+    """networks_epigraf.py:226-231."""
+    return dict(box_size=cfg['cube_scale'] * 2, num_proposal_steps=cfg['num_ray_steps'], num_fine_steps=cfg['num_ray_steps'],
+                clamp_mode='softplus', use_inf_depth=cfg['use_inf_depth'], ray_start=cfg['ray_start'], ray_end=cfg['ray_end'],
+                last_back=cfg.get('last_back', False), white_back=cfg.get('white_back', False),
+                density_bias=cfg.get('density_bias', 0.0), ray_marcher_type=cfg['ray_marcher_type'])
+
+
+def synthesis_forward(sd, cfg, ws, camera, u_coarse, u_fine, noise_mode='const', return_intermediates=False):
+    """SynthesisNetwork.forward, networks_epigraf.py:210-261 (eval, no adaptors).
+    camera: dict angles [B,3], fov [B], radius [B], look_at [B,3]."""
+    planes, inter = synthesis_backbone(sd, cfg, ws, noise_mode, return_intermediates=True)
+    h = w = cfg['img_resolution']
+    c2w = O.cam2world(camera['angles'], camera['radius'], camera['look_at'])
+    ray_o, ray_d = O.sample_rays(c2w, camera['fov'], h, w)
+    mlp = tuple(sd[f'synthesis.tri_plane_mlp.model.{i}.{n}'] for i in (0, 1) for n in ('weight', 'bias'))
+    (rgb, depth, wsum, fT), rinter = importance_render(planes, mlp, ray_o, ray_d, render_options(cfg), u_coarse, u_fine,
+                                                       return_intermediates=True)
+    B = ws.shape[0]
+    img = np.ascontiguousarray(rgb.reshape(B, h, w, 3).transpose(0, 3, 1, 2))
+    depth = depth.reshape(B, 1, h, w)
+    if return_intermediates:
+        inter.update(rinter)
+        inter.update(planes=planes, c2w=c2w, ray_o=ray_o, ray_d=ray_d)
+        return img, depth, inter
+    return img, depth
+
+
+def generator_forward(sd, cfg, z, c, camera, u_coarse, u_fine, noise_mode='const', truncation_psi=1.0):
+    """Generator.forward, networks_epigraf.py:288-291."""
+    ws = mapping_forward(sd, cfg, z, c, truncation_psi)
+    return synthesis_forward(sd, cfg, ws, camera, u_coarse, u_fine, noise_mode)

@@ -1,0 +1,84 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def tdgp():
+    """The product package (directory name starts with a digit -> importlib)."""
+    return importlib.import_module('3dgp_amd')
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    """CPU oracle (test infrastructure; never imported by the product)."""
+    import oracle as O
+    O.lib()
+    return O
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + '.npz')))
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return load_golden
+
+
+def max_rel(a, b, floor=1e-3):
+    """Image-level relative error: |a-b| / max(|b|, floor * max|b|)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = np.maximum(np.abs(b), floor * max(np.abs(b).max(), 1e-30))
+    return float((np.abs(a - b) / scale).max())
+
+
+def assert_close(a, b, tol, what='', floor=1e-3):
+    """floor=1e-3: the image-level max-rel of SURVEY.md 9.9.  floor=1.0: error relative to max|b| -- used for
+    reductions with cancellation (conv / FIR / dot products), where an output near zero carries the absolute
+    rounding noise of its O(1) terms."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, f'{what}: shape {a.shape} vs {b.shape}'
+    assert np.isfinite(a).all() == np.isfinite(b).all(), f'{what}: non-finite mismatch'
+    err = max_rel(a, b, floor)
+    assert err <= tol, f'{what}: max-rel {err:.3e} > {tol:.1e}'
+
+
+RGB_TOL = 1e-4        # north-star tolerance: max-rel RGB error vs the reference CPU/PyTorch path
+RANGE_TOL = 1e-5      # stricter, well-conditioned companion: max|delta| / max|ref|
+
+
+def assert_image_parity(img, g, what='img', key='img'):
+    """End-to-end image parity against a golden captured from the reference.
+
+    Two bounds, both asserted:
+      * range-normalised error  max|d| / max|ref|               <= RANGE_TOL (1e-5);
+      * per-pixel max-rel (|d| / max(|ref|, 1e-3 max|ref|)) <= max(RGB_TOL, 3 x ref self-noise),
+        where "ref self-noise" is the same metric between two runs of the REFERENCE ITSELF on identical
+        inputs (oneDNN vs native convolutions, 8 vs 1 thread; stored as `<key>_alt` by tools/gen_goldens.py).
+        Raw 'classical' RGB crosses zero, so the per-pixel metric is dominated by the reference's own fp32
+        summation-order noise (measured 0.4e-4 .. 1.7e-4); a bound below that noise would test torch's
+        thread scheduling, not this implementation.
+    """
+    ref = g[key]
+    rng = float(np.abs(np.asarray(img, np.float64) - ref).max() / np.abs(ref).max())
+    pix = max_rel(img, ref)
+    self_noise = max_rel(g[key + '_alt'], ref) if (key + '_alt') in g else 0.0
+    assert rng <= RANGE_TOL, f'{what}: range-normalised error {rng:.3e} > {RANGE_TOL:.0e}'
+    bound = max(RGB_TOL, 3 * self_noise)
+    assert pix <= bound, f'{what}: max-rel {pix:.3e} > {bound:.3e} (reference self-noise {self_noise:.3e})'
+    return rng, pix, self_noise

@@ -1,0 +1,189 @@
+"""The CPU oracle against golden vectors captured from the reference (tools/gen_goldens.py).
+
+Floating point: tolerance stated per test (reductions are order-dependent in torch).
+Integer rows (searchsorted indices, sort permutation): bit-exact on identical inputs.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_close, assert_image_parity, load_golden
+
+ACTS = ['linear', 'relu', 'lrelu', 'tanh', 'sigmoid', 'elu', 'selu', 'softplus', 'swish']
+
+
+@pytest.mark.parametrize('act', ACTS)
+def test_bias_act(oracle, act):
+    g = load_golden('bias_act')
+    y = oracle.bias_act(g['x'], g['b'], act=act)
+    assert_close(y, g[f'y_{act}'], 2e-6, act)
+
+
+def test_bias_act_variants(oracle):
+    g = load_golden('bias_act')
+    assert_close(oracle.bias_act(g['x'], g['b'], act='lrelu', gain=1.0, clamp=0.5), g['y_lrelu_gain1_clamp'], 1e-6)
+    assert_close(oracle.bias_act(g['x'], g['b'], act='lrelu', alpha=0.01, gain=2.0), g['y_lrelu_alpha'], 1e-6)
+    assert_close(oracle.bias_act(g['x'], None, act='linear', gain=0.5), g['y_linear_nobias'], 1e-7)
+    assert_close(oracle.bias_act(g['x'], g['b_dim3'], dim=3, act='relu'), g['y_relu_dim3'], 1e-6)
+    assert_close(oracle.bias_act(g['x2'], g['b'], act='lrelu'), g['y2_lrelu'], 1e-6)
+    assert_close(oracle.bias_act(g['x'], g['b'], act='swish', clamp=2.0), g['y_swish_channels_last'], 2e-6)
+
+
+def test_setup_filter(oracle):
+    g = load_golden('upfirdn2d')
+    np.testing.assert_array_equal(oracle.setup_filter([1, 3, 3, 1]), g['f1331'])
+    assert_close(oracle.setup_filter([1, 2, 3, 4], flip_filter=True, gain=2.0), g['f1331_flip_gain'], 1e-7)
+
+
+def test_upfirdn2d(oracle):
+    g = load_golden('upfirdn2d')
+    f = g['f1331']
+    tol = 2e-6
+    assert_close(oracle.upfirdn2d(g['x_f1'], f, padding=[1, 1, 1, 1], gain=4), g['y_f1'], tol, 'F1', 1.0)
+    assert_close(oracle.upsample2d(g['x_f2'], f), g['y_f2'], tol, 'F2', 1.0)
+    assert_close(oracle.upfirdn2d(g['x_odd'], f, padding=[2, 1, 2, 1]), g['y_filter2d'], tol, 'filter2d', 1.0)
+    assert_close(oracle.upfirdn2d(g['x_odd'], f, down=2, padding=[1, 1, 1, 1]), g['y_downsample2d'], tol, 'downsample2d', 1.0)
+    assert_close(oracle.upfirdn2d(g['x_odd'], f, padding=[-1, 2, 3, -1]), g['y_negpad'], tol, 'negpad', 1.0)
+    assert_close(oracle.upfirdn2d(g['x_odd'], g['f_asym'], padding=2), g['y_asym_noflip'], tol, 'asym', 1.0)
+    assert_close(oracle.upfirdn2d(g['x_odd'], g['f_asym'], padding=2, flip_filter=True), g['y_asym_flip'], tol, 'asym flip', 1.0)
+    assert_close(oracle.upfirdn2d(g['x_odd'], g['f_rect'], up=[3, 2], down=[2, 1], padding=[2, 1, 0, 3], gain=1.5),
+                 g['y_rect_up3_down2'], tol, 'rect', 1.0)
+    assert_close(oracle.upfirdn2d(g['x_odd'], None), g['y_identity'], 0, 'identity')
+    assert_close(oracle.upfirdn2d(g['x_f1_33'], f, padding=[1, 1, 1, 1], gain=4), g['y_f1_33'], tol, 'F1 33', 1.0)
+
+
+@pytest.mark.parametrize('tag', ['c3_up1', 'c3_up2', 'c3_up2_b1', 'c1_rgb', 'c3_up1_b1_nonoise'])
+def test_modconv(oracle, tag):
+    g = load_golden('modconv')
+    k, up, demod = g[f'{tag}_meta']
+    y = oracle.modulated_conv2d(g[f'{tag}_x'], g[f'{tag}_w'], g[f'{tag}_s'], noise=g.get(f'{tag}_noise'), up=int(up),
+                                demodulate=bool(demod), resample_filter=g['f'])
+    assert_close(y, g[f'{tag}_y'], 5e-6, tag, 1.0)
+
+
+@pytest.mark.parametrize('marcher', ['classical', 'mip'])
+def test_field(oracle, marcher):
+    g = load_golden('field')
+    out = oracle.triplane_field(g['planes'], g['coords'], g[f'{marcher}_w0'], g[f'{marcher}_b0'], g[f'{marcher}_w1'],
+                                g[f'{marcher}_b1'], scale=0.5, mlp_mode=marcher, return_feats=True)
+    assert_close(out['feats'], g['feats_mean'], 2e-6, 'bilinear+mean', 1.0)
+    assert_close(out['rgb'], g[f'{marcher}_rgb'], 5e-6, 'rgb', 1.0)
+    assert_close(out['sigma'], g[f'{marcher}_sigma'], 5e-6, 'sigma', 1.0)
+
+
+@pytest.mark.parametrize('marcher', ['classical', 'mip'])
+def test_stratified_and_importance(oracle, marcher):
+    g = load_golden('sampling')
+    sd = oracle.sample_stratified(g[f'{marcher}_u_coarse'][..., 0], marcher)
+    np.testing.assert_array_equal(sd, g[f'{marcher}_sdist'][..., 0])          # pure fp32 elementwise: bit-exact
+    sf, aux = oracle.sample_importance(g[f'{marcher}_sdist'], g[f'{marcher}_weights'], g[f'{marcher}_u_fine'], marcher,
+                                       return_aux=True)
+    # integer rows: bit-exact except where u sits within 4 ulp of a cdf knot (torch.sum is an fp32 cascade: 9.1/9.2)
+    inds_ref = g[f'{marcher}_inds']
+    mism = aux['inds'] != inds_ref
+    if mism.any():
+        r, j = np.nonzero(mism)
+        u = g[f'{marcher}_u_fine'][r, j]
+        knot = aux['cdf'][r, np.minimum(aux['inds'][r, j], inds_ref[r, j])]
+        assert (np.abs(u - knot) <= 4 * np.spacing(np.abs(knot).astype(np.float32))).all()
+    assert mism.sum() <= 2
+    ok = ~mism
+    np.testing.assert_array_equal(aux['below'][ok], g[f'{marcher}_below'][ok])
+    np.testing.assert_array_equal(aux['above'][ok], g[f'{marcher}_above'][ok])
+    assert_close(sf, g[f'{marcher}_sdist_fine'], 2e-5, 'sdist_fine')
+
+
+def test_unify(oracle):
+    g = load_golden('sampling')
+    d, c, s, perm = oracle.unify_samples(g['un_d1'], g['un_c1'], g['un_s1'], g['un_d2'], g['un_c2'], g['un_s2'], return_perm=True)
+    np.testing.assert_array_equal(perm, g['un_perm'])
+    np.testing.assert_array_equal(d, g['un_d'])
+    np.testing.assert_array_equal(c, g['un_c'])
+    np.testing.assert_array_equal(s, g['un_s'])
+
+
+@pytest.mark.parametrize('tag,kw', [('cl_inf', dict(use_inf_depth=True)), ('cl_noinf', dict(use_inf_depth=False)),
+                                    ('cl_lastback', dict(use_inf_depth=True, last_back=True)),
+                                    ('cl_relu', dict(use_inf_depth=True, clamp_mode='relu'))])
+def test_march_classical(oracle, tag, kw):
+    g = load_golden('marchers')
+    rgb, dep, w, fT = oracle.march_classical(g['colors'], g['densities'], g['depths'], **kw)
+    assert_close(w, g[f'{tag}_weights'], 1e-6, 'weights', 1.0)
+    assert_close(rgb, g[f'{tag}_rgb'], 5e-6, 'rgb', 1.0)
+    assert_close(dep, g[f'{tag}_depth'], 5e-6, 'depth', 1.0)
+    assert_close(fT, g[f'{tag}_T'], 2e-6, 'T')
+
+
+@pytest.mark.parametrize('tag,kw', [('mip_inf', dict(use_inf_depth=True)), ('mip_noinf_white', dict(use_inf_depth=False, white_back=True)),
+                                    ('mip_bias', dict(use_inf_depth=True, density_bias=-1.0))])
+def test_march_mip(oracle, tag, kw):
+    g = load_golden('marchers')
+    rgb, dep, w, fT = oracle.march_mip(g['colors01'], g['densities'], g['depths'], **kw)
+    assert_close(w, g[f'{tag}_weights'], 1e-6, 'weights', 1.0)
+    assert_close(rgb, g[f'{tag}_rgb'], 5e-6, 'rgb', 1.0)
+    assert_close(dep, g[f'{tag}_depth'], 5e-6, 'depth', 1.0)
+    assert_close(fT, g[f'{tag}_T'], 2e-6, 'T')
+
+
+def test_camera_and_rays(oracle):
+    g = load_golden('camera')
+    c2w = oracle.cam2world(g['angles'], g['radius'], g['look_at'])
+    assert_close(c2w, g['c2w'], 2e-6, 'c2w')
+    for hw in [(8, 8), (5, 7), (16, 16)]:
+        # the reference unpacks `w, h = resolution` (tri_plane_renderer.py:496): golden key AxB <=> w=A, h=B
+        o, d = oracle.sample_rays(g['c2w'], g['fov'], hw[1], hw[0])
+        assert_close(o, g['ray_o_%dx%d' % hw], 1e-7, 'ray_o')
+        assert_close(d, g['ray_d_%dx%d' % hw], 2e-6, 'ray_d', 1.0)
+    o, d = oracle.sample_rays(g['c2w'], g['fov'], 6, 6, g['patch_scales'], g['patch_offsets'])
+    assert_close(d, g['ray_d_patch'], 2e-6, 'ray_d patch', 1.0)
+    o, d = oracle.sample_rays(g['c2w'], 18.0, 4, 4)
+    assert_close(d, g['ray_d_scalar_fov'], 2e-6, 'ray_d scalar fov', 1.0)
+
+
+def test_mapping(oracle, tdgp):
+    g = load_golden('mapping')
+    for tag, cfg in [('c0', tdgp.config.config_tiny()), ('c10', tdgp.config.config_mid())]:
+        sd = tdgp.weights.random_state_dict(cfg, seed=11, exercise_all=True)
+        ws = oracle.mapping_forward(sd, cfg.to_dict(), g[f'{tag}_z'], g[f'{tag}_c'])
+        assert ws.shape == (3, cfg.num_ws, cfg.w_dim)
+        assert_close(ws, g[f'{tag}_ws'], 1e-5, 'ws', 1.0)
+        assert_close(oracle.mapping_forward(sd, cfg.to_dict(), g[f'{tag}_z'], g[f'{tag}_c'], 0.7), g[f'{tag}_ws_psi07'], 1e-5, 'psi', 1.0)
+        assert_close(oracle.mapping_forward(sd, cfg.to_dict(), g[f'{tag}_z'], g[f'{tag}_c'], 0.3, 3), g[f'{tag}_ws_psi03_cut3'], 1e-5, 'psi cut', 1.0)
+
+
+def _e2e(oracle, tdgp, tag, cfg, seed):
+    g = load_golden(tag)
+    sd = tdgp.weights.random_state_dict(cfg, seed=seed, exercise_all=True)
+    cam = {k[4:]: v for k, v in g.items() if k.startswith('cam_')}
+    ws = oracle.mapping_forward(sd, cfg.to_dict(), g['z'], g['c'])
+    assert_close(ws, g['ws'], 1e-5, 'ws', 1.0)
+    img, depth, inter = oracle.synthesis_forward(sd, cfg.to_dict(), g['ws'], cam, g['u_coarse'], g['u_fine'], 'const',
+                                                 return_intermediates=True)
+    return g, img, depth, inter
+
+
+def test_e2e_tiny(oracle, tdgp):
+    cfg = tdgp.config.config_tiny()
+    g, img, depth, inter = _e2e(oracle, tdgp, 'e2e_tiny', cfg, 21)
+    for r in cfg.block_resolutions:
+        assert_close(inter[f'x{r}'], g[f'x{r}'], 5e-6, f'x{r}', 1.0)
+    assert_close(inter['planes'], g['planes'], 5e-6, 'planes', 1.0)
+    assert_close(inter['c2w'], g['c2w'], 2e-6, 'c2w', 1.0)
+    assert_close(inter['ray_d'], g['ray_d'], 2e-6, 'ray_d', 1.0)
+    # the stated north-star tolerance: <= 1e-4 max-rel RGB vs the reference CPU path
+    assert_image_parity(img, g, 'img')
+    assert_image_parity(depth, g, 'depth', 'depth')
+
+
+def test_e2e_mid(oracle, tdgp):
+    g, img, depth, _ = _e2e(oracle, tdgp, 'e2e_mid', tdgp.config.config_mid(), 31)
+    assert_image_parity(img, g, 'img')
+    assert_image_parity(depth, g, 'depth', 'depth')
+
+
+def test_e2e_tiny_mip(oracle, tdgp):
+    cfg = tdgp.config.config_tiny()
+    cfg.ray_marcher_type = 'mip'
+    cfg.white_back = True
+    g, img, depth, _ = _e2e(oracle, tdgp, 'e2e_tiny_mip', cfg, 41)
+    assert_image_parity(img, g, 'img')
+    assert_image_parity(depth, g, 'depth', 'depth')
