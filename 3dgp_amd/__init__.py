@@ -1,7 +1,23 @@
 """3dgp_amd -- MI355X-native generator-forward hot path of 3DGP (gfx950 HIP kernels behind a C ABI).
 
-The directory name starts with a digit, so import it with
-``importlib.import_module('3dgp_amd')`` (tests/conftest.py and the repo-root scripts do).
+The directory name starts with a digit, so import it with ``importlib.import_module('3dgp_amd')``
+(tests/conftest.py and the repo-root scripts do).
+
+  config, weights      configuration + reference state-dict layout + deterministic synthetic weights (numpy only)
+  _lib                 ctypes binding of csrc/libtdgp_hip.so (include/tdgp.h)
+  ops                  bias_act / upfirdn2d / conv2d_resample / modulated_conv2d with the reference's signatures
+  renderer             camera, rays, tri-plane field, importance sampling, ray marchers
+  generator            Generator / SynthesisNetwork / MappingNetwork with the reference's state-dict names
+  compat               `src.*` module aliases so reference-style call sites resolve to this package
+  distributed          batch-sharded multi-GPU generation (one process per GPU, RCCL all-gather of features)
 """
-from . import config, weights  # noqa: F401
+from . import config, weights  # noqa: F401  (numpy only)
 from .config import GeneratorConfig  # noqa: F401
+
+
+def __getattr__(name):
+    # torch-dependent submodules are imported on first use
+    if name in ('_lib', 'ops', 'renderer', 'generator', 'compat', 'distributed', 'build'):
+        import importlib
+        return importlib.import_module(f'{__name__}.{name}')
+    raise AttributeError(name)

@@ -1,0 +1,108 @@
+"""ctypes binding of libtdgp_hip.so (the C ABI declared in include/tdgp.h).
+
+This is the "plugin loader" of the build: the counterpart of the reference's
+`custom_ops.get_plugin()` (src/torch_utils/custom_ops.py:59-155), except that nothing is compiled
+at run time -- the prebuilt gfx950 library is dlopen'ed.  If it is missing or fails to load the
+product path raises; there is no CPU or PyTorch fallback behind these entry points.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libtdgp_hip.so')
+
+P = c_void_p
+_PROTOTYPES = {
+    'tdgp_version': (c_int, []),
+    'tdgp_last_error': (c_char_p, []),
+    'tdgp_bias_act': (c_int, [P, P, P, c_int64, c_int, c_int64, c_int, c_float, c_float, c_float, c_int, P]),
+    'tdgp_upfirdn2d': (c_int, [P, P, P, c_int, c_int, c_int, c_int, POINTER(c_int64), c_int, c_int, POINTER(c_int64),
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    'tdgp_modconv_pack_bytes': (c_int64, [c_int, c_int, c_int]),
+    'tdgp_modconv_pack': (c_int, [P, P, c_int, c_int, c_int, P]),
+    'tdgp_modconv2d_workspace_bytes': (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'tdgp_modconv2d': (c_int, [P, P, P, P, c_int64, P, POINTER(c_float), P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_float, c_float, c_float, c_int, c_int, P, c_int64, P]),
+    'tdgp_style_affine': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    'tdgp_cam2world': (c_int, [P, P, P, P, c_int, P]),
+    'tdgp_sample_rays': (c_int, [P, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
+    'tdgp_sample_stratified': (c_int, [P, P, P, c_int64, c_int, c_int, c_float, c_float, P]),
+    'tdgp_planes_to_hwc': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'tdgp_triplane_field': (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_float,
+                                    c_int, P]),
+    'tdgp_ray_march': (c_int, [P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, P]),
+    'tdgp_sample_importance': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, P]),
+    'tdgp_unify_samples': (c_int, [P, P, P, c_int, P, P, P, c_int, P, P, P, P, c_int64, c_int, P]),
+    'tdgp_importance_from_coarse': (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, c_float, P]),
+    'tdgp_merge_composite': (c_int, [P, P, c_int, P, P, c_int, P, P, P, P, P, c_int64, c_int, c_int, c_float, P]),
+    'tdgp_rays_to_image': (c_int, [P, P, c_int, c_int, P]),
+}
+EXPORTS = tuple(_PROTOTYPES)
+
+_lib = None
+_load_error = None
+
+
+def load():
+    """dlopen the prebuilt library (once).  Raises RuntimeError if it is missing or broken."""
+    global _lib, _load_error
+    if _lib is not None:
+        return _lib
+    if _load_error is not None:
+        raise RuntimeError(_load_error)
+    if not os.path.exists(LIB_PATH):
+        _load_error = (f'{LIB_PATH} not found: the gfx950 HIP library is not built. Run `python -c "import __graft_entry__ as g; '
+                       f'g.build()"` (hipcc) first. There is no CPU/PyTorch fallback for the native ops.')
+        raise RuntimeError(_load_error)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    except (OSError, AttributeError) as e:
+        _load_error = f'failed to load {LIB_PATH}: {e}'
+        raise RuntimeError(_load_error) from e
+    _lib = lib
+    return _lib
+
+
+def available():
+    try:
+        load()
+        return True
+    except RuntimeError:
+        return False
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def call(name, *args):
+    """Call an entry point; non-zero return -> RuntimeError carrying tdgp_last_error()."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.tdgp_last_error()
+        raise RuntimeError(f'{name} failed ({rc}): {msg.decode() if msg else "?"}')
+
+
+def require_cuda(t, what):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise RuntimeError(f'{what} must reside on the GPU (got {getattr(t, "device", type(t))}); the HIP ops have no CPU path')
+
+
+def f32c(t):
+    """Contiguous fp32 view/copy."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

@@ -1,0 +1,595 @@
+// modconv.hip -- modulated convolution of the StyleGAN2 tri-plane backbone on the fp32 matrix cores.
+//
+// Replaces (eval / fused path): src/training/networks_stylegan2.py:31-88 modulated_conv2d
+//   -> conv2d_resample.py:46-141 -> conv2d_gradfix -> F.conv2d / F.conv_transpose2d (cuDNN grouped conv,
+//   groups = batch) -> upfirdn2d (up layers) -> `x.add_(noise)` -> bias_act; and for ToRGB the skip
+//   `img = upsample2d(img) + y` (networks_stylegan2.py:265-269).
+//
+// Formulation (identical algebra to the reference's own non-fused branch :67-76):
+//   y[b,o,p] = act( d[b,o] * sum_{c,tap} W[o,c,tap] * (s[b,c] * x[b,c,p+tap]) + noise[p] + bias[o] ) * gain
+//   d[b,o]   = rsqrt( sum_c s[b,c]^2 * (sum_tap W[o,c,tap]^2) + 1e-8 )
+// so every sample shares ONE weight matrix (no per-sample weight materialisation: the reference builds a
+// [B,Cout,Cin,3,3] tensor per call) and the modulation rides on the activation staging.
+//
+// Kernel: implicit GEMM, M = Cout, N = output pixels, K = Cin * taps, v_mfma_f32_32x32x2_f32 (exact fp32,
+// no TF32 -- the reference disables TF32 too: training_loop.py:76-77).
+//   * weights pre-packed k-major [Cin/KC][taps][KC][CoutP] -> the A tile is a straight 16-B-vector copy and
+//     A fragments are conflict-free ds_read_b32 (consecutive lanes = consecutive out-channels);
+//   * the block stages ONE halo'd, style-scaled activation patch [(rows+2) x (cols+2)] per input channel in LDS
+//     and reuses it for all taps (9x fewer global reads than an im2col stage); rows are "virtual rows"
+//     (sample-major), so small feature maps (4x4 ... 16x16) fill a 128/256-pixel tile with several samples;
+//   * 4 waves per block, each owning MTW x NTW tiles of 32x32 (64 fp32 accumulators for 2x2);
+//   * up=2 layers run as 4 sub-pixel phases of the stride-2 transposed conv (taps {4,2,2,1}) writing the
+//     (2H+1)x(2W+1) intermediate, followed by one fused FIR(4x4, gain 4) + demod + noise + bias + lrelu kernel;
+//   * ToRGB (1x1, no demod) fuses bias, the x2 FIR upsample of the previous image and the skip add, and can
+//     emit the renderer's channel-last plane layout directly.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KC3 = 8;    // packed channel chunk for 3x3 weights
+constexpr int KC1 = 32;   // packed channel chunk for 1x1 weights
+
+struct Phase {
+    int ntaps;
+    int tap_w[9];       // tap index in the packed weight layout
+    int tap_off_y[9];   // dy in {-1,0,1}
+    int tap_off_x[9];
+    int gridH, gridW;   // pixels computed by this phase
+    int oy_mul, oy_add, ox_mul, ox_add;
+};
+
+struct ConvParams {
+    const float* x; const float* wp; const float* styles; const float* dcoef; const float* noise;
+    const float* bias; const float* skip; float* y;
+    int64_t noise_bstride;
+    float fir[16];      // flipped filter * gain for the fused skip upsample
+    int B, Cin, Cout, CoutP, Hin, Win, T, KC;
+    int Hout, Wout;     // dims of the output tensor
+    int out_layout, out_feat;
+    int act; float alpha, gain, clamp;
+    int tw_log2;
+    int nphases;
+    Phase ph[4];
+};
+
+__device__ __forceinline__ float act_apply(float v, int act, float alpha) {
+    switch (act) {
+    case 1: return v;
+    case 2: return v > 0.f ? v : 0.f;
+    case 3: return v > 0.f ? v : v * alpha;
+    case 4: return tanhf(v);
+    case 5: return 1.0f / (1.0f + expf(-v));
+    case 6: return v > 0.f ? v : expm1f(v);
+    case 7: return v > 0.f ? 1.0507009873554804934193349852946f * v
+                           : (1.0507009873554804934193349852946f * 1.6732632423543772848170429916717f) * expm1f(v);
+    case 8: return v > 20.f ? v : log1pf(expf(v));
+    case 9: return (1.0f / (1.0f + expf(-v))) * v;
+    }
+    return v;
+}
+
+// x2 FIR upsample of the previous-resolution image at output pixel (oy,ox): upfirdn2d.upsample2d
+// (upfirdn2d.py:313-348: up 2, pad [2,1,2,1], gain 4), only the structurally non-zero taps.
+// img points at the (b, channel) plane; `stride` = element stride between neighbouring pixels (1 for NCHW, feat for
+// the channel-last plane layout).
+template <bool CL>
+__device__ __forceinline__ float skip_upsample(const float* __restrict__ img, int h2, int w2, int oy, int ox, const float* fir, int stride) {
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 4; ky++) {
+        const int uy = oy + ky - 2;
+        if (uy < 0 || uy >= 2 * h2 || (uy & 1)) continue;
+#pragma unroll
+        for (int kx = 0; kx < 4; kx++) {
+            const int ux = ox + kx - 2;
+            if (ux < 0 || ux >= 2 * w2 || (ux & 1)) continue;
+            acc = fmaf_(fir[ky * 4 + kx], img[(int64_t)((uy >> 1) * w2 + (ux >> 1)) * (CL ? stride : 1)], acc);
+        }
+    }
+    return acc;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution.  Block = 256 threads = WM x WN waves, wave tile = (MTW*32) x (NTW*32).
+// KCS = channels staged per K iteration (a multiple of the packed chunk p.KC), MAXT = max taps per phase.
+// -------------------------------------------------------------------------------------------------
+template <int MTW, int NTW, int WM, int WN, int KCS, int MAXT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
+    constexpr int BM = 32 * MTW * WM;
+    constexpr int NT = NTW * WN;            // 32-pixel subtiles per block
+    constexpr int BN = 32 * NT;
+    constexpr int XS_MAX = (BN / 4 + 2) * (4 + 2) > (BN / 32 + 2) * (32 + 2) ? (BN / 4 + 2) * (4 + 2) : (BN / 32 + 2) * (32 + 2);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                               // [MAXT*KCS][BM]
+    float* Xs = smem + MAXT * KCS * BM;             // [KCS][PSZ]
+
+    const Phase& ph = p.ph[blockIdx.z];
+    const int TW = 1 << p.tw_log2, RPS = 32 >> p.tw_log2;
+    const int TR = NT * RPS;                        // virtual rows per block tile
+    const int PR = TR + 2, PC = TW + 2;
+    const int PSZ = PR * PC;
+    const int tilesX = (ph.gridW + TW - 1) / TW;
+    const int VR = p.B * ph.gridH;
+    const int tilesY = (VR + TR - 1) / TR;
+    if ((int)blockIdx.x >= tilesX * tilesY) return;
+    const int ty = blockIdx.x / tilesX, tx = blockIdx.x % tilesX;
+    const int vr0 = ty * TR, n0 = tx * TW;
+    const int m0 = blockIdx.y * BM;
+
+    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+    const int l32 = l & 31, half = l >> 5;
+    const int wm = wv / WN, wn = wv % WN;
+
+    // ---- per-thread patch positions (fixed across the K loop) -------------------------------------
+    constexpr int NPOS = (XS_MAX + 255) / 256;
+    int pos_off[NPOS];          // element offset of (b', iy, ix) in x for channel 0, or -1
+    int pos_sb[NPOS];           // b' * Cin
+#pragma unroll
+    for (int k = 0; k < NPOS; k++) {
+        const int pos = tid + k * 256;
+        pos_off[k] = -1; pos_sb[k] = 0;
+        if (pos < PSZ) {
+            const int pr = pos / PC, pc = pos % PC;
+            const int vi = vr0 - 1 + pr, ix = n0 - 1 + pc;
+            if (vi >= 0 && ix >= 0 && ix < p.Win) {
+                const int bb = vi / ph.gridH, iy = vi % ph.gridH;
+                if (bb < p.B && iy < p.Hin) {
+                    pos_off[k] = ((bb * p.Cin) * p.Hin + iy) * p.Win + ix;
+                    pos_sb[k] = bb * p.Cin;
+                }
+            }
+        }
+    }
+    const int chw = p.Hin * p.Win;
+
+    // ---- per-lane pixel info for its NTW subtiles ------------------------------------------------
+    int px_base[NTW];           // LDS offset of the pixel inside the patch (tap (0,0) -> + PC + 1)
+    int px_mask[NTW];           // bit t: tap t reads a row of the same sample
+    int px_b[NTW], px_m[NTW], px_n[NTW];
+    bool px_ok[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; n++) {
+        const int sn = wn * NTW + n;
+        const int lr = sn * RPS + (l32 >> p.tw_log2), lc = l32 & (TW - 1);
+        const int vr = vr0 + lr, nn = n0 + lc;
+        const int bb = vr / ph.gridH, m = vr % ph.gridH;
+        px_b[n] = bb; px_m[n] = m; px_n[n] = nn;
+        px_ok[n] = vr < VR && nn < ph.gridW;
+        px_base[n] = lr * PC + lc;
+        int mask = 0;
+        for (int t = 0; t < ph.ntaps; t++) {
+            const int iy = m + ph.tap_off_y[t];
+            if (iy >= 0 && iy < p.Hin) mask |= 1 << t;
+        }
+        px_mask[n] = mask;
+    }
+
+    f32x16 acc[MTW][NTW];
+#pragma unroll
+    for (int m = 0; m < MTW; m++)
+#pragma unroll
+        for (int n = 0; n < NTW; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+
+    const int G = KCS / p.KC;                       // packed chunks per staged iteration
+    const int nchunks_packed = (p.Cin + p.KC - 1) / p.KC;
+    const int niter = (nchunks_packed + G - 1) / G;
+    const int arows = ph.ntaps * KCS;
+
+    for (int it = 0; it < niter; it++) {
+        __syncthreads();
+        // ---- stage A: rows (t, g, c8) -> As[(t*KCS + g*KC + c8)][BM] ---------------------------------
+        for (int e = tid; e < arows * (BM / 4); e += 256) {
+            const int row = e / (BM / 4), j4 = e % (BM / 4);
+            const int t = row / KCS, ci = row % KCS;
+            const int g = ci / p.KC, c8 = ci % p.KC;
+            const int cc = it * G + g;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int o = m0 + j4 * 4;
+            if (cc < nchunks_packed && o < p.CoutP)
+                v = *(const float4*)(p.wp + ((int64_t)(cc * p.T + ph.tap_w[t]) * p.KC + c8) * p.CoutP + o);
+            *(float4*)(As + row * BM + j4 * 4) = v;
+        }
+        // ---- stage X patch (style-modulated) ---------------------------------------------------------
+        const int c0 = it * KCS;
+#pragma unroll
+        for (int k = 0; k < NPOS; k++) {
+            const int pos = tid + k * 256;
+            if (pos < PSZ) {
+                const int off = pos_off[k];
+                for (int ci = 0; ci < KCS; ci++) {
+                    const int c = c0 + ci;
+                    float v = 0.f;
+                    if (off >= 0 && c < p.Cin) {
+                        v = p.x[(int64_t)off + (int64_t)c * chw];
+                        if (p.styles) v = v * p.styles[pos_sb[k] + c];
+                    }
+                    Xs[ci * PSZ + pos] = v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over (tap, channel pair) -------------------------------------------------------------
+        for (int t = 0; t < ph.ntaps; t++) {
+            const int toff = (ph.tap_off_y[t] + 1) * PC + (ph.tap_off_x[t] + 1);
+#pragma unroll 4
+            for (int kk = 0; kk < KCS / 2; kk++) {
+                const int ci = 2 * kk + half;
+                float a[MTW], bq[NTW];
+#pragma unroll
+                for (int m = 0; m < MTW; m++) a[m] = As[(t * KCS + ci) * BM + (wm * MTW + m) * 32 + l32];
+#pragma unroll
+                for (int n = 0; n < NTW; n++) {
+                    float v = Xs[ci * PSZ + px_base[n] + toff];
+                    bq[n] = ((px_mask[n] >> t) & 1) ? v : 0.f;
+                }
+#pragma unroll
+                for (int m = 0; m < MTW; m++)
+#pragma unroll
+                    for (int n = 0; n < NTW; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bq[n], acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------------
+    // Accumulators go through a per-wave 32x33 LDS tile (static register indices only on the write side), then a
+    // compact runtime loop applies demod/noise/bias/skip/activation and stores.  Two lane mappings:
+    //   layout 0 (NCHW):         lane = pixel (32 consecutive x -> 128-B row segments), loop over channels;
+    //   layout 1 (channel-last): lane = channel (32 consecutive features -> one 128-B texel line), loop over pixels.
+    __syncthreads();                                   // every wave is done with As / Xs
+    float* ct = smem + wv * (32 * 33);
+    const int h2 = p.Hout / 2, w2 = p.Wout / 2;
+#pragma unroll
+    for (int n = 0; n < NTW; n++) {
+        const int pb = px_b[n];
+        const int poy = px_m[n] * ph.oy_mul + ph.oy_add, pox = px_n[n] * ph.ox_mul + ph.ox_add;
+        const int pok = (px_ok[n] && poy < p.Hout && pox < p.Wout) ? 1 : 0;
+#pragma unroll
+        for (int m = 0; m < MTW; m++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) ct[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l32] = acc[m][n][r];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int obase = m0 + (wm * MTW + m) * 32;
+#pragma unroll 1
+            for (int rr = 0; rr < 16; rr++) {
+                const int sel = rr * 2 + half;         // 0..31
+                int o, b, oy, ox, ok;
+                float v;
+                if (p.out_layout == 0) {
+                    o = obase + sel; b = pb; oy = poy; ox = pox; ok = pok;
+                    v = ct[sel * 33 + l32];
+                } else {
+                    o = obase + l32;
+                    b = __shfl(pb, sel, 64); oy = __shfl(poy, sel, 64); ox = __shfl(pox, sel, 64); ok = __shfl(pok, sel, 64);
+                    v = ct[l32 * 33 + sel];
+                }
+                if (ok && o < p.Cout) {
+                    if (p.dcoef) v = v * p.dcoef[b * p.Cout + o];
+                    if (p.noise) v = v + p.noise[b * p.noise_bstride + (int64_t)oy * p.Wout + ox];
+                    if (p.bias) v = v + p.bias[o];
+                    int64_t addr;
+                    if (p.out_layout == 0) {
+                        if (p.skip) v = v + skip_upsample<false>(p.skip + ((int64_t)b * p.Cout + o) * h2 * w2, h2, w2, oy, ox, p.fir, 1);
+                        addr = (((int64_t)b * p.Cout + o) * p.Hout + oy) * p.Wout + ox;
+                    } else {
+                        const int pl = o / p.out_feat, f = o % p.out_feat;
+                        const int64_t plane = (int64_t)b * (p.Cout / p.out_feat) + pl;
+                        if (p.skip) v = v + skip_upsample<true>(p.skip + plane * h2 * w2 * p.out_feat + f, h2, w2, oy, ox, p.fir, p.out_feat);
+                        addr = ((plane * p.Hout + oy) * p.Wout + ox) * p.out_feat + f;
+                    }
+                    v = act_apply(v, p.act, p.alpha) * p.gain;
+                    if (p.clamp >= 0.f) v = v < -p.clamp ? -p.clamp : (v > p.clamp ? p.clamp : v);
+                    p.y[addr] = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// FIR (4x4, pad 1, gain folded into the taps) + demod + noise + bias + activation on the transposed-conv
+// intermediate Z [B,C,ZH,ZW] -> y [B,C,ZH-1,ZW-1].   (conv2d_resample.py:126 + networks_stylegan2.py:86-87,144)
+// One thread produces 4 consecutive outputs of a row from a 4x7 register window.
+// -------------------------------------------------------------------------------------------------
+struct FirParams {
+    const float* z; const float* dcoef; const float* noise; const float* bias; float* y;
+    int64_t noise_bstride;
+    float fir[16];
+    int B, C, ZH, ZW, OH, OW;
+    int act; float alpha, gain, clamp;
+};
+
+__global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
+    const int qW = (p.OW + 3) / 4;
+    const int64_t total = (int64_t)p.B * p.C * p.OH * qW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int oxq = (int)(i % qW);
+        int64_t r = i / qW;
+        const int oy = (int)(r % p.OH); r /= p.OH;
+        const int c = (int)(r % p.C);
+        const int b = (int)(r / p.C);
+        const int ox0 = oxq * 4;
+        const float* zp = p.z + ((int64_t)b * p.C + c) * p.ZH * p.ZW;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 4; ky++) {
+            const int zy = oy + ky - 1;
+            if (zy < 0 || zy >= p.ZH) continue;
+            float win[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                const int zx = ox0 - 1 + j;
+                win[j] = (zx >= 0 && zx < p.ZW) ? zp[zy * p.ZW + zx] : 0.f;
+            }
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+#pragma unroll
+                for (int kx = 0; kx < 4; kx++) acc[o] = fmaf_(p.fir[ky * 4 + kx], win[o + kx], acc[o]);
+        }
+        const float d = p.dcoef ? p.dcoef[b * p.C + c] : 1.f;
+        const float bv = p.bias ? p.bias[c] : 0.f;
+        float* yp = p.y + (((int64_t)b * p.C + c) * p.OH + oy) * p.OW + ox0;
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            if (ox0 + o >= p.OW) break;
+            float v = acc[o] * d;
+            if (p.noise) v = v + p.noise[b * p.noise_bstride + (int64_t)oy * p.OW + ox0 + o];
+            v = v + bv;
+            v = act_apply(v, p.act, p.alpha) * p.gain;
+            if (p.clamp >= 0.f) v = v < -p.clamp ? -p.clamp : (v > p.clamp ? p.clamp : v);
+            yp[o] = v;
+        }
+    }
+}
+
+// d[b,o] = rsqrt(sum_c s[b,c]^2 * wsq[c][o] + 1e-8)      (networks_stylegan2.py:62)
+__global__ __launch_bounds__(256) void demod_kernel(const float* __restrict__ styles, const float* __restrict__ wsq, float* __restrict__ d, int B,
+                                                   int Cin, int Cout, int CoutP) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Cout) return;
+    const int b = i / Cout, o = i % Cout;
+    float acc = 0.f;
+    for (int c = 0; c < Cin; c++) {
+        const float s = styles[b * Cin + c];
+        acc = fmaf_(s * s, wsq[(int64_t)c * CoutP + o], acc);
+    }
+    d[i] = 1.0f / sqrtf(acc + 1e-8f);
+}
+
+// weight [Cout,Cin,k,k] -> packed [nchunks][T][KC][CoutP] (zero padded) followed by wsq [Cin][CoutP]
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wsq, int Cout, int Cin, int T,
+                                                  int KC, int CoutP, int nchunks) {
+    const int64_t total = (int64_t)nchunks * T * KC * CoutP;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(i % CoutP);
+        int64_t r = i / CoutP;
+        const int c8 = (int)(r % KC); r /= KC;
+        const int t = (int)(r % T);
+        const int cc = (int)(r / T);
+        const int c = cc * KC + c8;
+        wp[i] = (o < Cout && c < Cin) ? w[((int64_t)o * Cin + c) * T + t] : 0.f;
+    }
+    const int64_t total2 = (int64_t)Cin * CoutP;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total2; i += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(i % CoutP), c = (int)(i / CoutP);
+        float acc = 0.f;
+        if (o < Cout)
+            for (int t = 0; t < T; t++) { const float v = w[((int64_t)o * Cin + c) * T + t]; acc = fmaf_(v, v, acc); }
+        wsq[i] = acc;
+    }
+}
+
+// One wave per (b,row): out[obase + b*olen + oidx] = (ws[b,widx,:] . (A[row,:] * wgain) + abias[row]) * scale[row]
+// row_meta[row] = (widx, obase, olen, oidx): every layer gets its own contiguous [B, Cin_l] block.
+__global__ __launch_bounds__(256) void style_affine_kernel(const float* __restrict__ ws, const float* __restrict__ A, const float* __restrict__ abias,
+                                                          const int32_t* __restrict__ meta, const float* __restrict__ scale, float* __restrict__ styles,
+                                                          int B, int num_ws, int w_dim, int rows, float wgain) {
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (gw >= (int64_t)B * rows) return;
+    const int b = (int)(gw / rows), row = (int)(gw % rows);
+    const int widx = meta[row * 4 + 0], obase = meta[row * 4 + 1], olen = meta[row * 4 + 2], oidx = meta[row * 4 + 3];
+    const float* x = ws + ((int64_t)b * num_ws + widx) * w_dim;
+    const float* a = A + (int64_t)row * w_dim;
+    float acc = 0.f;
+    for (int j = lane_id(); j < w_dim; j += 64) acc = fmaf_(x[j], a[j] * wgain, acc);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (lane_id() == 0) styles[(int64_t)obase + (int64_t)b * olen + oidx] = (acc + abias[row]) * scale[row];
+}
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+struct PackInfo { int T, KC, CoutP, nchunks; int64_t wp_floats, wsq_floats; };
+inline PackInfo pack_info(int Cout, int Cin, int k) {
+    PackInfo pi;
+    pi.T = k * k;
+    pi.KC = (k == 1) ? KC1 : KC3;
+    pi.CoutP = round_up(Cout, 4);
+    pi.nchunks = (Cin + pi.KC - 1) / pi.KC;
+    pi.wp_floats = (int64_t)pi.nchunks * pi.T * pi.KC * pi.CoutP;
+    pi.wsq_floats = (int64_t)Cin * pi.CoutP;
+    return pi;
+}
+
+template <int MTW, int NTW, int WM, int WN, int KCS, int MAXT>
+int launch_conv(const ConvParams& p, int max_grid_px_tiles, hipStream_t s) {
+    constexpr int BM = 32 * MTW * WM, NT = NTW * WN, BN = 32 * NT;
+    constexpr int XS_MAX = (BN / 4 + 2) * (4 + 2) > (BN / 32 + 2) * (32 + 2) ? (BN / 4 + 2) * (4 + 2) : (BN / 32 + 2) * (32 + 2);
+    const size_t lds = (size_t)(MAXT * KCS * BM + KCS * XS_MAX) * sizeof(float);
+    static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<MTW, NTW, WM, WN, KCS, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(max_grid_px_tiles, cdiv(p.Cout, BM), p.nphases);
+    hipLaunchKernelGGL((conv_mfma_kernel<MTW, NTW, WM, WN, KCS, MAXT>), grid, dim3(256), lds, s, p);
+    return 0;
+}
+
+// pixel tiles of the largest phase for a block covering NT 32-pixel subtiles
+inline int px_tiles(const ConvParams& p, int NT) {
+    const int TW = 1 << p.tw_log2, RPS = 32 >> p.tw_log2, TR = NT * RPS;
+    int mx = 0;
+    for (int i = 0; i < p.nphases; i++) {
+        const int t = cdiv(p.ph[i].gridW, TW) * cdiv(p.B * p.ph[i].gridH, TR);
+        mx = t > mx ? t : mx;
+    }
+    return mx;
+}
+
+inline int pick_tw_log2(int gridW) {
+    int tw = 4, lg = 2;
+    while (tw < 32 && tw < gridW) { tw <<= 1; lg++; }
+    return lg;
+}
+
+}  // namespace
+
+TDGP_API int64_t tdgp_modconv_pack_bytes(int Cout, int Cin, int k) {
+    if (Cout < 1 || Cin < 1 || (k != 1 && k != 3)) return -1;
+    const PackInfo pi = pack_info(Cout, Cin, k);
+    return (pi.wp_floats + pi.wsq_floats) * (int64_t)sizeof(float);
+}
+
+TDGP_API int tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int Cin, int k, tdgp_stream_t stream) {
+    TDGP_CHECK(weight && wpack, TDGP_EINVAL, "modconv_pack: null pointer");
+    TDGP_CHECK(Cout >= 1 && Cin >= 1, TDGP_EINVAL, "modconv_pack: bad channel counts");
+    TDGP_CHECK(k == 1 || k == 3, TDGP_EUNSUPPORTED, "modconv_pack: kernel size %d not on the generator path (1 or 3)", k);
+    const PackInfo pi = pack_info(Cout, Cin, k);
+    float* wp = (float*)wpack;
+    hipLaunchKernelGGL(pack_kernel, dim3((int)min((int64_t)4096, cdiv64(pi.wp_floats, 256))), dim3(256), 0, (hipStream_t)stream, weight, wp,
+                       wp + pi.wp_floats, Cout, Cin, pi.T, pi.KC, pi.CoutP, pi.nchunks);
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}
+
+TDGP_API int64_t tdgp_modconv2d_workspace_bytes(int B, int Cin, int Cout, int H, int W, int k, int up) {
+    int64_t bytes = (int64_t)B * Cout * sizeof(float);                                  // demod coefficients
+    bytes = (bytes + 255) / 256 * 256;
+    if (up == 2) bytes += (int64_t)B * Cout * (2 * H + 1) * (2 * W + 1) * sizeof(float);  // transposed-conv intermediate
+    return bytes;
+}
+
+TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styles, const float* noise, int64_t noise_bstride,
+                            const float* bias, const float* fir4x4, const float* skip, float* y, int B, int Cin, int Cout, int H, int W,
+                            int k, int up, int demodulate, int act, float alpha, float gain, float clamp, int out_layout, int out_feat,
+                            void* workspace, int64_t workspace_bytes, tdgp_stream_t stream) {
+    TDGP_CHECK(x && wpack && y, TDGP_EINVAL, "modconv2d: null pointer");
+    TDGP_CHECK(B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, TDGP_EINVAL, "modconv2d: bad shape");
+    TDGP_CHECK(k == 1 || k == 3, TDGP_EUNSUPPORTED, "modconv2d: kernel size %d not supported (1 or 3)", k);
+    TDGP_CHECK(up == 1 || (up == 2 && k == 3), TDGP_EUNSUPPORTED, "modconv2d: up=%d with k=%d not supported", up, k);
+    TDGP_CHECK(up == 1 || fir4x4, TDGP_EINVAL, "modconv2d: up=2 needs the 4x4 resample filter");
+    TDGP_CHECK(!skip || (up == 1 && k == 1 && fir4x4 && (H % 2) == 0 && (W % 2) == 0), TDGP_EINVAL, "modconv2d: skip needs k=1, up=1, even H/W and the filter");
+    TDGP_CHECK(!demodulate || styles, TDGP_EINVAL, "modconv2d: demodulate needs styles");
+    TDGP_CHECK(act >= 1 && act <= 9, TDGP_EUNSUPPORTED, "modconv2d: unknown activation %d", act);
+    TDGP_CHECK(out_layout == 0 || (out_layout == 1 && out_feat >= 1 && (Cout % out_feat) == 0 && up == 1), TDGP_EINVAL, "modconv2d: bad output layout");
+    TDGP_CHECK((int64_t)B * Cin * H * W <= INT32_MAX && (int64_t)B * Cout * H * up * W * up <= INT32_MAX, TDGP_EINVAL, "modconv2d: tensor too large");
+    const int64_t need = tdgp_modconv2d_workspace_bytes(B, Cin, Cout, H, W, k, up);
+    TDGP_CHECK((!demodulate && up == 1) || (workspace && workspace_bytes >= need), TDGP_EWORKSPACE, "modconv2d: workspace %lld < %lld bytes",
+               (long long)workspace_bytes, (long long)need);
+    hipStream_t s = (hipStream_t)stream;
+    const PackInfo pi = pack_info(Cout, Cin, k);
+    const float* wp = (const float*)wpack;
+    const float* wsq = wp + pi.wp_floats;
+    float* dco = nullptr;
+    float* z = nullptr;
+    if (workspace) {
+        dco = (float*)workspace;
+        z = (float*)((char*)workspace + (((int64_t)B * Cout * sizeof(float) + 255) / 256 * 256));
+    }
+    if (demodulate) {
+        hipLaunchKernelGGL(demod_kernel, dim3(cdiv(B * Cout, 256)), dim3(256), 0, s, styles, wsq, dco, B, Cin, Cout, pi.CoutP);
+    } else {
+        dco = nullptr;
+    }
+
+    ConvParams p;
+    p.x = x; p.wp = wp; p.styles = styles; p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutP = pi.CoutP; p.Hin = H; p.Win = W;
+    p.T = pi.T; p.KC = pi.KC;
+    for (int i = 0; i < 16; i++) p.fir[i] = 0.f;
+    if (fir4x4) {
+        // fir4x4 is a HOST pointer (the filter is a static 64-byte buffer; reading it on the host keeps the call async)
+        for (int ky = 0; ky < 4; ky++)
+            for (int kx = 0; kx < 4; kx++) p.fir[ky * 4 + kx] = fir4x4[(3 - ky) * 4 + (3 - kx)] * 4.0f;   // no flip_filter: taps = flipped f; gain up^2
+    }
+    if (up == 1) {
+        p.dcoef = dco; p.noise = noise; p.noise_bstride = noise_bstride; p.bias = bias; p.skip = skip; p.y = y;
+        p.Hout = H; p.Wout = W; p.out_layout = out_layout; p.out_feat = out_feat > 0 ? out_feat : 1;
+        p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+        p.nphases = 1;
+        Phase& ph = p.ph[0];
+        ph.ntaps = k * k;
+        for (int t = 0; t < k * k; t++) {
+            ph.tap_w[t] = t;
+            ph.tap_off_y[t] = (k == 3) ? t / 3 - 1 : 0;      // correlation, padding k/2 (conv2d_resample.py:132-134)
+            ph.tap_off_x[t] = (k == 3) ? t % 3 - 1 : 0;
+        }
+        ph.gridH = H; ph.gridW = W; ph.oy_mul = 1; ph.oy_add = 0; ph.ox_mul = 1; ph.ox_add = 0;
+        p.tw_log2 = pick_tw_log2(W);
+        if (k == 3) {
+            if (Cout > 64) launch_conv<2, 2, 2, 2, 8, 9>(p, px_tiles(p, 4), s);
+            else launch_conv<2, 2, 1, 4, 8, 9>(p, px_tiles(p, 8), s);
+        } else {
+            if (Cout > 64 && Cout <= 96) launch_conv<3, 1, 1, 4, 32, 1>(p, px_tiles(p, 4), s);
+            else if (Cout > 64) launch_conv<2, 2, 2, 2, 32, 1>(p, px_tiles(p, 4), s);
+            else launch_conv<2, 2, 1, 4, 32, 1>(p, px_tiles(p, 8), s);
+        }
+    } else {
+        // transposed conv, stride 2, UNFLIPPED weights (conv2d_resample.py:108-125): Z[2i+a, 2j+e] += w[a,e] * x[i,j]
+        const int ZH = 2 * H + 1, ZW = 2 * W + 1;
+        p.dcoef = nullptr; p.noise = nullptr; p.noise_bstride = 0; p.bias = nullptr; p.skip = nullptr; p.y = z;
+        p.Hout = ZH; p.Wout = ZW; p.out_layout = 0; p.out_feat = 1;
+        p.act = 1; p.alpha = 0.f; p.gain = 1.f; p.clamp = -1.f;
+        p.nphases = 4;
+        for (int py = 0; py < 2; py++)
+            for (int px = 0; px < 2; px++) {
+                Phase& ph = p.ph[py * 2 + px];
+                ph.ntaps = 0;
+                // row taps: py=0 -> (a=0, dy=0), (a=2, dy=-1); py=1 -> (a=1, dy=0)
+                for (int a = 0; a < 3; a++) {
+                    if ((a & 1) != py) continue;
+                    for (int e = 0; e < 3; e++) {
+                        if ((e & 1) != px) continue;
+                        const int t = ph.ntaps++;
+                        ph.tap_w[t] = a * 3 + e;
+                        ph.tap_off_y[t] = (a == 2) ? -1 : 0;
+                        ph.tap_off_x[t] = (e == 2) ? -1 : 0;
+                    }
+                }
+                ph.gridH = (py == 0) ? H + 1 : H;
+                ph.gridW = (px == 0) ? W + 1 : W;
+                ph.oy_mul = 2; ph.oy_add = py; ph.ox_mul = 2; ph.ox_add = px;
+            }
+        p.tw_log2 = pick_tw_log2(W + 1 > 32 ? 32 : W + 1);
+        if (Cout > 64) launch_conv<2, 2, 2, 2, 16, 4>(p, px_tiles(p, 4), s);
+        else launch_conv<2, 2, 1, 4, 16, 4>(p, px_tiles(p, 8), s);
+        FirParams f;
+        f.z = z; f.dcoef = dco; f.noise = noise; f.noise_bstride = noise_bstride; f.bias = bias; f.y = y;
+        for (int i = 0; i < 16; i++) f.fir[i] = p.fir[i];
+        f.B = B; f.C = Cout; f.ZH = ZH; f.ZW = ZW; f.OH = 2 * H; f.OW = 2 * W;
+        f.act = act; f.alpha = alpha; f.gain = gain; f.clamp = clamp;
+        const int64_t total = (int64_t)B * Cout * f.OH * ((f.OW + 3) / 4);
+        hipLaunchKernelGGL(fir_act_kernel, dim3((int)min((int64_t)(256 * 16), cdiv64(total, 256))), dim3(256), 0, s, f);
+    }
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}
+
+TDGP_API int tdgp_style_affine(const float* ws, const float* A, const float* abias, const int32_t* row_meta, const float* row_scale,
+                               float* styles, int B, int num_ws, int w_dim, int rows_total, tdgp_stream_t stream) {
+    TDGP_CHECK(ws && A && abias && row_meta && row_scale && styles, TDGP_EINVAL, "style_affine: null pointer");
+    TDGP_CHECK(B >= 1 && num_ws >= 1 && w_dim >= 1 && rows_total >= 1, TDGP_EINVAL, "style_affine: bad shape");
+    const int64_t waves = (int64_t)B * rows_total;
+    const float wgain = (float)(1.0 / sqrt((double)w_dim));
+    hipLaunchKernelGGL(style_affine_kernel, dim3((int)cdiv64(waves, 4)), dim3(256), 0, (hipStream_t)stream, ws, A, abias, row_meta, row_scale, styles, B,
+                       num_ws, w_dim, rows_total, wgain);
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}

@@ -1,0 +1,458 @@
+// sampling.hip -- per-ray stages of the volumetric renderer: stratified samples, ray marchers,
+// hierarchical importance resampling, depth merge + alpha compositing.
+//
+// Replaces ~40 eager PyTorch ops per chunk of src/training/tri_plane_renderer.py:
+//   :208-235 sample_stratified      :353-405 ClassicalRayMarcher     :300-348 MipRayMarcher2
+//   :237-255 sample_importance      :257-295 sample_pdf              :196-206 unify_samples
+//
+// Mapping: ONE 64-lane wavefront per ray (4 rays per 256-thread block), samples across lanes, per-wave LDS
+// scratch, no block-level synchronisation.  Scans (transmittance cumprod, cdf cumsum) are fp64 wave scans
+// rounded to fp32 per prefix, which reproduces torch's sequential-fp64 CPU accumulation;
+// reductions are fp64 wave sums rounded once.  exp/log1p are evaluated in fp64: these kernels are HBM/latency
+// bound (2S*20 B per ray), the fp64 transcendental costs nothing measurable and keeps the importance-sampling
+// integer decisions (searchsorted index, sort permutation) identical to the CPU oracle.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXS = 256;          // max samples per ray in one pass (2*S for the merged pass)
+constexpr int RAYS_PER_BLOCK = 4;
+
+struct WaveScratch {
+    float z[MAXS];      // depths (s- or t-space)
+    float sig[MAXS];    // densities
+    float w[MAXS + 4];  // weights / pdf scratch
+    float cdf[MAXS];
+    float bins[MAXS];
+    float col[3][MAXS]; // colours (merged pass)
+};
+
+__device__ __forceinline__ void wave_sync() {
+    // all LDS traffic of a wave is issued in order; this only stops the compiler from reordering across it
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float s2t(float s, float t_near, float t_far) { return s * t_far + (1.0f - s) * t_near; }
+
+// ------------------------------------------------------------------------------------------------
+// classical marcher on LDS-resident depths/densities: writes weights w[0..S), returns (final_T, sum w).
+// tri_plane_renderer.py:355-387.
+// flags: bit0 use_inf_depth, bit1 last_back, bit3 relu clamp
+// ------------------------------------------------------------------------------------------------
+__device__ void march_classical_lds(const float* z, const float* sig, float* w, int S, int flags, float& final_T, float& wagg) {
+    const int l = lane_id();
+    double carry = 1.0, wsum = 0.0;
+    for (int base = 0; base < S; base += 64) {
+        const int i = base + l;
+        float alpha = 0.f, fac = 1.0f;
+        if (i < S) {
+            float delta = (i < S - 1) ? (z[i + 1] - z[i]) : ((flags & 1) ? 1e10f : 1e-3f);
+            float sp = (flags & 8) ? (sig[i] > 0.f ? sig[i] : 0.f) : softplus20(sig[i]);
+            alpha = 1.0f - (float)exp((double)(-delta * sp));
+            fac = (1.0f - alpha) + 1e-10f;
+        }
+        double incl = wave_scan_f64<true>((double)fac) * carry;
+        double excl = shfl_up_f64(incl, 1);
+        if (l == 0) excl = carry;
+        float wi = alpha * (float)excl;
+        if (i < S) { w[i] = wi; wsum += (double)wi; }
+        carry = shfl_f64(incl, 63);
+    }
+    wsum = wave_sum_f64(wsum);
+    wagg = (float)wsum;
+    final_T = (float)carry;
+    wave_sync();
+    if ((flags & 2) && l == 0) w[S - 1] += (1.0f - wagg);
+    wave_sync();
+}
+
+// mip marcher weights on LDS-resident data: M = S (inf depth) or S-1 mid-point samples.
+// tri_plane_renderer.py:305-334.
+__device__ void march_mip_lds(const float* z, const float* sig, float* w, int S, int flags, float density_bias, float& final_T,
+                              float& wagg) {
+    const int l = lane_id();
+    const int M = (flags & 1) ? S : S - 1;
+    double carry = 1.0, wsum = 0.0;
+    for (int base = 0; base < M; base += 64) {
+        const int i = base + l;
+        float alpha = 0.f, fac = 1.0f;
+        if (i < M) {
+            float delta, smid;
+            if (i < S - 1) { delta = z[i + 1] - z[i]; smid = (sig[i] + sig[i + 1]) / 2.f; }
+            else { delta = 1e10f; smid = sig[S - 1]; }
+            float sp = softplus20(smid + density_bias);
+            float dd = sp * delta;
+            alpha = 1.0f - (float)exp((double)(-dd));
+            fac = (1.0f - alpha) + 1e-10f;
+        }
+        double incl = wave_scan_f64<true>((double)fac) * carry;
+        double excl = shfl_up_f64(incl, 1);
+        if (l == 0) excl = carry;
+        float wi = alpha * (float)excl;
+        if (i < M) { w[i] = wi; wsum += (double)wi; }
+        carry = shfl_f64(incl, 63);
+    }
+    wsum = wave_sum_f64(wsum);
+    wagg = (float)wsum;
+    final_T = (float)carry;
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// sample_importance + sample_pdf on LDS-resident z[S] (s-space) and weights w[Wn].
+// tri_plane_renderer.py:237-295.  Clobbers sc.w / sc.cdf / sc.bins.
+// Lane j produces sample j (strided by 64).  `emit(j, sample, ind, below, above)` consumes the results.
+// ------------------------------------------------------------------------------------------------
+template <typename Emit>
+__device__ void importance_lds(WaveScratch& sc, int S, int Wn, const float* u, int N, int mip, Emit emit) {
+    const int l = lane_id();
+    const float eps = 1e-5f;
+    float* w = sc.w;
+    // smoothed / offset weights, in place (two passes through registers)
+    if (mip) {
+        // max_pool1d(2,1,pad 1) -> Wn+1, avg_pool1d(2,1) -> Wn, + 0.01
+        float nv[MAXS / 64];
+#pragma unroll
+        for (int c = 0; c < MAXS / 64; c++) {
+            const int i = l + 64 * c;
+            if (i < Wn) {
+                float a = (i - 1 >= 0) ? w[i - 1] : -INFINITY, b = w[i], d = (i + 1 < Wn) ? w[i + 1] : -INFINITY;
+                float t0 = a > b ? a : b;      // tmp[i]   = max(w[i-1], w[i])
+                float t1 = b > d ? b : d;      // tmp[i+1] = max(w[i], w[i+1])
+                nv[c] = (t0 + t1) / 2.f + 0.01f;
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c < MAXS / 64; c++) {
+            const int i = l + 64 * c;
+            if (i < Wn) w[i] = nv[c];
+        }
+    } else {
+        for (int i = l; i < Wn; i += 64) w[i] = w[i] + 1e-5f;
+    }
+    wave_sync();
+    const int nb = S - 1, ns = Wn - 2, nc = ns + 1;
+    for (int i = l; i < nb; i += 64) sc.bins[i] = 0.5f * (sc.z[i] + sc.z[i + 1]);
+    // pdf normaliser
+    double tot = 0.0;
+    for (int i = l; i < ns; i += 64) tot += (double)(w[1 + i] + eps);
+    const float totf = (float)wave_sum_f64(tot);
+    // cdf = [0, cumsum(pdf)]
+    double carry = 0.0;
+    if (l == 0) sc.cdf[0] = 0.f;
+    for (int base = 0; base < ns; base += 64) {
+        const int i = base + l;
+        float pdf = (i < ns) ? (w[1 + i] + eps) / totf : 0.f;
+        double incl = wave_scan_f64<false>((double)pdf) + carry;
+        if (i < ns) sc.cdf[i + 1] = (float)incl;
+        carry = shfl_f64(incl, 63);
+    }
+    wave_sync();
+    for (int j = l; j < N; j += 64) {
+        const float uu = u[j];
+        int lo = 0, hi = nc;                       // searchsorted(right=True): first index with cdf > u
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (sc.cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+        }
+        const int ind = lo;
+        const int below = ind - 1 < 0 ? 0 : ind - 1;
+        const int above = ind > ns ? ns : ind;
+        const float cb = sc.cdf[below], ca = sc.cdf[above];
+        const float bb = sc.bins[below < nb ? below : nb - 1], ba = sc.bins[above < nb ? above : nb - 1];
+        float denom = ca - cb;
+        if (denom < eps) denom = 1.f;
+        const float smp = bb + (uu - cb) / denom * (ba - bb);
+        emit(j, smp, ind, below, above);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stratified_kernel(const float* __restrict__ u, float* __restrict__ sdist, float* __restrict__ tdist,
+                                                        int64_t n, int S, int marcher, float t_near, float t_far) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % S);
+        const float step = (1.f - 0.f) / (float)(S - 1);
+        auto lin = [&](int q) { return (S == 1) ? 0.f : ((q < S / 2) ? 0.f + step * (float)q : 1.f - step * (float)(S - 1 - q)); };
+        float s;
+        if (marcher == 0) {
+            float lower = (k == 0) ? lin(0) : 0.5f * (lin(k) + lin(k - 1));
+            float upper = (k == S - 1) ? lin(S - 1) : 0.5f * (lin(k + 1) + lin(k));
+            s = lower + (upper - lower) * u[i];
+        } else {
+            float delta = (float)((1.0 - 0.0) / (double)(S - 1));
+            s = lin(k) + u[i] * delta;
+        }
+        sdist[i] = s;
+        if (tdist) tdist[i] = s2t(s, t_near, t_far);
+    }
+}
+
+// generic marcher: colours [rays,S,C], densities [rays,S], depths [rays,S]
+__global__ __launch_bounds__(256) void ray_march_kernel(const float* __restrict__ colors, const float* __restrict__ dens,
+                                                       const float* __restrict__ depths, float* __restrict__ rgb, float* __restrict__ depth_o,
+                                                       float* __restrict__ weights, float* __restrict__ final_T, int64_t rays, int S, int C,
+                                                       int marcher, int flags, float density_bias) {
+    __shared__ WaveScratch scratch[RAYS_PER_BLOCK];
+    const int wv = threadIdx.x >> 6, l = lane_id();
+    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (r >= rays) return;
+    WaveScratch& sc = scratch[wv];
+    for (int i = l; i < S; i += 64) { sc.z[i] = depths[r * S + i]; sc.sig[i] = dens[r * S + i]; }
+    wave_sync();
+    float fT, wagg;
+    const int M = (marcher == 0) ? S : ((flags & 1) ? S : S - 1);
+    if (marcher == 0) march_classical_lds(sc.z, sc.sig, sc.w, S, flags, fT, wagg);
+    else march_mip_lds(sc.z, sc.sig, sc.w, S, flags, density_bias, fT, wagg);
+    if (weights) for (int i = l; i < M; i += 64) weights[r * M + i] = sc.w[i];
+    // composite: sum_i w_i * c_i  (products rounded to fp32, accumulated in fp64)
+    for (int c = 0; c <= C; c++) {          // c == C: depth
+        double acc = 0.0;
+        for (int i = l; i < M; i += 64) {
+            float v;
+            if (c < C) {
+                v = colors[(r * S + i) * C + c];
+                if (marcher == 1 && i < S - 1) v = (v + colors[(r * S + i + 1) * C + c]) / 2.f;
+            } else {
+                v = sc.z[i];
+                if (marcher == 1 && i < S - 1) v = (v + sc.z[i + 1]) / 2.f;
+            }
+            acc += (double)(sc.w[i] * v);
+        }
+        float out = (float)wave_sum_f64(acc);
+        if (marcher == 1 && c < C) {
+            if (flags & 4) out = out + 1.0f - wagg;
+            out = out * 2.0f - 1.0f;
+        }
+        if (l == 0) { if (c < C) rgb[r * C + c] = out; else depth_o[r] = out; }
+    }
+    if (l == 0) final_T[r] = fT;
+}
+
+__global__ __launch_bounds__(256) void sample_importance_kernel(const float* __restrict__ z, const float* __restrict__ weights,
+                                                               const float* __restrict__ u, float* __restrict__ samples, int32_t* __restrict__ inds,
+                                                               int32_t* __restrict__ below, int32_t* __restrict__ above, float* __restrict__ cdf_o,
+                                                               int64_t rays, int S, int Wn, int N, int mip) {
+    __shared__ WaveScratch scratch[RAYS_PER_BLOCK];
+    const int wv = threadIdx.x >> 6, l = lane_id();
+    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (r >= rays) return;
+    WaveScratch& sc = scratch[wv];
+    for (int i = l; i < S; i += 64) sc.z[i] = z[r * S + i];
+    for (int i = l; i < Wn; i += 64) sc.w[i] = weights[r * Wn + i];
+    wave_sync();
+    importance_lds(sc, S, Wn, u + r * N, N, mip, [&](int j, float smp, int ind, int bl, int ab) {
+        samples[r * N + j] = smp;
+        if (inds) { inds[r * N + j] = ind; below[r * N + j] = bl; above[r * N + j] = ab; }
+    });
+    if (cdf_o) for (int i = l; i < Wn - 1; i += 64) cdf_o[r * (Wn - 1) + i] = sc.cdf[i];
+}
+
+// fused: coarse march (s-space) -> importance sampling -> fine depths (t-space)
+__global__ __launch_bounds__(256) void importance_from_coarse_kernel(const float* __restrict__ rgbs, const float* __restrict__ sdist,
+                                                                    const float* __restrict__ u_fine, float* __restrict__ tfine,
+                                                                    float* __restrict__ sfine, int32_t* __restrict__ inds, int64_t rays, int S, int N,
+                                                                    int marcher, int flags, float density_bias, float t_near, float t_far) {
+    __shared__ WaveScratch scratch[RAYS_PER_BLOCK];
+    const int wv = threadIdx.x >> 6, l = lane_id();
+    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (r >= rays) return;
+    WaveScratch& sc = scratch[wv];
+    for (int i = l; i < S; i += 64) { sc.z[i] = sdist[r * S + i]; sc.sig[i] = rgbs[(r * S + i) * 4 + 3]; }
+    wave_sync();
+    float fT, wagg;
+    int Wn = S;
+    if (marcher == 0) march_classical_lds(sc.z, sc.sig, sc.w, S, flags, fT, wagg);
+    else { march_mip_lds(sc.z, sc.sig, sc.w, S, flags, density_bias, fT, wagg); Wn = (flags & 1) ? S : S - 1; }
+    importance_lds(sc, S, Wn, u_fine + r * N, N, marcher, [&](int j, float smp, int ind, int, int) {
+        tfine[r * N + j] = s2t(smp, t_near, t_far);
+        if (sfine) sfine[r * N + j] = smp;
+        if (inds) inds[r * N + j] = ind;
+    });
+}
+
+// stable rank of every element of key[0..M) under (key, index) order -> pos[]; brute force from LDS broadcasts
+__device__ __forceinline__ void stable_ranks(const float* key, int M, int* rank /* per-lane, MAXS/64 entries */) {
+    const int l = lane_id();
+    float k[MAXS / 64];
+#pragma unroll
+    for (int c = 0; c < MAXS / 64; c++) { const int i = l + 64 * c; k[c] = i < M ? key[i] : 0.f; rank[c] = 0; }
+    for (int m = 0; m < M; m++) {
+        const float km = key[m];                   // same address on every lane: LDS broadcast
+#pragma unroll
+        for (int c = 0; c < MAXS / 64; c++) {
+            const int i = l + 64 * c;
+            rank[c] += (km < k[c] || (km == k[c] && m < i)) ? 1 : 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void unify_kernel(const float* __restrict__ d1, const float* __restrict__ c1, const float* __restrict__ s1, int S1,
+                                                   const float* __restrict__ d2, const float* __restrict__ c2, const float* __restrict__ s2, int S2,
+                                                   float* __restrict__ d, float* __restrict__ c, float* __restrict__ s, int32_t* __restrict__ perm,
+                                                   int64_t rays, int C) {
+    __shared__ WaveScratch scratch[RAYS_PER_BLOCK];
+    const int wv = threadIdx.x >> 6, l = lane_id();
+    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (r >= rays) return;
+    WaveScratch& sc = scratch[wv];
+    const int M = S1 + S2;
+    for (int i = l; i < M; i += 64) sc.z[i] = i < S1 ? d1[r * S1 + i] : d2[r * S2 + (i - S1)];
+    wave_sync();
+    int rank[MAXS / 64];
+    stable_ranks(sc.z, M, rank);
+#pragma unroll
+    for (int cc = 0; cc < MAXS / 64; cc++) {
+        const int i = l + 64 * cc;
+        if (i >= M) continue;
+        const int pos = rank[cc];
+        d[r * M + pos] = sc.z[i];
+        s[r * M + pos] = i < S1 ? s1[r * S1 + i] : s2[r * S2 + (i - S1)];
+        for (int k = 0; k < C; k++) c[(r * M + pos) * C + k] = i < S1 ? c1[(r * S1 + i) * C + k] : c2[(r * S2 + (i - S1)) * C + k];
+        if (perm) perm[r * M + pos] = i;
+    }
+}
+
+// fused: merge coarse + fine by depth (stable), march in t-space, composite.
+__global__ __launch_bounds__(256) void merge_composite_kernel(const float* __restrict__ rgbs1, const float* __restrict__ t1, int S1,
+                                                             const float* __restrict__ rgbs2, const float* __restrict__ t2, int S2,
+                                                             float* __restrict__ rgb, float* __restrict__ depth_o, float* __restrict__ wsum_o,
+                                                             float* __restrict__ final_T, int32_t* __restrict__ perm, int64_t rays, int marcher,
+                                                             int flags, float density_bias) {
+    __shared__ WaveScratch scratch[RAYS_PER_BLOCK];
+    const int wv = threadIdx.x >> 6, l = lane_id();
+    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (r >= rays) return;
+    WaveScratch& sc = scratch[wv];
+    const int M = S1 + S2;
+    // unsorted keys -> sc.cdf (scratch), ranks, scatter into sorted sc.z / sc.sig / sc.col
+    for (int i = l; i < M; i += 64) sc.cdf[i] = i < S1 ? t1[r * S1 + i] : t2[r * S2 + (i - S1)];
+    wave_sync();
+    int rank[MAXS / 64];
+    stable_ranks(sc.cdf, M, rank);
+#pragma unroll
+    for (int cc = 0; cc < MAXS / 64; cc++) {
+        const int i = l + 64 * cc;
+        if (i >= M) continue;
+        const int pos = rank[cc];
+        const float4 v = i < S1 ? ((const float4*)rgbs1)[r * S1 + i] : ((const float4*)rgbs2)[r * S2 + (i - S1)];
+        sc.z[pos] = sc.cdf[i];
+        sc.col[0][pos] = v.x; sc.col[1][pos] = v.y; sc.col[2][pos] = v.z; sc.sig[pos] = v.w;
+        if (perm) perm[r * M + pos] = i;
+    }
+    wave_sync();
+    float fT, wagg;
+    const int Mm = (marcher == 0) ? M : ((flags & 1) ? M : M - 1);
+    if (marcher == 0) march_classical_lds(sc.z, sc.sig, sc.w, M, flags, fT, wagg);
+    else march_mip_lds(sc.z, sc.sig, sc.w, M, flags, density_bias, fT, wagg);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0}, wacc = 0.0;
+    for (int i = l; i < Mm; i += 64) {
+        const float wi = sc.w[i];
+        wacc += (double)wi;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float v = c < 3 ? sc.col[c][i] : sc.z[i];
+            if (marcher == 1 && i < M - 1) v = (v + (c < 3 ? sc.col[c][i + 1] : sc.z[i + 1])) / 2.f;
+            acc[c] += (double)(wi * v);
+        }
+    }
+    float out[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) out[c] = (float)wave_sum_f64(acc[c]);
+    const float wtot = (float)wave_sum_f64(wacc);     // weights.sum(2): final weights incl. last_back
+    if (marcher == 1) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (flags & 4) out[c] = out[c] + 1.0f - wagg;
+            out[c] = out[c] * 2.0f - 1.0f;
+        }
+    }
+    if (l == 0) {
+        rgb[r * 3 + 0] = out[0]; rgb[r * 3 + 1] = out[1]; rgb[r * 3 + 2] = out[2];
+        depth_o[r] = out[3];
+        if (wsum_o) wsum_o[r] = wtot;
+        if (final_T) final_T[r] = fT;
+    }
+}
+
+inline int ray_blocks(int64_t rays) { return (int)cdiv64(rays, RAYS_PER_BLOCK); }
+
+}  // namespace
+
+TDGP_API int tdgp_sample_stratified(const float* u, float* sdist, float* tdist, int64_t rays, int S, int marcher, float t_near,
+                                    float t_far, tdgp_stream_t stream) {
+    TDGP_CHECK(u && sdist, TDGP_EINVAL, "sample_stratified: null pointer");
+    TDGP_CHECK(S >= 2 && rays >= 0, TDGP_EINVAL, "sample_stratified: need S >= 2");
+    TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "sample_stratified: unknown ray marcher %d", marcher);
+    const int64_t n = rays * S;
+    if (n == 0) return TDGP_OK;
+    hipLaunchKernelGGL(stratified_kernel, dim3((int)min((int64_t)8192, cdiv64(n, 256))), dim3(256), 0, (hipStream_t)stream, u, sdist, tdist, n, S,
+                       marcher, t_near, t_far);
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}
+
+TDGP_API int tdgp_ray_march(const float* colors, const float* densities, const float* depths, float* rgb, float* depth, float* weights,
+                            float* final_T, int64_t rays, int S, int C, int marcher, int flags, float density_bias, tdgp_stream_t stream) {
+    TDGP_CHECK(colors && densities && depths && rgb && depth && final_T, TDGP_EINVAL, "ray_march: null pointer");
+    TDGP_CHECK(S >= 2 && S <= MAXS, TDGP_EUNSUPPORTED, "ray_march: S=%d outside [2,%d]", S, MAXS);
+    TDGP_CHECK(C >= 1 && C <= 8, TDGP_EUNSUPPORTED, "ray_march: C=%d outside [1,8]", C);
+    TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "ray_march: unknown ray marcher %d", marcher);
+    if (rays == 0) return TDGP_OK;
+    hipLaunchKernelGGL(ray_march_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, colors, densities, depths, rgb, depth, weights,
+                       final_T, rays, S, C, marcher, flags, density_bias);
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}
+
+TDGP_API int tdgp_sample_importance(const float* z, const float* weights, const float* u, float* samples, int32_t* inds, int32_t* below,
+                                    int32_t* above, float* cdf, int64_t rays, int S, int Wn, int N, int marcher, tdgp_stream_t stream) {
+    TDGP_CHECK(z && weights && u && samples, TDGP_EINVAL, "sample_importance: null pointer");
+    TDGP_CHECK(!inds || (below && above), TDGP_EINVAL, "sample_importance: inds/below/above come together");
+    TDGP_CHECK(S >= 4 && S <= MAXS && Wn >= 3 && Wn <= S && N >= 1, TDGP_EUNSUPPORTED, "sample_importance: bad S=%d Wn=%d N=%d", S, Wn, N);
+    if (rays == 0) return TDGP_OK;
+    hipLaunchKernelGGL(sample_importance_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, z, weights, u, samples, inds, below,
+                       above, cdf, rays, S, Wn, N, marcher);
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}
+
+TDGP_API int tdgp_unify_samples(const float* d1, const float* c1, const float* s1, int S1, const float* d2, const float* c2, const float* s2,
+                                int S2, float* d, float* c, float* s, int32_t* perm, int64_t rays, int C, tdgp_stream_t stream) {
+    TDGP_CHECK(d1 && c1 && s1 && d2 && c2 && s2 && d && c && s, TDGP_EINVAL, "unify_samples: null pointer");
+    TDGP_CHECK(S1 >= 1 && S2 >= 1 && S1 + S2 <= MAXS, TDGP_EUNSUPPORTED, "unify_samples: S1+S2=%d > %d", S1 + S2, MAXS);
+    if (rays == 0) return TDGP_OK;
+    hipLaunchKernelGGL(unify_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, d1, c1, s1, S1, d2, c2, s2, S2, d, c, s, perm, rays, C);
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}
+
+TDGP_API int tdgp_importance_from_coarse(const float* rgbs_coarse, const float* sdist, const float* u_fine, float* tdist_fine,
+                                         float* sdist_fine, int32_t* inds, int64_t rays, int S, int N, int marcher, int flags,
+                                         float density_bias, float t_near, float t_far, tdgp_stream_t stream) {
+    TDGP_CHECK(rgbs_coarse && sdist && u_fine && tdist_fine, TDGP_EINVAL, "importance_from_coarse: null pointer");
+    TDGP_CHECK(S >= 4 && S <= MAXS && N >= 1, TDGP_EUNSUPPORTED, "importance_from_coarse: bad S=%d N=%d", S, N);
+    TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "importance_from_coarse: unknown ray marcher %d", marcher);
+    if (rays == 0) return TDGP_OK;
+    hipLaunchKernelGGL(importance_from_coarse_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, sdist, u_fine,
+                       tdist_fine, sdist_fine, inds, rays, S, N, marcher, flags, density_bias, t_near, t_far);
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}
+
+TDGP_API int tdgp_merge_composite(const float* rgbs_coarse, const float* t_coarse, int S1, const float* rgbs_fine, const float* t_fine, int S2,
+                                  float* rgb, float* depth, float* wsum, float* final_T, int32_t* perm, int64_t rays, int marcher, int flags,
+                                  float density_bias, tdgp_stream_t stream) {
+    TDGP_CHECK(rgbs_coarse && t_coarse && rgbs_fine && t_fine && rgb && depth, TDGP_EINVAL, "merge_composite: null pointer");
+    TDGP_CHECK(S1 >= 1 && S2 >= 1 && S1 + S2 <= MAXS, TDGP_EUNSUPPORTED, "merge_composite: S1+S2=%d > %d", S1 + S2, MAXS);
+    TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "merge_composite: unknown ray marcher %d", marcher);
+    if (rays == 0) return TDGP_OK;
+    hipLaunchKernelGGL(merge_composite_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, t_coarse, S1, rgbs_fine,
+                       t_fine, S2, rgb, depth, wsum, final_T, perm, rays, marcher, flags, density_bias);
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}

@@ -1,0 +1,363 @@
+"""Generator forward (z, c, camera -> RGB) on the HIP kernels.
+
+Module tree, attribute names and state-dict keys are the reference's (verified by a strict
+`load_state_dict` into the reference Generator in tools/gen_goldens.py), so a state-dict exported from a reference
+checkpoint loads unchanged:
+  Generator                 src/training/networks_epigraf.py:266-291
+    .mapping   MappingNetwork            src/training/layers.py:66-177
+    .synthesis SynthesisNetwork          networks_epigraf.py:134-261
+       .tri_plane_decoder SynthesisBlocksSequence   :73-129
+            .b{res} SynthesisBlock                  networks_stylegan2.py:180-276
+                 .conv0 / .conv1 SynthesisLayer     :93-150
+                 .torgb ToRGBLayer                  :155-175
+       .tri_plane_mlp TriPlaneMLP                   networks_epigraf.py:29-68
+       .renderer ImportanceRenderer                 tri_plane_renderer.py:118-295
+Inference only (eval-mode semantics: fused modconv, no density noise, no patch sampling); fp32 (`fp32_only`).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .config import GeneratorConfig
+from .ops import bias_act as _bias_act
+from .ops import modconv as _modconv
+from .ops import upfirdn2d as _upfirdn2d
+from . import renderer as _renderer
+
+
+class TensorGroup(dict):
+    """Minimal stand-in for dnnlib.TensorGroup (attribute access to a dict of tensors)."""
+    __getattr__ = dict.__getitem__
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def normalize_2nd_moment(x, dim=1, eps=1e-8):
+    """layers.py:16-17."""
+    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+
+
+class FullyConnectedLayer(torch.nn.Module):
+    """layers.py:22-61.  Tiny GEMMs: torch.addmm / matmul on rocBLAS (plumbing), activation through bias_act."""
+
+    def __init__(self, in_features, out_features, activation='linear', bias=True, lr_multiplier=1, weight_init=1, bias_init=0):
+        super().__init__()
+        self.in_features, self.out_features, self.activation = in_features, out_features, activation
+        self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) * (weight_init / lr_multiplier))
+        self.bias = torch.nn.Parameter(torch.full([out_features], float(bias_init) / lr_multiplier)) if bias else None
+        self.weight_gain = lr_multiplier / np.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        w = self.weight.to(x.dtype) * self.weight_gain
+        b = self.bias
+        if b is not None:
+            b = b.to(x.dtype)
+            if self.bias_gain != 1:
+                b = b * self.bias_gain
+        if self.activation == 'linear' and b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return _bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+
+
+class MappingNetwork(torch.nn.Module):
+    """layers.py:66-177 without camera conditioning (`camera_cond` is off in every 3dgp config of the hot path)."""
+
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=2, lr_multiplier=0.01):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.num_ws, self.num_layers = z_dim, c_dim, w_dim, num_ws, num_layers
+        embed_features = w_dim if c_dim > 0 else 0
+        if c_dim > 0:
+            self.embed = FullyConnectedLayer(c_dim, embed_features)
+        feats = [z_dim + embed_features] + [w_dim] * num_layers
+        for i in range(num_layers):
+            setattr(self, f'fc{i}', FullyConnectedLayer(feats[i], feats[i + 1], activation='lrelu', lr_multiplier=lr_multiplier))
+        self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    def forward(self, z, c, camera_angles=None, truncation_psi=1, truncation_cutoff=None, update_emas=False):
+        if camera_angles is not None:
+            raise NotImplementedError('camera-conditioned mapping (camera_cond) is off in the 3dgp configs')
+        if update_emas:
+            raise NotImplementedError('update_emas is a training-time option')
+        x = None
+        if self.z_dim > 0:
+            assert z.shape[1] == self.z_dim, f'Wrong shape: z {tuple(z.shape)}'
+            x = normalize_2nd_moment(z.to(torch.float32))
+        if self.c_dim > 0:
+            assert c.shape[1] == self.c_dim, f'Wrong shape: c {tuple(c.shape)}'
+            y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
+            x = torch.cat([x, y], dim=1) if x is not None else y
+        for i in range(self.num_layers):
+            x = getattr(self, f'fc{i}')(x)
+        if self.num_ws is not None:
+            x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            if self.num_ws is None or truncation_cutoff is None:
+                x = self.w_avg.lerp(x, truncation_psi)
+            else:
+                x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+
+class SynthesisLayer(torch.nn.Module):
+    """networks_stylegan2.py:93-150: affine -> modulated 3x3 conv (optionally x2 up + FIR) -> noise -> bias -> lrelu*sqrt2,
+    executed as one tdgp_modconv2d call."""
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, up=1, use_noise=True, activation='lrelu',
+                 conv_clamp=None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.w_dim, self.resolution = in_channels, out_channels, w_dim, resolution
+        self.up, self.use_noise, self.activation, self.conv_clamp = up, use_noise, activation, conv_clamp
+        self.register_buffer('resample_filter', _upfirdn2d.setup_filter([1, 3, 3, 1]))
+        self.padding = kernel_size // 2
+        self.act_gain = _bias_act.activation_funcs[activation].def_gain
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]))
+        if use_noise:
+            self.register_buffer('noise_const', torch.randn([resolution, resolution]))
+            self.noise_strength = torch.nn.Parameter(torch.zeros([]))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+
+    def _noise(self, batch, noise_mode, device):
+        assert noise_mode in ['random', 'const', 'none']
+        if not self.use_noise or noise_mode == 'none':
+            return None
+        if noise_mode == 'random':
+            return torch.randn([batch, 1, self.resolution, self.resolution], device=device) * self.noise_strength
+        return self.noise_const * self.noise_strength
+
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, styles=None):
+        if styles is None:
+            styles = self.affine(w)
+        noise = self._noise(x.shape[0], noise_mode, x.device)
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        fir = _modconv.fir_host_array(self.resample_filter) if self.up == 2 else None
+        return _modconv.modconv_forward(x, _modconv._packed(self.weight), styles, noise=noise, bias=self.bias, up=self.up, demodulate=True,
+                                        act=self.activation, gain=self.act_gain * gain, clamp=clamp, fir=fir)
+
+
+class ToRGBLayer(torch.nn.Module):
+    """networks_stylegan2.py:155-175 (+ the skip add of SynthesisBlock.forward :265-269 when `skip` is given)."""
+
+    def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.w_dim, self.conv_clamp = in_channels, out_channels, w_dim, conv_clamp
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+
+    def forward(self, x, w, fused_modconv=True, styles=None, skip=None, fir=None, out_layout=0, out_feat=0):
+        if styles is None:
+            styles = self.affine(w) * self.weight_gain
+        return _modconv.modconv_forward(x, _modconv._packed(self.weight), styles, bias=self.bias, demodulate=False, act='linear', gain=1.0,
+                                        clamp=self.conv_clamp, skip=skip, fir=fir, out_layout=out_layout, out_feat=out_feat)
+
+
+class SynthesisBlock(torch.nn.Module):
+    """networks_stylegan2.py:180-276, architecture 'skip', fp32."""
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, use_noise=True, conv_clamp=None):
+        super().__init__()
+        self.in_channels, self.w_dim, self.resolution, self.img_channels, self.is_last = in_channels, w_dim, resolution, img_channels, is_last
+        self.register_buffer('resample_filter', _upfirdn2d.setup_filter([1, 3, 3, 1]))
+        self.num_conv = 0
+        self.num_torgb = 1
+        if in_channels == 0:
+            self.const = torch.nn.Parameter(torch.randn([out_channels, resolution, resolution]))
+        else:
+            self.conv0 = SynthesisLayer(in_channels, out_channels, w_dim=w_dim, resolution=resolution, up=2, use_noise=use_noise, conv_clamp=conv_clamp)
+            self.num_conv += 1
+        self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution, use_noise=use_noise, conv_clamp=conv_clamp)
+        self.num_conv += 1
+        self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
+
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, styles=None, hwc_feat=0, **layer_kwargs):
+        """-> (x, img).  `styles` (optional) = pre-computed [conv0?, conv1, torgb] style tensors; `hwc_feat` > 0 keeps the
+        running image in the channel-last plane layout [B, C/feat, H, W, feat]."""
+        assert ws.shape[1] == self.num_conv + self.num_torgb and ws.shape[2] == self.w_dim, f'Wrong shape: ws {tuple(ws.shape)}'
+        w_iter = iter(ws.unbind(dim=1))
+        s_iter = iter(styles) if styles is not None else iter([None] * 3)
+        if self.in_channels == 0:
+            x = self.const.to(torch.float32).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+        else:
+            x = self.conv0(x.to(torch.float32), next(w_iter), styles=next(s_iter), **layer_kwargs)
+        x = self.conv1(x, next(w_iter), styles=next(s_iter), **layer_kwargs)
+        fir = _modconv.fir_host_array(self.resample_filter) if img is not None else None
+        img = self.torgb(x, next(w_iter), styles=next(s_iter), skip=img, fir=fir, out_layout=1 if hwc_feat else 0, out_feat=hwc_feat)
+        return x, img
+
+
+class SynthesisBlocksSequence(torch.nn.Module):
+    """networks_epigraf.py:73-129: 4x4 const -> ... -> tri_plane.res; returns the (3*feat)-channel plane image."""
+
+    def __init__(self, cfg: GeneratorConfig, out_channels):
+        super().__init__()
+        self.cfg = cfg
+        self.out_channels = out_channels
+        self.block_resolutions = cfg.block_resolutions
+        ch = cfg.channels
+        self.num_ws = 0
+        for i, res in enumerate(self.block_resolutions):
+            is_last = res == cfg.tri_plane_res
+            block = SynthesisBlock(ch[res // 2] if i > 0 else 0, ch[res], w_dim=cfg.w_dim, resolution=res, img_channels=out_channels,
+                                   is_last=is_last, use_noise=cfg.use_noise, conv_clamp=None)
+            self.num_ws += block.num_conv + (block.num_torgb if is_last else 0)
+            setattr(self, f'b{res}', block)
+        self._affine_pack = None
+
+    # ---- all style affines of the backbone in one launch (tdgp_style_affine) -------------------------------------
+    def _layers(self):
+        w_idx = 0
+        for res in self.block_resolutions:
+            blk = getattr(self, f'b{res}')
+            k = 0
+            if blk.in_channels != 0:
+                yield blk.conv0, w_idx + k, 1.0
+                k += 1
+            yield blk.conv1, w_idx + k, 1.0
+            k += 1
+            yield blk.torgb, w_idx + k, float(blk.torgb.weight_gain)
+            w_idx += blk.num_conv
+
+    def invalidate_cache(self):
+        self._affine_pack = None
+
+    def _pack_affines(self, device):
+        key = tuple((l.affine.weight.data_ptr(), l.affine.weight._version, l.affine.bias._version) for l, _, _ in self._layers())
+        if self._affine_pack is not None and self._affine_pack['key'] == key:
+            return self._affine_pack
+        A, ab, scale, meta, blocks = [], [], [], [], []
+        row0 = 0
+        for layer, widx, post in self._layers():
+            cin = layer.affine.out_features
+            A.append(layer.affine.weight.detach().float())
+            ab.append(layer.affine.bias.detach().float())
+            scale.append(torch.full([cin], post, dtype=torch.float32))
+            meta.append((widx, row0, cin))
+            blocks.append((row0, cin))
+            row0 += cin
+        pack = dict(key=key, A=torch.cat(A).contiguous().to(device), ab=torch.cat(ab).contiguous().to(device),
+                    scale=torch.cat(scale).to(device), rows=row0, blocks=blocks, meta_spec=meta, meta={})
+        self._affine_pack = pack
+        return pack
+
+    def all_styles(self, ws):
+        """-> list of per-layer style tensors [B, Cin_l] in layer order (conv0?, conv1, torgb per block)."""
+        pack = self._pack_affines(ws.device)
+        B = ws.shape[0]
+        meta = pack['meta'].get(B)
+        if meta is None:
+            rows = []
+            for widx, row0, cin in pack['meta_spec']:
+                o = torch.arange(cin, dtype=torch.int32)
+                rows.append(torch.stack([torch.full_like(o, widx), torch.full_like(o, row0 * B), torch.full_like(o, cin), o], 1))
+            meta = pack['meta'][B] = torch.cat(rows).contiguous().to(ws.device)
+        ws = _lib.f32c(ws)
+        out = torch.empty([B * pack['rows']], dtype=torch.float32, device=ws.device)
+        with torch.cuda.device(ws.device):
+            _lib.call('tdgp_style_affine', ws.data_ptr(), pack['A'].data_ptr(), pack['ab'].data_ptr(), meta.data_ptr(), pack['scale'].data_ptr(),
+                      out.data_ptr(), B, ws.shape[1], ws.shape[2], pack['rows'], _lib.stream_of(ws))
+        return [out[row0 * B:(row0 + cin) * B].view(B, cin) for row0, cin in pack['blocks']]
+
+    def forward(self, ws, x=None, hwc=False, **block_kwargs):
+        """ws [B, num_ws, w_dim] -> planes [B, out_channels, R, R] (NCHW), or HWCPlanes [B,3,R,R,feat] when hwc=True."""
+        assert ws.shape[1] == self.num_ws and ws.shape[2] == self.cfg.w_dim, f'Wrong shape: ws {tuple(ws.shape)}'
+        _lib.require_cuda(ws, 'ws')
+        ws = ws.to(torch.float32)
+        styles = self.all_styles(ws)
+        feat = self.out_channels // 3 if hwc else 0
+        img = None
+        w_idx = s_idx = 0
+        for res in self.block_resolutions:
+            blk = getattr(self, f'b{res}')
+            n = blk.num_conv + blk.num_torgb
+            x, img = blk(x, img, ws.narrow(1, w_idx, n), styles=styles[s_idx:s_idx + n], hwc_feat=feat, **block_kwargs)
+            w_idx += blk.num_conv
+            s_idx += n
+        return _renderer.HWCPlanes(img) if hwc else img
+
+
+class SynthesisNetwork(torch.nn.Module):
+    """networks_epigraf.py:134-261 (eval; adaptors disabled)."""
+
+    def __init__(self, cfg: GeneratorConfig, img_resolution, img_channels=3):
+        super().__init__()
+        self.cfg = cfg
+        self.img_resolution, self.img_channels = img_resolution, img_channels
+        self.tri_plane_decoder = SynthesisBlocksSequence(cfg, out_channels=cfg.feat_dim * 3)
+        self.tri_plane_mlp = _renderer.TriPlaneMLP(cfg.feat_dim, cfg.mlp_hid, out_dim=img_channels, ray_marcher_type=cfg.ray_marcher_type)
+        self.num_ws = self.tri_plane_decoder.num_ws
+        self.test_resolution = img_resolution
+        self.renderer = _renderer.ImportanceRenderer(ray_marcher_type=cfg.ray_marcher_type)
+        self._default_render_options = dict(max_batch_res=cfg.max_batch_res, return_depth=False, return_depth_adapted=False, return_weights=False,
+                                            concat_depth=False, cut_quantile=0.0, density_bias=cfg.density_bias)
+
+    def rendering_options(self, render_opts):
+        """networks_epigraf.py:226-231."""
+        cfg = self.cfg
+        return dict(box_size=cfg.cube_scale * 2, num_proposal_steps=cfg.num_ray_steps, clamp_mode='softplus', use_inf_depth=cfg.use_inf_depth,
+                    ray_start=cfg.ray_start, ray_end=cfg.ray_end, num_fine_steps=cfg.num_ray_steps, density_noise=0.0, last_back=cfg.last_back,
+                    white_back=cfg.white_back, max_batch_res=render_opts['max_batch_res'], cut_quantile=render_opts['cut_quantile'],
+                    density_bias=render_opts['density_bias'])
+
+    @torch.no_grad()
+    def compute_densities(self, ws, coords, max_batch_res=32, **block_kwargs):
+        """networks_epigraf.py:196-208: sigma at explicit coordinates."""
+        planes = self.tri_plane_decoder(ws[:, :self.tri_plane_decoder.num_ws], hwc=True, **block_kwargs)
+        return _renderer.simple_tri_plane_renderer(planes, coords, self.tri_plane_mlp, scale=self.cfg.cube_scale)['sigma']
+
+    @torch.no_grad()
+    def forward(self, ws, camera_params, patch_params=None, render_opts={}, u_coarse=None, u_fine=None, update_emas=False, **block_kwargs):
+        """ws [B,num_ws,w_dim]; camera_params {angles [B,3], fov [B], radius [B], look_at [B,3]} -> img [B,3,h,w]
+        (or TensorGroup(img, depth) with render_opts['return_depth'])."""
+        if self.training:
+            raise NotImplementedError('the HIP path implements the eval-mode forward (training is SURVEY.md 8f rank 4)')
+        render_opts = {**self._default_render_options, **render_opts}
+        if render_opts['return_depth_adapted'] or render_opts['concat_depth']:
+            raise NotImplementedError('depth adaptor outputs need the DepthAdaptor (SURVEY.md 8f rank 1)')
+        B = ws.shape[0]
+        planes = self.tri_plane_decoder(ws[:, :self.tri_plane_decoder.num_ws], hwc=True, **block_kwargs)
+        h = w = self.test_resolution
+        cam = camera_params
+        get = (lambda k: cam[k]) if isinstance(cam, dict) else (lambda k: getattr(cam, k))
+        c2w = _renderer.compute_cam2world_matrix(cam)
+        ray_o, ray_d = _renderer.sample_rays(c2w, fov=get('fov'), resolution=(h, w), patch_params=patch_params, device=ws.device)
+        opts = self.rendering_options(render_opts)
+        opts['u_coarse'], opts['u_fine'] = u_coarse, u_fine
+        rgb, depth, _w, _T = self.renderer(planes, self.tri_plane_mlp, ray_o, ray_d, opts)
+        img = torch.empty([B, self.img_channels, h, w], dtype=torch.float32, device=ws.device)
+        with torch.cuda.device(ws.device):
+            _lib.call('tdgp_rays_to_image', rgb.data_ptr(), img.data_ptr(), B, h * w, _lib.stream_of(rgb))
+        if render_opts['return_depth']:
+            return TensorGroup(img=img, depth=depth.reshape(B, 1, h, w))
+        return img
+
+
+class Generator(torch.nn.Module):
+    """networks_epigraf.py:266-291: forward(z, c, camera_params, camera_angles_cond, truncation_psi, truncation_cutoff,
+    update_emas, **synthesis_kwargs)."""
+
+    def __init__(self, cfg: GeneratorConfig, img_resolution=None, img_channels=3):
+        super().__init__()
+        self.cfg = cfg
+        self.z_dim, self.c_dim, self.w_dim = cfg.z_dim, cfg.c_dim, cfg.w_dim
+        self.img_resolution = img_resolution or cfg.img_resolution
+        self.img_channels = img_channels
+        self.synthesis = SynthesisNetwork(cfg, img_resolution=self.img_resolution, img_channels=img_channels)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = MappingNetwork(z_dim=cfg.z_dim, c_dim=cfg.c_dim, w_dim=cfg.w_dim, num_ws=self.num_ws, num_layers=cfg.map_depth)
+        self.eval()
+
+    def load_numpy_state_dict(self, sd, strict=True):
+        """Load a {reference key: numpy array} state-dict (weights.random_state_dict or an exported checkpoint)."""
+        res = self.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()}, strict=strict)
+        self.synthesis.tri_plane_decoder.invalidate_cache()
+        return res
+
+    @torch.no_grad()
+    def forward(self, z, c, camera_params, camera_angles_cond=None, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        ws = self.mapping(z, c, camera_angles=camera_angles_cond, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff,
+                          update_emas=update_emas)
+        return self.synthesis(ws, camera_params=camera_params, update_emas=update_emas, **synthesis_kwargs)

@@ -1,0 +1,138 @@
+"""Modulated convolution on the fp32 matrix cores (forward).
+
+`modulated_conv2d` keeps the reference's signature (src/training/networks_stylegan2.py:31-43) and runs the
+native kernel `tdgp_modconv2d` (include/tdgp.h) -- the reference has no native op here, it issues cuDNN
+grouped convolutions from Python (conv2d_resample.py / conv2d_gradfix.py:113-115).
+
+`PackedConv` / `synthesis_layer` / `torgb_layer` are the fused forms the generator uses: modulation +
+convolution (+ x2 FIR upsampling) + demodulation + noise + bias + activation in one native call, i.e. the whole
+of SynthesisLayer.forward (:128-145) / ToRGBLayer.forward + skip add (:168-172, :265-269).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .bias_act import activation_funcs
+
+_FIR_HOST_CACHE = {}
+
+
+def fir_host_array(resample_filter):
+    """Host copy of the 4x4 resample filter as a ctypes float[16] (the C ABI takes it as a host pointer)."""
+    if resample_filter is None:
+        return None
+    if isinstance(resample_filter, np.ndarray):
+        f = np.ascontiguousarray(resample_filter, dtype=np.float32)
+    else:
+        key = (resample_filter.data_ptr(), resample_filter._version, str(resample_filter.device))
+        f = _FIR_HOST_CACHE.get(key)
+        if f is None:
+            f = np.ascontiguousarray(resample_filter.detach().float().cpu().numpy())
+            if len(_FIR_HOST_CACHE) > 64:
+                _FIR_HOST_CACHE.clear()
+            _FIR_HOST_CACHE[key] = f
+    if f.shape != (4, 4):
+        raise NotImplementedError(f'modulated_conv2d: resample_filter of shape {tuple(f.shape)} (the generator path uses 4x4)')
+    return (ctypes.c_float * 16)(*f.reshape(-1).tolist())
+
+
+class PackedConv:
+    """Weights of one conv layer packed for the MFMA kernel (done once; weights are static at inference)."""
+
+    def __init__(self, weight):
+        _lib.require_cuda(weight, 'weight')
+        cout, cin, kh, kw = weight.shape
+        if kh != kw or kh not in (1, 3):
+            raise NotImplementedError(f'modulated_conv2d: {kh}x{kw} kernels are not on the generator path (1x1 / 3x3)')
+        self.cout, self.cin, self.k = int(cout), int(cin), int(kh)
+        nbytes = _lib.load().tdgp_modconv_pack_bytes(self.cout, self.cin, self.k)
+        self.buf = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)
+        w = _lib.f32c(weight.detach())
+        with torch.cuda.device(weight.device):
+            _lib.call('tdgp_modconv_pack', w.data_ptr(), self.buf.data_ptr(), self.cout, self.cin, self.k, _lib.stream_of(w))
+
+
+_PACK_CACHE = {}
+
+
+def _packed(weight):
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device))
+    pk = _PACK_CACHE.get(key)
+    if pk is None:
+        if len(_PACK_CACHE) > 256:
+            _PACK_CACHE.clear()
+        pk = _PACK_CACHE[key] = PackedConv(weight)
+    return pk
+
+
+def modconv_forward(x, packed, styles, noise=None, bias=None, up=1, demodulate=True, act='linear', alpha=None, gain=None, clamp=None,
+                    fir=None, skip=None, out_layout=0, out_feat=0):
+    """One call of tdgp_modconv2d.  x [B,Cin,H,W] fp32 NCHW; returns [B,Cout,H*up,W*up] (out_layout 0) or the
+    channel-last plane tensor [B,Cout/out_feat,H,W,out_feat] (out_layout 1)."""
+    _lib.require_cuda(x, 'x')
+    x = _lib.f32c(x)
+    B, cin, H, W = x.shape
+    if cin != packed.cin:
+        raise RuntimeError(f'modulated_conv2d: x has {cin} channels, weight expects {packed.cin}')
+    spec = activation_funcs[act]
+    alpha = float(spec.def_alpha if alpha is None else alpha)
+    gain = float(spec.def_gain if gain is None else gain)
+    clamp = float(-1 if clamp is None else clamp)
+    if styles is not None:
+        styles = _lib.f32c(styles)
+        if tuple(styles.shape) != (B, cin):
+            raise RuntimeError(f'modulated_conv2d: styles must be [{B},{cin}], got {tuple(styles.shape)}')
+    nbs = 0
+    if noise is not None:
+        noise = _lib.f32c(noise)
+        if noise.numel() == H * up * W * up:
+            nbs = 0
+        elif noise.numel() == B * H * up * W * up:
+            nbs = H * up * W * up
+        else:
+            raise RuntimeError(f'modulated_conv2d: noise of shape {tuple(noise.shape)} does not broadcast to [B,1,{H * up},{W * up}]')
+    if bias is not None:
+        bias = _lib.f32c(bias)
+    if skip is not None:
+        skip = _lib.f32c(skip)
+    cout = packed.cout
+    if out_layout == 0:
+        y = torch.empty([B, cout, H * up, W * up], dtype=torch.float32, device=x.device)
+    else:
+        y = torch.empty([B, cout // out_feat, H, W, out_feat], dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    ws_bytes = lib.tdgp_modconv2d_workspace_bytes(B, cin, cout, H, W, packed.k, up)
+    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call('tdgp_modconv2d', x.data_ptr(), packed.buf.data_ptr(), _lib.ptr(styles), _lib.ptr(noise), nbs, _lib.ptr(bias), fir,
+                  _lib.ptr(skip), y.data_ptr(), B, cin, cout, H, W, packed.k, up, int(bool(demodulate)), spec.cuda_idx, alpha, gain, clamp,
+                  out_layout, out_feat, ws.data_ptr(), ws_bytes, _lib.stream_of(x))
+    return y
+
+
+def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True, flip_weight=True,
+                     fused_modconv=True):
+    """Signature of the reference's modulated_conv2d (networks_stylegan2.py:31-43).
+
+    Supported forms = the ones the generator forward issues: k in {1,3} with padding == k // 2, down == 1,
+    up == 1 (flip_weight=True, correlation) or up == 2 (flip_weight=False, 4x4 resample_filter).  Both values of
+    `fused_modconv` give the same result (the two branches of the reference are algebraically identical).
+    """
+    _lib.require_cuda(x, 'x')
+    cout, cin, kh, kw = weight.shape
+    if x.ndim != 4 or x.shape[1] != cin:
+        raise RuntimeError(f'modulated_conv2d: x must be [B,{cin},H,W], got {tuple(x.shape)}')
+    if down != 1:
+        raise NotImplementedError('modulated_conv2d: down > 1 is not on the generator path')
+    if padding != kh // 2:
+        raise NotImplementedError(f'modulated_conv2d: padding={padding} with a {kh}x{kw} kernel (generator path uses k // 2)')
+    if up not in (1, 2) or (up == 2 and kh != 3):
+        raise NotImplementedError(f'modulated_conv2d: up={up} with a {kh}x{kw} kernel')
+    if kh > 1 and bool(flip_weight) != (up == 1):
+        raise NotImplementedError('modulated_conv2d: flip_weight must be (up == 1) as in SynthesisLayer.forward (networks_stylegan2.py:138)')
+    if x.dtype != torch.float32:
+        raise NotImplementedError('modulated_conv2d: fp32 only (fp32_only=true in configs/model/3dgp.yaml)')
+    fir = fir_host_array(resample_filter) if up == 2 else None
+    return modconv_forward(x, _packed(weight), styles, noise=noise, bias=None, up=up, demodulate=demodulate, act='linear', gain=1.0, fir=fir)

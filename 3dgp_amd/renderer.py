@@ -1,0 +1,337 @@
+"""Volumetric renderer of the generator forward: camera, rays, tri-plane field, importance sampling, compositing.
+
+Same callables, argument order and return tuples as the reference's Python layer
+(src/training/tri_plane_renderer.py, src/training/rendering_utils.py, src/training/networks_epigraf.py):
+  compute_cam2world_matrix(camera_params)                                   rendering_utils.py:194
+  sample_rays(c2w, fov, resolution, patch_params=None, device=None)          tri_plane_renderer.py:487
+  simple_tri_plane_renderer(x, coords, mlp, scale=1.0) -> {'rgb','sigma'}    tri_plane_renderer.py:560
+  ImportanceRenderer(ray_marcher_type).forward(planes, decoder, ray_origins, ray_directions, rendering_options)
+      -> (rgb [B,R,C], depth [B,R,1], weights.sum(2) [B,R,1], final_transmittance [B,R])      :126-170
+  ClassicalRayMarcher / MipRayMarcher2 .forward(colors, densities, depths, rendering_options)   :353 / :300
+  TriPlaneMLP                                                                 networks_epigraf.py:29-68
+The reference runs these as ~40 eager PyTorch ops per 1M-point chunk; here each stage is one HIP kernel through
+the C ABI (include/tdgp.h) and the run_batchwise chunking (training_utils.py:171) disappears (results do not
+depend on it: every op is per-point / per-ray).
+
+Random numbers: the reference draws `torch.rand_like([B,R,S,1])` (:225) and `torch.rand(B*R, S)` (:279) inside the
+renderer.  Here they may be supplied explicitly as `rendering_options['u_coarse']` / `['u_fine']` (that is how parity
+is defined); when absent they are drawn on the device in the same order and shapes.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+MARCHER_IDS = {'classical': 0, 'mip': 1}
+
+
+def _marcher_flags(opts, marcher):
+    flags = 0
+    if opts.get('use_inf_depth', True):
+        flags |= 1
+    if opts.get('last_back', False) and marcher == 'classical':
+        flags |= 2
+    if opts.get('white_back', False) and marcher == 'mip':
+        flags |= 4
+    mode = opts.get('clamp_mode', 'softplus')
+    if mode == 'relu':
+        if marcher == 'mip':
+            raise AssertionError('MipRayMarcher only supports `clamp_mode`=`softplus`!')
+        flags |= 8
+    elif mode != 'softplus':
+        raise NotImplementedError(f'Uknown clamp mode: {mode}')
+    if opts.get('cut_quantile', 0.0) > 0.0:
+        raise NotImplementedError('cut_quantile > 0 (NFS metric only) is outside the accelerated path')
+    if opts.get('sp_beta', 1.0) != 1.0:
+        raise NotImplementedError('softplus beta != 1 is not on the generator path')
+    if opts.get('white_back_end_idx', 0) > 0 or opts.get('fill_mode') is not None:
+        raise NotImplementedError('white_back_end_idx / fill_mode debugging options are not on the generator path')
+    return flags
+
+
+# ------------------------------------------------------------------------------------------------ camera + rays
+
+def compute_cam2world_matrix(camera_params):
+    """camera_params: mapping/attribute bag with angles [B,3], radius [B], look_at [B,3] -> c2w [B,4,4]."""
+    get = (lambda k: camera_params[k]) if isinstance(camera_params, dict) else (lambda k: getattr(camera_params, k))
+    angles, radius, look_at = (_lib.f32c(get(k)) for k in ('angles', 'radius', 'look_at'))
+    _lib.require_cuda(angles, 'camera_params.angles')
+    B = angles.shape[0]
+    c2w = torch.empty([B, 4, 4], dtype=torch.float32, device=angles.device)
+    with torch.cuda.device(angles.device):
+        _lib.call('tdgp_cam2world', angles.data_ptr(), radius.data_ptr(), look_at.data_ptr(), c2w.data_ptr(), B, _lib.stream_of(angles))
+    return c2w
+
+
+def sample_rays(c2w, fov, resolution, patch_params=None, device=None):
+    """-> (ray_o_world, ray_d_world), each [B, h*w, 3]; ray r <-> pixel (r // w, r % w).
+    `w, h = resolution` exactly as the reference unpacks it (tri_plane_renderer.py:496)."""
+    _lib.require_cuda(c2w, 'c2w')
+    c2w = _lib.f32c(c2w)
+    B = c2w.shape[0]
+    w, h = resolution
+    if isinstance(fov, torch.Tensor):
+        fov_t, stride = _lib.f32c(fov.to(c2w.device)), 1
+        if fov_t.numel() != B:
+            raise RuntimeError(f'sample_rays: fov must have {B} elements')
+    else:
+        fov_t, stride = torch.tensor([float(fov)], dtype=torch.float32, device=c2w.device), 0
+    ps = po = None
+    if patch_params is not None:
+        ps, po = _lib.f32c(patch_params['scales']), _lib.f32c(patch_params['offsets'])
+        if tuple(ps.shape) != (B, 2) or tuple(po.shape) != (B, 2):
+            raise AssertionError(f'Wrong shape: patch scales/offsets must be [{B}, 2]')
+        if stride == 0:
+            fov_t, stride = fov_t.expand(B).contiguous(), 1
+    ray_o = torch.empty([B, h * w, 3], dtype=torch.float32, device=c2w.device)
+    ray_d = torch.empty_like(ray_o)
+    with torch.cuda.device(c2w.device):
+        _lib.call('tdgp_sample_rays', c2w.data_ptr(), fov_t.data_ptr(), stride, _lib.ptr(ps), _lib.ptr(po), ray_o.data_ptr(), ray_d.data_ptr(),
+                  B, h, w, _lib.stream_of(c2w))
+    return ray_o, ray_d
+
+
+# ------------------------------------------------------------------------------------------------ tri-plane field
+
+class TriPlaneMLP(torch.nn.Module):
+    """Parameter holder with the reference's layout: model.{0,1}.{weight,bias} = FC(feat->hid, lrelu), FC(hid->4, linear)
+    (networks_epigraf.py:29-44, layers.py:22-40).  The arithmetic lives in the fused field kernel."""
+
+    class _FC(torch.nn.Module):
+        def __init__(self, i, o):
+            super().__init__()
+            self.weight = torch.nn.Parameter(torch.randn([o, i]))
+            self.bias = torch.nn.Parameter(torch.zeros([o]))
+
+    def __init__(self, feat_dim, hid_dim, out_dim=3, ray_marcher_type='classical'):
+        super().__init__()
+        self.ray_marcher_type = ray_marcher_type
+        self.out_dim = out_dim
+        self.model = torch.nn.Sequential(self._FC(feat_dim, hid_dim), self._FC(hid_dim, out_dim + 1))
+
+
+def _mlp_params(mlp):
+    """(w0, b0, w1, b1, marcher) from our TriPlaneMLP or any module shaped like the reference's."""
+    model = getattr(mlp, 'model', None)
+    if model is None or isinstance(model, torch.nn.Identity) or len(model) != 2:
+        raise NotImplementedError('tri-plane decoder must be the 2-layer TriPlaneMLP (tri_plane.mlp.n_layers == 2)')
+    marcher = getattr(mlp, 'ray_marcher_type', None)
+    if marcher is None:
+        marcher = getattr(getattr(mlp, 'cfg', None), 'ray_marcher_type', 'classical')
+    ps = [_lib.f32c(t.detach()) for t in (model[0].weight, model[0].bias, model[1].weight, model[1].bias)]
+    if ps[2].shape[0] != 4:
+        raise NotImplementedError('tri-plane decoder must output rgb + sigma (4 values)')
+    return (*ps, marcher)
+
+
+class HWCPlanes:
+    """Tri-planes already in the field kernel's layout [B,3,H,W,F] (what the fused backbone emits)."""
+
+    def __init__(self, tensor):
+        assert tensor.ndim == 5
+        self.t = tensor
+
+
+def planes_to_hwc(x):
+    """NCHW [B,3F,H,W] (or the reference's 5-D view [B,3,F,H,W]) -> HWCPlanes [B,3,H,W,F]."""
+    if isinstance(x, HWCPlanes):
+        return x
+    _lib.require_cuda(x, 'planes')
+    if x.ndim == 5:
+        x = x.reshape(x.shape[0], x.shape[1] * x.shape[2], x.shape[3], x.shape[4])
+    assert x.shape[1] % 3 == 0, f'We use 3 planes: {x.shape}'
+    x = _lib.f32c(x)
+    B, c3, H, W = x.shape
+    out = torch.empty([B, 3, H, W, c3 // 3], dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call('tdgp_planes_to_hwc', x.data_ptr(), out.data_ptr(), B, c3 // 3, H, W, _lib.stream_of(x))
+    return HWCPlanes(out)
+
+
+def _field(planes, mlp_params, scale, coords=None, ray_o=None, ray_d=None, t=None, tap_idx=None):
+    w0, b0, w1, b1, marcher = mlp_params
+    p = planes.t
+    B, _, H, W, F = p.shape
+    if coords is not None:
+        coords = _lib.f32c(coords)
+        P, S = coords.shape[1], 1
+    else:
+        P, S = t.shape[1] * t.shape[2], t.shape[2]
+    rgbs = torch.empty([B, P, 4], dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device):
+        _lib.call('tdgp_triplane_field', p.data_ptr(), _lib.ptr(coords), _lib.ptr(ray_o), _lib.ptr(ray_d), _lib.ptr(t), w0.data_ptr(),
+                  b0.data_ptr(), w1.data_ptr(), b1.data_ptr(), rgbs.data_ptr(), _lib.ptr(tap_idx), B, P, S, F, H, W, w0.shape[0],
+                  float(scale), MARCHER_IDS[marcher], _lib.stream_of(p))
+    return rgbs
+
+
+def simple_tri_plane_renderer(x, coords, mlp, scale=1.0, return_taps=False):
+    """x: [B, 3*feat, H, W] (or HWCPlanes); coords: [B, P, 3] -> {'rgb': [B,P,3], 'sigma': [B,P,1]}."""
+    planes = planes_to_hwc(x)
+    _lib.require_cuda(coords, 'coords')
+    B = planes.t.shape[0]
+    assert coords.ndim == 3 and coords.shape[0] == B and coords.shape[2] == 3, f'Wrong shape: coords {tuple(coords.shape)}'
+    taps = torch.empty([B, coords.shape[1], 3, 2], dtype=torch.int32, device=coords.device) if return_taps else None
+    rgbs = _field(planes, _mlp_params(mlp), scale, coords=coords, tap_idx=taps)
+    out = {'rgb': rgbs[..., :3], 'sigma': rgbs[..., 3:4]}
+    if return_taps:
+        out['taps'] = taps
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ marchers
+
+def _march(colors, densities, depths, opts, marcher):
+    _lib.require_cuda(colors, 'colors')
+    colors, densities, depths = _lib.f32c(colors), _lib.f32c(densities), _lib.f32c(depths)
+    B, R, S, C = colors.shape
+    flags = _marcher_flags(opts, marcher)
+    M = S if (marcher == 'classical' or (flags & 1)) else S - 1
+    rgb = torch.empty([B, R, C], dtype=torch.float32, device=colors.device)
+    depth = torch.empty([B, R, 1], dtype=torch.float32, device=colors.device)
+    weights = torch.empty([B, R, M, 1], dtype=torch.float32, device=colors.device)
+    final_T = torch.empty([B, R], dtype=torch.float32, device=colors.device)
+    with torch.cuda.device(colors.device):
+        _lib.call('tdgp_ray_march', colors.data_ptr(), densities.data_ptr(), depths.data_ptr(), rgb.data_ptr(), depth.data_ptr(),
+                  weights.data_ptr(), final_T.data_ptr(), B * R, S, C, MARCHER_IDS[marcher], flags, float(opts.get('density_bias', 0.0)),
+                  _lib.stream_of(colors))
+    return rgb, depth, weights, final_T
+
+
+class ClassicalRayMarcher(torch.nn.Module):
+    def forward(self, colors, densities, depths, rendering_options):
+        """[B,R,S,C], [B,R,S,1], [B,R,S,1] -> (rgb [B,R,C], depth [B,R,1], weights [B,R,S,1], final_transmittance [B,R])."""
+        return _march(colors, densities, depths, rendering_options, 'classical')
+
+
+class MipRayMarcher2(torch.nn.Module):
+    def forward(self, colors, densities, depths, rendering_options):
+        return _march(colors, densities, depths, rendering_options, 'mip')
+
+
+# ------------------------------------------------------------------------------------------------ importance renderer
+
+class ImportanceRenderer(torch.nn.Module):
+    def __init__(self, ray_marcher_type: str):
+        super().__init__()
+        assert ray_marcher_type in ['classical', 'mip']
+        self.ray_marcher_type = ray_marcher_type
+        self.ray_marcher = ClassicalRayMarcher() if ray_marcher_type == 'classical' else MipRayMarcher2()
+
+    # -- stages, exposed with the reference's method names -------------------------------------------------------
+    def sample_stratified(self, ray_origins, ray_start, ray_end, num_proposal_steps, disparity_sampling=False, noise=None):
+        """-> sdist_coarse [B,R,S,1] (tri_plane_renderer.py:208-235; the scalar ray_start/ray_end branch -- the tensor and
+        disparity branches are never taken by the generator)."""
+        if disparity_sampling or isinstance(ray_start, torch.Tensor):
+            raise NotImplementedError('disparity / per-ray-limit stratified sampling is dead code on the generator path')
+        if not (ray_start == 0.0 and ray_end == 1.0):
+            raise NotImplementedError('stratified sampling happens in s-space [0, 1] (tri_plane_renderer.py:133-136)')
+        B, R, _ = ray_origins.shape
+        S = num_proposal_steps
+        u = torch.rand([B, R, S, 1], device=ray_origins.device) if noise is None else _lib.f32c(noise)
+        sdist = torch.empty([B, R, S, 1], dtype=torch.float32, device=ray_origins.device)
+        with torch.cuda.device(u.device):
+            _lib.call('tdgp_sample_stratified', u.data_ptr(), sdist.data_ptr(), None, B * R, S, MARCHER_IDS[self.ray_marcher_type], 0.0, 1.0,
+                      _lib.stream_of(u))
+        return sdist
+
+    def sample_importance(self, z_vals, weights, N_importance, u=None, return_aux=False):
+        """z_vals [B,R,S,1], weights [B,R,Wn,1] -> importance_z_vals [B,R,N,1] (tri_plane_renderer.py:237-295)."""
+        _lib.require_cuda(z_vals, 'z_vals')
+        B, R, S, _ = z_vals.shape
+        z, w = _lib.f32c(z_vals), _lib.f32c(weights)
+        Wn = w.shape[2]
+        u = torch.rand([B * R, N_importance], device=z.device) if u is None else _lib.f32c(u)
+        out = torch.empty([B, R, N_importance, 1], dtype=torch.float32, device=z.device)
+        aux = None
+        if return_aux:
+            aux = {k: torch.empty([B * R, N_importance], dtype=torch.int32, device=z.device) for k in ('inds', 'below', 'above')}
+            aux['cdf'] = torch.empty([B * R, Wn - 1], dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            _lib.call('tdgp_sample_importance', z.data_ptr(), w.data_ptr(), u.data_ptr(), out.data_ptr(),
+                      _lib.ptr(aux['inds']) if aux else None, _lib.ptr(aux['below']) if aux else None, _lib.ptr(aux['above']) if aux else None,
+                      _lib.ptr(aux['cdf']) if aux else None, B * R, S, Wn, N_importance, MARCHER_IDS[self.ray_marcher_type], _lib.stream_of(z))
+        return (out, aux) if return_aux else out
+
+    def unify_samples(self, depths1, colors1, densities1, depths2, colors2, densities2, return_perm=False):
+        """Concatenate, sort by depth (stable), gather (tri_plane_renderer.py:196-206)."""
+        _lib.require_cuda(depths1, 'depths1')
+        d1, c1, s1, d2, c2, s2 = (_lib.f32c(t) for t in (depths1, colors1, densities1, depths2, colors2, densities2))
+        B, R, S1, C = c1.shape
+        S2 = c2.shape[2]
+        M = S1 + S2
+        dev = d1.device
+        d = torch.empty([B, R, M, 1], dtype=torch.float32, device=dev)
+        c = torch.empty([B, R, M, C], dtype=torch.float32, device=dev)
+        s = torch.empty([B, R, M, 1], dtype=torch.float32, device=dev)
+        perm = torch.empty([B, R, M], dtype=torch.int32, device=dev) if return_perm else None
+        with torch.cuda.device(dev):
+            _lib.call('tdgp_unify_samples', d1.data_ptr(), c1.data_ptr(), s1.data_ptr(), S1, d2.data_ptr(), c2.data_ptr(), s2.data_ptr(), S2,
+                      d.data_ptr(), c.data_ptr(), s.data_ptr(), _lib.ptr(perm), B * R, C, _lib.stream_of(d1))
+        return (d, c, s, perm) if return_perm else (d, c, s)
+
+    def run_model(self, planes, decoder, sample_coordinates, rendering_options):
+        """Field evaluation at explicit coordinates (tri_plane_renderer.py:172-187)."""
+        if rendering_options.get('density_noise', 0.0) > 0.0:
+            raise NotImplementedError('density_noise > 0 is a training-time option')
+        return simple_tri_plane_renderer(planes, sample_coordinates, decoder, scale=rendering_options['box_size'] / 2)
+
+    # -- the whole chain ---------------------------------------------------------------------------------------------
+    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, return_intermediates=False):
+        opts = rendering_options
+        marcher = self.ray_marcher_type
+        _lib.require_cuda(ray_origins, 'ray_origins')
+        if isinstance(opts.get('ray_start'), str):
+            raise NotImplementedError("ray_start='auto' (use_full_box) is never resolved by the reference renderer either (SURVEY.md 8a)")
+        if opts.get('density_noise', 0.0) > 0.0:
+            raise NotImplementedError('density_noise > 0 is a training-time option')
+        planes = planes_to_hwc(planes)
+        mlp = _mlp_params(decoder)
+        if mlp[4] != marcher:
+            raise RuntimeError(f'decoder was built for ray_marcher_type={mlp[4]}, renderer for {marcher}')
+        ray_o, ray_d = _lib.f32c(ray_origins), _lib.f32c(ray_directions)
+        B, R, _ = ray_o.shape
+        S, N = int(opts['num_proposal_steps']), int(opts['num_fine_steps'])
+        t_near, t_far = float(opts['ray_start']), float(opts['ray_end'])
+        scale = opts['box_size'] / 2
+        flags = _marcher_flags(opts, marcher)
+        mid, dbias = MARCHER_IDS[marcher], float(opts.get('density_bias', 0.0))
+        dev = ray_o.device
+        u_coarse = opts.get('u_coarse')
+        u_coarse = torch.rand([B, R, S, 1], device=dev) if u_coarse is None else _lib.f32c(u_coarse.to(dev))
+        if u_coarse.numel() != B * R * S:
+            raise RuntimeError(f'u_coarse must have {B}x{R}x{S} elements')
+        stream = _lib.stream_of(ray_o)
+        with torch.cuda.device(dev):
+            sdist = torch.empty([B, R, S], dtype=torch.float32, device=dev)
+            tdist = torch.empty([B, R, S], dtype=torch.float32, device=dev)
+            _lib.call('tdgp_sample_stratified', u_coarse.data_ptr(), sdist.data_ptr(), tdist.data_ptr(), B * R, S, mid, t_near, t_far, stream)
+            rgbs_c = _field(planes, mlp, scale, ray_o=ray_o, ray_d=ray_d, t=tdist)
+            if N > 0:
+                u_fine = opts.get('u_fine')
+                u_fine = torch.rand([B * R, N], device=dev) if u_fine is None else _lib.f32c(u_fine.to(dev))
+                if u_fine.numel() != B * R * N:
+                    raise RuntimeError(f'u_fine must have {B * R}x{N} elements')
+                tfine = torch.empty([B, R, N], dtype=torch.float32, device=dev)
+                sfine = torch.empty([B, R, N], dtype=torch.float32, device=dev) if return_intermediates else None
+                inds = torch.empty([B * R, N], dtype=torch.int32, device=dev) if return_intermediates else None
+                _lib.call('tdgp_importance_from_coarse', rgbs_c.data_ptr(), sdist.data_ptr(), u_fine.data_ptr(), tfine.data_ptr(),
+                          _lib.ptr(sfine), _lib.ptr(inds), B * R, S, N, mid, flags, dbias, t_near, t_far, stream)
+                rgbs_f = _field(planes, mlp, scale, ray_o=ray_o, ray_d=ray_d, t=tfine)
+                rgb = torch.empty([B, R, 3], dtype=torch.float32, device=dev)
+                depth = torch.empty([B, R, 1], dtype=torch.float32, device=dev)
+                wsum = torch.empty([B, R, 1], dtype=torch.float32, device=dev)
+                final_T = torch.empty([B, R], dtype=torch.float32, device=dev)
+                perm = torch.empty([B, R, S + N], dtype=torch.int32, device=dev) if return_intermediates else None
+                _lib.call('tdgp_merge_composite', rgbs_c.data_ptr(), tdist.data_ptr(), S, rgbs_f.data_ptr(), tfine.data_ptr(), N, rgb.data_ptr(),
+                          depth.data_ptr(), wsum.data_ptr(), final_T.data_ptr(), _lib.ptr(perm), B * R, mid, flags, dbias, stream)
+            else:
+                rgbs4 = rgbs_c.reshape(B, R, S, 4)
+                rgb, depth, w, final_T = _march(rgbs4[..., :3], rgbs4[..., 3:4], sdist.reshape(B, R, S, 1), opts, marcher)
+                wsum = w.sum(2)
+                rgbs_f = tfine = sfine = inds = perm = None
+        out = (rgb, depth, wsum, final_T)
+        if return_intermediates:
+            return out, dict(sdist_coarse=sdist, tdist_coarse=tdist, rgbs_coarse=rgbs_c, tdist_fine=tfine, sdist_fine=sfine, inds=inds,
+                             rgbs_fine=rgbs_f, perm=perm)
+        return out

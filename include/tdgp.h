@@ -1,0 +1,196 @@
+/*
+ * tdgp.h -- C ABI of libtdgp_hip.so: the MI355X (gfx950) generator-forward hot path of 3DGP.
+ *
+ * Conventions:
+ *   - plain pointers and sizes only; every data pointer is a DEVICE pointer unless marked "host";
+ *   - the library never allocates, frees or synchronises: the caller owns all memory (outputs and
+ *     workspaces are caller-allocated) and passes the HIP stream to launch on;
+ *   - every function returns 0 on success or a negative TDGP_E* code; tdgp_last_error() returns a
+ *     thread-local message.  Nothing throws across the ABI;
+ *   - fp32 unless a `dtype` argument says otherwise (TDGP_F32 / TDGP_F16 / TDGP_BF16);
+ *   - re-entrant; no global mutable state.
+ *
+ * Each entry point cites the reference interface it replaces (file:line under the reference tree).
+ * The reference binds its two native ops through pybind (bias_act.cpp:94, upfirdn2d.cpp:102); the
+ * modulated convolution and the renderer have no native boundary in the reference (plain PyTorch
+ * functions) -- their entry points here take the same operands as those Python functions.
+ */
+#ifndef TDGP_H
+#define TDGP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDGP_OK            0
+#define TDGP_EINVAL       -1   /* bad argument (shape / range / null)         */
+#define TDGP_EUNSUPPORTED -2   /* valid request this build has no kernel for  */
+#define TDGP_ELAUNCH      -3   /* HIP launch error                            */
+#define TDGP_EWORKSPACE   -4   /* workspace too small                         */
+
+#define TDGP_F32  0
+#define TDGP_F16  1
+#define TDGP_BF16 2
+
+typedef void* tdgp_stream_t;   /* hipStream_t */
+
+int         tdgp_version(void);
+const char* tdgp_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * bias_act forward:  y = clamp(gain * act(x + b[(i / stepB) % sizeB]))
+ * replaces: src/torch_utils/ops/bias_act.cpp:32 `bias_act(x,b,xref,yref,dy,grad=0,dim,act,alpha,gain,clamp)`
+ * act = the reference's cuda_idx 1..9 (bias_act.py:21-31); clamp < 0 disables; b may be NULL.
+ * n <= INT_MAX (bias_act.cpp:40).  x and y dense with identical layout.
+ * --------------------------------------------------------------------------------------------- */
+int tdgp_bias_act(const void* x, const void* b, void* y, int64_t n, int sizeB, int64_t stepB,
+                  int act, float alpha, float gain, float clamp, int dtype, tdgp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * upfirdn2d forward on [N,C,H,W] with arbitrary element strides.
+ * replaces: src/torch_utils/ops/upfirdn2d.cpp:16
+ *   `upfirdn2d(x,f,upx,upy,downx,downy,padx0,padx1,pady0,pady1,flip,gain)`
+ * f: fp32 [fH,fW] contiguous.  outH/outW must equal (in*up + pad0 + pad1 - f + down) / down.
+ * x_strides / y_strides: host arrays of 4 element strides (N,C,H,W).
+ * --------------------------------------------------------------------------------------------- */
+int tdgp_upfirdn2d(const void* x, const float* f, void* y, int N, int C, int inH, int inW,
+                   const int64_t* x_strides, int outH, int outW, const int64_t* y_strides,
+                   int fH, int fW, int upx, int upy, int downx, int downy,
+                   int padx0, int padx1, int pady0, int pady1, int flip, float gain,
+                   int dtype, tdgp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Modulated convolution (new native boundary; the reference runs cuDNN grouped convs from Python).
+ * replaces: src/training/networks_stylegan2.py:31 `modulated_conv2d(x, weight, styles, noise, up,
+ *           padding=k//2, resample_filter, demodulate, flip_weight=(up==1), fused_modconv=True)`
+ *           + conv2d_resample.py:46 + the bias_act that follows it in SynthesisLayer/ToRGBLayer
+ *           (networks_stylegan2.py:139-144,170-171), + for ToRGB the skip-connection
+ *           `img = upsample2d(img) + y` (networks_stylegan2.py:265-269).
+ *
+ * Weights are static across calls, so they are packed once:
+ *   tdgp_modconv_pack_bytes  -> bytes of the packed buffer for (Cout,Cin,k)
+ *   tdgp_modconv_pack        -> wpack (MFMA-friendly k-major layout + sum_k w^2 per (o,c))
+ * Forward:
+ *   y[b,o] = act( d[b,o] * conv(x[b]*s[b,:], W)[o] + noise + bias[o] ) * gain  (+ skip term)
+ *   d[b,o] = rsqrt(sum_c s[b,c]^2 * wsq[o,c] + 1e-8) if demodulate else 1
+ *   up=2: transposed conv (stride 2) followed by the 4x4 FIR `fir4x4` with gain 4 (pad 1,1,1,1).
+ *   fir4x4: HOST pointer to the 16 filter taps (a static 64-byte buffer: upfirdn2d.setup_filter([1,3,3,1])).
+ * noise: NULL, or [H,W] (noise_bstride = 0), or [B,1,H,W] (noise_bstride = H*W); already multiplied
+ *        by noise_strength by the caller.
+ * skip: NULL or the previous-resolution image (same layout as the output: [B,Cout,H/2,W/2] for out_layout 0,
+ *       [B,Cout/feat,H/2,W/2,feat] for out_layout 1) to be FIR-upsampled x2 with `fir4x4` (gain 4) and added
+ *       (only with up=1, k=1).
+ * out_layout: 0 = NCHW, 1 = plane-major channel-last [B, Cout/feat, H, W, feat] (the renderer's layout;
+ *       `feat` = out_feat).
+ * workspace: tdgp_modconv2d_workspace_bytes(...) bytes (0 allowed when it returns 0).
+ * --------------------------------------------------------------------------------------------- */
+int64_t tdgp_modconv_pack_bytes(int Cout, int Cin, int k);
+int     tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int Cin, int k, tdgp_stream_t stream);
+int64_t tdgp_modconv2d_workspace_bytes(int B, int Cin, int Cout, int H, int W, int k, int up);
+int     tdgp_modconv2d(const float* x, const void* wpack, const float* styles, const float* noise,
+                       int64_t noise_bstride, const float* bias, const float* fir4x4, const float* skip,
+                       float* y, int B, int Cin, int Cout, int H, int W, int k, int up, int demodulate,
+                       int act, float alpha, float gain, float clamp, int out_layout, int out_feat,
+                       void* workspace, int64_t workspace_bytes, tdgp_stream_t stream);
+
+/* Batched style affines for all layers of the backbone in one launch:
+ *   out[obase + b*olen + oidx] = ((ws[b, widx, :] . A[row, :]) * (1/sqrt(w_dim)) + abias[row]) * row_scale[row]
+ * replaces: the per-layer `self.affine(w)` FullyConnectedLayer calls (networks_stylegan2.py:130,169;
+ * layers.py:42-58) and ToRGB's `* weight_gain` (:169).
+ * A: concatenated affine weights [rows_total, w_dim]; abias [rows_total]; row_scale [rows_total] (1, or 1/sqrt(Cin)
+ * for ToRGB); row_meta: int32 [rows_total,4] = (widx, obase, olen, oidx) so that layer l owns the contiguous block
+ * styles[obase_l : obase_l + B*Cin_l] viewed as [B, Cin_l]. */
+int tdgp_style_affine(const float* ws, const float* A, const float* abias, const int32_t* row_meta,
+                      const float* row_scale, float* styles, int B, int num_ws, int w_dim, int rows_total,
+                      tdgp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Camera + rays.
+ * replaces: src/training/rendering_utils.py:194 `compute_cam2world_matrix(camera_params)`,
+ *           src/training/tri_plane_renderer.py:487 `sample_rays(c2w, fov, resolution, patch_params)`
+ * fov in degrees; fov_stride 1 = per-sample tensor, 0 = one shared scalar. patch_* may be NULL.
+ * Ray r of sample b is pixel (row r / w, col r % w).
+ * --------------------------------------------------------------------------------------------- */
+int tdgp_cam2world(const float* angles, const float* radius, const float* look_at, float* c2w, int B,
+                   tdgp_stream_t stream);
+int tdgp_sample_rays(const float* c2w, const float* fov, int fov_stride, const float* patch_scales,
+                     const float* patch_offsets, float* ray_o, float* ray_d, int B, int h, int w,
+                     tdgp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Renderer pieces.
+ * replaces (all src/training/tri_plane_renderer.py unless noted):
+ *   :208  ImportanceRenderer.sample_stratified            -> tdgp_sample_stratified
+ *   :560  simple_tri_plane_renderer + networks_epigraf.py:46 TriPlaneMLP.forward -> tdgp_triplane_field
+ *   :353 / :300  ClassicalRayMarcher / MipRayMarcher2      -> tdgp_ray_march
+ *   :237,:257  sample_importance / sample_pdf              -> tdgp_sample_importance
+ *   :196  unify_samples                                    -> tdgp_unify_samples
+ *   :126  ImportanceRenderer.forward (whole chain)         -> the fused pair
+ *                 tdgp_importance_from_coarse + tdgp_merge_composite
+ * marcher: 0 = classical, 1 = mip.
+ * --------------------------------------------------------------------------------------------- */
+
+/* u [rays,S] uniforms -> sdist [rays,S] (s-space) and, if tdist != NULL, t = s*t_far + (1-s)*t_near. */
+int tdgp_sample_stratified(const float* u, float* sdist, float* tdist, int64_t rays, int S, int marcher,
+                           float t_near, float t_far, tdgp_stream_t stream);
+
+/* NCHW planes [B,3F,H,W] -> plane-major channel-last [B,3,H,W,F] (the field kernel's layout). */
+int tdgp_planes_to_hwc(const float* planes_nchw, float* planes_hwc, int B, int F, int H, int W,
+                       tdgp_stream_t stream);
+
+/* Tri-plane bilinear lookup (align_corners, zero padding) + mean + tiny MLP, fused.
+ * planes_hwc: [B,3,H,W,F].  Points are given either as coords [B,P,3] (ray_o = NULL), or as rays:
+ * ray_o/ray_d [B,R,3] and t [B,R,S] with P = R*S, point p = ray p/S at depth t[p].
+ * w0 [hid,F], b0 [hid], w1 [4,hid], b1 [4] are the RAW module parameters (gains 1/sqrt(F), 1/sqrt(hid),
+ * lrelu 0.2 * sqrt(2) applied inside, layers.py:39-58).
+ * out: rgbs [B,P,4] = (r,g,b,sigma); marcher=1 applies sigmoid*1.002-0.001 to rgb (networks_epigraf.py:61-62).
+ * tap_idx: optional int32 [B,P,3,2] = (floor ix, floor iy) per plane, for integer-row parity tests.
+ * Requires F % 4 == 0, F <= 64, hid % 16 == 0, hid <= 128. */
+int tdgp_triplane_field(const float* planes_hwc, const float* coords, const float* ray_o, const float* ray_d,
+                        const float* t, const float* w0, const float* b0, const float* w1, const float* b1,
+                        float* rgbs, int32_t* tap_idx, int B, int64_t P, int S, int F, int H, int W, int hid,
+                        float scale, int marcher, tdgp_stream_t stream);
+
+/* Generic marcher on [rays,S,C] colours, [rays,S] densities/depths (any S <= 256, C <= 8).
+ * weights: [rays,S] (classical, or mip with inf depth) / [rays,S-1] (mip without); may be NULL.
+ * flags: bit0 use_inf_depth, bit1 last_back (classical), bit2 white_back (mip), bit3 clamp_mode relu. */
+int tdgp_ray_march(const float* colors, const float* densities, const float* depths, float* rgb,
+                   float* depth, float* weights, float* final_T, int64_t rays, int S, int C, int marcher,
+                   int flags, float density_bias, tdgp_stream_t stream);
+
+/* sample_importance: z [rays,S] (s-space), weights [rays,Wn], u [rays,N] -> samples [rays,N].
+ * Optional outputs: inds/below/above int32 [rays,N] (searchsorted right=True, clamped), cdf [rays,Wn-1]. */
+int tdgp_sample_importance(const float* z, const float* weights, const float* u, float* samples,
+                           int32_t* inds, int32_t* below, int32_t* above, float* cdf,
+                           int64_t rays, int S, int Wn, int N, int marcher, tdgp_stream_t stream);
+
+/* unify_samples: concat + stable sort by depth + gather; perm (int32 [rays,S1+S2]) optional. */
+int tdgp_unify_samples(const float* d1, const float* c1, const float* s1, int S1,
+                       const float* d2, const float* c2, const float* s2, int S2,
+                       float* d, float* c, float* s, int32_t* perm, int64_t rays, int C,
+                       tdgp_stream_t stream);
+
+/* Fused chain, step 1: coarse march (s-space depths) -> importance sampling -> fine depths in t-space.
+ * rgbs_coarse [rays,S,4], sdist [rays,S], u_fine [rays,N] -> tdist_fine [rays,N] (+ optional sdist_fine, inds). */
+int tdgp_importance_from_coarse(const float* rgbs_coarse, const float* sdist, const float* u_fine,
+                                float* tdist_fine, float* sdist_fine, int32_t* inds,
+                                int64_t rays, int S, int N, int marcher, int flags, float density_bias,
+                                float t_near, float t_far, tdgp_stream_t stream);
+
+/* Fused chain, step 2: merge coarse+fine by depth (stable), march in t-space.
+ * rgbs_* [rays,S*,4], t_* [rays,S*] -> rgb [rays,3], depth [rays], wsum [rays], final_T [rays];
+ * perm optional int32 [rays,S1+S2]. */
+int tdgp_merge_composite(const float* rgbs_coarse, const float* t_coarse, int S1,
+                         const float* rgbs_fine, const float* t_fine, int S2,
+                         float* rgb, float* depth, float* wsum, float* final_T, int32_t* perm,
+                         int64_t rays, int marcher, int flags, float density_bias, tdgp_stream_t stream);
+
+/* [B, h*w, 3] ray colours -> [B,3,h,w] image (networks_epigraf.py:242). */
+int tdgp_rays_to_image(const float* rgb, float* img, int B, int hw, tdgp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDGP_H */

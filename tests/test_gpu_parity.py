@@ -1,0 +1,389 @@
+"""HIP path (through the C ABI) vs the CPU oracle and vs golden vectors captured from the reference.
+
+Bars (stated per test):
+  * integer rows (bilinear tap indices, searchsorted indices, sort permutation): bit-exact on identical inputs;
+  * fp32 elementwise chains that decide those integers (stratified samples, ray points): bit-exact;
+  * reductions (conv / FIR / dot products / compositing): relative to the tensor scale, <= 2e-6 .. 1e-5;
+  * end-to-end RGB: the north-star 1e-4 max-rel (see conftest.assert_image_parity for the exact definition).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, assert_image_parity, load_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def T(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(DEV)
+
+
+def N(t):
+    return t.detach().float().cpu().numpy()
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _require_native(tdgp):
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    tdgp._lib.load()        # raises if libtdgp_hip.so is missing: GPU tests never run on a fallback
+
+
+# ------------------------------------------------------------------------------------------------ bias_act
+
+ACTS = ['linear', 'relu', 'lrelu', 'tanh', 'sigmoid', 'elu', 'selu', 'softplus', 'swish']
+
+
+@pytest.mark.parametrize('act', ACTS)
+def test_bias_act_golden(tdgp, act):
+    g = load_golden('bias_act')
+    y = tdgp.ops.bias_act.bias_act(T(g['x']), T(g['b']), act=act)
+    assert_close(N(y), g[f'y_{act}'], 2e-6, act)
+
+
+def test_bias_act_variants(tdgp, oracle):
+    g = load_golden('bias_act')
+    ba = tdgp.ops.bias_act.bias_act
+    assert_close(N(ba(T(g['x']), T(g['b']), act='lrelu', gain=1.0, clamp=0.5)), g['y_lrelu_gain1_clamp'], 1e-6)
+    assert_close(N(ba(T(g['x']), None, act='linear', gain=0.5)), g['y_linear_nobias'], 1e-7)
+    assert_close(N(ba(T(g['x']), T(g['b_dim3']), dim=3, act='relu')), g['y_relu_dim3'], 1e-6)
+    assert_close(N(ba(T(g['x2']), T(g['b']), act='lrelu')), g['y2_lrelu'], 1e-6)
+    xcl = T(g['x']).contiguous(memory_format=torch.channels_last)
+    y = ba(xcl, T(g['b']), act='swish', clamp=2.0)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    assert_close(N(y.contiguous()), g['y_swish_channels_last'], 2e-6)
+    # larger, odd-sized (vector body + scalar tail), every activation, vs the oracle
+    rs = np.random.RandomState(0)
+    x = (rs.randn(3, 7, 33, 31) * 2).astype(np.float32)
+    b = rs.randn(7).astype(np.float32)
+    for act in ACTS:
+        assert_close(N(ba(T(x), T(b), act=act)), oracle.bias_act(x, b, act=act), 2e-6, act)
+    # the MLP shape of the renderer: [P, 64] with bias over the last dim
+    x = rs.randn(4099, 64).astype(np.float32)
+    b = rs.randn(64).astype(np.float32)
+    assert_close(N(ba(T(x), T(b), act='lrelu')), oracle.bias_act(x, b, act='lrelu'), 1e-6)
+    # bf16 / fp16 I/O (fp32 math inside)
+    for dt, tol in ((torch.bfloat16, 1e-2), (torch.float16, 2e-3)):
+        y = ba(T(x, dt), T(b, dt), act='lrelu')
+        assert y.dtype == dt
+        ref = oracle.bias_act(N(T(x, dt)), N(T(b, dt)), act='lrelu')
+        assert_close(N(y), ref, tol, str(dt))
+    # error contract (bias_act.cpp:35-51)
+    with pytest.raises(RuntimeError):
+        ba(T(x), T(rs.randn(3).astype(np.float32)), act='lrelu')
+    assert ba(T(np.zeros((0, 4), np.float32)), None, act='relu').shape == (0, 4)
+
+
+# ------------------------------------------------------------------------------------------------ upfirdn2d
+
+def test_upfirdn2d_golden(tdgp):
+    g = load_golden('upfirdn2d')
+    u = tdgp.ops.upfirdn2d
+    f = T(g['f1331'])
+    np.testing.assert_array_equal(N(u.setup_filter([1, 3, 3, 1])), g['f1331'])
+    tol = 2e-6
+    assert_close(N(u.upfirdn2d(T(g['x_f1']), f, padding=[1, 1, 1, 1], gain=4)), g['y_f1'], tol, 'F1', 1.0)
+    assert_close(N(u.upsample2d(T(g['x_f2']), f)), g['y_f2'], tol, 'F2', 1.0)
+    assert_close(N(u.filter2d(T(g['x_odd']), f)), g['y_filter2d'], tol, 'filter2d', 1.0)
+    assert_close(N(u.downsample2d(T(g['x_odd']), f)), g['y_downsample2d'], tol, 'downsample2d', 1.0)
+    assert_close(N(u.upfirdn2d(T(g['x_odd']), f, padding=[-1, 2, 3, -1])), g['y_negpad'], tol, 'negpad', 1.0)
+    assert_close(N(u.upfirdn2d(T(g['x_odd']), T(g['f_asym']), padding=2)), g['y_asym_noflip'], tol, 'asym', 1.0)
+    assert_close(N(u.upfirdn2d(T(g['x_odd']), T(g['f_asym']), padding=2, flip_filter=True)), g['y_asym_flip'], tol, 'asym flip', 1.0)
+    assert_close(N(u.upfirdn2d(T(g['x_odd']), T(g['f_rect']), up=[3, 2], down=[2, 1], padding=[2, 1, 0, 3], gain=1.5)),
+                 g['y_rect_up3_down2'], tol, 'rect', 1.0)
+    assert_close(N(u.upfirdn2d(T(g['x_odd']), None)), g['y_identity'], 0, 'identity')
+    assert_close(N(u.upfirdn2d(T(g['x_f1_33']), f, padding=[1, 1, 1, 1], gain=4)), g['y_f1_33'], tol, 'F1 33', 1.0)
+
+
+def test_upfirdn2d_oracle(tdgp, oracle):
+    u = tdgp.ops.upfirdn2d
+    rs = np.random.RandomState(1)
+    f = oracle.setup_filter([1, 3, 3, 1])
+    for shape in [(2, 5, 65, 65), (1, 3, 17, 40)]:
+        x = rs.randn(*shape).astype(np.float32)
+        assert_close(N(u.upfirdn2d(T(x), T(f), padding=[1, 1, 1, 1], gain=4)), oracle.upfirdn2d(x, f, padding=[1, 1, 1, 1], gain=4), 2e-6, 'F1', 1.0)
+        assert_close(N(u.upsample2d(T(x), T(f))), oracle.upsample2d(x, f), 2e-6, 'F2', 1.0)
+    # separable 8-tap filter goes out as two launches (upfirdn2d.py:241-245)
+    f8 = u.setup_filter([1, 2, 3, 4, 4, 3, 2, 1])
+    assert f8.ndim == 1
+    x = rs.randn(1, 2, 19, 23).astype(np.float32)
+    ref = oracle.upfirdn2d(x, np.outer(N(f8), N(f8)).astype(np.float32), padding=[4, 3, 4, 3])
+    assert_close(N(u.upfirdn2d(T(x), f8.to(DEV), padding=[4, 3, 4, 3])), ref, 2e-6, 'separable', 1.0)
+    # channels_last input keeps its layout (upfirdn2d.cpp:38)
+    x = rs.randn(2, 8, 12, 12).astype(np.float32)
+    y = u.upfirdn2d(T(x).contiguous(memory_format=torch.channels_last), T(f), up=2, padding=[2, 1, 2, 1], gain=4)
+    assert_close(N(y.contiguous()), oracle.upsample2d(x, f), 2e-6, 'channels_last', 1.0)
+    with pytest.raises(RuntimeError):
+        u.upfirdn2d(T(x), T(f), padding=-8)          # output must be at least 1x1
+
+
+# ------------------------------------------------------------------------------------------------ modulated conv
+
+@pytest.mark.parametrize('tag', ['c3_up1', 'c3_up2', 'c3_up2_b1', 'c1_rgb', 'c3_up1_b1_nonoise'])
+def test_modconv_golden(tdgp, tag):
+    g = load_golden('modconv')
+    k, up, demod = (int(v) for v in g[f'{tag}_meta'])
+    noise = g.get(f'{tag}_noise')
+    y = tdgp.ops.modconv.modulated_conv2d(T(g[f'{tag}_x']), T(g[f'{tag}_w']), T(g[f'{tag}_s']), noise=None if noise is None else T(noise), up=up,
+                                          padding=k // 2, resample_filter=T(g['f']), demodulate=bool(demod), flip_weight=(up == 1))
+    assert_close(N(y), g[f'{tag}_y'], 5e-6, tag, 1.0)
+
+
+@pytest.mark.parametrize('B,cin,cout,H,k,up', [
+    (2, 64, 128, 32, 3, 1),      # 128x128 tile config
+    (2, 40, 48, 64, 3, 1),       # 64x256 tile config, channel tails
+    (5, 32, 160, 4, 3, 1),       # 4x4 maps: several samples per pixel tile
+    (3, 24, 136, 8, 3, 2),       # up-layer, straddling tiles, odd phase grids 9x9
+    (1, 72, 64, 33, 3, 2),       # odd input size, phase grid 34 > one 32-column tile
+    (2, 64, 96, 32, 1, 1),       # ToRGB config (96 = 3 x 32 rows)
+    (2, 48, 20, 16, 1, 1),
+])
+def test_modconv_oracle(tdgp, oracle, B, cin, cout, H, k, up):
+    rs = np.random.RandomState(cin + cout)
+    x = rs.randn(B, cin, H, H).astype(np.float32)
+    w = rs.randn(cout, cin, k, k).astype(np.float32)
+    s = (1 + 0.5 * rs.randn(B, cin)).astype(np.float32)
+    noise = (0.3 * rs.randn(B, 1, H * up, H * up)).astype(np.float32) if k == 3 else None
+    f = oracle.setup_filter([1, 3, 3, 1])
+    ref = oracle.modulated_conv2d(x, w, s, noise=noise, up=up, demodulate=(k == 3), resample_filter=f)
+    y = tdgp.ops.modconv.modulated_conv2d(T(x), T(w), T(s), noise=None if noise is None else T(noise), up=up, padding=k // 2,
+                                          resample_filter=T(f), demodulate=(k == 3), flip_weight=(up == 1))
+    assert_close(N(y), ref, 1e-5, 'modconv', 1.0)
+
+
+def test_fused_layers_oracle(tdgp, oracle):
+    """SynthesisLayer / ToRGB+skip as single fused calls (bias, lrelu*sqrt2, x2 FIR skip, channel-last output)."""
+    rs = np.random.RandomState(5)
+    mc = tdgp.ops.modconv
+    B, cin, cout, H = 2, 32, 48, 16
+    x = rs.randn(B, cin, H, H).astype(np.float32)
+    w = rs.randn(cout, cin, 3, 3).astype(np.float32)
+    s = (1 + 0.5 * rs.randn(B, cin)).astype(np.float32)
+    bias = rs.randn(cout).astype(np.float32)
+    f = oracle.setup_filter([1, 3, 3, 1])
+    for up in (1, 2):
+        noise = (0.3 * rs.randn(H * up, H * up)).astype(np.float32)
+        ref = oracle.bias_act(oracle.modulated_conv2d(x, w, s, noise=noise, up=up, resample_filter=f), bias, act='lrelu')
+        y = mc.modconv_forward(T(x), mc.PackedConv(T(w)), T(s), noise=T(noise), bias=T(bias), up=up, demodulate=True, act='lrelu',
+                               fir=mc.fir_host_array(f))
+        assert_close(N(y), ref, 1e-5, f'layer up{up}', 1.0)
+    # ToRGB with skip: img = upsample2d(prev) + torgb(x), NCHW and channel-last plane layouts
+    crgb = 24
+    w1 = rs.randn(crgb, cin, 1, 1).astype(np.float32)
+    prev = rs.randn(B, crgb, H // 2, H // 2).astype(np.float32)
+    ref = oracle.upsample2d(prev, f) + oracle.bias_act(oracle.modulated_conv2d(x, w1, s, demodulate=False), bias[:crgb])
+    pk = mc.PackedConv(T(w1))
+    y0 = mc.modconv_forward(T(x), pk, T(s), bias=T(bias[:crgb]), demodulate=False, skip=T(prev), fir=mc.fir_host_array(f))
+    assert_close(N(y0), ref, 1e-5, 'torgb nchw', 1.0)
+    feat = 8
+    prev_cl = T(prev).reshape(B, 3, feat, H // 2, H // 2).permute(0, 1, 3, 4, 2).contiguous()
+    y1 = mc.modconv_forward(T(x), pk, T(s), bias=T(bias[:crgb]), demodulate=False, skip=prev_cl, fir=mc.fir_host_array(f), out_layout=1, out_feat=feat)
+    assert y1.shape == (B, 3, H, H, feat)
+    assert_close(N(y1.permute(0, 1, 4, 2, 3).reshape(B, crgb, H, H)), ref, 1e-5, 'torgb channel-last', 1.0)
+
+
+# ------------------------------------------------------------------------------------------------ camera / rays
+
+def test_camera_and_rays(tdgp, oracle):
+    g = load_golden('camera')
+    R = tdgp.renderer
+    c2w = R.compute_cam2world_matrix(dict(angles=T(g['angles']), radius=T(g['radius']), look_at=T(g['look_at'])))
+    assert_close(N(c2w), g['c2w'], 2e-6, 'c2w', 1.0)
+    for hw in [(8, 8), (5, 7), (16, 16)]:
+        o, d = R.sample_rays(T(g['c2w']), T(g['fov']), resolution=hw)
+        assert_close(N(o), g['ray_o_%dx%d' % hw], 1e-7, 'ray_o')
+        assert_close(N(d), g['ray_d_%dx%d' % hw], 2e-6, 'ray_d', 1.0)
+    o, d = R.sample_rays(T(g['c2w']), T(g['fov']), resolution=(6, 6), patch_params=dict(scales=T(g['patch_scales']), offsets=T(g['patch_offsets'])))
+    assert_close(N(d), g['ray_d_patch'], 2e-6, 'ray_d patch', 1.0)
+    o, d = R.sample_rays(T(g['c2w']), 18.0, resolution=(4, 4))
+    assert_close(N(d), g['ray_d_scalar_fov'], 2e-6, 'ray_d scalar fov', 1.0)
+    # bit-exact vs the oracle (same fp32 chain, fp64 transcendentals on both sides)
+    oo, od = oracle.sample_rays(g['c2w'], g['fov'], 16, 16)
+    o, d = R.sample_rays(T(g['c2w']), T(g['fov']), resolution=(16, 16))
+    np.testing.assert_array_equal(N(o), oo)
+    np.testing.assert_array_equal(N(d), od)
+
+
+# ------------------------------------------------------------------------------------------------ field
+
+def _mlp(tdgp, w0, b0, w1, b1, marcher):
+    m = tdgp.renderer.TriPlaneMLP(w0.shape[1], w0.shape[0], 3, marcher).to(DEV)
+    with torch.no_grad():
+        m.model[0].weight.copy_(T(w0)); m.model[0].bias.copy_(T(b0)); m.model[1].weight.copy_(T(w1)); m.model[1].bias.copy_(T(b1))
+    return m
+
+
+@pytest.mark.parametrize('marcher', ['classical', 'mip'])
+def test_field_golden(tdgp, oracle, marcher):
+    g = load_golden('field')
+    ws = [g[f'{marcher}_{n}'] for n in ('w0', 'b0', 'w1', 'b1')]
+    out = tdgp.renderer.simple_tri_plane_renderer(T(g['planes']), T(g['coords']), _mlp(tdgp, *ws, marcher), scale=0.5, return_taps=True)
+    assert_close(N(out['rgb']), g[f'{marcher}_rgb'], 5e-6, 'rgb', 1.0)
+    assert_close(N(out['sigma']), g[f'{marcher}_sigma'], 5e-6, 'sigma', 1.0)
+    ref = oracle.triplane_field(g['planes'], g['coords'], *ws, scale=0.5, mlp_mode=marcher, return_taps=True)
+    np.testing.assert_array_equal(out['taps'].cpu().numpy(), ref['taps'])        # INT row: bilinear tap indices
+
+
+def test_field_hot_shape(tdgp, oracle):
+    """feat 32 / hid 64 (the 3dgp.yaml shape), planes 64^2, points beyond the cube (zero padding), ragged point count."""
+    rs = np.random.RandomState(9)
+    B, F, H, hid, P = 2, 32, 64, 64, 16 * 37 + 5
+    planes = rs.randn(B, 3 * F, H, H).astype(np.float32)
+    coords = ((rs.rand(B, P, 3) * 2 - 1) * 0.64).astype(np.float32)
+    ws = [rs.randn(hid, F).astype(np.float32), (0.3 * rs.randn(hid)).astype(np.float32), rs.randn(4, hid).astype(np.float32),
+          (0.3 * rs.randn(4)).astype(np.float32)]
+    out = tdgp.renderer.simple_tri_plane_renderer(T(planes), T(coords), _mlp(tdgp, *ws, 'classical'), scale=0.5, return_taps=True)
+    ref = oracle.triplane_field(planes, coords, *ws, scale=0.5, return_taps=True)
+    np.testing.assert_array_equal(out['taps'].cpu().numpy(), ref['taps'])
+    assert_close(N(out['rgb']), ref['rgb'], 5e-6, 'rgb', 1.0)
+    assert_close(N(out['sigma']), ref['sigma'], 5e-6, 'sigma', 1.0)
+    assert tdgp.renderer.simple_tri_plane_renderer(T(planes), T(coords[:, :0]), _mlp(tdgp, *ws, 'classical'), scale=0.5)['rgb'].shape == (B, 0, 3)
+
+
+# ------------------------------------------------------------------------------------------------ sampling stages
+
+@pytest.mark.parametrize('marcher', ['classical', 'mip'])
+def test_stratified_importance(tdgp, oracle, marcher):
+    g = load_golden('sampling')
+    R = tdgp.renderer.ImportanceRenderer(marcher)
+    u = g[f'{marcher}_u_coarse']
+    sd = R.sample_stratified(T(np.zeros(u.shape[:2] + (3,), np.float32)), 0.0, 1.0, u.shape[2], noise=T(u))
+    np.testing.assert_array_equal(N(sd), g[f'{marcher}_sdist'])                  # bit-exact vs the reference
+    sf, aux = R.sample_importance(T(g[f'{marcher}_sdist']), T(g[f'{marcher}_weights']), u.shape[2], u=T(g[f'{marcher}_u_fine']), return_aux=True)
+    osf, oaux = oracle.sample_importance(g[f'{marcher}_sdist'], g[f'{marcher}_weights'], g[f'{marcher}_u_fine'], marcher, return_aux=True)
+    for k in ('inds', 'below', 'above'):                                         # INT rows: bit-exact vs the oracle
+        np.testing.assert_array_equal(aux[k].cpu().numpy().astype(np.int64), oaux[k])
+    np.testing.assert_array_equal(N(aux['cdf']), oaux['cdf'])
+    np.testing.assert_array_equal(N(sf), osf)
+    assert_close(N(sf), g[f'{marcher}_sdist_fine'], 2e-5, 'sdist_fine vs reference')
+
+
+def test_unify(tdgp):
+    g = load_golden('sampling')
+    R = tdgp.renderer.ImportanceRenderer('classical')
+    d, c, s, perm = R.unify_samples(*(T(g[k]) for k in ('un_d1', 'un_c1', 'un_s1', 'un_d2', 'un_c2', 'un_s2')), return_perm=True)
+    np.testing.assert_array_equal(perm.cpu().numpy().astype(np.int64), g['un_perm'])   # INT row: sort permutation
+    np.testing.assert_array_equal(N(d), g['un_d'])
+    np.testing.assert_array_equal(N(c), g['un_c'])
+    np.testing.assert_array_equal(N(s), g['un_s'])
+
+
+@pytest.mark.parametrize('tag,kw', [('cl_inf', dict(use_inf_depth=True)), ('cl_noinf', dict(use_inf_depth=False)),
+                                    ('cl_lastback', dict(use_inf_depth=True, last_back=True)), ('cl_relu', dict(use_inf_depth=True, clamp_mode='relu'))])
+def test_march_classical(tdgp, oracle, tag, kw):
+    g = load_golden('marchers')
+    rgb, dep, w, fT = tdgp.renderer.ClassicalRayMarcher()(T(g['colors']), T(g['densities']), T(g['depths']), dict(kw))
+    assert_close(N(w), g[f'{tag}_weights'], 1e-6, 'weights', 1.0)
+    assert_close(N(rgb), g[f'{tag}_rgb'], 5e-6, 'rgb', 1.0)
+    assert_close(N(dep), g[f'{tag}_depth'], 5e-6, 'depth', 1.0)
+    assert_close(N(fT), g[f'{tag}_T'], 2e-6, 'T')
+    orgb, odep, ow, ofT = oracle.march_classical(g['colors'], g['densities'], g['depths'], **kw)
+    np.testing.assert_array_equal(N(w), ow)                                       # same fp64 scan, same fp64 exp: bit-exact
+    np.testing.assert_array_equal(N(fT), ofT)
+    assert_close(N(rgb), orgb, 1e-6, 'rgb vs oracle', 1.0)
+
+
+@pytest.mark.parametrize('tag,kw', [('mip_inf', dict(use_inf_depth=True)), ('mip_noinf_white', dict(use_inf_depth=False, white_back=True)),
+                                    ('mip_bias', dict(use_inf_depth=True, density_bias=-1.0))])
+def test_march_mip(tdgp, tag, kw):
+    g = load_golden('marchers')
+    rgb, dep, w, fT = tdgp.renderer.MipRayMarcher2()(T(g['colors01']), T(g['densities']), T(g['depths']), dict(kw))
+    assert_close(N(w), g[f'{tag}_weights'], 1e-6, 'weights', 1.0)
+    assert_close(N(rgb), g[f'{tag}_rgb'], 5e-6, 'rgb', 1.0)
+    assert_close(N(dep), g[f'{tag}_depth'], 5e-6, 'depth', 1.0)
+    assert_close(N(fT), g[f'{tag}_T'], 2e-6, 'T')
+
+
+# ------------------------------------------------------------------------------------------------ end to end
+
+def _gen(tdgp, cfg, seed):
+    G = tdgp.generator.Generator(cfg)
+    G.load_numpy_state_dict(tdgp.weights.random_state_dict(cfg, seed=seed, exercise_all=True))
+    return G.to(DEV)
+
+
+def _cam(g):
+    return {k[4:]: T(v) for k, v in g.items() if k.startswith('cam_')}
+
+
+def test_mapping(tdgp):
+    g = load_golden('mapping')
+    for tag, cfg in [('c0', tdgp.config.config_tiny()), ('c10', tdgp.config.config_mid())]:
+        G = _gen(tdgp, cfg, 11)
+        assert_close(N(G.mapping(T(g[f'{tag}_z']), T(g[f'{tag}_c']))), g[f'{tag}_ws'], 1e-5, 'ws', 1.0)
+        assert_close(N(G.mapping(T(g[f'{tag}_z']), T(g[f'{tag}_c']), truncation_psi=0.7)), g[f'{tag}_ws_psi07'], 1e-5, 'psi', 1.0)
+        assert_close(N(G.mapping(T(g[f'{tag}_z']), T(g[f'{tag}_c']), truncation_psi=0.3, truncation_cutoff=3)), g[f'{tag}_ws_psi03_cut3'], 1e-5, 'cut', 1.0)
+
+
+def test_e2e_tiny(tdgp, oracle):
+    cfg = tdgp.config.config_tiny()
+    g = load_golden('e2e_tiny')
+    G = _gen(tdgp, cfg, 21)
+    ws = T(g['ws'])
+    planes = G.synthesis.tri_plane_decoder(ws, noise_mode='const')
+    assert_close(N(planes), g['planes'], 5e-6, 'planes (NCHW)', 1.0)
+    hwc = G.synthesis.tri_plane_decoder(ws, noise_mode='const', hwc=True).t
+    np.testing.assert_array_equal(N(hwc.permute(0, 1, 4, 2, 3).reshape(planes.shape)), N(planes))
+    out = G.synthesis(ws, camera_params=_cam(g), noise_mode='const', render_opts=dict(return_depth=True), u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
+    assert_image_parity(N(out.img), g, 'img')
+    assert_image_parity(N(out.depth), g, 'depth', 'depth')
+    img2 = G(T(g['z']), T(g['c']), _cam(g), noise_mode='const', u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
+    assert_image_parity(N(img2), g, 'img via Generator.forward')
+    img3 = G.synthesis(ws, camera_params=_cam(g), noise_mode='none', u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
+    assert_close(N(img3), g['img_noise_none'], 1e-5, 'img noise none', 1.0)
+    # renderer integer rows on the golden planes: inds and sort permutation vs the oracle, exact
+    from oracle.pipeline import render_options
+    sd = tdgp.weights.random_state_dict(cfg, seed=21, exercise_all=True)
+    mlp = tuple(sd[f'synthesis.tri_plane_mlp.model.{i}.{n}'] for i in (0, 1) for n in ('weight', 'bias'))
+    (orgb, odep, _, _), ointer = oracle.importance_render(g['planes'], mlp, g['ray_o'], g['ray_d'], render_options(cfg.to_dict()), g['u_coarse'],
+                                                          g['u_fine'], return_intermediates=True)
+    opts = G.synthesis.rendering_options(G.synthesis._default_render_options)
+    opts.update(u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
+    (rgb, dep, _, _), inter = G.synthesis.renderer(T(g['planes']), G.synthesis.tri_plane_mlp, T(g['ray_o']), T(g['ray_d']), opts, return_intermediates=True)
+    np.testing.assert_array_equal(N(inter['sdist_coarse']), ointer['sdist_coarse'])
+    assert_close(N(rgb), orgb, 1e-5, 'renderer rgb vs oracle', 1.0)
+    # the chain is not bit-identical (fp32 MFMA vs fp64-accumulated MLP), so integer rows may flip only where u sits on a cdf knot
+    mism_i = (inter['inds'].cpu().numpy().reshape(-1) != g['inds'].reshape(-1)).mean()
+    mism_p = (inter['perm'].cpu().numpy().reshape(-1) != g['perm'].reshape(-1)).mean()
+    assert mism_i < 2e-3 and mism_p < 5e-3, (mism_i, mism_p)
+
+
+def test_e2e_mid(tdgp):
+    cfg = tdgp.config.config_mid()
+    g = load_golden('e2e_mid')
+    G = _gen(tdgp, cfg, 31)
+    out = G.synthesis(T(g['ws']), camera_params=_cam(g), noise_mode='const', render_opts=dict(return_depth=True), u_coarse=T(g['u_coarse']),
+                      u_fine=T(g['u_fine']))
+    assert_image_parity(N(out.img), g, 'img')
+    assert_image_parity(N(out.depth), g, 'depth', 'depth')
+
+
+def test_e2e_tiny_mip(tdgp):
+    cfg = tdgp.config.config_tiny()
+    cfg.ray_marcher_type = 'mip'
+    cfg.white_back = True
+    g = load_golden('e2e_tiny_mip')
+    G = _gen(tdgp, cfg, 41)
+    out = G.synthesis(T(g['ws']), camera_params=_cam(g), noise_mode='const', render_opts=dict(return_depth=True), u_coarse=T(g['u_coarse']),
+                      u_fine=T(g['u_fine']))
+    assert_image_parity(N(out.img), g, 'img')
+    assert_image_parity(N(out.depth), g, 'depth', 'depth')
+
+
+def test_e2e_vs_oracle_bigger(tdgp, oracle):
+    """A configuration with the hot MLP shape (feat 32, hid 64), 128^2 planes, 48^2 rays x 24 steps: HIP vs oracle."""
+    cfg = tdgp.GeneratorConfig(z_dim=64, w_dim=64, c_dim=0, cbase=4096, cmax=96, tri_plane_res=128, feat_dim=32, mlp_hid=64, num_ray_steps=24,
+                               img_resolution=48)
+    sd = tdgp.weights.random_state_dict(cfg, seed=5, exercise_all=True)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=2, seed=6)
+    G = tdgp.generator.Generator(cfg)
+    G.load_numpy_state_dict(sd)
+    G = G.to(DEV)
+    ws = oracle.mapping_forward(sd, cfg.to_dict(), inp['z'], inp['c'])
+    oimg, odepth = oracle.synthesis_forward(sd, cfg.to_dict(), ws, inp['camera'], inp['u_coarse'], inp['u_fine'], 'const')
+    out = G.synthesis(T(ws), camera_params={k: T(v) for k, v in inp['camera'].items()}, noise_mode='const', render_opts=dict(return_depth=True),
+                      u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']))
+    assert_image_parity(N(out.img), dict(img=oimg), 'img vs oracle')
+    assert_image_parity(N(out.depth), dict(depth=odepth), 'depth vs oracle', 'depth')
