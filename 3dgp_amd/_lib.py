@@ -18,6 +18,8 @@ P = c_void_p
 _PROTOTYPES = {
     'tdgp_version': (c_int, []),
     'tdgp_last_error': (c_char_p, []),
+    'tdgp_profile_enable': (c_int, [c_int]),
+    'tdgp_profile_report': (c_int64, [c_char_p, c_int64]),
     'tdgp_bias_act': (c_int, [P, P, P, c_int64, c_int, c_int64, c_int, c_float, c_float, c_float, c_int, P]),
     'tdgp_upfirdn2d': (c_int, [P, P, P, c_int, c_int, c_int, c_int, POINTER(c_int64), c_int, c_int, POINTER(c_int64),
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
@@ -106,3 +108,21 @@ def f32c(t):
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+def profile_enable(on=True):
+    """Start (and clear) / stop per-kernel HIP-event timing inside the library."""
+    load().tdgp_profile_enable(int(bool(on)))
+
+
+def profile_report():
+    """-> {kernel: dict(launches, total_ms, avg_ms, min_ms, max_ms)}; blocks until the recorded launches finished."""
+    lib = load()
+    need = lib.tdgp_profile_report(None, 0)
+    buf = ctypes.create_string_buffer(int(need) + 16)
+    lib.tdgp_profile_report(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, n, tot, mn, mx = line.split()
+        out[name] = dict(launches=int(n), total_ms=float(tot), avg_ms=float(tot) / max(int(n), 1), min_ms=float(mn), max_ms=float(mx))
+    return out

@@ -98,25 +98,25 @@ int launch(const void* x, const void* b, void* y, int64_t n, int sizeB, int64_t 
             const int n4 = (int)(n / 4);
             const int blocks = (int)min((int64_t)maxBlocks, cdiv64(n4, 256));
             if (b && (stepB % 4) == 0)
-                hipLaunchKernelGGL((bias_act_f32x4<ACT, true>), dim3(blocks), dim3(256), 0, s, (const float4*)x, (const float*)b,
+                TDGP_LAUNCH("bias_act_f32x4", (bias_act_f32x4<ACT, true>), dim3(blocks), dim3(256), 0, s, (const float4*)x, (const float*)b,
                                    (float4*)y, n4, sizeB, (int)stepB, alpha, gain, clamp);
             else
-                hipLaunchKernelGGL((bias_act_f32x4<ACT, false>), dim3(blocks), dim3(256), 0, s, (const float4*)x, (const float*)b,
+                TDGP_LAUNCH("bias_act_f32x4", (bias_act_f32x4<ACT, false>), dim3(blocks), dim3(256), 0, s, (const float4*)x, (const float*)b,
                                    (float4*)y, n4, sizeB, (int)stepB, alpha, gain, clamp);
             done = (int64_t)n4 * 4;
         }
         if (done < n) {
             const int blocks = (int)min((int64_t)maxBlocks, cdiv64(n - done, 256));
-            hipLaunchKernelGGL((bias_act_scalar<ACT, float>), dim3(blocks), dim3(256), 0, s, (const float*)x, (const float*)b,
+            TDGP_LAUNCH("bias_act_scalar", (bias_act_scalar<ACT, float>), dim3(blocks), dim3(256), 0, s, (const float*)x, (const float*)b,
                                (float*)y, done, n, sizeB, stepB, alpha, gain, clamp);
         }
     } else if (dtype == TDGP_F16) {
         const int blocks = (int)min((int64_t)maxBlocks, cdiv64(n, 256));
-        hipLaunchKernelGGL((bias_act_scalar<ACT, __half>), dim3(blocks), dim3(256), 0, s, (const __half*)x, (const __half*)b,
+        TDGP_LAUNCH("bias_act_scalar", (bias_act_scalar<ACT, __half>), dim3(blocks), dim3(256), 0, s, (const __half*)x, (const __half*)b,
                            (__half*)y, (int64_t)0, n, sizeB, stepB, alpha, gain, clamp);
     } else {
         const int blocks = (int)min((int64_t)maxBlocks, cdiv64(n, 256));
-        hipLaunchKernelGGL((bias_act_scalar<ACT, hip_bfloat16>), dim3(blocks), dim3(256), 0, s, (const hip_bfloat16*)x,
+        TDGP_LAUNCH("bias_act_scalar", (bias_act_scalar<ACT, hip_bfloat16>), dim3(blocks), dim3(256), 0, s, (const hip_bfloat16*)x,
                            (const hip_bfloat16*)b, (hip_bfloat16*)y, (int64_t)0, n, sizeB, stepB, alpha, gain, clamp);
     }
     return 0;

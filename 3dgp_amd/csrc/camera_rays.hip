@@ -101,7 +101,7 @@ TDGP_API int tdgp_cam2world(const float* angles, const float* radius, const floa
     TDGP_CHECK(angles && radius && look_at && c2w, TDGP_EINVAL, "cam2world: null pointer");
     TDGP_CHECK(B >= 0, TDGP_EINVAL, "cam2world: negative batch");
     if (B == 0) return TDGP_OK;
-    hipLaunchKernelGGL(cam2world_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, angles, radius, look_at, c2w, B);
+    TDGP_LAUNCH("cam2world_kernel", cam2world_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, angles, radius, look_at, c2w, B);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }
@@ -114,7 +114,7 @@ TDGP_API int tdgp_sample_rays(const float* c2w, const float* fov, int fov_stride
     TDGP_CHECK(fov_stride == 0 || fov_stride == 1, TDGP_EINVAL, "sample_rays: fov_stride must be 0 or 1");
     if (B == 0) return TDGP_OK;
     const int64_t total = (int64_t)B * h * w;
-    hipLaunchKernelGGL(sample_rays_kernel, dim3((int)min((int64_t)4096, cdiv64(total, 256))), dim3(256), 0, (hipStream_t)stream, c2w, fov,
+    TDGP_LAUNCH("sample_rays_kernel", sample_rays_kernel, dim3((int)min((int64_t)4096, cdiv64(total, 256))), dim3(256), 0, (hipStream_t)stream, c2w, fov,
                        fov_stride, patch_scales, patch_offsets, ray_o, ray_d, B, h, w);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
@@ -124,7 +124,7 @@ TDGP_API int tdgp_rays_to_image(const float* rgb, float* img, int B, int hw, tdg
     TDGP_CHECK(rgb && img, TDGP_EINVAL, "rays_to_image: null pointer");
     if (B == 0 || hw == 0) return TDGP_OK;
     const int64_t total = (int64_t)B * 3 * hw;
-    hipLaunchKernelGGL(rays_to_image_kernel, dim3((int)min((int64_t)4096, cdiv64(total, 256))), dim3(256), 0, (hipStream_t)stream, rgb, img, B, hw);
+    TDGP_LAUNCH("rays_to_image_kernel", rays_to_image_kernel, dim3((int)min((int64_t)4096, cdiv64(total, 256))), dim3(256), 0, (hipStream_t)stream, rgb, img, B, hw);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }

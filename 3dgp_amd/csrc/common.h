@@ -30,6 +30,22 @@ void tdgp_set_error(const char* fmt, ...);
         }                                                                      \
     } while (0)
 
+// Optional per-kernel timing (tdgp_profile_enable / tdgp_profile_report): HIP events recorded around every launch
+// on the launch stream, the counterpart of the reference's `misc.profiled_function` ranges (misc.py:101-106).
+bool tdgp_prof_on();
+void tdgp_prof_begin(const char* name, hipStream_t s);
+void tdgp_prof_end(hipStream_t s);
+struct ProfScope {
+    hipStream_t s; bool on;
+    ProfScope(const char* name, hipStream_t st) : s(st), on(tdgp_prof_on()) { if (on) tdgp_prof_begin(name, s); }
+    ~ProfScope() { if (on) tdgp_prof_end(s); }
+};
+#define TDGP_LAUNCH(NAME, KERNEL, GRID, BLOCK, LDS, STREAM, ...)              \
+    do {                                                                      \
+        ProfScope ps_(NAME, STREAM);                                          \
+        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);    \
+    } while (0)
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

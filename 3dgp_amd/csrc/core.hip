@@ -1,5 +1,6 @@
 // core.hip -- version / error plumbing of the C ABI.
 #include "common.h"
+#include <string.h>
 
 static thread_local char g_err[512] = "";
 
@@ -12,3 +13,76 @@ void tdgp_set_error(const char* fmt, ...) {
 
 TDGP_API int tdgp_version(void) { return 100; }
 TDGP_API const char* tdgp_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------------------
+// per-kernel timing
+// ---------------------------------------------------------------------------------------------------------
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+struct ProfEvent { const char* name; hipEvent_t a, b; };
+std::mutex g_mu;
+std::vector<ProfEvent> g_events;
+std::atomic<int> g_on{0};
+thread_local ProfEvent g_cur;
+}  // namespace
+
+bool tdgp_prof_on() { return g_on.load(std::memory_order_relaxed) != 0; }
+
+void tdgp_prof_begin(const char* name, hipStream_t s) {
+    g_cur.name = name;
+    (void)hipEventCreate(&g_cur.a);
+    (void)hipEventCreate(&g_cur.b);
+    (void)hipEventRecord(g_cur.a, s);
+}
+
+void tdgp_prof_end(hipStream_t s) {
+    (void)hipEventRecord(g_cur.b, s);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_events.push_back(g_cur);
+}
+
+static void prof_clear() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& e : g_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    g_events.clear();
+}
+
+TDGP_API int tdgp_profile_enable(int on) {
+    prof_clear();
+    g_on.store(on ? 1 : 0);
+    return TDGP_OK;
+}
+
+// Writes one line per kernel: "<name> <launches> <total_ms> <min_ms> <max_ms>\n".  Blocks until the recorded events
+// have completed (the only entry point that synchronises).  Returns the number of bytes needed (incl. NUL).
+TDGP_API int64_t tdgp_profile_report(char* buf, int64_t cap) {
+    struct Acc { int64_t n = 0; double tot = 0, mn = 1e30, mx = 0; };
+    std::map<std::string, Acc> acc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto& e : g_events) {
+            (void)hipEventSynchronize(e.b);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) continue;
+            Acc& a = acc[e.name];
+            a.n++; a.tot += ms; a.mn = ms < a.mn ? ms : a.mn; a.mx = ms > a.mx ? ms : a.mx;
+        }
+    }
+    std::string out;
+    char line[256];
+    for (auto& kv : acc) {
+        snprintf(line, sizeof(line), "%s %lld %.6f %.6f %.6f\n", kv.first.c_str(), (long long)kv.second.n, kv.second.tot, kv.second.mn, kv.second.mx);
+        out += line;
+    }
+    if (buf && cap > 0) {
+        const int64_t n = (int64_t)out.size() < cap - 1 ? (int64_t)out.size() : cap - 1;
+        memcpy(buf, out.data(), (size_t)n);
+        buf[n] = 0;
+    }
+    return (int64_t)out.size() + 1;
+}

@@ -229,7 +229,7 @@ void launch_field(const FieldParams& p, hipStream_t s) {
     const int64_t ntiles = (p.total + 15) / 16;
     const int64_t want = cdiv64(ntiles, 4);                 // one tile per wave
     const int blocks = (int)min((int64_t)(256 * 8), want);  // persistent-ish grid: 8 blocks per CU, waves stride over tiles
-    hipLaunchKernelGGL((triplane_field_kernel<FQ, MT>), dim3(blocks), dim3(256), 0, s, p);
+    TDGP_LAUNCH("triplane_field_kernel", (triplane_field_kernel<FQ, MT>), dim3(blocks), dim3(256), 0, s, p);
 }
 
 }  // namespace
@@ -241,7 +241,7 @@ TDGP_API int tdgp_planes_to_hwc(const float* planes_nchw, float* planes_hwc, int
     const int HW = H * W;
     const int tpp = cdiv(HW, 64);
     const int64_t ntiles = (int64_t)B * 3 * tpp;
-    hipLaunchKernelGGL(planes_to_hwc_kernel, dim3((int)min((int64_t)65535, ntiles)), dim3(256), F * 65 * sizeof(float), (hipStream_t)stream,
+    TDGP_LAUNCH("planes_to_hwc_kernel", planes_to_hwc_kernel, dim3((int)min((int64_t)65535, ntiles)), dim3(256), F * 65 * sizeof(float), (hipStream_t)stream,
                        planes_nchw, planes_hwc, F, HW, ntiles, tpp);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;

@@ -429,7 +429,7 @@ int launch_conv(const ConvParams& p, int max_grid_px_tiles, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid(max_grid_px_tiles, cdiv(p.Cout, BM), p.nphases);
-    hipLaunchKernelGGL((conv_mfma_kernel<MTW, NTW, WM, WN, KCS, MAXT>), grid, dim3(256), lds, s, p);
+    TDGP_LAUNCH("conv_mfma_kernel", (conv_mfma_kernel<MTW, NTW, WM, WN, KCS, MAXT>), grid, dim3(256), lds, s, p);
     return 0;
 }
 
@@ -464,7 +464,7 @@ TDGP_API int tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int C
     TDGP_CHECK(k == 1 || k == 3, TDGP_EUNSUPPORTED, "modconv_pack: kernel size %d not on the generator path (1 or 3)", k);
     const PackInfo pi = pack_info(Cout, Cin, k);
     float* wp = (float*)wpack;
-    hipLaunchKernelGGL(pack_kernel, dim3((int)min((int64_t)4096, cdiv64(pi.wp_floats, 256))), dim3(256), 0, (hipStream_t)stream, weight, wp,
+    TDGP_LAUNCH("pack_kernel", pack_kernel, dim3((int)min((int64_t)4096, cdiv64(pi.wp_floats, 256))), dim3(256), 0, (hipStream_t)stream, weight, wp,
                        wp + pi.wp_floats, Cout, Cin, pi.T, pi.KC, pi.CoutP, pi.nchunks);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
@@ -505,7 +505,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         z = (float*)((char*)workspace + (((int64_t)B * Cout * sizeof(float) + 255) / 256 * 256));
     }
     if (demodulate) {
-        hipLaunchKernelGGL(demod_kernel, dim3(cdiv(B * Cout, 256)), dim3(256), 0, s, styles, wsq, dco, B, Cin, Cout, pi.CoutP);
+        TDGP_LAUNCH("demod_kernel", demod_kernel, dim3(cdiv(B * Cout, 256)), dim3(256), 0, s, styles, wsq, dco, B, Cin, Cout, pi.CoutP);
     } else {
         dco = nullptr;
     }
@@ -576,7 +576,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         f.B = B; f.C = Cout; f.ZH = ZH; f.ZW = ZW; f.OH = 2 * H; f.OW = 2 * W;
         f.act = act; f.alpha = alpha; f.gain = gain; f.clamp = clamp;
         const int64_t total = (int64_t)B * Cout * f.OH * ((f.OW + 3) / 4);
-        hipLaunchKernelGGL(fir_act_kernel, dim3((int)min((int64_t)(256 * 16), cdiv64(total, 256))), dim3(256), 0, s, f);
+        TDGP_LAUNCH("fir_act_kernel", fir_act_kernel, dim3((int)min((int64_t)(256 * 16), cdiv64(total, 256))), dim3(256), 0, s, f);
     }
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
@@ -588,7 +588,7 @@ TDGP_API int tdgp_style_affine(const float* ws, const float* A, const float* abi
     TDGP_CHECK(B >= 1 && num_ws >= 1 && w_dim >= 1 && rows_total >= 1, TDGP_EINVAL, "style_affine: bad shape");
     const int64_t waves = (int64_t)B * rows_total;
     const float wgain = (float)(1.0 / sqrt((double)w_dim));
-    hipLaunchKernelGGL(style_affine_kernel, dim3((int)cdiv64(waves, 4)), dim3(256), 0, (hipStream_t)stream, ws, A, abias, row_meta, row_scale, styles, B,
+    TDGP_LAUNCH("style_affine_kernel", style_affine_kernel, dim3((int)cdiv64(waves, 4)), dim3(256), 0, (hipStream_t)stream, ws, A, abias, row_meta, row_scale, styles, B,
                        num_ws, w_dim, rows_total, wgain);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;

@@ -390,7 +390,7 @@ TDGP_API int tdgp_sample_stratified(const float* u, float* sdist, float* tdist, 
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "sample_stratified: unknown ray marcher %d", marcher);
     const int64_t n = rays * S;
     if (n == 0) return TDGP_OK;
-    hipLaunchKernelGGL(stratified_kernel, dim3((int)min((int64_t)8192, cdiv64(n, 256))), dim3(256), 0, (hipStream_t)stream, u, sdist, tdist, n, S,
+    TDGP_LAUNCH("stratified_kernel", stratified_kernel, dim3((int)min((int64_t)8192, cdiv64(n, 256))), dim3(256), 0, (hipStream_t)stream, u, sdist, tdist, n, S,
                        marcher, t_near, t_far);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
@@ -403,7 +403,7 @@ TDGP_API int tdgp_ray_march(const float* colors, const float* densities, const f
     TDGP_CHECK(C >= 1 && C <= 8, TDGP_EUNSUPPORTED, "ray_march: C=%d outside [1,8]", C);
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "ray_march: unknown ray marcher %d", marcher);
     if (rays == 0) return TDGP_OK;
-    hipLaunchKernelGGL(ray_march_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, colors, densities, depths, rgb, depth, weights,
+    TDGP_LAUNCH("ray_march_kernel", ray_march_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, colors, densities, depths, rgb, depth, weights,
                        final_T, rays, S, C, marcher, flags, density_bias);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
@@ -415,7 +415,7 @@ TDGP_API int tdgp_sample_importance(const float* z, const float* weights, const 
     TDGP_CHECK(!inds || (below && above), TDGP_EINVAL, "sample_importance: inds/below/above come together");
     TDGP_CHECK(S >= 4 && S <= MAXS && Wn >= 3 && Wn <= S && N >= 1, TDGP_EUNSUPPORTED, "sample_importance: bad S=%d Wn=%d N=%d", S, Wn, N);
     if (rays == 0) return TDGP_OK;
-    hipLaunchKernelGGL(sample_importance_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, z, weights, u, samples, inds, below,
+    TDGP_LAUNCH("sample_importance_kernel", sample_importance_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, z, weights, u, samples, inds, below,
                        above, cdf, rays, S, Wn, N, marcher);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
@@ -426,7 +426,7 @@ TDGP_API int tdgp_unify_samples(const float* d1, const float* c1, const float* s
     TDGP_CHECK(d1 && c1 && s1 && d2 && c2 && s2 && d && c && s, TDGP_EINVAL, "unify_samples: null pointer");
     TDGP_CHECK(S1 >= 1 && S2 >= 1 && S1 + S2 <= MAXS, TDGP_EUNSUPPORTED, "unify_samples: S1+S2=%d > %d", S1 + S2, MAXS);
     if (rays == 0) return TDGP_OK;
-    hipLaunchKernelGGL(unify_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, d1, c1, s1, S1, d2, c2, s2, S2, d, c, s, perm, rays, C);
+    TDGP_LAUNCH("unify_kernel", unify_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, d1, c1, s1, S1, d2, c2, s2, S2, d, c, s, perm, rays, C);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }
@@ -438,7 +438,7 @@ TDGP_API int tdgp_importance_from_coarse(const float* rgbs_coarse, const float* 
     TDGP_CHECK(S >= 4 && S <= MAXS && N >= 1, TDGP_EUNSUPPORTED, "importance_from_coarse: bad S=%d N=%d", S, N);
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "importance_from_coarse: unknown ray marcher %d", marcher);
     if (rays == 0) return TDGP_OK;
-    hipLaunchKernelGGL(importance_from_coarse_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, sdist, u_fine,
+    TDGP_LAUNCH("importance_from_coarse_kernel", importance_from_coarse_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, sdist, u_fine,
                        tdist_fine, sdist_fine, inds, rays, S, N, marcher, flags, density_bias, t_near, t_far);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
@@ -451,7 +451,7 @@ TDGP_API int tdgp_merge_composite(const float* rgbs_coarse, const float* t_coars
     TDGP_CHECK(S1 >= 1 && S2 >= 1 && S1 + S2 <= MAXS, TDGP_EUNSUPPORTED, "merge_composite: S1+S2=%d > %d", S1 + S2, MAXS);
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "merge_composite: unknown ray marcher %d", marcher);
     if (rays == 0) return TDGP_OK;
-    hipLaunchKernelGGL(merge_composite_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, t_coarse, S1, rgbs_fine,
+    TDGP_LAUNCH("merge_composite_kernel", merge_composite_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, t_coarse, S1, rgbs_fine,
                        t_fine, S2, rgb, depth, wsum, final_T, perm, rays, marcher, flags, density_bias);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;

@@ -136,14 +136,14 @@ TDGP_API int tdgp_upfirdn2d(const void* x, const float* f, void* y, int N, int C
     if (fast) {
         const int64_t total = (int64_t)N * C * outH * ((outW + 3) / 4);
         const int blocks = (int)min((int64_t)(256 * 16), cdiv64(total, 256));
-        if (upx == 1) hipLaunchKernelGGL((upfirdn2d_4x4<1>), dim3(blocks), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((upfirdn2d_4x4<2>), dim3(blocks), dim3(256), 0, s, p);
+        if (upx == 1) TDGP_LAUNCH("upfirdn2d_4x4", (upfirdn2d_4x4<1>), dim3(blocks), dim3(256), 0, s, p);
+        else TDGP_LAUNCH("upfirdn2d_4x4", (upfirdn2d_4x4<2>), dim3(blocks), dim3(256), 0, s, p);
     } else {
         const int64_t total = (int64_t)N * C * outH * outW;
         const int blocks = (int)min((int64_t)(256 * 16), cdiv64(total, 256));
-        if (dtype == TDGP_F32) hipLaunchKernelGGL((upfirdn2d_generic<float>), dim3(blocks), dim3(256), 0, s, p);
-        else if (dtype == TDGP_F16) hipLaunchKernelGGL((upfirdn2d_generic<__half>), dim3(blocks), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((upfirdn2d_generic<hip_bfloat16>), dim3(blocks), dim3(256), 0, s, p);
+        if (dtype == TDGP_F32) TDGP_LAUNCH("upfirdn2d_generic", (upfirdn2d_generic<float>), dim3(blocks), dim3(256), 0, s, p);
+        else if (dtype == TDGP_F16) TDGP_LAUNCH("upfirdn2d_generic", (upfirdn2d_generic<__half>), dim3(blocks), dim3(256), 0, s, p);
+        else TDGP_LAUNCH("upfirdn2d_generic", (upfirdn2d_generic<hip_bfloat16>), dim3(blocks), dim3(256), 0, s, p);
     }
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;

@@ -1,0 +1,91 @@
+"""Batch-sharded multi-GPU generation: one process per GPU, weights replicated, images independent.
+
+What the reference does: `calc_metrics.py:144-149` spawns one process per GPU; each rank generates
+its own images and the per-batch feature block is exchanged with `world` sequential broadcasts
+(`metric_utils.py:145-155`, `stack(ys, dim=1).flatten(0, 1)` -> item i of the gathered block came from rank i % world).
+Here the exchange is ONE `all_gather_into_tensor` (RCCL over xGMI on the GPU box: 512 KiB per rank, latency-bound),
+optionally issued on a side stream so it overlaps the next generator step.  There is no other collective on the path:
+the generator forward itself never communicates.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'      # 'nccl' is RCCL on ROCm
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def rank_seed(seed, rank, world):
+    """Per-rank RNG seed `seed * world + rank` (training_loop.py:73-74)."""
+    return seed * world + rank
+
+
+def shard_items(num_items, rank, world):
+    """Global item i is produced by rank i % world (the interleave of metric_utils.py:154)."""
+    return list(range(rank, num_items, world))
+
+
+class FeatureGatherer:
+    """All-gather of per-rank feature blocks [B, F] into the interleaved [B * world, F] block of
+    `FeatureStats.append_torch` (metric_utils.py:145-155)."""
+
+    def __init__(self, group=None, side_stream=True):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.stream = torch.cuda.Stream() if (side_stream and torch.cuda.is_available() and self.world > 1) else None
+        self._pending = None
+
+    def gather(self, y):
+        """Blocking form: returns the interleaved block."""
+        self.gather_async(y)
+        return self.wait()
+
+    def gather_async(self, y):
+        assert y.ndim == 2
+        if self.world == 1:
+            self._pending = (y, None)
+            return
+        y = y.contiguous()
+        out = torch.empty([self.world, y.shape[0], y.shape[1]], dtype=y.dtype, device=y.device)
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                dist.all_gather_into_tensor(out, y, group=self.group)
+            y.record_stream(self.stream)
+        else:
+            dist.all_gather_into_tensor(out, y, group=self.group)
+        self._pending = (out, self.stream)
+
+    def wait(self):
+        out, stream = self._pending
+        self._pending = None
+        if out.ndim == 2:
+            return out
+        if stream is not None:
+            torch.cuda.current_stream().wait_stream(stream)
+        return out.permute(1, 0, 2).flatten(0, 1)       # == torch.stack(ys, dim=1).flatten(0, 1)
+
+
+def stand_in_features(img, num_features=2048):
+    """Throughput-only stand-in for the Inception pool features (the detector is a URL-fetched TorchScript pickle,
+    frechet_inception_distance.py:22 -- unavailable offline): a fixed average-pool projection of the image to [B, 2048]
+    so that the collective moves the same 512 KiB per 64 images as the real pipeline."""
+    B = img.shape[0]
+    f = torch.nn.functional.adaptive_avg_pool2d(img.float(), (26, 26)).flatten(1)      # 3*26*26 = 2028
+    if f.shape[1] < num_features:
+        f = torch.nn.functional.pad(f, (0, num_features - f.shape[1]))
+    return f[:, :num_features].contiguous()

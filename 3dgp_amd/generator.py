@@ -225,7 +225,7 @@ class SynthesisBlocksSequence(torch.nn.Module):
         self._affine_pack = None
 
     def _pack_affines(self, device):
-        key = tuple((l.affine.weight.data_ptr(), l.affine.weight._version, l.affine.bias._version) for l, _, _ in self._layers())
+        key = tuple((l.affine.weight.data_ptr(), l.affine.weight._version, l.affine.bias.data_ptr(), l.affine.bias._version) for l, _, _ in self._layers())
         if self._affine_pack is not None and self._affine_pack['key'] == key:
             return self._affine_pack
         A, ab, scale, meta, blocks = [], [], [], [], []

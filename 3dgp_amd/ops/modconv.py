@@ -9,6 +9,7 @@ convolution (+ x2 FIR upsampling) + demodulation + noise + bias + activation in 
 of SynthesisLayer.forward (:128-145) / ToRGBLayer.forward + skip add (:168-172, :265-269).
 """
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -16,7 +17,20 @@ import torch
 from .. import _lib
 from .bias_act import activation_funcs
 
-_FIR_HOST_CACHE = {}
+# Per-tensor caches are keyed by the tensor OBJECT (weak reference) and validated with (data_ptr, _version): an address
+# alone is not an identity -- the caching allocator hands a freed block to the next tensor of the same size.
+_FIR_HOST_CACHE = weakref.WeakKeyDictionary()
+_PACK_CACHE = weakref.WeakKeyDictionary()
+
+
+def _cached(cache, tensor, make):
+    stamp = (tensor.data_ptr(), tensor._version, tuple(tensor.shape))
+    hit = cache.get(tensor)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    val = make(tensor)
+    cache[tensor] = (stamp, val)
+    return val
 
 
 def fir_host_array(resample_filter):
@@ -26,13 +40,7 @@ def fir_host_array(resample_filter):
     if isinstance(resample_filter, np.ndarray):
         f = np.ascontiguousarray(resample_filter, dtype=np.float32)
     else:
-        key = (resample_filter.data_ptr(), resample_filter._version, str(resample_filter.device))
-        f = _FIR_HOST_CACHE.get(key)
-        if f is None:
-            f = np.ascontiguousarray(resample_filter.detach().float().cpu().numpy())
-            if len(_FIR_HOST_CACHE) > 64:
-                _FIR_HOST_CACHE.clear()
-            _FIR_HOST_CACHE[key] = f
+        f = _cached(_FIR_HOST_CACHE, resample_filter, lambda t: np.ascontiguousarray(t.detach().float().cpu().numpy()))
     if f.shape != (4, 4):
         raise NotImplementedError(f'modulated_conv2d: resample_filter of shape {tuple(f.shape)} (the generator path uses 4x4)')
     return (ctypes.c_float * 16)(*f.reshape(-1).tolist())
@@ -54,17 +62,9 @@ class PackedConv:
             _lib.call('tdgp_modconv_pack', w.data_ptr(), self.buf.data_ptr(), self.cout, self.cin, self.k, _lib.stream_of(w))
 
 
-_PACK_CACHE = {}
-
-
 def _packed(weight):
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device))
-    pk = _PACK_CACHE.get(key)
-    if pk is None:
-        if len(_PACK_CACHE) > 256:
-            _PACK_CACHE.clear()
-        pk = _PACK_CACHE[key] = PackedConv(weight)
-    return pk
+    """PackedConv of a weight tensor, re-packed when the tensor is written in place (load_state_dict) or moved."""
+    return _cached(_PACK_CACHE, weight, PackedConv)
 
 
 def modconv_forward(x, packed, styles, noise=None, bias=None, up=1, demodulate=True, act='linear', alpha=None, gain=None, clamp=None,

@@ -158,6 +158,8 @@ def _field(planes, mlp_params, scale, coords=None, ray_o=None, ray_d=None, t=Non
     else:
         P, S = t.shape[1] * t.shape[2], t.shape[2]
     rgbs = torch.empty([B, P, 4], dtype=torch.float32, device=p.device)
+    if B * P == 0:
+        return rgbs
     with torch.cuda.device(p.device):
         _lib.call('tdgp_triplane_field', p.data_ptr(), _lib.ptr(coords), _lib.ptr(ray_o), _lib.ptr(ray_d), _lib.ptr(t), w0.data_ptr(),
                   b0.data_ptr(), w1.data_ptr(), b1.data_ptr(), rgbs.data_ptr(), _lib.ptr(tap_idx), B, P, S, F, H, W, w0.shape[0],

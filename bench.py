@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Generator-forward throughput on MI355X: img/s at 256^2, 64 ray steps (BASELINE.json metric), one JSON line.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one generator forward (mapping -> tri-plane backbone -> volumetric renderer) over one batch of synthetic
+inputs per GPU, inputs and random-init weights resident in HBM before the timed region.  N > 1: one process per GPU,
+the batch is sharded by image (weak scaling: per-GPU batch fixed), and the FID-style feature block is all-gathered
+over RCCL on a side stream (3dgp_amd/distributed.py) -- the only collective on the path.
+
+Besides the contract fields the line carries
+  roofline     -- the dominant kernel (by HIP-event time measured here, on the launch stream, through the library's
+                  per-kernel event hooks): algorithmic FLOP per launch / average launch duration vs the fp32 MFMA peak;
+  cpu_baseline -- the CPU oracle (oracle/, a port of the reference's CPU/PyTorch path) timed on the host cores
+                  (rank 0, N == 1 only) on a bounded sample of the same workload;
+  kernels      -- per-kernel ms/step breakdown of the same profiled steps.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_flops(cfg):
+    """Algorithmic FLOP per image of the two MFMA kernels: 2 * MAC of every conv launch; 5376 per field point."""
+    ch = cfg.channels
+    conv = 0
+    launches = 0
+    for i, r in enumerate(cfg.block_resolutions):
+        c = ch[r]
+        if i > 0:
+            conv += 2 * ch[r // 2] * c * 9 * (r // 2) ** 2        # stride-2 transposed conv: 9 taps per INPUT pixel
+            launches += 1
+        conv += 2 * c * c * 9 * r * r                              # conv1
+        conv += 2 * c * cfg.plane_channels * r * r                 # ToRGB 1x1
+        launches += 2
+    pts = 2 * cfg.img_resolution ** 2 * cfg.num_ray_steps          # coarse + fine
+    field = pts * (2 * (cfg.feat_dim * cfg.mlp_hid + 4 * cfg.mlp_hid) + 3 * 4 * 2 * cfg.feat_dim)   # MLP 4608 + bilerp 768 @ (32,64)
+    return dict(conv_mfma_kernel=(conv, launches), triplane_field_kernel=(field, 2))
+
+
+def cpu_baseline(tdgp, cfg, strip_rays=8192):
+    """Time the CPU oracle on ONE image of the same workload: the whole backbone + a strip of rays (scaled to the full
+    image).  Bounded to ~10-30 s of host time."""
+    import oracle as O
+    from oracle.pipeline import render_options
+    cores = os.cpu_count() or 1
+    O.set_threads(cores)
+    sd = tdgp.weights.random_state_dict(cfg, seed=0)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=1, seed=0)
+    t0 = time.time()
+    ws = O.mapping_forward(sd, cfg.to_dict(), inp['z'], inp['c'])
+    planes = O.synthesis_backbone(sd, cfg.to_dict(), ws, 'const')
+    t_backbone = time.time() - t0
+    R = cfg.img_resolution ** 2
+    strip = min(strip_rays, R)
+    c2w = O.cam2world(inp['camera']['angles'], inp['camera']['radius'], inp['camera']['look_at'])
+    ro, rd = O.sample_rays(c2w, inp['camera']['fov'], cfg.img_resolution, cfg.img_resolution)
+    mlp = tuple(sd[f'synthesis.tri_plane_mlp.model.{i}.{n}'] for i in (0, 1) for n in ('weight', 'bias'))
+    t0 = time.time()
+    O.importance_render(planes, mlp, ro[:, :strip], rd[:, :strip], render_options(cfg.to_dict()), inp['u_coarse'][:, :strip], inp['u_fine'][:strip])
+    t_strip = time.time() - t0
+    t_img = t_backbone + t_strip * (R / strip)
+    return dict(value=round(1.0 / t_img, 5), unit='img/s', cores=cores, kind='port',
+                sample=f'1 image: full tri-plane backbone ({t_backbone:.2f} s) + {strip} of {R} rays rendered ({t_strip:.2f} s) scaled to the image; '
+                       f'OpenMP oracle (oracle/tdgp_oracle.c), {cores} threads')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--config', default='c3', choices=['c1', 'c2', 'c3', 'c4'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-steps', type=int, default=2)
+    args = ap.parse_args()
+
+    tdgp = importlib.import_module('3dgp_amd')
+    D = tdgp.distributed
+    rank, world, local_rank = D.init_from_env('nccl')
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    tdgp._lib.load()                       # the HIP library must be there: no fallback
+
+    cfg = getattr(tdgp.config, f'config_{args.config}')()
+    G = tdgp.generator.Generator(cfg)
+    G.load_numpy_state_dict(tdgp.weights.random_state_dict(cfg, seed=0))        # random-init weights, identical on every rank
+    G = G.to(dev)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=args.batch, seed=D.rank_seed(0, rank, world))
+    T = lambda a: torch.as_tensor(a).to(dev)   # noqa: E731
+    z, c = T(inp['z']), T(inp['c'])
+    cam = {k: T(v) for k, v in inp['camera'].items()}
+    u_coarse, u_fine = T(inp['u_coarse']), T(inp['u_fine'])
+    gather = D.FeatureGatherer() if world > 1 else None
+
+    def step():
+        img = G(z, c, cam, noise_mode='const', u_coarse=u_coarse, u_fine=u_fine)
+        if gather is not None:
+            if gather._pending is not None:
+                gather.wait()
+            gather.gather_async(D.stand_in_features(img))
+        return img
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img = step()
+    if gather is not None and gather._pending is not None:
+        gather.wait()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(img).all()
+
+    # ---- per-kernel timing of the same step (HIP events on the launch stream, inside the library) -------------------
+    tdgp._lib.profile_enable(True)
+    for _ in range(args.profile_steps):
+        G(z, c, cam, noise_mode='const', u_coarse=u_coarse, u_fine=u_fine)
+    torch.cuda.synchronize()
+    prof = tdgp._lib.profile_report()
+    tdgp._lib.profile_enable(False)
+    kernels = {k: dict(ms_per_step=round(v['total_ms'] / args.profile_steps, 4), launches_per_step=v['launches'] // args.profile_steps,
+                       avg_ms=round(v['avg_ms'], 5)) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])}
+    dominant = next(iter(kernels))
+    flops = algorithmic_flops(cfg)
+    roofline = None
+    if dominant in flops:
+        fl_img, launches_img = flops[dominant]
+        k = kernels[dominant]
+        fl_per_launch = fl_img * args.batch / k['launches_per_step']
+        achieved = fl_per_launch / (k['avg_ms'] * 1e-3) / 1e12
+        roofline = dict(kernel=dominant, bound='mfma', achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
+                        frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        flop_per_launch=fl_per_launch, avg_launch_ms=k['avg_ms'], launches_per_step=k['launches_per_step'])
+
+    if rank == 0:
+        total_imgs = args.batch * world * args.steps
+        out = {
+            'metric': 'generator-forward img/s @256^2, 64 steps' if args.config in ('c3', 'c4') else f'generator-forward img/s ({args.config})',
+            'value': round(total_imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[2]: ImageNet 256x256, {cfg.num_ray_steps}(+{cfg.num_ray_steps}) ray steps, cmax {cfg.cmax}, '
+                                   f'c_dim {cfg.c_dim}, tri-plane {cfg.tri_plane_res}^2 x {cfg.plane_channels}, full HIP path' if args.config == 'c3'
+                       else args.config, 'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'img_resolution': cfg.img_resolution,
+                       'num_ray_steps': cfg.num_ray_steps, 'parallelism': f'dp{world} (batch-sharded, weights replicated)'},
+            'roofline': roofline, 'kernels': kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(tdgp, cfg)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

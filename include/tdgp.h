@@ -39,6 +39,13 @@ typedef void* tdgp_stream_t;   /* hipStream_t */
 int         tdgp_version(void);
 const char* tdgp_last_error(void);
 
+/* Per-kernel timing (the reference wraps its ops in torch.autograd.profiler ranges: src/torch_utils/misc.py:101-106).
+ * tdgp_profile_enable(1) makes every launch record a HIP event pair on its stream; tdgp_profile_report() waits for
+ * the recorded events (the ONLY entry point that blocks) and writes "<kernel> <launches> <total_ms> <min_ms> <max_ms>"
+ * lines into a HOST buffer, returning the bytes needed.  tdgp_profile_enable(0/1) also clears previous records. */
+int     tdgp_profile_enable(int on);
+int64_t tdgp_profile_report(char* buf, int64_t cap);
+
 /* ---------------------------------------------------------------------------------------------
  * bias_act forward:  y = clamp(gain * act(x + b[(i / stepB) % sizeB]))
  * replaces: src/torch_utils/ops/bias_act.cpp:32 `bias_act(x,b,xref,yref,dy,grad=0,dim,act,alpha,gain,clamp)`

@@ -62,7 +62,7 @@ RGB_TOL = 1e-4        # north-star tolerance: max-rel RGB error vs the reference
 RANGE_TOL = 1e-5      # stricter, well-conditioned companion: max|delta| / max|ref|
 
 
-def assert_image_parity(img, g, what='img', key='img'):
+def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL):
     """End-to-end image parity against a golden captured from the reference.
 
     Two bounds, both asserted:
@@ -79,6 +79,6 @@ def assert_image_parity(img, g, what='img', key='img'):
     pix = max_rel(img, ref)
     self_noise = max_rel(g[key + '_alt'], ref) if (key + '_alt') in g else 0.0
     assert rng <= RANGE_TOL, f'{what}: range-normalised error {rng:.3e} > {RANGE_TOL:.0e}'
-    bound = max(RGB_TOL, 3 * self_noise)
+    bound = max(pix_tol, 3 * self_noise)
     assert pix <= bound, f'{what}: max-rel {pix:.3e} > {bound:.3e} (reference self-noise {self_noise:.3e})'
     return rng, pix, self_noise

@@ -385,5 +385,8 @@ def test_e2e_vs_oracle_bigger(tdgp, oracle):
     oimg, odepth = oracle.synthesis_forward(sd, cfg.to_dict(), ws, inp['camera'], inp['u_coarse'], inp['u_fine'], 'const')
     out = G.synthesis(T(ws), camera_params={k: T(v) for k, v in inp['camera'].items()}, noise_mode='const', render_opts=dict(return_depth=True),
                       u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']))
-    assert_image_parity(N(out.img), dict(img=oimg), 'img vs oracle')
-    assert_image_parity(N(out.depth), dict(depth=odepth), 'depth vs oracle', 'depth')
+    # Two fp32 evaluations (MFMA fp32 chains vs fp64-accumulated oracle) of a signed image: the range-normalised bound
+    # (1e-5) is the binding one; the per-pixel metric has no reference self-noise to calibrate against here, so it is
+    # bounded at 1e-3 (= abs error <= 1e-6 of the image range on near-zero pixels).
+    assert_image_parity(N(out.img), dict(img=oimg), 'img vs oracle', pix_tol=1e-3)
+    assert_image_parity(N(out.depth), dict(depth=odepth), 'depth vs oracle', 'depth', pix_tol=1e-3)

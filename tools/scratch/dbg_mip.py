@@ -1,0 +1,28 @@
+import sys, importlib, numpy as np, torch
+sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+from conftest import load_golden
+import oracle as O
+from oracle.pipeline import render_options
+t = importlib.import_module('3dgp_amd')
+cfg = t.config.config_tiny(); cfg.ray_marcher_type='mip'; cfg.white_back=True
+g = load_golden('e2e_tiny_mip')
+sd = t.weights.random_state_dict(cfg, seed=41, exercise_all=True)
+G = t.generator.Generator(cfg); G.load_numpy_state_dict(sd); G=G.to('cuda')
+T = lambda a: torch.as_tensor(a).cuda()
+cam = {k[4:]: v for k, v in g.items() if k.startswith('cam_')}
+oimg, odep, ointer = O.synthesis_forward(sd, cfg.to_dict(), g['ws'], cam, g['u_coarse'], g['u_fine'], 'const', return_intermediates=True)
+planes = G.synthesis.tri_plane_decoder(T(g['ws']), noise_mode='const')
+print('planes', np.abs(planes.cpu().numpy()-ointer['planes']).max())
+opts = G.synthesis.rendering_options(G.synthesis._default_render_options); opts.update(u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
+(rgb, dep, ws_, fT), inter = G.synthesis.renderer(T(ointer['planes']), G.synthesis.tri_plane_mlp, T(ointer['ray_o']), T(ointer['ray_d']), opts, return_intermediates=True)
+B,R,S = inter['sdist_coarse'].shape
+print('sdist', np.abs(inter['sdist_coarse'].cpu().numpy()-ointer['sdist_coarse']).max())
+rc = inter['rgbs_coarse'].cpu().numpy().reshape(B,R,S,4)
+print('col_c', np.abs(rc[...,:3]-ointer['colors_coarse']).max(), 'sig_c', np.abs(rc[...,3:]-ointer['densities_coarse']).max())
+print('sfine', np.abs(inter['sdist_fine'].cpu().numpy()-ointer['sdist_fine'][...,0]).max())
+rf = inter['rgbs_fine'].cpu().numpy().reshape(B,R,S,4)
+print('col_f', np.abs(rf[...,:3]-ointer['colors_fine']).max())
+mlp = tuple(sd[f'synthesis.tri_plane_mlp.model.{i}.{n}'] for i in (0, 1) for n in ('weight', 'bias'))
+(orgb, odepth, ow, oT) = O.importance_render(ointer['planes'], mlp, ointer['ray_o'], ointer['ray_d'], render_options(cfg.to_dict()), g['u_coarse'], g['u_fine'])
+print('rgb', np.abs(rgb.cpu().numpy()-orgb).max(), 'depth', np.abs(dep.cpu().numpy()-odepth).max(), 'wsum', np.abs(ws_.cpu().numpy()-ow).max(), 'T', np.abs(fT.cpu().numpy()-oT).max())
+print(rgb.cpu().numpy()[0,:3], orgb[0,:3])
