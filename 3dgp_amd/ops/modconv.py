@@ -19,17 +19,20 @@ from .bias_act import activation_funcs
 
 # Per-tensor caches are keyed by the tensor OBJECT (weak reference) and validated with (data_ptr, _version): an address
 # alone is not an identity -- the caching allocator hands a freed block to the next tensor of the same size.
-_FIR_HOST_CACHE = weakref.WeakKeyDictionary()
-_PACK_CACHE = weakref.WeakKeyDictionary()
+_FIR_HOST_CACHE = {}
+_PACK_CACHE = {}
 
 
 def _cached(cache, tensor, make):
+    """cache: {id(tensor): (weakref, stamp, value)}; entries die with their tensor (tensors cannot key a WeakKeyDictionary:
+    weakref equality falls back to elementwise tensor ==)."""
     stamp = (tensor.data_ptr(), tensor._version, tuple(tensor.shape))
-    hit = cache.get(tensor)
-    if hit is not None and hit[0] == stamp:
-        return hit[1]
+    key = id(tensor)
+    hit = cache.get(key)
+    if hit is not None and hit[0]() is tensor and hit[1] == stamp:
+        return hit[2]
     val = make(tensor)
-    cache[tensor] = (stamp, val)
+    cache[key] = (weakref.ref(tensor, lambda _r, k=key, c=cache: c.pop(k, None)), stamp, val)
     return val
 
 
