@@ -41,17 +41,23 @@ struct Phase {
     int oy_mul, oy_add, ox_mul, ox_add;
 };
 
-struct ConvParams {
-    const float* x; const float* wp; const float* styles; const float* dcoef; const float* noise;
-    const float* bias; const float* skip; float* y;
+// Everything the output stage needs (shared by the conv kernel's own epilogue and the split-K reduction kernel).
+struct EpiParams {
+    const float* dcoef; const float* noise; const float* bias; const float* skip; float* y;
     int64_t noise_bstride;
     float fir[16];      // flipped filter * gain for the fused skip upsample
-    int B, Cin, Cout, CoutP, Hin, Win, T, KC;
-    int Hout, Wout;     // dims of the output tensor
+    int B, Cout, Hout, Wout;    // dims of the output tensor
     int out_layout, out_feat;
     int act; float alpha, gain, clamp;
+};
+
+struct ConvParams {
+    const float* x; const float* wp; const float* styles;
+    float* partial;     // split-K: raw partial sums [ksplit][B,Cout,Hout,Wout]
+    EpiParams e;
+    int B, Cin, Cout, CoutP, Hin, Win, T, KC;
     int tw_log2;
-    int nphases;
+    int nphases, ksplit;
     Phase ph[4];
 };
 
@@ -92,6 +98,27 @@ __device__ __forceinline__ float skip_upsample(const float* __restrict__ img, in
     return acc;
 }
 
+// demod * acc + noise + bias (+ FIR-upsampled skip) -> activation * gain -> clamp -> store (NCHW or channel-last planes)
+__device__ __forceinline__ void epilogue_store(const EpiParams& e, float v, int b, int o, int oy, int ox) {
+    if (e.dcoef) v = v * e.dcoef[b * e.Cout + o];
+    if (e.noise) v = v + e.noise[b * e.noise_bstride + (int64_t)oy * e.Wout + ox];
+    if (e.bias) v = v + e.bias[o];
+    const int h2 = e.Hout / 2, w2 = e.Wout / 2;
+    int64_t addr;
+    if (e.out_layout == 0) {
+        if (e.skip) v = v + skip_upsample<false>(e.skip + ((int64_t)b * e.Cout + o) * h2 * w2, h2, w2, oy, ox, e.fir, 1);
+        addr = (((int64_t)b * e.Cout + o) * e.Hout + oy) * e.Wout + ox;
+    } else {
+        const int pl = o / e.out_feat, f = o % e.out_feat;
+        const int64_t plane = (int64_t)b * (e.Cout / e.out_feat) + pl;
+        if (e.skip) v = v + skip_upsample<true>(e.skip + plane * h2 * w2 * e.out_feat + f, h2, w2, oy, ox, e.fir, e.out_feat);
+        addr = ((plane * e.Hout + oy) * e.Wout + ox) * e.out_feat + f;
+    }
+    v = act_apply(v, e.act, e.alpha) * e.gain;
+    if (e.clamp >= 0.f) v = v < -e.clamp ? -e.clamp : (v > e.clamp ? e.clamp : v);
+    e.y[addr] = v;
+}
+
 // -------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution.  Block = 256 threads = WM x WN waves, wave tile = (MTW*32) x (NTW*32).
 // KCS = channels staged per K iteration (a multiple of the packed chunk p.KC), MAXT = max taps per phase.
@@ -106,7 +133,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     float* As = smem;                               // [MAXT*KCS][BM]
     float* Xs = smem + MAXT * KCS * BM;             // [KCS][PSZ]
 
-    const Phase& ph = p.ph[blockIdx.z];
+    const int phase_id = blockIdx.z % p.nphases, ks = blockIdx.z / p.nphases;
+    const Phase& ph = p.ph[phase_id];
     const int TW = 1 << p.tw_log2, RPS = 32 >> p.tw_log2;
     const int TR = NT * RPS;                        // virtual rows per block tile
     const int PR = TR + 2, PC = TW + 2;
@@ -179,8 +207,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     const int nchunks_packed = (p.Cin + p.KC - 1) / p.KC;
     const int niter = (nchunks_packed + G - 1) / G;
     const int arows = ph.ntaps * KCS;
+    // split-K: this block reduces iterations [it0, it1)
+    const int it_per = (niter + p.ksplit - 1) / p.ksplit;
+    const int it0 = ks * it_per, it1 = min(niter, it0 + it_per);
 
-    for (int it = 0; it < niter; it++) {
+    for (int it = it0; it < it1; it++) {
         __syncthreads();
         // ---- stage A: rows (t, g, c8) -> As[(t*KCS + g*KC + c8)][BM] ---------------------------------
         for (int e = tid; e < arows * (BM / 4); e += 256) {
@@ -240,14 +271,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     // compact runtime loop applies demod/noise/bias/skip/activation and stores.  Two lane mappings:
     //   layout 0 (NCHW):         lane = pixel (32 consecutive x -> 128-B row segments), loop over channels;
     //   layout 1 (channel-last): lane = channel (32 consecutive features -> one 128-B texel line), loop over pixels.
+    // Split-K blocks store raw partial sums (NCHW) instead; splitk_reduce_kernel finishes the job.
     __syncthreads();                                   // every wave is done with As / Xs
     float* ct = smem + wv * (32 * 33);
-    const int h2 = p.Hout / 2, w2 = p.Wout / 2;
+    const EpiParams& e = p.e;
+    const bool raw = p.ksplit > 1;
+    float* part = raw ? p.partial + (int64_t)ks * e.B * e.Cout * e.Hout * e.Wout : nullptr;
 #pragma unroll
     for (int n = 0; n < NTW; n++) {
         const int pb = px_b[n];
         const int poy = px_m[n] * ph.oy_mul + ph.oy_add, pox = px_n[n] * ph.ox_mul + ph.ox_add;
-        const int pok = (px_ok[n] && poy < p.Hout && pox < p.Wout) ? 1 : 0;
+        const int pok = (px_ok[n] && poy < e.Hout && pox < e.Wout) ? 1 : 0;
 #pragma unroll
         for (int m = 0; m < MTW; m++) {
 #pragma unroll
@@ -260,7 +294,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
                 const int sel = rr * 2 + half;         // 0..31
                 int o, b, oy, ox, ok;
                 float v;
-                if (p.out_layout == 0) {
+                if (raw || e.out_layout == 0) {
                     o = obase + sel; b = pb; oy = poy; ox = pox; ok = pok;
                     v = ct[sel * 33 + l32];
                 } else {
@@ -268,28 +302,29 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
                     b = __shfl(pb, sel, 64); oy = __shfl(poy, sel, 64); ox = __shfl(pox, sel, 64); ok = __shfl(pok, sel, 64);
                     v = ct[l32 * 33 + sel];
                 }
-                if (ok && o < p.Cout) {
-                    if (p.dcoef) v = v * p.dcoef[b * p.Cout + o];
-                    if (p.noise) v = v + p.noise[b * p.noise_bstride + (int64_t)oy * p.Wout + ox];
-                    if (p.bias) v = v + p.bias[o];
-                    int64_t addr;
-                    if (p.out_layout == 0) {
-                        if (p.skip) v = v + skip_upsample<false>(p.skip + ((int64_t)b * p.Cout + o) * h2 * w2, h2, w2, oy, ox, p.fir, 1);
-                        addr = (((int64_t)b * p.Cout + o) * p.Hout + oy) * p.Wout + ox;
-                    } else {
-                        const int pl = o / p.out_feat, f = o % p.out_feat;
-                        const int64_t plane = (int64_t)b * (p.Cout / p.out_feat) + pl;
-                        if (p.skip) v = v + skip_upsample<true>(p.skip + plane * h2 * w2 * p.out_feat + f, h2, w2, oy, ox, p.fir, p.out_feat);
-                        addr = ((plane * p.Hout + oy) * p.Wout + ox) * p.out_feat + f;
-                    }
-                    v = act_apply(v, p.act, p.alpha) * p.gain;
-                    if (p.clamp >= 0.f) v = v < -p.clamp ? -p.clamp : (v > p.clamp ? p.clamp : v);
-                    p.y[addr] = v;
+                if (ok && o < e.Cout) {
+                    if (raw) part[(((int64_t)b * e.Cout + o) * e.Hout + oy) * e.Wout + ox] = v;
+                    else epilogue_store(e, v, b, o, oy, ox);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+    }
+}
+
+// Split-K reduction: y = epilogue(sum_ks partial[ks]) ; one thread per output element, ks summed in order (deterministic).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, EpiParams e) {
+    const int64_t slice = (int64_t)e.B * e.Cout * e.Hout * e.Wout;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < slice; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int k = 0; k < ksplit; k++) v += partial[k * slice + i];
+        const int ox = (int)(i % e.Wout);
+        int64_t r = i / e.Wout;
+        const int oy = (int)(r % e.Hout); r /= e.Hout;
+        const int o = (int)(r % e.Cout);
+        const int b = (int)(r / e.Cout);
+        epilogue_store(e, v, b, o, oy, ox);
     }
 }
 
@@ -306,61 +341,84 @@ struct FirParams {
     int act; float alpha, gain, clamp;
 };
 
+// Block = one 16x64 output tile of one (b,c) plane: the (16+3)x(64+3) input tile is staged in LDS with coalesced row
+// loads, each thread then produces 4 consecutive outputs from a 4x7 window.  HBM traffic = Z read once + y written once.
+constexpr int FIR_TH = 16, FIR_TW = 64;
 __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
-    const int qW = (p.OW + 3) / 4;
-    const int64_t total = (int64_t)p.B * p.C * p.OH * qW;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int oxq = (int)(i % qW);
-        int64_t r = i / qW;
-        const int oy = (int)(r % p.OH); r /= p.OH;
+    __shared__ float zt[(FIR_TH + 3) * (FIR_TW + 4)];
+    constexpr int ZP = FIR_TW + 4;
+    const int tilesX = (p.OW + FIR_TW - 1) / FIR_TW, tilesY = (p.OH + FIR_TH - 1) / FIR_TH;
+    const int64_t ntiles = (int64_t)p.B * p.C * tilesY * tilesX;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = (int)(t % tilesX);
+        int64_t r = t / tilesX;
+        const int ty = (int)(r % tilesY); r /= tilesY;
         const int c = (int)(r % p.C);
         const int b = (int)(r / p.C);
-        const int ox0 = oxq * 4;
+        const int oy0 = ty * FIR_TH, ox0 = tx * FIR_TW;
         const float* zp = p.z + ((int64_t)b * p.C + c) * p.ZH * p.ZW;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ky = 0; ky < 4; ky++) {
-            const int zy = oy + ky - 1;
-            if (zy < 0 || zy >= p.ZH) continue;
-            float win[7];
-#pragma unroll
-            for (int j = 0; j < 7; j++) {
-                const int zx = ox0 - 1 + j;
-                win[j] = (zx >= 0 && zx < p.ZW) ? zp[zy * p.ZW + zx] : 0.f;
-            }
-#pragma unroll
-            for (int o = 0; o < 4; o++)
-#pragma unroll
-                for (int kx = 0; kx < 4; kx++) acc[o] = fmaf_(p.fir[ky * 4 + kx], win[o + kx], acc[o]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < (FIR_TH + 3) * (FIR_TW + 3); i += 256) {
+            const int ry = i / (FIR_TW + 3), rx = i % (FIR_TW + 3);
+            const int zy = oy0 - 1 + ry, zx = ox0 - 1 + rx;
+            zt[ry * ZP + rx] = (zy >= 0 && zy < p.ZH && zx >= 0 && zx < p.ZW) ? zp[(int64_t)zy * p.ZW + zx] : 0.f;
         }
-        const float d = p.dcoef ? p.dcoef[b * p.C + c] : 1.f;
-        const float bv = p.bias ? p.bias[c] : 0.f;
-        float* yp = p.y + (((int64_t)b * p.C + c) * p.OH + oy) * p.OW + ox0;
+        __syncthreads();
+        const int ly = threadIdx.x >> 4, lx = (threadIdx.x & 15) * 4;
+        const int oy = oy0 + ly;
+        if (oy < p.OH && ox0 + lx < p.OW) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
-            if (ox0 + o >= p.OW) break;
-            float v = acc[o] * d;
-            if (p.noise) v = v + p.noise[b * p.noise_bstride + (int64_t)oy * p.OW + ox0 + o];
-            v = v + bv;
-            v = act_apply(v, p.act, p.alpha) * p.gain;
-            if (p.clamp >= 0.f) v = v < -p.clamp ? -p.clamp : (v > p.clamp ? p.clamp : v);
-            yp[o] = v;
+            for (int ky = 0; ky < 4; ky++) {
+                float win[7];
+#pragma unroll
+                for (int j = 0; j < 7; j++) win[j] = zt[(ly + ky) * ZP + lx + j];
+#pragma unroll
+                for (int o = 0; o < 4; o++)
+#pragma unroll
+                    for (int kx = 0; kx < 4; kx++) acc[o] = fmaf_(p.fir[ky * 4 + kx], win[o + kx], acc[o]);
+            }
+            const float d = p.dcoef ? p.dcoef[b * p.C + c] : 1.f;
+            const float bv = p.bias ? p.bias[c] : 0.f;
+            float* yp = p.y + (((int64_t)b * p.C + c) * p.OH + oy) * p.OW + ox0 + lx;
+            float out[4];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                float v = acc[o] * d;
+                if (p.noise && ox0 + lx + o < p.OW) v = v + p.noise[b * p.noise_bstride + (int64_t)oy * p.OW + ox0 + lx + o];
+                v = v + bv;
+                v = act_apply(v, p.act, p.alpha) * p.gain;
+                if (p.clamp >= 0.f) v = v < -p.clamp ? -p.clamp : (v > p.clamp ? p.clamp : v);
+                out[o] = v;
+            }
+            if (ox0 + lx + 3 < p.OW && (p.OW & 3) == 0) *(float4*)yp = make_float4(out[0], out[1], out[2], out[3]);
+            else
+                for (int o = 0; o < 4 && ox0 + lx + o < p.OW; o++) yp[o] = out[o];
         }
     }
 }
 
 // d[b,o] = rsqrt(sum_c s[b,c]^2 * wsq[c][o] + 1e-8)      (networks_stylegan2.py:62)
-__global__ __launch_bounds__(256) void demod_kernel(const float* __restrict__ styles, const float* __restrict__ wsq, float* __restrict__ d, int B,
-                                                   int Cin, int Cout, int CoutP) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * Cout) return;
-    const int b = i / Cout, o = i % Cout;
+// block (64 out-channels x 16 channel slices): coalesced wsq rows, 16-way split of the Cin loop, LDS tree at the end.
+__global__ __launch_bounds__(1024) void demod_kernel(const float* __restrict__ styles, const float* __restrict__ wsq, float* __restrict__ d, int B,
+                                                    int Cin, int Cout, int CoutP) {
+    __shared__ float red[16][64];
+    const int ol = threadIdx.x & 63, cs = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + ol, b = blockIdx.y;
     float acc = 0.f;
-    for (int c = 0; c < Cin; c++) {
-        const float s = styles[b * Cin + c];
-        acc = fmaf_(s * s, wsq[(int64_t)c * CoutP + o], acc);
+    if (o < Cout)
+        for (int c = cs; c < Cin; c += 16) {
+            const float s = styles[b * Cin + c];
+            acc = fmaf_(s * s, wsq[(int64_t)c * CoutP + o], acc);
+        }
+    red[cs][ol] = acc;
+    __syncthreads();
+    if (cs == 0 && o < Cout) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) t += red[k][ol];
+        d[b * Cout + o] = 1.0f / sqrtf(t + 1e-8f);
     }
-    d[i] = 1.0f / sqrtf(acc + 1e-8f);
 }
 
 // weight [Cout,Cin,k,k] -> packed [nchunks][T][KC][CoutP] (zero padded) followed by wsq [Cin][CoutP]
@@ -418,21 +476,6 @@ inline PackInfo pack_info(int Cout, int Cin, int k) {
     return pi;
 }
 
-template <int MTW, int NTW, int WM, int WN, int KCS, int MAXT>
-int launch_conv(const ConvParams& p, int max_grid_px_tiles, hipStream_t s) {
-    constexpr int BM = 32 * MTW * WM, NT = NTW * WN, BN = 32 * NT;
-    constexpr int XS_MAX = (BN / 4 + 2) * (4 + 2) > (BN / 32 + 2) * (32 + 2) ? (BN / 4 + 2) * (4 + 2) : (BN / 32 + 2) * (32 + 2);
-    const size_t lds = (size_t)(MAXT * KCS * BM + KCS * XS_MAX) * sizeof(float);
-    static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<MTW, NTW, WM, WN, KCS, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    dim3 grid(max_grid_px_tiles, cdiv(p.Cout, BM), p.nphases);
-    TDGP_LAUNCH("conv_mfma_kernel", (conv_mfma_kernel<MTW, NTW, WM, WN, KCS, MAXT>), grid, dim3(256), lds, s, p);
-    return 0;
-}
-
 // pixel tiles of the largest phase for a block covering NT 32-pixel subtiles
 inline int px_tiles(const ConvParams& p, int NT) {
     const int TW = 1 << p.tw_log2, RPS = 32 >> p.tw_log2, TR = NT * RPS;
@@ -444,10 +487,62 @@ inline int px_tiles(const ConvParams& p, int NT) {
     return mx;
 }
 
+// Split-K factor: low-resolution layers have K = Cin*9 = 4608 but only a handful of output tiles, so a plain launch
+// leaves most of the 256 CUs idle behind a 64-iteration serial K loop.  Split K until ~2 blocks per CU exist.
+inline int pick_ksplit(int blocks, int niter) {
+    if (blocks >= 256 || niter < 4) return 1;
+    int ks = cdiv(512, blocks);
+    if (ks > niter / 2) ks = niter / 2;
+    if (ks > 32) ks = 32;
+    return ks < 1 ? 1 : ks;
+}
+
+template <int MTW, int NTW, int WM, int WN, int KCS, int MAXT>
+int launch_conv(ConvParams& p, float* partial, int64_t partial_floats, hipStream_t s) {
+    constexpr int BM = 32 * MTW * WM, NT = NTW * WN, BN = 32 * NT;
+    constexpr int XS_MAX = (BN / 4 + 2) * (4 + 2) > (BN / 32 + 2) * (32 + 2) ? (BN / 4 + 2) * (4 + 2) : (BN / 32 + 2) * (32 + 2);
+    const size_t lds = (size_t)(MAXT * KCS * BM + KCS * XS_MAX) * sizeof(float);
+    static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<MTW, NTW, WM, WN, KCS, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int gx = px_tiles(p, NT), gy = cdiv(p.Cout, BM);
+    const int niter = cdiv(cdiv(p.Cin, p.KC), KCS / p.KC);
+    const int64_t slice = (int64_t)p.e.B * p.e.Cout * p.e.Hout * p.e.Wout;
+    int ks = pick_ksplit(gx * gy * p.nphases, niter);
+    while (ks > 1 && ks * slice > partial_floats) ks--;          // never exceed the caller's workspace
+    p.ksplit = ks;
+    p.partial = partial;
+    dim3 grid(gx, gy, p.nphases * ks);
+    TDGP_LAUNCH("conv_mfma_kernel", (conv_mfma_kernel<MTW, NTW, WM, WN, KCS, MAXT>), grid, dim3(256), lds, s, p);
+    if (ks > 1)
+        TDGP_LAUNCH("splitk_reduce_kernel", splitk_reduce_kernel, dim3((int)min((int64_t)2048, cdiv64(slice, 256))), dim3(256), 0, s, partial, ks, p.e);
+    return 0;
+}
+
 inline int pick_tw_log2(int gridW) {
     int tw = 4, lg = 2;
     while (tw < 32 && tw < gridW) { tw <<= 1; lg++; }
     return lg;
+}
+
+// Workspace layout: [demod coefficients B*Cout] [transposed-conv intermediate, up=2 only] [split-K partial sums]
+struct WsLayout { int64_t dco, z, partial, partial_floats, total; };
+WsLayout ws_layout(int B, int Cin, int Cout, int H, int W, int k, int up) {
+    WsLayout w;
+    auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+    w.dco = 0;
+    w.z = al((int64_t)B * Cout * sizeof(float));
+    const int64_t out_elems = (up == 2) ? (int64_t)B * Cout * (2 * H + 1) * (2 * W + 1) : (int64_t)B * Cout * H * W;
+    w.partial = w.z + (up == 2 ? al(out_elems * (int64_t)sizeof(float)) : 0);
+    // split-K is only chosen for launches with < 256 blocks: bound its buffer at 32 slices and 64 MiB
+    int64_t pf = out_elems * 32;
+    const int64_t cap = ((int64_t)64 << 20) / 4;
+    if (pf > cap) pf = (cap / out_elems) * out_elems;
+    w.partial_floats = pf;
+    w.total = w.partial + al(pf * (int64_t)sizeof(float));
+    return w;
 }
 
 }  // namespace
@@ -470,11 +565,9 @@ TDGP_API int tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int C
     return TDGP_OK;
 }
 
+
 TDGP_API int64_t tdgp_modconv2d_workspace_bytes(int B, int Cin, int Cout, int H, int W, int k, int up) {
-    int64_t bytes = (int64_t)B * Cout * sizeof(float);                                  // demod coefficients
-    bytes = (bytes + 255) / 256 * 256;
-    if (up == 2) bytes += (int64_t)B * Cout * (2 * H + 1) * (2 * W + 1) * sizeof(float);  // transposed-conv intermediate
-    return bytes;
+    return ws_layout(B, Cin, Cout, H, W, k, up).total;
 }
 
 TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styles, const float* noise, int64_t noise_bstride,
@@ -490,39 +583,35 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
     TDGP_CHECK(!demodulate || styles, TDGP_EINVAL, "modconv2d: demodulate needs styles");
     TDGP_CHECK(act >= 1 && act <= 9, TDGP_EUNSUPPORTED, "modconv2d: unknown activation %d", act);
     TDGP_CHECK(out_layout == 0 || (out_layout == 1 && out_feat >= 1 && (Cout % out_feat) == 0 && up == 1), TDGP_EINVAL, "modconv2d: bad output layout");
-    TDGP_CHECK((int64_t)B * Cin * H * W <= INT32_MAX && (int64_t)B * Cout * H * up * W * up <= INT32_MAX, TDGP_EINVAL, "modconv2d: tensor too large");
-    const int64_t need = tdgp_modconv2d_workspace_bytes(B, Cin, Cout, H, W, k, up);
-    TDGP_CHECK((!demodulate && up == 1) || (workspace && workspace_bytes >= need), TDGP_EWORKSPACE, "modconv2d: workspace %lld < %lld bytes",
-               (long long)workspace_bytes, (long long)need);
+    TDGP_CHECK((int64_t)B * Cin * H * W <= INT32_MAX && (int64_t)B * Cout * (H * up + 1) * (W * up + 1) <= INT32_MAX, TDGP_EINVAL, "modconv2d: tensor too large");
+    const WsLayout wl = ws_layout(B, Cin, Cout, H, W, k, up);
+    TDGP_CHECK(workspace && workspace_bytes >= wl.total, TDGP_EWORKSPACE, "modconv2d: workspace %lld < %lld bytes", (long long)workspace_bytes,
+               (long long)wl.total);
     hipStream_t s = (hipStream_t)stream;
     const PackInfo pi = pack_info(Cout, Cin, k);
     const float* wp = (const float*)wpack;
     const float* wsq = wp + pi.wp_floats;
-    float* dco = nullptr;
-    float* z = nullptr;
-    if (workspace) {
-        dco = (float*)workspace;
-        z = (float*)((char*)workspace + (((int64_t)B * Cout * sizeof(float) + 255) / 256 * 256));
-    }
-    if (demodulate) {
-        TDGP_LAUNCH("demod_kernel", demod_kernel, dim3(cdiv(B * Cout, 256)), dim3(256), 0, s, styles, wsq, dco, B, Cin, Cout, pi.CoutP);
-    } else {
-        dco = nullptr;
-    }
+    float* dco = (float*)((char*)workspace + wl.dco);
+    float* z = (float*)((char*)workspace + wl.z);
+    float* partial = (float*)((char*)workspace + wl.partial);
+    if (demodulate) TDGP_LAUNCH("demod_kernel", demod_kernel, dim3(cdiv(Cout, 64), B), dim3(1024), 0, s, styles, wsq, dco, B, Cin, Cout, pi.CoutP);
+    else dco = nullptr;
 
     ConvParams p;
     p.x = x; p.wp = wp; p.styles = styles; p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutP = pi.CoutP; p.Hin = H; p.Win = W;
-    p.T = pi.T; p.KC = pi.KC;
-    for (int i = 0; i < 16; i++) p.fir[i] = 0.f;
+    p.T = pi.T; p.KC = pi.KC; p.ksplit = 1; p.partial = nullptr;
+    EpiParams& e = p.e;
+    e.B = B; e.Cout = Cout;
+    for (int i = 0; i < 16; i++) e.fir[i] = 0.f;
     if (fir4x4) {
         // fir4x4 is a HOST pointer (the filter is a static 64-byte buffer; reading it on the host keeps the call async)
         for (int ky = 0; ky < 4; ky++)
-            for (int kx = 0; kx < 4; kx++) p.fir[ky * 4 + kx] = fir4x4[(3 - ky) * 4 + (3 - kx)] * 4.0f;   // no flip_filter: taps = flipped f; gain up^2
+            for (int kx = 0; kx < 4; kx++) e.fir[ky * 4 + kx] = fir4x4[(3 - ky) * 4 + (3 - kx)] * 4.0f;   // no flip_filter: taps = flipped f; gain up^2
     }
     if (up == 1) {
-        p.dcoef = dco; p.noise = noise; p.noise_bstride = noise_bstride; p.bias = bias; p.skip = skip; p.y = y;
-        p.Hout = H; p.Wout = W; p.out_layout = out_layout; p.out_feat = out_feat > 0 ? out_feat : 1;
-        p.act = act; p.alpha = alpha; p.gain = gain; p.clamp = clamp;
+        e.dcoef = dco; e.noise = noise; e.noise_bstride = noise_bstride; e.bias = bias; e.skip = skip; e.y = y;
+        e.Hout = H; e.Wout = W; e.out_layout = out_layout; e.out_feat = out_feat > 0 ? out_feat : 1;
+        e.act = act; e.alpha = alpha; e.gain = gain; e.clamp = clamp;
         p.nphases = 1;
         Phase& ph = p.ph[0];
         ph.ntaps = k * k;
@@ -534,33 +623,33 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         ph.gridH = H; ph.gridW = W; ph.oy_mul = 1; ph.oy_add = 0; ph.ox_mul = 1; ph.ox_add = 0;
         p.tw_log2 = pick_tw_log2(W);
         if (k == 3) {
-            if (Cout > 64) launch_conv<2, 2, 2, 2, 8, 9>(p, px_tiles(p, 4), s);
-            else launch_conv<2, 2, 1, 4, 8, 9>(p, px_tiles(p, 8), s);
+            if (Cout > 64) launch_conv<2, 2, 2, 2, 8, 9>(p, partial, wl.partial_floats, s);
+            else launch_conv<2, 2, 1, 4, 8, 9>(p, partial, wl.partial_floats, s);
         } else {
-            if (Cout > 64 && Cout <= 96) launch_conv<3, 1, 1, 4, 32, 1>(p, px_tiles(p, 4), s);
-            else if (Cout > 64) launch_conv<2, 2, 2, 2, 32, 1>(p, px_tiles(p, 4), s);
-            else launch_conv<2, 2, 1, 4, 32, 1>(p, px_tiles(p, 8), s);
+            if (Cout > 64 && Cout <= 96) launch_conv<3, 1, 1, 4, 32, 1>(p, partial, wl.partial_floats, s);
+            else if (Cout > 64) launch_conv<2, 2, 2, 2, 32, 1>(p, partial, wl.partial_floats, s);
+            else launch_conv<2, 2, 1, 4, 32, 1>(p, partial, wl.partial_floats, s);
         }
     } else {
         // transposed conv, stride 2, UNFLIPPED weights (conv2d_resample.py:108-125): Z[2i+a, 2j+e] += w[a,e] * x[i,j]
         const int ZH = 2 * H + 1, ZW = 2 * W + 1;
-        p.dcoef = nullptr; p.noise = nullptr; p.noise_bstride = 0; p.bias = nullptr; p.skip = nullptr; p.y = z;
-        p.Hout = ZH; p.Wout = ZW; p.out_layout = 0; p.out_feat = 1;
-        p.act = 1; p.alpha = 0.f; p.gain = 1.f; p.clamp = -1.f;
+        e.dcoef = nullptr; e.noise = nullptr; e.noise_bstride = 0; e.bias = nullptr; e.skip = nullptr; e.y = z;
+        e.Hout = ZH; e.Wout = ZW; e.out_layout = 0; e.out_feat = 1;
+        e.act = 1; e.alpha = 0.f; e.gain = 1.f; e.clamp = -1.f;
         p.nphases = 4;
         for (int py = 0; py < 2; py++)
             for (int px = 0; px < 2; px++) {
                 Phase& ph = p.ph[py * 2 + px];
                 ph.ntaps = 0;
-                // row taps: py=0 -> (a=0, dy=0), (a=2, dy=-1); py=1 -> (a=1, dy=0)
+                // row taps: py=0 -> (a=0, dy=0), (a=2, dy=-1); py=1 -> (a=1, dy=0); same for columns
                 for (int a = 0; a < 3; a++) {
                     if ((a & 1) != py) continue;
-                    for (int e = 0; e < 3; e++) {
-                        if ((e & 1) != px) continue;
+                    for (int ee = 0; ee < 3; ee++) {
+                        if ((ee & 1) != px) continue;
                         const int t = ph.ntaps++;
-                        ph.tap_w[t] = a * 3 + e;
+                        ph.tap_w[t] = a * 3 + ee;
                         ph.tap_off_y[t] = (a == 2) ? -1 : 0;
-                        ph.tap_off_x[t] = (e == 2) ? -1 : 0;
+                        ph.tap_off_x[t] = (ee == 2) ? -1 : 0;
                     }
                 }
                 ph.gridH = (py == 0) ? H + 1 : H;
@@ -568,15 +657,15 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 ph.oy_mul = 2; ph.oy_add = py; ph.ox_mul = 2; ph.ox_add = px;
             }
         p.tw_log2 = pick_tw_log2(W + 1 > 32 ? 32 : W + 1);
-        if (Cout > 64) launch_conv<2, 2, 2, 2, 16, 4>(p, px_tiles(p, 4), s);
-        else launch_conv<2, 2, 1, 4, 16, 4>(p, px_tiles(p, 8), s);
+        if (Cout > 64) launch_conv<2, 2, 2, 2, 16, 4>(p, partial, wl.partial_floats, s);
+        else launch_conv<2, 2, 1, 4, 16, 4>(p, partial, wl.partial_floats, s);
         FirParams f;
         f.z = z; f.dcoef = dco; f.noise = noise; f.noise_bstride = noise_bstride; f.bias = bias; f.y = y;
-        for (int i = 0; i < 16; i++) f.fir[i] = p.fir[i];
+        for (int i = 0; i < 16; i++) f.fir[i] = e.fir[i];
         f.B = B; f.C = Cout; f.ZH = ZH; f.ZW = ZW; f.OH = 2 * H; f.OW = 2 * W;
         f.act = act; f.alpha = alpha; f.gain = gain; f.clamp = clamp;
-        const int64_t total = (int64_t)B * Cout * f.OH * ((f.OW + 3) / 4);
-        TDGP_LAUNCH("fir_act_kernel", fir_act_kernel, dim3((int)min((int64_t)(256 * 16), cdiv64(total, 256))), dim3(256), 0, s, f);
+        const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, FIR_TH) * cdiv(f.OW, FIR_TW);
+        TDGP_LAUNCH("fir_act_kernel", fir_act_kernel, dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
     }
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
