@@ -211,39 +211,71 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     const int it_per = (niter + p.ksplit - 1) / p.ksplit;
     const int it0 = ks * it_per, it1 = min(niter, it0 + it_per);
 
-    for (int it = it0; it < it1; it++) {
-        __syncthreads();
-        // ---- stage A: rows (t, g, c8) -> As[(t*KCS + g*KC + c8)][BM] ---------------------------------
-        for (int e = tid; e < arows * (BM / 4); e += 256) {
-            const int row = e / (BM / 4), j4 = e % (BM / 4);
-            const int t = row / KCS, ci = row % KCS;
-            const int g = ci / p.KC, c8 = ci % p.KC;
-            const int cc = it * G + g;
+    // ---- K loop, software pipelined: the global loads of chunk it+1 (packed weights as 16-B vectors, the halo'd
+    // activation patch as scalars) are issued BEFORE the MFMA loop of chunk it and only waited for when they are
+    // written to LDS after it, so HBM/L2 latency hides behind ~9k cycles of matrix work instead of being exposed
+    // between two barriers.  One LDS buffer, two barriers per chunk (read-done, write-done).
+    constexpr int NA = (MAXT * KCS * (BM / 4) + 255) / 256;     // float4 of the A tile per thread
+    float4 a_reg[NA];
+    float x_reg[NPOS][KCS];
+
+    auto load_stage = [&](int it) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int e = tid + i * 256;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int o = m0 + j4 * 4;
-            if (cc < nchunks_packed && o < p.CoutP)
-                v = *(const float4*)(p.wp + ((int64_t)(cc * p.T + ph.tap_w[t]) * p.KC + c8) * p.CoutP + o);
-            *(float4*)(As + row * BM + j4 * 4) = v;
+            if (e < arows * (BM / 4)) {
+                const int row = e / (BM / 4), j4 = e % (BM / 4);
+                const int t = row / KCS, ci = row % KCS;
+                const int g = ci / p.KC, c8 = ci % p.KC;
+                const int cc = it * G + g;
+                const int o = m0 + j4 * 4;
+                if (cc < nchunks_packed && o < p.CoutP)
+                    v = *(const float4*)(p.wp + ((int64_t)(cc * p.T + ph.tap_w[t]) * p.KC + c8) * p.CoutP + o);
+            }
+            a_reg[i] = v;
         }
-        // ---- stage X patch (style-modulated) ---------------------------------------------------------
+        const int c0 = it * KCS;
+#pragma unroll
+        for (int k = 0; k < NPOS; k++) {
+            const int off = pos_off[k];
+#pragma unroll
+            for (int ci = 0; ci < KCS; ci++) {
+                const int c = c0 + ci;
+                x_reg[k][ci] = (off >= 0 && c < p.Cin) ? p.x[(int64_t)off + (int64_t)c * chw] : 0.f;
+            }
+        }
+    };
+    auto store_stage = [&](int it) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int e = tid + i * 256;
+            if (e < arows * (BM / 4)) *(float4*)(As + (e / (BM / 4)) * BM + (e % (BM / 4)) * 4) = a_reg[i];
+        }
         const int c0 = it * KCS;
 #pragma unroll
         for (int k = 0; k < NPOS; k++) {
             const int pos = tid + k * 256;
             if (pos < PSZ) {
-                const int off = pos_off[k];
+#pragma unroll
                 for (int ci = 0; ci < KCS; ci++) {
                     const int c = c0 + ci;
-                    float v = 0.f;
-                    if (off >= 0 && c < p.Cin) {
-                        v = p.x[(int64_t)off + (int64_t)c * chw];
-                        if (p.styles) v = v * p.styles[pos_sb[k] + c];
-                    }
+                    float v = x_reg[k][ci];
+                    if (p.styles && pos_off[k] >= 0 && c < p.Cin) v = v * p.styles[pos_sb[k] + c];     // modulation rides on the staging
                     Xs[ci * PSZ + pos] = v;
                 }
             }
         }
-        __syncthreads();
+    };
+
+    if (it0 < it1) {
+        load_stage(it0);
+        store_stage(it0);
+    }
+    __syncthreads();
+    for (int it = it0; it < it1; it++) {
+        const bool more = it + 1 < it1;
+        if (more) load_stage(it + 1);
         // ---- MFMA over (tap, channel pair) -------------------------------------------------------------
         for (int t = 0; t < ph.ntaps; t++) {
             const int toff = (ph.tap_off_y[t] + 1) * PC + (ph.tap_off_x[t] + 1);
@@ -263,6 +295,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
                     for (int n = 0; n < NTW; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bq[n], acc[m][n], 0, 0, 0);
             }
+        }
+        __syncthreads();                               // everyone finished reading As / Xs
+        if (more) {
+            store_stage(it + 1);
+            __syncthreads();
         }
     }
 

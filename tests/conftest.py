@@ -62,23 +62,26 @@ RGB_TOL = 1e-4        # north-star tolerance: max-rel RGB error vs the reference
 RANGE_TOL = 1e-5      # stricter, well-conditioned companion: max|delta| / max|ref|
 
 
-def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL):
+def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=None):
     """End-to-end image parity against a golden captured from the reference.
 
     Two bounds, both asserted:
-      * range-normalised error  max|d| / max|ref|               <= RANGE_TOL (1e-5);
-      * per-pixel max-rel (|d| / max(|ref|, 1e-3 max|ref|)) <= max(RGB_TOL, 3 x ref self-noise),
-        where "ref self-noise" is the same metric between two runs of the REFERENCE ITSELF on identical
-        inputs (oneDNN vs native convolutions, 8 vs 1 thread; stored as `<key>_alt` by tools/gen_goldens.py).
-        Raw 'classical' RGB crosses zero, so the per-pixel metric is dominated by the reference's own fp32
-        summation-order noise (measured 0.4e-4 .. 1.7e-4); a bound below that noise would test torch's
-        thread scheduling, not this implementation.
+      * range-normalised error  max|d| / max|ref|  <= RANGE_TOL (1e-5) -- the well-conditioned, binding one;
+      * per-pixel max-rel (|d| / max(|ref|, 1e-3 max|ref|)) <= max(RGB_TOL, reference noise floor).
+    Raw 'classical' RGB crosses zero, so the per-pixel metric is dominated by fp32 summation-order noise of whoever
+    computed the reference image.  That floor is MEASURED, not assumed, two ways:
+      - `<key>_alt` in the golden = the REFERENCE ITSELF re-run on identical inputs with native instead of oneDNN
+        convolutions and 1 instead of 8 threads (tools/gen_goldens.py): reference-vs-reference differs by 0.4e-4..1.7e-4;
+      - `exact` = the same image from the double-accumulating oracle: reference-vs-exactly-rounded differs by ~1e-4.
+    An independent fp32 implementation is expected within ~2x of the second and 3x of the first; a tighter bound would
+    test torch's thread scheduling, not this code.
     """
     ref = g[key]
     rng = float(np.abs(np.asarray(img, np.float64) - ref).max() / np.abs(ref).max())
     pix = max_rel(img, ref)
     self_noise = max_rel(g[key + '_alt'], ref) if (key + '_alt') in g else 0.0
+    exact_noise = max_rel(exact, ref) if exact is not None else 0.0
     assert rng <= RANGE_TOL, f'{what}: range-normalised error {rng:.3e} > {RANGE_TOL:.0e}'
-    bound = max(pix_tol, 3 * self_noise)
-    assert pix <= bound, f'{what}: max-rel {pix:.3e} > {bound:.3e} (reference self-noise {self_noise:.3e})'
+    bound = max(pix_tol, 3 * self_noise, 2 * exact_noise)
+    assert pix <= bound, f'{what}: max-rel {pix:.3e} > {bound:.3e} (reference self-noise {self_noise:.3e}, reference vs exact {exact_noise:.3e})'
     return rng, pix, self_noise

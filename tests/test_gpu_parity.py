@@ -308,6 +308,13 @@ def _cam(g):
     return {k[4:]: T(v) for k, v in g.items() if k.startswith('cam_')}
 
 
+def _exact(oracle, tdgp, cfg, seed, g):
+    """The same image from the double-accumulating oracle: calibrates the reference's own fp32 noise (conftest.assert_image_parity)."""
+    sd = tdgp.weights.random_state_dict(cfg, seed=seed, exercise_all=True)
+    cam = {k[4:]: v for k, v in g.items() if k.startswith('cam_')}
+    return oracle.synthesis_forward(sd, cfg.to_dict(), g['ws'], cam, g['u_coarse'], g['u_fine'], 'const')
+
+
 def test_mapping(tdgp):
     g = load_golden('mapping')
     for tag, cfg in [('c0', tdgp.config.config_tiny()), ('c10', tdgp.config.config_mid())]:
@@ -327,10 +334,11 @@ def test_e2e_tiny(tdgp, oracle):
     hwc = G.synthesis.tri_plane_decoder(ws, noise_mode='const', hwc=True).t
     np.testing.assert_array_equal(N(hwc.permute(0, 1, 4, 2, 3).reshape(planes.shape)), N(planes))
     out = G.synthesis(ws, camera_params=_cam(g), noise_mode='const', render_opts=dict(return_depth=True), u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
-    assert_image_parity(N(out.img), g, 'img')
-    assert_image_parity(N(out.depth), g, 'depth', 'depth')
+    ex_img, ex_depth = _exact(oracle, tdgp, cfg, 21, g)
+    assert_image_parity(N(out.img), g, 'img', exact=ex_img)
+    assert_image_parity(N(out.depth), g, 'depth', 'depth', exact=ex_depth)
     img2 = G(T(g['z']), T(g['c']), _cam(g), noise_mode='const', u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
-    assert_image_parity(N(img2), g, 'img via Generator.forward')
+    assert_image_parity(N(img2), g, 'img via Generator.forward', exact=ex_img)
     img3 = G.synthesis(ws, camera_params=_cam(g), noise_mode='none', u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
     assert_close(N(img3), g['img_noise_none'], 1e-5, 'img noise none', 1.0)
     # renderer integer rows on the golden planes: inds and sort permutation vs the oracle, exact
@@ -350,17 +358,18 @@ def test_e2e_tiny(tdgp, oracle):
     assert mism_i < 2e-3 and mism_p < 5e-3, (mism_i, mism_p)
 
 
-def test_e2e_mid(tdgp):
+def test_e2e_mid(tdgp, oracle):
     cfg = tdgp.config.config_mid()
     g = load_golden('e2e_mid')
     G = _gen(tdgp, cfg, 31)
     out = G.synthesis(T(g['ws']), camera_params=_cam(g), noise_mode='const', render_opts=dict(return_depth=True), u_coarse=T(g['u_coarse']),
                       u_fine=T(g['u_fine']))
-    assert_image_parity(N(out.img), g, 'img')
-    assert_image_parity(N(out.depth), g, 'depth', 'depth')
+    ex_img, ex_depth = _exact(oracle, tdgp, cfg, 31, g)
+    assert_image_parity(N(out.img), g, 'img', exact=ex_img)
+    assert_image_parity(N(out.depth), g, 'depth', 'depth', exact=ex_depth)
 
 
-def test_e2e_tiny_mip(tdgp):
+def test_e2e_tiny_mip(tdgp, oracle):
     cfg = tdgp.config.config_tiny()
     cfg.ray_marcher_type = 'mip'
     cfg.white_back = True
@@ -368,8 +377,9 @@ def test_e2e_tiny_mip(tdgp):
     G = _gen(tdgp, cfg, 41)
     out = G.synthesis(T(g['ws']), camera_params=_cam(g), noise_mode='const', render_opts=dict(return_depth=True), u_coarse=T(g['u_coarse']),
                       u_fine=T(g['u_fine']))
-    assert_image_parity(N(out.img), g, 'img')
-    assert_image_parity(N(out.depth), g, 'depth', 'depth')
+    ex_img, ex_depth = _exact(oracle, tdgp, cfg, 41, g)
+    assert_image_parity(N(out.img), g, 'img', exact=ex_img)
+    assert_image_parity(N(out.depth), g, 'depth', 'depth', exact=ex_depth)
 
 
 def test_e2e_vs_oracle_bigger(tdgp, oracle):
