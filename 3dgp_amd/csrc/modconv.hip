@@ -24,13 +24,14 @@
 //   * ToRGB (1x1, no demod) fuses bias, the x2 FIR upsample of the previous image and the skip add, and can
 //     emit the renderer's channel-last plane layout directly.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int KC3 = 8;    // packed channel chunk for 3x3 weights
-constexpr int KC1 = 32;   // packed channel chunk for 1x1 weights
+constexpr int KC3 = 4;    // packed channel chunk for 3x3 weights
+constexpr int KC1 = 16;   // packed channel chunk for 1x1 weights
 
 struct Phase {
     int ntaps;
@@ -43,7 +44,8 @@ struct Phase {
 
 // Everything the output stage needs (shared by the conv kernel's own epilogue and the split-K reduction kernel).
 struct EpiParams {
-    const float* dcoef; const float* noise; const float* bias; const float* skip; float* y;
+    const float* __restrict__ dcoef; const float* __restrict__ noise; const float* __restrict__ bias; const float* __restrict__ skip;
+    float* __restrict__ y;
     int64_t noise_bstride;
     float fir[16];      // flipped filter * gain for the fused skip upsample
     int B, Cout, Hout, Wout;    // dims of the output tensor
@@ -58,6 +60,7 @@ struct ConvParams {
     int B, Cin, Cout, CoutP, Hin, Win, T, KC;
     int tw_log2;
     int nphases, ksplit;
+    int dbg;            // TDGP_CONV_DBG ablations: bit0 skip the MFMA loop, bit1 skip re-staging (timing experiments only)
     Phase ph[4];
 };
 
@@ -78,27 +81,38 @@ __device__ __forceinline__ float act_apply(float v, int act, float alpha) {
 }
 
 // x2 FIR upsample of the previous-resolution image at output pixel (oy,ox): upfirdn2d.upsample2d
-// (upfirdn2d.py:313-348: up 2, pad [2,1,2,1], gain 4), only the structurally non-zero taps.
+// (upfirdn2d.py:313-348: up 2, pad [2,1,2,1], gain 4).  Of the 4x4 taps only a 2x2 subset hits non-zero (even) positions
+// of the zero-stuffed image: rows r0 = (oy-1)>>1 and r0+1 with taps ky = (oy&1), (oy&1)+2 -- same for columns.
+// Branch-free: 4 clamped loads issued together, invalid taps get weight 0.
 // img points at the (b, channel) plane; `stride` = element stride between neighbouring pixels (1 for NCHW, feat for
 // the channel-last plane layout).
-template <bool CL>
-__device__ __forceinline__ float skip_upsample(const float* __restrict__ img, int h2, int w2, int oy, int ox, const float* fir, int stride) {
-    float acc = 0.f;
-#pragma unroll
-    for (int ky = 0; ky < 4; ky++) {
-        const int uy = oy + ky - 2;
-        if (uy < 0 || uy >= 2 * h2 || (uy & 1)) continue;
-#pragma unroll
-        for (int kx = 0; kx < 4; kx++) {
-            const int ux = ox + kx - 2;
-            if (ux < 0 || ux >= 2 * w2 || (ux & 1)) continue;
-            acc = fmaf_(fir[ky * 4 + kx], img[(int64_t)((uy >> 1) * w2 + (ux >> 1)) * (CL ? stride : 1)], acc);
-        }
-    }
-    return acc;
+struct SkipTaps { int i00, i01, i10, i11; float w00, w01, w10, w11; };
+__device__ __forceinline__ SkipTaps skip_taps(int h2, int w2, int oy, int ox, const float* fir) {
+    SkipTaps t;
+    const int r0 = (oy - 1) >> 1, c0 = (ox - 1) >> 1;           // arithmetic shift: -1 for oy = 0
+    const int ky0 = oy & 1, kx0 = ox & 1;
+    const bool vr0 = r0 >= 0, vr1 = r0 + 1 < h2, vc0 = c0 >= 0, vc1 = c0 + 1 < w2;
+    const int ra = vr0 ? r0 : 0, rb = vr1 ? r0 + 1 : h2 - 1, ca = vc0 ? c0 : 0, cb = vc1 ? c0 + 1 : w2 - 1;
+    t.i00 = ra * w2 + ca; t.i01 = ra * w2 + cb; t.i10 = rb * w2 + ca; t.i11 = rb * w2 + cb;
+    t.w00 = (vr0 && vc0) ? fir[ky0 * 4 + kx0] : 0.f;
+    t.w01 = (vr0 && vc1) ? fir[ky0 * 4 + kx0 + 2] : 0.f;
+    t.w10 = (vr1 && vc0) ? fir[(ky0 + 2) * 4 + kx0] : 0.f;
+    t.w11 = (vr1 && vc1) ? fir[(ky0 + 2) * 4 + kx0 + 2] : 0.f;
+    return t;
+}
+__device__ __forceinline__ float skip_eval(const float* __restrict__ img, const SkipTaps& t, int stride) {
+    const float a = img[(int64_t)t.i00 * stride], b = img[(int64_t)t.i01 * stride], c = img[(int64_t)t.i10 * stride], d = img[(int64_t)t.i11 * stride];
+    return fmaf_(t.w11, d, fmaf_(t.w10, c, fmaf_(t.w01, b, t.w00 * a)));
 }
 
-// demod * acc + noise + bias (+ FIR-upsampled skip) -> activation * gain -> clamp -> store (NCHW or channel-last planes)
+__device__ __forceinline__ float finish_act(const EpiParams& e, float v) {
+    v = act_apply(v, e.act, e.alpha) * e.gain;
+    if (e.clamp >= 0.f) v = v < -e.clamp ? -e.clamp : (v > e.clamp ? e.clamp : v);
+    return v;
+}
+
+// demod * acc + noise + bias (+ FIR-upsampled skip) -> activation * gain -> clamp -> store (NCHW or channel-last planes);
+// element-at-a-time form used by the split-K reduction.
 __device__ __forceinline__ void epilogue_store(const EpiParams& e, float v, int b, int o, int oy, int ox) {
     if (e.dcoef) v = v * e.dcoef[b * e.Cout + o];
     if (e.noise) v = v + e.noise[b * e.noise_bstride + (int64_t)oy * e.Wout + ox];
@@ -106,22 +120,97 @@ __device__ __forceinline__ void epilogue_store(const EpiParams& e, float v, int 
     const int h2 = e.Hout / 2, w2 = e.Wout / 2;
     int64_t addr;
     if (e.out_layout == 0) {
-        if (e.skip) v = v + skip_upsample<false>(e.skip + ((int64_t)b * e.Cout + o) * h2 * w2, h2, w2, oy, ox, e.fir, 1);
+        if (e.skip) v = v + skip_eval(e.skip + ((int64_t)b * e.Cout + o) * h2 * w2, skip_taps(h2, w2, oy, ox, e.fir), 1);
         addr = (((int64_t)b * e.Cout + o) * e.Hout + oy) * e.Wout + ox;
     } else {
         const int pl = o / e.out_feat, f = o % e.out_feat;
         const int64_t plane = (int64_t)b * (e.Cout / e.out_feat) + pl;
-        if (e.skip) v = v + skip_upsample<true>(e.skip + plane * h2 * w2 * e.out_feat + f, h2, w2, oy, ox, e.fir, e.out_feat);
+        if (e.skip) v = v + skip_eval(e.skip + plane * h2 * w2 * e.out_feat + f, skip_taps(h2, w2, oy, ox, e.fir), e.out_feat);
         addr = ((plane * e.Hout + oy) * e.Wout + ox) * e.out_feat + f;
     }
-    v = act_apply(v, e.act, e.alpha) * e.gain;
-    if (e.clamp >= 0.f) v = v < -e.clamp ? -e.clamp : (v > e.clamp ? e.clamp : v);
-    e.y[addr] = v;
+    e.y[addr] = finish_act(e, v);
+}
+
+// Output stage for one 32(channels) x 32(pixels) accumulator tile parked in a per-wave LDS tile ct[32][33].
+// Called from ONE place inside a rolled loop over the wave's tiles (code size, registers).
+//   layout 0 (NCHW) and raw split-K partials: lane = pixel (32 consecutive x -> 128-B row segments), 16 channels per lane;
+//   layout 1 (channel-last planes):           lane = channel (32 consecutive features = one 128-B texel line), 16 pixels
+//                                             per lane, pixel coordinates fetched from the owning lane by shuffle.
+// Side inputs (demod, bias, noise, skip taps) are loaded in batches of 8 before the math so their latencies overlap.
+__device__ __forceinline__ void epilogue_tile(const EpiParams& e, const float* ct, int obase, int pb, int poy, int pox, int pok, float* part) {
+    const int l = lane_id(), l32 = l & 31, half = l >> 5;
+    const int h2 = e.Hout / 2, w2 = e.Wout / 2;
+    const bool raw = part != nullptr;
+    if (raw || e.out_layout == 0) {
+        float* dst = raw ? part : e.y;
+        const int pix = (pb * e.Cout * e.Hout + poy) * e.Wout + pox;          // + o * Hout * Wout   (tensor < 2^31 elements)
+        const int cstride = e.Hout * e.Wout;
+        const float nz = (!raw && e.noise && pok) ? e.noise[pb * e.noise_bstride + (int64_t)poy * e.Wout + pox] : 0.f;
+        SkipTaps st;
+        if (!raw && e.skip) st = skip_taps(h2, w2, poy, pox, e.fir);
+#pragma unroll 1
+        for (int g = 0; g < 2; g++) {
+            float dv[8], bv[8], sk[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int o = obase + (g * 8 + q) * 2 + half;
+                const bool ok = pok && o < e.Cout;
+                dv[q] = (!raw && e.dcoef && ok) ? e.dcoef[pb * e.Cout + o] : 1.f;
+                bv[q] = (!raw && e.bias && ok) ? e.bias[o] : 0.f;
+                sk[q] = (!raw && e.skip && ok) ? skip_eval(e.skip + ((int64_t)pb * e.Cout + o) * h2 * w2, st, 1) : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int sel = (g * 8 + q) * 2 + half;
+                const int o = obase + sel;
+                if (pok && o < e.Cout) {
+                    float v = ct[sel * 33 + l32];
+                    if (!raw) v = finish_act(e, ((v * dv[q] + nz) + bv[q]) + sk[q]);
+                    dst[pix + o * cstride] = v;
+                }
+            }
+        }
+    } else {
+        const int o = obase + l32;
+        const bool okc = o < e.Cout;
+        const int pl = o / e.out_feat, f = o % e.out_feat;
+        const int planes = e.Cout / e.out_feat;
+        const float bias = (e.bias && okc) ? e.bias[o] : 0.f;
+#pragma unroll 1
+        for (int g = 0; g < 2; g++) {
+            float sk[8], dv[8], nz[8];
+            int addr[8], okp[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int sel = (g * 8 + q) * 2 + half;
+                const int b = __shfl(pb, sel, 64), oy = __shfl(poy, sel, 64), ox = __shfl(pox, sel, 64);
+                okp[q] = __shfl(pok, sel, 64) && okc;
+                const int plane = b * planes + pl;
+                addr[q] = ((plane * e.Hout + oy) * e.Wout + ox) * e.out_feat + f;
+                dv[q] = (e.dcoef && okp[q]) ? e.dcoef[b * e.Cout + o] : 1.f;
+                nz[q] = (e.noise && okp[q]) ? e.noise[b * e.noise_bstride + (int64_t)oy * e.Wout + ox] : 0.f;
+                sk[q] = (e.skip && okp[q]) ? skip_eval(e.skip + (int64_t)plane * h2 * w2 * e.out_feat + f, skip_taps(h2, w2, oy, ox, e.fir), e.out_feat) : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (okp[q]) {
+                    const float v = ct[l32 * 33 + (g * 8 + q) * 2 + half];
+                    e.y[addr[q]] = finish_act(e, ((v * dv[q] + nz[q]) + bias) + sk[q]);
+                }
+            }
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution.  Block = 256 threads = WM x WN waves, wave tile = (MTW*32) x (NTW*32).
 // KCS = channels staged per K iteration (a multiple of the packed chunk p.KC), MAXT = max taps per phase.
+//
+// K loop: double-buffered LDS, ONE barrier per iteration.
+//   issue global loads of chunk it+1 (packed weights as 16-B vectors, the halo'd activation patch as scalars)
+//   -> MFMA over chunk it from LDS buffer `cur` (fragments double-buffered in registers: the ds_reads of step s+1
+//      are issued before the MFMAs of step s, no scalar loads inside, so LDS latency hides behind the matrix pipe)
+//   -> write the landed registers (x style) into LDS buffer `cur ^ 1` -> barrier.
 // -------------------------------------------------------------------------------------------------
 template <int MTW, int NTW, int WM, int WN, int KCS, int MAXT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
@@ -129,9 +218,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     constexpr int NT = NTW * WN;            // 32-pixel subtiles per block
     constexpr int BN = 32 * NT;
     constexpr int XS_MAX = (BN / 4 + 2) * (4 + 2) > (BN / 32 + 2) * (32 + 2) ? (BN / 4 + 2) * (4 + 2) : (BN / 32 + 2) * (32 + 2);
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                               // [MAXT*KCS][BM]
-    float* Xs = smem + MAXT * KCS * BM;             // [KCS][PSZ]
+    constexpr int AS_SZ = MAXT * KCS * BM, XS_SZ = KCS * XS_MAX, BUF_SZ = AS_SZ + XS_SZ + 64;   // +64: fragment prefetch past the last row
+    constexpr int KH = KCS / 2;             // k-steps (of 2 channels) per tap; even
+    static_assert(KH % 2 == 0, "KCS must be a multiple of 4");
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][As | Xs], then the tap-offset table
+    int* toff_tab = (int*)(smem + 2 * BUF_SZ);                      // [MAXT + 2]
 
     const int phase_id = blockIdx.z % p.nphases, ks = blockIdx.z / p.nphases;
     const Phase& ph = p.ph[phase_id];
@@ -150,6 +241,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
     const int l32 = l & 31, half = l >> 5;
     const int wm = wv / WN, wn = wv % WN;
+
+    if (tid < MAXT + 2) toff_tab[tid] = tid < ph.ntaps ? (ph.tap_off_y[tid] + 1) * PC + (ph.tap_off_x[tid] + 1) : 0;
 
     // ---- per-thread patch positions (fixed across the K loop) -------------------------------------
     constexpr int NPOS = (XS_MAX + 255) / 256;
@@ -186,7 +279,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         const int bb = vr / ph.gridH, m = vr % ph.gridH;
         px_b[n] = bb; px_m[n] = m; px_n[n] = nn;
         px_ok[n] = vr < VR && nn < ph.gridW;
-        px_base[n] = lr * PC + lc;
+        px_base[n] = lr * PC + lc + half * PSZ;     // + the lane's channel of the pair
         int mask = 0;
         for (int t = 0; t < ph.ntaps; t++) {
             const int iy = m + ph.tap_off_y[t];
@@ -207,146 +300,143 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     const int nchunks_packed = (p.Cin + p.KC - 1) / p.KC;
     const int niter = (nchunks_packed + G - 1) / G;
     const int arows = ph.ntaps * KCS;
-    // split-K: this block reduces iterations [it0, it1)
-    const int it_per = (niter + p.ksplit - 1) / p.ksplit;
+    const int it_per = (niter + p.ksplit - 1) / p.ksplit;          // split-K: this block reduces iterations [it0, it1)
     const int it0 = ks * it_per, it1 = min(niter, it0 + it_per);
 
-    // ---- K loop, software pipelined: the global loads of chunk it+1 (packed weights as 16-B vectors, the halo'd
-    // activation patch as scalars) are issued BEFORE the MFMA loop of chunk it and only waited for when they are
-    // written to LDS after it, so HBM/L2 latency hides behind ~9k cycles of matrix work instead of being exposed
-    // between two barriers.  One LDS buffer, two barriers per chunk (read-done, write-done).
     constexpr int NA = (MAXT * KCS * (BM / 4) + 255) / 256;     // float4 of the A tile per thread
     float4 a_reg[NA];
-    float x_reg[NPOS][KCS];
+    float x_reg[NPOS][KCS], s_reg[NPOS][KCS];
+    // Everything about a thread's staging slots that does not depend on the K iteration is computed once: global offsets
+    // advance by a uniform stride per iteration (the packed weights are zero-padded to whole iterations).
+    int a_goff[NA], a_loff[NA];                       // global float offset at iteration 0 (-1: slot unused), LDS float offset
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int e = tid + i * 256;
+        a_goff[i] = -1; a_loff[i] = 0;
+        if (e < arows * (BM / 4)) {
+            const int row = e / (BM / 4), j4 = e % (BM / 4);
+            const int t = row / KCS, ci = row % KCS;
+            const int g = ci / p.KC, c8 = ci % p.KC;
+            const int o = m0 + j4 * 4;
+            a_loff[i] = row * BM + j4 * 4;
+            if (o < p.CoutP) a_goff[i] = ((g * p.T + ph.tap_w[t]) * p.KC + c8) * p.CoutP + o;
+        }
+    }
+    const int a_gstride = G * p.T * p.KC * p.CoutP;
 
     auto load_stage = [&](int it) {
+        const float* wp_it = p.wp + (int64_t)it * a_gstride;
 #pragma unroll
-        for (int i = 0; i < NA; i++) {
-            const int e = tid + i * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < arows * (BM / 4)) {
-                const int row = e / (BM / 4), j4 = e % (BM / 4);
-                const int t = row / KCS, ci = row % KCS;
-                const int g = ci / p.KC, c8 = ci % p.KC;
-                const int cc = it * G + g;
-                const int o = m0 + j4 * 4;
-                if (cc < nchunks_packed && o < p.CoutP)
-                    v = *(const float4*)(p.wp + ((int64_t)(cc * p.T + ph.tap_w[t]) * p.KC + c8) * p.CoutP + o);
-            }
-            a_reg[i] = v;
-        }
+        for (int i = 0; i < NA; i++) a_reg[i] = a_goff[i] >= 0 ? *(const float4*)(wp_it + a_goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
         const int c0 = it * KCS;
+        const float* x_it = p.x + (int64_t)c0 * chw;
 #pragma unroll
         for (int k = 0; k < NPOS; k++) {
             const int off = pos_off[k];
 #pragma unroll
             for (int ci = 0; ci < KCS; ci++) {
-                const int c = c0 + ci;
-                x_reg[k][ci] = (off >= 0 && c < p.Cin) ? p.x[(int64_t)off + (int64_t)c * chw] : 0.f;
+                const bool ok = off >= 0 && c0 + ci < p.Cin;
+                x_reg[k][ci] = ok ? x_it[off + ci * chw] : 0.f;
+                s_reg[k][ci] = (ok && p.styles) ? p.styles[pos_sb[k] + c0 + ci] : 1.f;
             }
         }
     };
-    auto store_stage = [&](int it) {
+    auto store_stage = [&](float* As, float* Xs) {
 #pragma unroll
-        for (int i = 0; i < NA; i++) {
-            const int e = tid + i * 256;
-            if (e < arows * (BM / 4)) *(float4*)(As + (e / (BM / 4)) * BM + (e % (BM / 4)) * 4) = a_reg[i];
-        }
-        const int c0 = it * KCS;
+        for (int i = 0; i < NA; i++)
+            if (tid + i * 256 < arows * (BM / 4)) *(float4*)(As + a_loff[i]) = a_reg[i];
 #pragma unroll
         for (int k = 0; k < NPOS; k++) {
             const int pos = tid + k * 256;
             if (pos < PSZ) {
 #pragma unroll
-                for (int ci = 0; ci < KCS; ci++) {
-                    const int c = c0 + ci;
-                    float v = x_reg[k][ci];
-                    if (p.styles && pos_off[k] >= 0 && c < p.Cin) v = v * p.styles[pos_sb[k] + c];     // modulation rides on the staging
-                    Xs[ci * PSZ + pos] = v;
-                }
+                for (int ci = 0; ci < KCS; ci++) Xs[ci * PSZ + pos] = x_reg[k][ci] * s_reg[k][ci];     // modulation rides on the staging
             }
         }
     };
 
     if (it0 < it1) {
         load_stage(it0);
-        store_stage(it0);
+        store_stage(smem, smem + AS_SZ);
     }
     __syncthreads();
+    int cur = 0;
     for (int it = it0; it < it1; it++) {
-        const bool more = it + 1 < it1;
+        const bool more = it + 1 < it1 && !(p.dbg & 2);
         if (more) load_stage(it + 1);
-        // ---- MFMA over (tap, channel pair) -------------------------------------------------------------
-        for (int t = 0; t < ph.ntaps; t++) {
-            const int toff = (ph.tap_off_y[t] + 1) * PC + (ph.tap_off_x[t] + 1);
-#pragma unroll 4
-            for (int kk = 0; kk < KCS / 2; kk++) {
-                const int ci = 2 * kk + half;
-                float a[MTW], bq[NTW];
+        const float* As = smem + cur * BUF_SZ + (wm * MTW) * 32 + l32 + half * BM;
+        const float* Xs = smem + cur * BUF_SZ + AS_SZ;
+        // ---- MFMA over (tap, channel pair); fragments of step s+1 are in flight while step s multiplies ------
+        float fa[2][MTW], fb[2][NTW];
+        bool fk[2][NTW];                                  // tap-row validity of the staged B values (applied at use, not at load)
+        int toff_cur = toff_tab[0], toff_nxt = toff_tab[1];
+        auto load_frag = [&](int buf, int row2, int kk, int toff, int t) {
+            if (p.dbg & 4) {      // ablation: no LDS reads at all
 #pragma unroll
-                for (int m = 0; m < MTW; m++) a[m] = As[(t * KCS + ci) * BM + (wm * MTW + m) * 32 + l32];
+                for (int m = 0; m < MTW; m++) fa[buf][m] = (float)(row2 + m);
 #pragma unroll
-                for (int n = 0; n < NTW; n++) {
-                    float v = Xs[ci * PSZ + px_base[n] + toff];
-                    bq[n] = ((px_mask[n] >> t) & 1) ? v : 0.f;
-                }
+                for (int n = 0; n < NTW; n++) { fb[buf][n] = (float)(kk + toff); fk[buf][n] = true; }
+                return;
+            }
+#pragma unroll
+            for (int m = 0; m < MTW; m++) fa[buf][m] = As[row2 * 2 * BM + m * 32];
+#pragma unroll
+            for (int n = 0; n < NTW; n++) {
+                fb[buf][n] = Xs[2 * kk * PSZ + px_base[n] + toff];
+                fk[buf][n] = (px_mask[n] >> t) & 1;
+            }
+        };
+        const int ntaps = (p.dbg & 1) ? 0 : ph.ntaps;
+        load_frag(0, 0, 0, toff_cur, 0);
+        for (int t = 0; t < ntaps; t++) {
+#pragma unroll
+            for (int kk = 0; kk < KH; kk++) {
+                const int cb = kk & 1, nb = cb ^ 1;
+                if (kk + 1 < KH) load_frag(nb, t * KH + kk + 1, kk + 1, toff_cur, t);
+                else load_frag(nb, (t + 1) * KH, 0, toff_nxt, t + 1);          // first step of the next tap (harmless past the end)
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ds_reads ABOVE this step's MFMAs (hipcc would sink them to their use)
+                float bq[NTW];
+#pragma unroll
+                for (int n = 0; n < NTW; n++) bq[n] = fk[cb][n] ? fb[cb][n] : 0.f;
 #pragma unroll
                 for (int m = 0; m < MTW; m++)
 #pragma unroll
-                    for (int n = 0; n < NTW; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bq[n], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < NTW; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][m], bq[n], acc[m][n], 0, 0, 0);
             }
+            toff_cur = toff_nxt;
+            toff_nxt = toff_tab[t + 2];
         }
-        __syncthreads();                               // everyone finished reading As / Xs
-        if (more) {
-            store_stage(it + 1);
-            __syncthreads();
-        }
+        if (more) store_stage(smem + (cur ^ 1) * BUF_SZ, smem + (cur ^ 1) * BUF_SZ + AS_SZ);
+        if (!(p.dbg & 8)) __syncthreads();             // cur fully read, cur^1 fully written
+        cur ^= 1;
     }
 
-    // ---- epilogue -------------------------------------------------------------------------------------
-    // Accumulators go through a per-wave 32x33 LDS tile (static register indices only on the write side), then a
-    // compact runtime loop applies demod/noise/bias/skip/activation and stores.  Two lane mappings:
-    //   layout 0 (NCHW):         lane = pixel (32 consecutive x -> 128-B row segments), loop over channels;
-    //   layout 1 (channel-last): lane = channel (32 consecutive features -> one 128-B texel line), loop over pixels.
-    // Split-K blocks store raw partial sums (NCHW) instead; splitk_reduce_kernel finishes the job.
-    __syncthreads();                                   // every wave is done with As / Xs
+    // ---- epilogue: accumulators -> per-wave 32x33 LDS tile -> epilogue_tile() ---------------------------------------
+    // The loop over the wave's tiles stays rolled; the accumulator tile is selected with a compile-time-indexed if-chain
+    // so the accumulators never need dynamic register indexing.
     float* ct = smem + wv * (32 * 33);
     const EpiParams& e = p.e;
-    const bool raw = p.ksplit > 1;
-    float* part = raw ? p.partial + (int64_t)ks * e.B * e.Cout * e.Hout * e.Wout : nullptr;
-#pragma unroll
-    for (int n = 0; n < NTW; n++) {
-        const int pb = px_b[n];
-        const int poy = px_m[n] * ph.oy_mul + ph.oy_add, pox = px_n[n] * ph.ox_mul + ph.ox_add;
-        const int pok = (px_ok[n] && poy < e.Hout && pox < e.Wout) ? 1 : 0;
-#pragma unroll
-        for (int m = 0; m < MTW; m++) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) ct[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l32] = acc[m][n][r];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int obase = m0 + (wm * MTW + m) * 32;
+    float* part = (p.ksplit > 1) ? p.partial + (int64_t)ks * e.B * e.Cout * e.Hout * e.Wout : nullptr;
 #pragma unroll 1
-            for (int rr = 0; rr < 16; rr++) {
-                const int sel = rr * 2 + half;         // 0..31
-                int o, b, oy, ox, ok;
-                float v;
-                if (raw || e.out_layout == 0) {
-                    o = obase + sel; b = pb; oy = poy; ox = pox; ok = pok;
-                    v = ct[sel * 33 + l32];
-                } else {
-                    o = obase + l32;
-                    b = __shfl(pb, sel, 64); oy = __shfl(poy, sel, 64); ox = __shfl(pox, sel, 64); ok = __shfl(pok, sel, 64);
-                    v = ct[l32 * 33 + sel];
-                }
-                if (ok && o < e.Cout) {
-                    if (raw) part[(((int64_t)b * e.Cout + o) * e.Hout + oy) * e.Wout + ox] = v;
-                    else epilogue_store(e, v, b, o, oy, ox);
-                }
+    for (int tile = 0; tile < MTW * NTW; tile++) {
+        int pb = 0, pm = 0, pn = 0, pk = 0;
+#pragma unroll
+        for (int k = 0; k < MTW * NTW; k++) {
+            if (tile == k) {
+                constexpr int dummy = 0; (void)dummy;
+#pragma unroll
+                for (int r = 0; r < 16; r++) ct[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l32] = acc[k % MTW][k / MTW][r];
+                pb = px_b[k / MTW]; pm = px_m[k / MTW]; pn = px_n[k / MTW]; pk = px_ok[k / MTW] ? 1 : 0;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
+        const int m = tile % MTW;
+        const int poy = pm * ph.oy_mul + ph.oy_add, pox = pn * ph.ox_mul + ph.ox_add;
+        const int pok = (pk && poy < e.Hout && pox < e.Wout) ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        epilogue_tile(e, ct, m0 + (wm * MTW + m) * 32, pb, poy, pox, pok, part);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -507,7 +597,7 @@ inline PackInfo pack_info(int Cout, int Cin, int k) {
     pi.T = k * k;
     pi.KC = (k == 1) ? KC1 : KC3;
     pi.CoutP = round_up(Cout, 4);
-    pi.nchunks = (Cin + pi.KC - 1) / pi.KC;
+    pi.nchunks = round_up((Cin + pi.KC - 1) / pi.KC, 2);      // zero-padded to whole K iterations (G <= 2 packed chunks each)
     pi.wp_floats = (int64_t)pi.nchunks * pi.T * pi.KC * pi.CoutP;
     pi.wsq_floats = (int64_t)Cin * pi.CoutP;
     return pi;
@@ -538,7 +628,7 @@ template <int MTW, int NTW, int WM, int WN, int KCS, int MAXT>
 int launch_conv(ConvParams& p, float* partial, int64_t partial_floats, hipStream_t s) {
     constexpr int BM = 32 * MTW * WM, NT = NTW * WN, BN = 32 * NT;
     constexpr int XS_MAX = (BN / 4 + 2) * (4 + 2) > (BN / 32 + 2) * (32 + 2) ? (BN / 4 + 2) * (4 + 2) : (BN / 32 + 2) * (32 + 2);
-    const size_t lds = (size_t)(MAXT * KCS * BM + KCS * XS_MAX) * sizeof(float);
+    const size_t lds = (size_t)(2 * (MAXT * KCS * BM + KCS * XS_MAX + 64) + MAXT + 2 + 14) * sizeof(float);
     static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<MTW, NTW, WM, WN, KCS, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -637,6 +727,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
     ConvParams p;
     p.x = x; p.wp = wp; p.styles = styles; p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutP = pi.CoutP; p.Hin = H; p.Win = W;
     p.T = pi.T; p.KC = pi.KC; p.ksplit = 1; p.partial = nullptr;
+    { const char* dv = getenv("TDGP_CONV_DBG"); p.dbg = dv ? atoi(dv) : 0; }
     EpiParams& e = p.e;
     e.B = B; e.Cout = Cout;
     for (int i = 0; i < 16; i++) e.fir[i] = 0.f;
@@ -660,12 +751,12 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         ph.gridH = H; ph.gridW = W; ph.oy_mul = 1; ph.oy_add = 0; ph.ox_mul = 1; ph.ox_add = 0;
         p.tw_log2 = pick_tw_log2(W);
         if (k == 3) {
-            if (Cout > 64) launch_conv<2, 2, 2, 2, 8, 9>(p, partial, wl.partial_floats, s);
-            else launch_conv<2, 2, 1, 4, 8, 9>(p, partial, wl.partial_floats, s);
+            if (Cout > 64) launch_conv<2, 2, 2, 2, 4, 9>(p, partial, wl.partial_floats, s);
+            else launch_conv<2, 2, 1, 4, 4, 9>(p, partial, wl.partial_floats, s);
         } else {
             if (Cout > 64 && Cout <= 96) launch_conv<3, 1, 1, 4, 32, 1>(p, partial, wl.partial_floats, s);
-            else if (Cout > 64) launch_conv<2, 2, 2, 2, 32, 1>(p, partial, wl.partial_floats, s);
-            else launch_conv<2, 2, 1, 4, 32, 1>(p, partial, wl.partial_floats, s);
+            else if (Cout > 64) launch_conv<2, 2, 2, 2, 16, 1>(p, partial, wl.partial_floats, s);
+            else launch_conv<2, 2, 1, 4, 16, 1>(p, partial, wl.partial_floats, s);
         }
     } else {
         // transposed conv, stride 2, UNFLIPPED weights (conv2d_resample.py:108-125): Z[2i+a, 2j+e] += w[a,e] * x[i,j]
@@ -694,8 +785,8 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 ph.oy_mul = 2; ph.oy_add = py; ph.ox_mul = 2; ph.ox_add = px;
             }
         p.tw_log2 = pick_tw_log2(W + 1 > 32 ? 32 : W + 1);
-        if (Cout > 64) launch_conv<2, 2, 2, 2, 16, 4>(p, partial, wl.partial_floats, s);
-        else launch_conv<2, 2, 1, 4, 16, 4>(p, partial, wl.partial_floats, s);
+        if (Cout > 64) launch_conv<2, 2, 2, 2, 8, 4>(p, partial, wl.partial_floats, s);
+        else launch_conv<2, 2, 1, 4, 8, 4>(p, partial, wl.partial_floats, s);
         FirParams f;
         f.z = z; f.dcoef = dco; f.noise = noise; f.noise_bstride = noise_bstride; f.bias = bias; f.y = y;
         for (int i = 0; i < 16; i++) f.fir[i] = e.fir[i];
