@@ -60,7 +60,7 @@ class FeatureGatherer:
             self._pending = (y, None)
             return
         y = y.contiguous()
-        out = torch.empty([self.world, y.shape[0], y.shape[1]], dtype=y.dtype, device=y.device)
+        out = torch.empty([self.world * y.shape[0], y.shape[1]], dtype=y.dtype, device=y.device)    # rank-major concatenation
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
@@ -68,7 +68,7 @@ class FeatureGatherer:
             y.record_stream(self.stream)
         else:
             dist.all_gather_into_tensor(out, y, group=self.group)
-        self._pending = (out, self.stream)
+        self._pending = (out.view(self.world, y.shape[0], y.shape[1]), self.stream)
 
     def wait(self):
         out, stream = self._pending
