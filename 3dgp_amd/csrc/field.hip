@@ -39,8 +39,11 @@ struct FieldParams {
     int64_t total;         // B*P
     int64_t P;
     int S, H, W;
-    float scale, g0, g1;
+    float scale, inv_scale, g0, g1;
+    int scale_is_pow2;     // scale is a power of two: x * (1/scale) == x / scale exactly
     int marcher;
+    int ray_h, ray_w;      // > 0: rays form a [B, ray_h, ray_w] image -> waves walk 4x4-pixel tiles (cache locality); 0: linear point order
+    int64_t R;             // rays per sample
 };
 
 template <int N>
@@ -71,32 +74,143 @@ __device__ __forceinline__ float div3(float x) {
     return fmaf_(rem, r, q0);
 }
 
-template <int FQ, int MT>
-__global__ __launch_bounds__(256) void triplane_field_kernel(FieldParams p) {
+template <int FQ, int MT, bool TAPS>
+__global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
     constexpr int F = FQ * 4;
     constexpr int HID = MT * 16;
-    // W1s arranged [mt][q][o][r] so that lane (q) reads its 4 weights for output o with one 16-B LDS read
-    __shared__ __attribute__((aligned(16))) float w1s[MT * 4 * 4 * 4];
+    // MFMA A operands, one float per lane per k-step, stored [step][lane] (conflict-free ds_read_b32, shared by the 4 waves):
+    //   layer 1: a0s[mt*FQ + s][lane]  = W0[mt*16 + (lane&15)][(lane>>4)*FQ + s] / sqrt(F)
+    //   layer 2: a1s[mt*4 + r][lane]   = (lane&15) < 4 ? W1[lane&15][mt*16 + 4*(lane>>4) + r] * sqrt(2)/sqrt(HID) : 0
+    __shared__ float a0s[MT * FQ * 64];
+    __shared__ float a1s[MT * 4 * 64];
     __shared__ float b0s[HID];
-    for (int i = threadIdx.x; i < MT * 64; i += blockDim.x) {
-        int r = i & 3, o = (i >> 2) & 3, q = (i >> 4) & 3, mt = i >> 6;
-        w1s[i] = p.w1[o * HID + mt * 16 + 4 * q + r] * p.g1;
+    const float sqrt2 = 1.41421353816986083984375f;    // (float)sqrt(2): lrelu gain, folded into the layer-2 weights
+    for (int i = threadIdx.x; i < MT * FQ * 64; i += blockDim.x) {
+        const int ln = i & 63, ms = i >> 6, mt = ms / FQ, sidx = ms % FQ;
+        a0s[i] = p.w0[(mt * 16 + (ln & 15)) * F + (ln >> 4) * FQ + sidx] * p.g0;
+    }
+    for (int i = threadIdx.x; i < MT * 4 * 64; i += blockDim.x) {
+        const int ln = i & 63, ms = i >> 6, mt = ms >> 2, r = ms & 3, o = ln & 15;
+        a1s[i] = o < 4 ? (p.w1[o * HID + mt * 16 + 4 * (ln >> 4) + r] * p.g1) * sqrt2 : 0.f;
     }
     for (int i = threadIdx.x; i < HID; i += blockDim.x) b0s[i] = p.b0[i];
     __syncthreads();
 
     const int l = lane_id();
     const int pt = l & 15, q = l >> 4;
-    // A operand of layer 1: lane holds W0s[mt*16 + pt][q*FQ + s]
-    float a0[MT][FQ];
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int s = 0; s < FQ; s++) a0[mt][s] = p.w0[(mt * 16 + pt) * F + q * FQ + s] * p.g0;
-    const float b1v[4] = {p.b1[0], p.b1[1], p.b1[2], p.b1[3]};
-    const float sqrt2 = 1.41421353816986083984375f;    // (float)sqrt(2)
     const float sx = (float)(p.W - 1) / 2.f, sy = (float)(p.H - 1) / 2.f;
+    const int plane_elems = p.H * p.W * F;
 
+    // ---- one 16-point tile: gather + blend + MLP; lane (pt, q).  `bplanes` = planes of the point's sample -----------
+    auto eval_tile = [&](float cx, float cy, float cz, const float* __restrict__ bplanes, int64_t gp, bool valid) {
+        float qc[3];
+        if (p.scale_is_pow2) { qc[0] = cx * p.inv_scale; qc[1] = cy * p.inv_scale; qc[2] = cz * p.inv_scale; }   // exact == cx / scale
+        else { qc[0] = cx / p.scale; qc[1] = cy / p.scale; qc[2] = cz / p.scale; }                                 // :576 true division
+
+        // All 12 taps of the tile are put in flight before any of them is consumed (3 planes x 4 taps x FQ floats per lane).
+        float tap[3][4][FQ];
+        float wgt[3][4];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            const float u = qc[pl == 2 ? 1 : 0];          // planes (x,y), (x,z), (y,z): width <- first coordinate (:577-581)
+            const float v = qc[pl == 0 ? 1 : 2];
+            const float ix = (u + 1.0f) * sx, iy = (v + 1.0f) * sy;   // align_corners=True unnormalisation
+            const float fx = floorf(ix), fy = floorf(iy);
+            const float tw = ix - fx, te = 1.0f - tw, tn = iy - fy, ts = 1.0f - tn;
+            const float cfx = fx < -2.f ? -2.f : (fx > (float)p.W ? (float)p.W : fx);
+            const float cfy = fy < -2.f ? -2.f : (fy > (float)p.H ? (float)p.H : fy);
+            const int x0 = (int)cfx, y0 = (int)cfy;
+            if (TAPS) {
+                if (p.tap_idx && q == 0 && valid) {
+                    p.tap_idx[(gp * 3 + pl) * 2 + 0] = x0;
+                    p.tap_idx[(gp * 3 + pl) * 2 + 1] = y0;
+                }
+            }
+            const bool vx0 = x0 >= 0 && x0 < p.W, vx1 = x0 + 1 >= 0 && x0 + 1 < p.W;
+            const bool vy0 = y0 >= 0 && y0 < p.H, vy1 = y0 + 1 >= 0 && y0 + 1 < p.H;
+            // zero padding: an out-of-range tap keeps a clamped (in-bounds) address and gets weight 0
+            wgt[pl][0] = (vx0 && vy0) ? ts * te : 0.f;    // nw
+            wgt[pl][1] = (vx1 && vy0) ? ts * tw : 0.f;    // ne
+            wgt[pl][2] = (vx0 && vy1) ? tn * te : 0.f;    // sw
+            wgt[pl][3] = (vx1 && vy1) ? tn * tw : 0.f;    // se
+            const float* base = bplanes + pl * plane_elems + q * FQ;
+            const int xa = min(max(x0, 0), p.W - 1), xb = min(max(x0 + 1, 0), p.W - 1);
+            const int ya = min(max(y0, 0), p.H - 1), yb = min(max(y0 + 1, 0), p.H - 1);
+            const int ra = ya * p.W, rb = yb * p.W;         // 32-bit element offsets inside one plane (< 2^31)
+            load_vec<FQ>(base + (ra + xa) * F, tap[pl][0]);
+            load_vec<FQ>(base + (ra + xb) * F, tap[pl][1]);
+            load_vec<FQ>(base + (rb + xa) * F, tap[pl][2]);
+            load_vec<FQ>(base + (rb + xb) * F, tap[pl][3]);
+        }
+        float g[FQ];
+#pragma unroll
+        for (int s = 0; s < FQ; s++) {
+            float pa[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+                pa[pl] = fmaf_(tap[pl][3][s], wgt[pl][3], fmaf_(tap[pl][2][s], wgt[pl][2], fmaf_(tap[pl][1][s], wgt[pl][1], tap[pl][0][s] * wgt[pl][0])));
+            g[s] = div3((pa[0] + pa[1]) + pa[2]);          // x.mean(dim=1)
+        }
+
+        // layer 1 on the matrix cores: h^T[hid x 16 pts] = W0s * g^T
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < FQ; s++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0s[(mt * FQ + s) * 64 + l], g[s], acc[mt], 0, 0, 0);
+
+        // bias + lrelu(0.2) lane-locally (each lane owns 4*MT hidden units of ITS point), then layer 2 on the matrix cores as
+        // out^T[16 (4 used) x 16 pts] = W1s * h^T: k-slot = lane quarter, exactly the layout layer 1 left behind; rows 0..3
+        // of the result (r,g,b,sigma) land in the four accumulator registers of the q == 0 lanes.
+        f32x4 o4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float v = acc[mt][r] + b0s[mt * 16 + 4 * q + r];
+                const float h = fmaxf(v, 0.2f * v);                      // leaky_relu(v, 0.2); the sqrt(2) gain lives in a1s
+                o4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1s[(mt * 4 + r) * 64 + l], h, o4, 0, 0, 0);
+            }
+        if (q == 0 && valid) {
+            float o[4] = {p.b1[0] + o4[0], p.b1[1] + o4[1], p.b1[2] + o4[2], p.b1[3] + o4[3]};
+            if (p.marcher == 1) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) o[c] = (1.0f / (1.0f + expf(-o[c]))) * (1.f + 2.f * 0.001f) - 0.001f;
+            }
+            ((float4*)p.rgbs)[gp] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    };
+
+    if (p.ray_w > 0) {
+        // Image-coherent walk: a block owns an 8x8-pixel patch (wave = one 4x4 quadrant, lane pt = pixel in it) and marches
+        // all S samples of those rays, so the 16 points of a tile are neighbours in texture space (a few texels apart) and
+        // the patch's footprint stays in L1.  Patches are dealt to blocks so that each XCD (block id mod 8 on gfx950) owns a
+        // contiguous band of the image and therefore a compact slice of the tri-planes in its private L2.
+        const int pX = (p.ray_w + 7) / 8, pY = (p.ray_h + 7) / 8;
+        const int npatch = (int)(p.total / p.P) * pX * pY;
+        const int nb = gridDim.x, per = nb / 8;
+        const int lb = (nb % 8 == 0) ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
+        const int wvi = threadIdx.x >> 6;
+        const int dy = pt >> 2, dx = pt & 3;
+        for (int patch = lb; patch < npatch; patch += nb) {
+            const int px = patch % pX, py = (patch / pX) % pY, b = patch / (pX * pY);       // uniform
+            const int y = py * 8 + (wvi >> 1) * 4 + dy, x = px * 8 + (wvi & 1) * 4 + dx;
+            const bool rvalid = y < p.ray_h && x < p.ray_w;
+            const int ray = b * (int)p.R + (rvalid ? y * p.ray_w + x : 0);                   // B*R*S < 2^31 (checked on the host)
+            const float ox = p.ray_o[ray * 3 + 0], oy = p.ray_o[ray * 3 + 1], oz = p.ray_o[ray * 3 + 2];
+            const float dxr = p.ray_d[ray * 3 + 0], dyr = p.ray_d[ray * 3 + 1], dzr = p.ray_d[ray * 3 + 2];
+            const float* bplanes = p.planes + (int64_t)b * 3 * plane_elems;
+            const float* tp = p.t + (int64_t)ray * p.S;
+            const int gp0 = ray * p.S;
+            for (int k = 0; k < p.S; k++) {
+                const float tt = tp[k];
+                eval_tile(ox + tt * dxr, oy + tt * dyr, oz + tt * dzr, bplanes, gp0 + k, rvalid);   // tri_plane_renderer.py:141 (unfused mul, add)
+            }
+        }
+        return;
+    }
     const int64_t ntiles = (p.total + 15) / 16;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -111,95 +225,11 @@ __global__ __launch_bounds__(256) void triplane_field_kernel(FieldParams p) {
         } else {
             const int64_t ray = gpc / p.S;
             const float tt = p.t[gpc];
-            cx = p.ray_o[ray * 3 + 0] + tt * p.ray_d[ray * 3 + 0];      // tri_plane_renderer.py:141 (unfused mul, add)
+            cx = p.ray_o[ray * 3 + 0] + tt * p.ray_d[ray * 3 + 0];
             cy = p.ray_o[ray * 3 + 1] + tt * p.ray_d[ray * 3 + 1];
             cz = p.ray_o[ray * 3 + 2] + tt * p.ray_d[ray * 3 + 2];
         }
-        const float qc[3] = {cx / p.scale, cy / p.scale, cz / p.scale};   // :576 true division
-
-        float g[FQ];
-        float pl_acc[3][FQ];
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-            const float u = qc[pl == 2 ? 1 : 0];          // planes (x,y), (x,z), (y,z): width <- first coordinate (:577-581)
-            const float v = qc[pl == 0 ? 1 : 2];
-            const float ix = (u + 1.0f) * sx, iy = (v + 1.0f) * sy;   // align_corners=True unnormalisation
-            const float fx = floorf(ix), fy = floorf(iy);
-            const float tw = ix - fx, te = 1.0f - tw, tn = iy - fy, ts = 1.0f - tn;
-            const float nw = ts * te, ne = ts * tw, sw = tn * te, se = tn * tw;
-            const float cfx = fx < -2.f ? -2.f : (fx > (float)p.W ? (float)p.W : fx);
-            const float cfy = fy < -2.f ? -2.f : (fy > (float)p.H ? (float)p.H : fy);
-            const int x0 = (int)cfx, y0 = (int)cfy;
-            if (p.tap_idx && q == 0 && valid) {
-                p.tap_idx[(gp * 3 + pl) * 2 + 0] = x0;
-                p.tap_idx[(gp * 3 + pl) * 2 + 1] = y0;
-            }
-            const bool vx0 = x0 >= 0 && x0 < p.W, vx1 = x0 + 1 >= 0 && x0 + 1 < p.W;
-            const bool vy0 = y0 >= 0 && y0 < p.H, vy1 = y0 + 1 >= 0 && y0 + 1 < p.H;
-            const float* base = p.planes + ((int64_t)(b * 3 + pl) * p.H * p.W) * F + q * FQ;
-            // clamped addresses (always in bounds); invalid taps are zeroed after the load
-            const int xa = min(max(x0, 0), p.W - 1), xb = min(max(x0 + 1, 0), p.W - 1);
-            const int ya = min(max(y0, 0), p.H - 1), yb = min(max(y0 + 1, 0), p.H - 1);
-            float t00[FQ], t01[FQ], t10[FQ], t11[FQ];
-            load_vec<FQ>(base + ((int64_t)ya * p.W + xa) * F, t00);
-            load_vec<FQ>(base + ((int64_t)ya * p.W + xb) * F, t01);
-            load_vec<FQ>(base + ((int64_t)yb * p.W + xa) * F, t10);
-            load_vec<FQ>(base + ((int64_t)yb * p.W + xb) * F, t11);
-            const bool m00 = vx0 && vy0, m01 = vx1 && vy0, m10 = vx0 && vy1, m11 = vx1 && vy1;
-#pragma unroll
-            for (int s = 0; s < FQ; s++) {
-                float acc = (m00 ? t00[s] : 0.f) * nw;
-                acc = acc + (m01 ? t01[s] : 0.f) * ne;
-                acc = acc + (m10 ? t10[s] : 0.f) * sw;
-                acc = acc + (m11 ? t11[s] : 0.f) * se;
-                pl_acc[pl][s] = acc;
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < FQ; s++) g[s] = div3((pl_acc[0][s] + pl_acc[1][s]) + pl_acc[2][s]);   // x.mean(dim=1)
-
-        // layer 1 on the matrix cores
-        f32x4 acc[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < FQ; s++)
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mt][s], g[s], acc[mt], 0, 0, 0);
-
-        // bias + lrelu(0.2) * sqrt(2), then layer 2: lane-local partial dot products
-        float o4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            float h[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = acc[mt][r] + b0s[mt * 16 + 4 * q + r];
-                v = v > 0.f ? v : v * 0.2f;
-                h[r] = v * sqrt2;
-            }
-#pragma unroll
-            for (int o = 0; o < 4; o++) {
-                const float4 wv = *(const float4*)&w1s[((mt * 4 + q) * 4 + o) * 4];
-                o4[o] = fmaf_(h[0], wv.x, o4[o]);
-                o4[o] = fmaf_(h[1], wv.y, o4[o]);
-                o4[o] = fmaf_(h[2], wv.z, o4[o]);
-                o4[o] = fmaf_(h[3], wv.w, o4[o]);
-            }
-        }
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-            o4[o] += __shfl_xor(o4[o], 16, 64);
-            o4[o] += __shfl_xor(o4[o], 32, 64);
-            o4[o] = b1v[o] + o4[o];
-        }
-        if (q == 0 && valid) {
-            if (p.marcher == 1) {
-#pragma unroll
-                for (int o = 0; o < 3; o++) o4[o] = (1.0f / (1.0f + expf(-o4[o]))) * (1.f + 2.f * 0.001f) - 0.001f;
-            }
-            ((float4*)p.rgbs)[gp] = make_float4(o4[0], o4[1], o4[2], o4[3]);
-        }
+        eval_tile(cx, cy, cz, p.planes + (int64_t)b * 3 * plane_elems, gp, valid);
     }
 }
 
@@ -224,12 +254,20 @@ __global__ __launch_bounds__(256) void planes_to_hwc_kernel(const float* __restr
     }
 }
 
+template <int FQ, int MT, bool TAPS>
+void launch_field_t(const FieldParams& p, hipStream_t s) {
+    int64_t want;
+    if (p.ray_w > 0) want = (p.total / p.P) * cdiv(p.ray_w, 8) * cdiv(p.ray_h, 8);      // one 8x8-pixel patch per block
+    else want = cdiv64((p.total + 15) / 16, 4);                                          // one 16-point tile per wave
+    int blocks = (int)min((int64_t)(256 * 8), want);         // persistent-ish grid: <= 8 blocks per CU, blocks stride over the work
+    if (blocks > 8) blocks -= blocks % 8;                    // whole rounds of the 8 XCDs (the in-kernel XCD remap needs it)
+    TDGP_LAUNCH("triplane_field_kernel", (triplane_field_kernel<FQ, MT, TAPS>), dim3(blocks), dim3(256), 0, s, p);
+}
+
 template <int FQ, int MT>
 void launch_field(const FieldParams& p, hipStream_t s) {
-    const int64_t ntiles = (p.total + 15) / 16;
-    const int64_t want = cdiv64(ntiles, 4);                 // one tile per wave
-    const int blocks = (int)min((int64_t)(256 * 8), want);  // persistent-ish grid: 8 blocks per CU, waves stride over tiles
-    TDGP_LAUNCH("triplane_field_kernel", (triplane_field_kernel<FQ, MT>), dim3(blocks), dim3(256), 0, s, p);
+    if (p.tap_idx) { launch_field_t<FQ, MT, true>(p, s); return; }
+    launch_field_t<FQ, MT, false>(p, s);
 }
 
 }  // namespace
@@ -249,7 +287,7 @@ TDGP_API int tdgp_planes_to_hwc(const float* planes_nchw, float* planes_hwc, int
 
 TDGP_API int tdgp_triplane_field(const float* planes_hwc, const float* coords, const float* ray_o, const float* ray_d, const float* t,
                                  const float* w0, const float* b0, const float* w1, const float* b1, float* rgbs, int32_t* tap_idx, int B,
-                                 int64_t P, int S, int F, int H, int W, int hid, float scale, int marcher, tdgp_stream_t stream) {
+                                 int64_t P, int S, int ray_w, int F, int H, int W, int hid, float scale, int marcher, tdgp_stream_t stream) {
     TDGP_CHECK(planes_hwc && w0 && b0 && w1 && b1 && rgbs, TDGP_EINVAL, "triplane_field: null pointer");
     TDGP_CHECK(coords || (ray_o && ray_d && t && S >= 1), TDGP_EINVAL, "triplane_field: need coords, or ray_o/ray_d/t with S >= 1");
     TDGP_CHECK(B >= 0 && P >= 0 && H >= 2 && W >= 2, TDGP_EINVAL, "triplane_field: bad shape");
@@ -260,8 +298,15 @@ TDGP_API int tdgp_triplane_field(const float* planes_hwc, const float* coords, c
     p.planes = planes_hwc; p.coords = coords; p.ray_o = ray_o; p.ray_d = ray_d; p.t = t;
     p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1; p.rgbs = rgbs; p.tap_idx = tap_idx;
     p.total = (int64_t)B * P; p.P = P; p.S = coords ? 1 : S; p.H = H; p.W = W; p.scale = scale;
+    { int ex; p.scale_is_pow2 = (frexpf(scale, &ex) == 0.5f) ? 1 : 0; p.inv_scale = 1.0f / scale; }
+    TDGP_CHECK((int64_t)B * P <= INT32_MAX / 4 && (int64_t)3 * H * W * F <= INT32_MAX, TDGP_EINVAL, "triplane_field: tensor too large");
     p.g0 = (float)(1.0 / sqrt((double)F)); p.g1 = (float)(1.0 / sqrt((double)hid));    // weight_gain, layers.py:39
     p.marcher = marcher;
+    p.R = coords ? 0 : P / S; p.ray_w = 0; p.ray_h = 0;
+    if (!coords && ray_w > 0) {
+        TDGP_CHECK((p.R % ray_w) == 0, TDGP_EINVAL, "triplane_field: ray_w=%d does not divide the %lld rays", ray_w, (long long)p.R);
+        p.ray_w = ray_w; p.ray_h = (int)(p.R / ray_w);
+    }
     hipStream_t s = (hipStream_t)stream;
     bool ok = true;
 #define FIELD_CASE(FF, HH) else if (F == FF && hid == HH) launch_field<FF / 4, HH / 16>(p, s);

@@ -252,29 +252,6 @@ __global__ __launch_bounds__(256) void sample_importance_kernel(const float* __r
     if (cdf_o) for (int i = l; i < Wn - 1; i += 64) cdf_o[r * (Wn - 1) + i] = sc.cdf[i];
 }
 
-// fused: coarse march (s-space) -> importance sampling -> fine depths (t-space)
-__global__ __launch_bounds__(256) void importance_from_coarse_kernel(const float* __restrict__ rgbs, const float* __restrict__ sdist,
-                                                                    const float* __restrict__ u_fine, float* __restrict__ tfine,
-                                                                    float* __restrict__ sfine, int32_t* __restrict__ inds, int64_t rays, int S, int N,
-                                                                    int marcher, int flags, float density_bias, float t_near, float t_far) {
-    __shared__ WaveScratch scratch[RAYS_PER_BLOCK];
-    const int wv = threadIdx.x >> 6, l = lane_id();
-    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
-    if (r >= rays) return;
-    WaveScratch& sc = scratch[wv];
-    for (int i = l; i < S; i += 64) { sc.z[i] = sdist[r * S + i]; sc.sig[i] = rgbs[(r * S + i) * 4 + 3]; }
-    wave_sync();
-    float fT, wagg;
-    int Wn = S;
-    if (marcher == 0) march_classical_lds(sc.z, sc.sig, sc.w, S, flags, fT, wagg);
-    else { march_mip_lds(sc.z, sc.sig, sc.w, S, flags, density_bias, fT, wagg); Wn = (flags & 1) ? S : S - 1; }
-    importance_lds(sc, S, Wn, u_fine + r * N, N, marcher, [&](int j, float smp, int ind, int, int) {
-        tfine[r * N + j] = s2t(smp, t_near, t_far);
-        if (sfine) sfine[r * N + j] = smp;
-        if (inds) inds[r * N + j] = ind;
-    });
-}
-
 // stable rank of every element of key[0..M) under (key, index) order -> pos[]; brute force from LDS broadcasts
 __device__ __forceinline__ void stable_ranks(const float* key, int M, int* rank /* per-lane, MAXS/64 entries */) {
     const int l = lane_id();
@@ -287,6 +264,46 @@ __device__ __forceinline__ void stable_ranks(const float* key, int M, int* rank 
         for (int c = 0; c < MAXS / 64; c++) {
             const int i = l + 64 * c;
             rank[c] += (km < k[c] || (km == k[c] && m < i)) ? 1 : 0;
+        }
+    }
+}
+
+// fused: coarse march (s-space) -> importance sampling -> fine depths (t-space), WRITTEN IN ASCENDING DEPTH ORDER.
+// The reference leaves the fine samples in draw order and sorts coarse+fine together later (unify_samples); sorting the
+// fine list here (stable, by (t, draw index)) changes nothing in that final order but makes the j-th fine sample of
+// neighbouring rays neighbours in space (texture locality of the second field pass) and turns the later merge into a
+// merge of two sorted lists.  fine_perm[pos] = draw index of the sample stored at pos.
+__global__ __launch_bounds__(256) void importance_from_coarse_kernel(const float* __restrict__ rgbs, const float* __restrict__ sdist,
+                                                                    const float* __restrict__ u_fine, float* __restrict__ tfine,
+                                                                    float* __restrict__ sfine, int32_t* __restrict__ inds,
+                                                                    int32_t* __restrict__ fine_perm, int64_t rays, int S, int N,
+                                                                    int marcher, int flags, float density_bias, float t_near, float t_far) {
+    __shared__ WaveScratch scratch[RAYS_PER_BLOCK];
+    const int wv = threadIdx.x >> 6, l = lane_id();
+    const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
+    if (r >= rays) return;
+    WaveScratch& sc = scratch[wv];
+    for (int i = l; i < S; i += 64) { sc.z[i] = sdist[r * S + i]; sc.sig[i] = rgbs[(r * S + i) * 4 + 3]; }
+    wave_sync();
+    float fT, wagg;
+    int Wn = S;
+    if (marcher == 0) march_classical_lds(sc.z, sc.sig, sc.w, S, flags, fT, wagg);
+    else { march_mip_lds(sc.z, sc.sig, sc.w, S, flags, density_bias, fT, wagg); Wn = (flags & 1) ? S : S - 1; }
+    float* tkey = sc.col[0];
+    importance_lds(sc, S, Wn, u_fine + r * N, N, marcher, [&](int j, float smp, int ind, int, int) {
+        tkey[j] = s2t(smp, t_near, t_far);
+        if (sfine) sfine[r * N + j] = smp;
+        if (inds) inds[r * N + j] = ind;
+    });
+    wave_sync();
+    int rank[MAXS / 64];
+    stable_ranks(tkey, N, rank);
+#pragma unroll
+    for (int c = 0; c < MAXS / 64; c++) {
+        const int j = l + 64 * c;
+        if (j < N) {
+            tfine[r * N + rank[c]] = tkey[j];
+            if (fine_perm) fine_perm[r * N + rank[c]] = j;
         }
     }
 }
@@ -321,19 +338,45 @@ __global__ __launch_bounds__(256) void unify_kernel(const float* __restrict__ d1
 __global__ __launch_bounds__(256) void merge_composite_kernel(const float* __restrict__ rgbs1, const float* __restrict__ t1, int S1,
                                                              const float* __restrict__ rgbs2, const float* __restrict__ t2, int S2,
                                                              float* __restrict__ rgb, float* __restrict__ depth_o, float* __restrict__ wsum_o,
-                                                             float* __restrict__ final_T, int32_t* __restrict__ perm, int64_t rays, int marcher,
-                                                             int flags, float density_bias) {
+                                                             float* __restrict__ final_T, int32_t* __restrict__ perm, const int32_t* __restrict__ perm2, int64_t rays,
+                                                             int marcher, int flags, float density_bias) {
     __shared__ WaveScratch scratch[RAYS_PER_BLOCK];
     const int wv = threadIdx.x >> 6, l = lane_id();
     const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
     if (r >= rays) return;
     WaveScratch& sc = scratch[wv];
     const int M = S1 + S2;
-    // unsorted keys -> sc.cdf (scratch), ranks, scatter into sorted sc.z / sc.sig / sc.col
+    // keys -> sc.cdf (scratch), ranks, scatter into sorted sc.z / sc.sig / sc.col
     for (int i = l; i < M; i += 64) sc.cdf[i] = i < S1 ? t1[r * S1 + i] : t2[r * S2 + (i - S1)];
     wave_sync();
+    // both lists already ascending (stratified coarse samples; fine samples sorted by importance_from_coarse)?  Then the
+    // stable merge position is the element's own index plus a binary search in the OTHER list; otherwise (arbitrary caller
+    // data, or the ~1e-10-probability ulp inversion of s -> t) fall back to the brute-force stable rank.
+    bool bad = false;
+    for (int i = l; i < M; i += 64)
+        if (i + 1 < M && i + 1 != S1 && sc.cdf[i + 1] < sc.cdf[i]) bad = true;
     int rank[MAXS / 64];
-    stable_ranks(sc.cdf, M, rank);
+    if (__any(bad)) {
+        stable_ranks(sc.cdf, M, rank);
+    } else {
+#pragma unroll
+        for (int cc = 0; cc < MAXS / 64; cc++) {
+            const int i = l + 64 * cc;
+            rank[cc] = 0;
+            if (i < M) {
+                const float v = sc.cdf[i];
+                const bool fine = i >= S1;
+                const float* other = fine ? sc.cdf : sc.cdf + S1;
+                int lo = 0, hi = fine ? S1 : S2;
+                while (lo < hi) {                  // fine: #coarse <= v (coarse wins ties);  coarse: #fine < v
+                    const int mid = (lo + hi) >> 1;
+                    const float o = other[mid];
+                    if (fine ? (o <= v) : (o < v)) lo = mid + 1; else hi = mid;
+                }
+                rank[cc] = (fine ? i - S1 : i) + lo;
+            }
+        }
+    }
 #pragma unroll
     for (int cc = 0; cc < MAXS / 64; cc++) {
         const int i = l + 64 * cc;
@@ -342,7 +385,7 @@ __global__ __launch_bounds__(256) void merge_composite_kernel(const float* __res
         const float4 v = i < S1 ? ((const float4*)rgbs1)[r * S1 + i] : ((const float4*)rgbs2)[r * S2 + (i - S1)];
         sc.z[pos] = sc.cdf[i];
         sc.col[0][pos] = v.x; sc.col[1][pos] = v.y; sc.col[2][pos] = v.z; sc.sig[pos] = v.w;
-        if (perm) perm[r * M + pos] = i;
+        if (perm) perm[r * M + pos] = i < S1 ? i : S1 + (perm2 ? perm2[r * S2 + (i - S1)] : i - S1);
     }
     wave_sync();
     float fT, wagg;
@@ -432,27 +475,27 @@ TDGP_API int tdgp_unify_samples(const float* d1, const float* c1, const float* s
 }
 
 TDGP_API int tdgp_importance_from_coarse(const float* rgbs_coarse, const float* sdist, const float* u_fine, float* tdist_fine,
-                                         float* sdist_fine, int32_t* inds, int64_t rays, int S, int N, int marcher, int flags,
+                                         float* sdist_fine, int32_t* inds, int32_t* fine_perm, int64_t rays, int S, int N, int marcher, int flags,
                                          float density_bias, float t_near, float t_far, tdgp_stream_t stream) {
     TDGP_CHECK(rgbs_coarse && sdist && u_fine && tdist_fine, TDGP_EINVAL, "importance_from_coarse: null pointer");
     TDGP_CHECK(S >= 4 && S <= MAXS && N >= 1, TDGP_EUNSUPPORTED, "importance_from_coarse: bad S=%d N=%d", S, N);
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "importance_from_coarse: unknown ray marcher %d", marcher);
     if (rays == 0) return TDGP_OK;
     TDGP_LAUNCH("importance_from_coarse_kernel", importance_from_coarse_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, sdist, u_fine,
-                       tdist_fine, sdist_fine, inds, rays, S, N, marcher, flags, density_bias, t_near, t_far);
+                       tdist_fine, sdist_fine, inds, fine_perm, rays, S, N, marcher, flags, density_bias, t_near, t_far);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }
 
 TDGP_API int tdgp_merge_composite(const float* rgbs_coarse, const float* t_coarse, int S1, const float* rgbs_fine, const float* t_fine, int S2,
-                                  float* rgb, float* depth, float* wsum, float* final_T, int32_t* perm, int64_t rays, int marcher, int flags,
-                                  float density_bias, tdgp_stream_t stream) {
+                                  float* rgb, float* depth, float* wsum, float* final_T, int32_t* perm, const int32_t* fine_perm, int64_t rays,
+                                  int marcher, int flags, float density_bias, tdgp_stream_t stream) {
     TDGP_CHECK(rgbs_coarse && t_coarse && rgbs_fine && t_fine && rgb && depth, TDGP_EINVAL, "merge_composite: null pointer");
     TDGP_CHECK(S1 >= 1 && S2 >= 1 && S1 + S2 <= MAXS, TDGP_EUNSUPPORTED, "merge_composite: S1+S2=%d > %d", S1 + S2, MAXS);
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "merge_composite: unknown ray marcher %d", marcher);
     if (rays == 0) return TDGP_OK;
     TDGP_LAUNCH("merge_composite_kernel", merge_composite_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, t_coarse, S1, rgbs_fine,
-                       t_fine, S2, rgb, depth, wsum, final_T, perm, rays, marcher, flags, density_bias);
+                       t_fine, S2, rgb, depth, wsum, final_T, perm, fine_perm, rays, marcher, flags, density_bias);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }

@@ -326,6 +326,7 @@ class SynthesisNetwork(torch.nn.Module):
         ray_o, ray_d = _renderer.sample_rays(c2w, fov=get('fov'), resolution=(h, w), patch_params=patch_params, device=ws.device)
         opts = self.rendering_options(render_opts)
         opts['u_coarse'], opts['u_fine'] = u_coarse, u_fine
+        opts['ray_grid_w'] = w                      # rays are the row-major pixels of an h x w image (sample_rays)
         rgb, depth, _w, _T = self.renderer(planes, self.tri_plane_mlp, ray_o, ray_d, opts)
         img = torch.empty([B, self.img_channels, h, w], dtype=torch.float32, device=ws.device)
         with torch.cuda.device(ws.device):

@@ -148,7 +148,7 @@ def planes_to_hwc(x):
     return HWCPlanes(out)
 
 
-def _field(planes, mlp_params, scale, coords=None, ray_o=None, ray_d=None, t=None, tap_idx=None):
+def _field(planes, mlp_params, scale, coords=None, ray_o=None, ray_d=None, t=None, tap_idx=None, ray_w=0):
     w0, b0, w1, b1, marcher = mlp_params
     p = planes.t
     B, _, H, W, F = p.shape
@@ -162,7 +162,7 @@ def _field(planes, mlp_params, scale, coords=None, ray_o=None, ray_d=None, t=Non
         return rgbs
     with torch.cuda.device(p.device):
         _lib.call('tdgp_triplane_field', p.data_ptr(), _lib.ptr(coords), _lib.ptr(ray_o), _lib.ptr(ray_d), _lib.ptr(t), w0.data_ptr(),
-                  b0.data_ptr(), w1.data_ptr(), b1.data_ptr(), rgbs.data_ptr(), _lib.ptr(tap_idx), B, P, S, F, H, W, w0.shape[0],
+                  b0.data_ptr(), w1.data_ptr(), b1.data_ptr(), rgbs.data_ptr(), _lib.ptr(tap_idx), B, P, S, int(ray_w), F, H, W, w0.shape[0],
                   float(scale), MARCHER_IDS[marcher], _lib.stream_of(p))
     return rgbs
 
@@ -303,12 +303,17 @@ class ImportanceRenderer(torch.nn.Module):
         u_coarse = torch.rand([B, R, S, 1], device=dev) if u_coarse is None else _lib.f32c(u_coarse.to(dev))
         if u_coarse.numel() != B * R * S:
             raise RuntimeError(f'u_coarse must have {B}x{R}x{S} elements')
+        # rays of an h x w image in row-major order (sample_rays): let the field kernel walk 4x4-pixel tiles
+        ray_w = opts.get('ray_grid_w')
+        if ray_w is None:
+            side = int(round(R ** 0.5))
+            ray_w = side if side * side == R else 0
         stream = _lib.stream_of(ray_o)
         with torch.cuda.device(dev):
             sdist = torch.empty([B, R, S], dtype=torch.float32, device=dev)
             tdist = torch.empty([B, R, S], dtype=torch.float32, device=dev)
             _lib.call('tdgp_sample_stratified', u_coarse.data_ptr(), sdist.data_ptr(), tdist.data_ptr(), B * R, S, mid, t_near, t_far, stream)
-            rgbs_c = _field(planes, mlp, scale, ray_o=ray_o, ray_d=ray_d, t=tdist)
+            rgbs_c = _field(planes, mlp, scale, ray_o=ray_o, ray_d=ray_d, t=tdist, ray_w=ray_w)
             if N > 0:
                 u_fine = opts.get('u_fine')
                 u_fine = torch.rand([B * R, N], device=dev) if u_fine is None else _lib.f32c(u_fine.to(dev))
@@ -317,23 +322,24 @@ class ImportanceRenderer(torch.nn.Module):
                 tfine = torch.empty([B, R, N], dtype=torch.float32, device=dev)
                 sfine = torch.empty([B, R, N], dtype=torch.float32, device=dev) if return_intermediates else None
                 inds = torch.empty([B * R, N], dtype=torch.int32, device=dev) if return_intermediates else None
+                fperm = torch.empty([B * R, N], dtype=torch.int32, device=dev) if return_intermediates else None
                 _lib.call('tdgp_importance_from_coarse', rgbs_c.data_ptr(), sdist.data_ptr(), u_fine.data_ptr(), tfine.data_ptr(),
-                          _lib.ptr(sfine), _lib.ptr(inds), B * R, S, N, mid, flags, dbias, t_near, t_far, stream)
-                rgbs_f = _field(planes, mlp, scale, ray_o=ray_o, ray_d=ray_d, t=tfine)
+                          _lib.ptr(sfine), _lib.ptr(inds), _lib.ptr(fperm), B * R, S, N, mid, flags, dbias, t_near, t_far, stream)
+                rgbs_f = _field(planes, mlp, scale, ray_o=ray_o, ray_d=ray_d, t=tfine, ray_w=ray_w)
                 rgb = torch.empty([B, R, 3], dtype=torch.float32, device=dev)
                 depth = torch.empty([B, R, 1], dtype=torch.float32, device=dev)
                 wsum = torch.empty([B, R, 1], dtype=torch.float32, device=dev)
                 final_T = torch.empty([B, R], dtype=torch.float32, device=dev)
                 perm = torch.empty([B, R, S + N], dtype=torch.int32, device=dev) if return_intermediates else None
                 _lib.call('tdgp_merge_composite', rgbs_c.data_ptr(), tdist.data_ptr(), S, rgbs_f.data_ptr(), tfine.data_ptr(), N, rgb.data_ptr(),
-                          depth.data_ptr(), wsum.data_ptr(), final_T.data_ptr(), _lib.ptr(perm), B * R, mid, flags, dbias, stream)
+                          depth.data_ptr(), wsum.data_ptr(), final_T.data_ptr(), _lib.ptr(perm), _lib.ptr(fperm), B * R, mid, flags, dbias, stream)
             else:
                 rgbs4 = rgbs_c.reshape(B, R, S, 4)
                 rgb, depth, w, final_T = _march(rgbs4[..., :3], rgbs4[..., 3:4], sdist.reshape(B, R, S, 1), opts, marcher)
                 wsum = w.sum(2)
-                rgbs_f = tfine = sfine = inds = perm = None
+                rgbs_f = tfine = sfine = inds = perm = fperm = None
         out = (rgb, depth, wsum, final_T)
         if return_intermediates:
             return out, dict(sdist_coarse=sdist, tdist_coarse=tdist, rgbs_coarse=rgbs_c, tdist_fine=tfine, sdist_fine=sfine, inds=inds,
-                             rgbs_fine=rgbs_f, perm=perm)
+                             rgbs_fine=rgbs_f, perm=perm, fine_perm=fperm)
         return out

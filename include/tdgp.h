@@ -149,7 +149,9 @@ int tdgp_planes_to_hwc(const float* planes_nchw, float* planes_hwc, int B, int F
 
 /* Tri-plane bilinear lookup (align_corners, zero padding) + mean + tiny MLP, fused.
  * planes_hwc: [B,3,H,W,F].  Points are given either as coords [B,P,3] (ray_o = NULL), or as rays:
- * ray_o/ray_d [B,R,3] and t [B,R,S] with P = R*S, point p = ray p/S at depth t[p].
+ * ray_o/ray_d [B,R,3] and t [B,R,S] with P = R*S, point p = ray p/S at depth t[p].  In ray mode `ray_w` > 0 declares that
+ * the R rays of a sample form a [R/ray_w, ray_w] image (ray r = pixel (r / ray_w, r % ray_w)): the kernel then walks 4x4-pixel
+ * tiles for cache locality (results are identical); ray_w = 0 keeps the linear point order.
  * w0 [hid,F], b0 [hid], w1 [4,hid], b1 [4] are the RAW module parameters (gains 1/sqrt(F), 1/sqrt(hid),
  * lrelu 0.2 * sqrt(2) applied inside, layers.py:39-58).
  * out: rgbs [B,P,4] = (r,g,b,sigma); marcher=1 applies sigmoid*1.002-0.001 to rgb (networks_epigraf.py:61-62).
@@ -157,7 +159,7 @@ int tdgp_planes_to_hwc(const float* planes_nchw, float* planes_hwc, int B, int F
  * Requires F % 4 == 0, F <= 64, hid % 16 == 0, hid <= 128. */
 int tdgp_triplane_field(const float* planes_hwc, const float* coords, const float* ray_o, const float* ray_d,
                         const float* t, const float* w0, const float* b0, const float* w1, const float* b1,
-                        float* rgbs, int32_t* tap_idx, int B, int64_t P, int S, int F, int H, int W, int hid,
+                        float* rgbs, int32_t* tap_idx, int B, int64_t P, int S, int ray_w, int F, int H, int W, int hid,
                         float scale, int marcher, tdgp_stream_t stream);
 
 /* Generic marcher on [rays,S,C] colours, [rays,S] densities/depths (any S <= 256, C <= 8).
@@ -180,19 +182,24 @@ int tdgp_unify_samples(const float* d1, const float* c1, const float* s1, int S1
                        tdgp_stream_t stream);
 
 /* Fused chain, step 1: coarse march (s-space depths) -> importance sampling -> fine depths in t-space.
- * rgbs_coarse [rays,S,4], sdist [rays,S], u_fine [rays,N] -> tdist_fine [rays,N] (+ optional sdist_fine, inds). */
+ * rgbs_coarse [rays,S,4], sdist [rays,S], u_fine [rays,N] -> tdist_fine [rays,N] WRITTEN IN ASCENDING DEPTH ORDER (stable):
+ * the reference keeps draw order and sorts coarse+fine together afterwards, so the final composite is unchanged, but the
+ * second field pass becomes spatially coherent and the merge below is a merge of two sorted lists.
+ * Optional: sdist_fine [rays,N] and inds int32 [rays,N] in DRAW order; fine_perm int32 [rays,N]: draw index of sorted slot. */
 int tdgp_importance_from_coarse(const float* rgbs_coarse, const float* sdist, const float* u_fine,
-                                float* tdist_fine, float* sdist_fine, int32_t* inds,
+                                float* tdist_fine, float* sdist_fine, int32_t* inds, int32_t* fine_perm,
                                 int64_t rays, int S, int N, int marcher, int flags, float density_bias,
                                 float t_near, float t_far, tdgp_stream_t stream);
 
-/* Fused chain, step 2: merge coarse+fine by depth (stable), march in t-space.
- * rgbs_* [rays,S*,4], t_* [rays,S*] -> rgb [rays,3], depth [rays], wsum [rays], final_T [rays];
- * perm optional int32 [rays,S1+S2]. */
+/* Fused chain, step 2: merge coarse+fine by depth (stable, coarse before fine on ties), march in t-space.
+ * rgbs_* [rays,S*,4], t_* [rays,S*] (any order; ascending lists take a fast path) -> rgb [rays,3], depth [rays],
+ * wsum [rays], final_T [rays]; perm optional int32 [rays,S1+S2] = index into the concatenation [coarse ; fine in draw
+ * order] (fine_perm, optional, maps the fine list's slots back to draw order; NULL = identity). */
 int tdgp_merge_composite(const float* rgbs_coarse, const float* t_coarse, int S1,
                          const float* rgbs_fine, const float* t_fine, int S2,
                          float* rgb, float* depth, float* wsum, float* final_T, int32_t* perm,
-                         int64_t rays, int marcher, int flags, float density_bias, tdgp_stream_t stream);
+                         const int32_t* fine_perm, int64_t rays, int marcher, int flags, float density_bias,
+                         tdgp_stream_t stream);
 
 /* [B, h*w, 3] ray colours -> [B,3,h,w] image (networks_epigraf.py:242). */
 int tdgp_rays_to_image(const float* rgb, float* img, int B, int hw, tdgp_stream_t stream);

@@ -296,6 +296,43 @@ def test_march_mip(tdgp, tag, kw):
     assert_close(N(fT), g[f'{tag}_T'], 2e-6, 'T')
 
 
+def test_fused_chain_equals_op_level_chain(tdgp):
+    """ImportanceRenderer.forward (fused kernels, fine samples pre-sorted, sorted-merge fast path) must equal the same chain
+    issued stage by stage through the reference-named methods (sample_stratified -> run_model -> ray_marcher ->
+    sample_importance -> run_model -> unify_samples -> ray_marcher), for both marchers."""
+    rs = np.random.RandomState(3)
+    B, F, H, hid, hw, S = 2, 8, 32, 16, 12, 16
+    planes = T(rs.randn(B, 3 * F, H, H))
+    for marcher in ('classical', 'mip'):
+        mlp = _mlp(tdgp, rs.randn(hid, F), 0.3 * rs.randn(hid), rs.randn(4, hid), 0.3 * rs.randn(4), marcher)
+        cam = dict(angles=T([[0.3, 1.2, 0.0], [-0.6, 1.8, 0.0]]), radius=T([1.0, 1.0]), look_at=T(np.zeros((2, 3))))
+        ro, rd = tdgp.renderer.sample_rays(tdgp.renderer.compute_cam2world_matrix(cam), T([25.0, 40.0]), (hw, hw))
+        R = hw * hw
+        u1, u2 = T(rs.rand(B, R, S, 1)), T(rs.rand(B * R, S))
+        opts = dict(box_size=1.0, num_proposal_steps=S, num_fine_steps=S, clamp_mode='softplus', use_inf_depth=True, ray_start=0.75, ray_end=1.25,
+                    white_back=(marcher == 'mip'), density_bias=0.0)
+        rend = tdgp.renderer.ImportanceRenderer(marcher)
+        rgb, depth, wsum, fT = rend(planes, mlp, ro, rd, dict(opts, u_coarse=u1, u_fine=u2))
+        # stage by stage
+        s2t = lambda s: s * opts['ray_end'] + (1 - s) * opts['ray_start']     # noqa: E731
+        sd = rend.sample_stratified(ro, 0.0, 1.0, S, noise=u1)
+        td = s2t(sd)
+        pts = (ro.unsqueeze(-2) + td * rd.unsqueeze(-2)).reshape(B, -1, 3)
+        out = rend.run_model(planes, mlp, pts, opts)
+        cc, dc = out['rgb'].reshape(B, R, S, 3), out['sigma'].reshape(B, R, S, 1)
+        _, _, w, _ = rend.ray_marcher(cc, dc, sd, opts)
+        sf = rend.sample_importance(sd, w, S, u=u2)
+        tf = s2t(sf)
+        out = rend.run_model(planes, mlp, (ro.unsqueeze(-2) + tf * rd.unsqueeze(-2)).reshape(B, -1, 3), opts)
+        cf, df = out['rgb'].reshape(B, R, S, 3), out['sigma'].reshape(B, R, S, 1)
+        d_all, c_all, s_all = rend.unify_samples(td, cc, dc, tf, cf, df)
+        rgb2, depth2, w2, fT2 = rend.ray_marcher(c_all, s_all, d_all, opts)
+        np.testing.assert_array_equal(N(rgb), N(rgb2))
+        np.testing.assert_array_equal(N(depth), N(depth2))
+        np.testing.assert_array_equal(N(fT), N(fT2))
+        assert_close(N(wsum), N(w2.sum(2)), 1e-6, 'weights.sum', 1.0)
+
+
 # ------------------------------------------------------------------------------------------------ end to end
 
 def _gen(tdgp, cfg, seed):

@@ -1,5 +1,5 @@
 import sys, os, importlib, numpy as np, torch, time
-sys.path.insert(0,'.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 t = importlib.import_module('3dgp_amd'); mc = t.ops.modconv
 def run(B,cin,cout,H,k,up,reps=10):
     x = torch.randn(B,cin,H,H,device='cuda'); w = torch.randn(cout,cin,k,k,device='cuda'); s = torch.rand(B,cin,device='cuda')+0.5

@@ -1,5 +1,5 @@
 import sys, importlib, numpy as np, torch
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0,'tests')
 from conftest import load_golden
 import oracle as O
 from oracle.pipeline import render_options
