@@ -66,6 +66,20 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ p, float* v) 
     }
 }
 
+// The FQ floats this lane owns of one texel (F = 4*FQ floats): piece c4 of every 64-B group (FQ % 4 == 0), else a contiguous run.
+template <int FQ>
+__device__ __forceinline__ void load_texel(const float* __restrict__ texel, int c4, float* v) {
+    if constexpr (FQ % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < FQ / 4; j++) {
+            const float4 t = *(const float4*)(texel + 16 * j + 4 * c4);
+            v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+        }
+    } else {
+        load_vec<FQ>(texel + c4 * FQ, v);
+    }
+}
+
 // correctly rounded x / 3 without the hardware division sequence (Markstein: q1 = fma(fma(-3,q0,x), r, q0))
 __device__ __forceinline__ float div3(float x) {
     const float r = 0.333333343267440796f;        // RN(1/3)
@@ -74,12 +88,17 @@ __device__ __forceinline__ float div3(float x) {
     return fmaf_(rem, r, q0);
 }
 
+// Channel held in value slot s of the lane that serves k-slot q.  A texel (F floats) is fetched by 4 adjacent lanes as
+// 16-B pieces: piece c4 of every 64-B group -> channels 16*j + 4*c4 + {0..3}; the lane with piece index c4 later feeds
+// MFMA k-slot q = c4, so slot s = 4*j + i holds channel 16*j + 4*q + i.  (FQ < 4: scalar loads, channel = q*FQ + s.)
+__host__ __device__ __forceinline__ int feat_of(int s, int q, int FQ) { return FQ % 4 == 0 ? 16 * (s >> 2) + 4 * q + (s & 3) : q * FQ + s; }
+
 template <int FQ, int MT, bool TAPS>
 __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
     constexpr int F = FQ * 4;
     constexpr int HID = MT * 16;
     // MFMA A operands, one float per lane per k-step, stored [step][lane] (conflict-free ds_read_b32, shared by the 4 waves):
-    //   layer 1: a0s[mt*FQ + s][lane]  = W0[mt*16 + (lane&15)][(lane>>4)*FQ + s] / sqrt(F)
+    //   layer 1: a0s[mt*FQ + s][lane]  = W0[mt*16 + (lane&15)][feat_of(s, lane>>4)] / sqrt(F)
     //   layer 2: a1s[mt*4 + r][lane]   = (lane&15) < 4 ? W1[lane&15][mt*16 + 4*(lane>>4) + r] * sqrt(2)/sqrt(HID) : 0
     __shared__ float a0s[MT * FQ * 64];
     __shared__ float a1s[MT * 4 * 64];
@@ -87,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
     const float sqrt2 = 1.41421353816986083984375f;    // (float)sqrt(2): lrelu gain, folded into the layer-2 weights
     for (int i = threadIdx.x; i < MT * FQ * 64; i += blockDim.x) {
         const int ln = i & 63, ms = i >> 6, mt = ms / FQ, sidx = ms % FQ;
-        a0s[i] = p.w0[(mt * 16 + (ln & 15)) * F + (ln >> 4) * FQ + sidx] * p.g0;
+        a0s[i] = p.w0[(mt * 16 + (ln & 15)) * F + feat_of(sidx, ln >> 4, FQ)] * p.g0;
     }
     for (int i = threadIdx.x; i < MT * 4 * 64; i += blockDim.x) {
         const int ln = i & 63, ms = i >> 6, mt = ms >> 2, r = ms & 3, o = ln & 15;
@@ -101,8 +120,17 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
     const float sx = (float)(p.W - 1) / 2.f, sy = (float)(p.H - 1) / 2.f;
     const int plane_elems = p.H * p.W * F;
 
-    // ---- one 16-point tile: gather + blend + MLP; lane (pt, q).  `bplanes` = planes of the point's sample -----------
-    auto eval_tile = [&](float cx, float cy, float cz, const float* __restrict__ bplanes, int64_t gp, bool valid) {
+    // Two lane layouts per 16-point tile:
+    //   gather layout  lane = 4*pt + c4 : the 4 lanes of a point are ADJACENT and read adjacent 16-B pieces of each texel, so a
+    //                  64-lane dwordx4 load is 16 fully used 64-B requests (lane = q*16+pt would make it 64 quarter-used ones:
+    //                  the L1 tag rate, not bandwidth, was the limiter -- 1.7k of 1.9k cycles per tile);
+    //   MFMA layout    lane = 16*q + pt : what v_mfma_f32_16x16x4_f32 wants (k-slot = lane >> 4).
+    // The blended features hop from one to the other with FQ ds_bpermute_b32 (piece index c4 becomes k-slot q).
+    const int gpt = (FQ % 4 == 0) ? (l >> 2) : pt, gc4 = (FQ % 4 == 0) ? (l & 3) : q;
+
+    // ---- one 16-point tile.  (cx,cy,cz,gvalid,ggp) describe the point of THIS lane in the gather layout; (gp,valid) the point
+    // whose result this lane stores (MFMA layout, q == 0 lanes).  `bplanes` = planes of the sample ------------------------------
+    auto eval_tile = [&](float cx, float cy, float cz, const float* __restrict__ bplanes, int64_t ggp, bool gvalid, int64_t gp, bool valid) {
         float qc[3];
         if (p.scale_is_pow2) { qc[0] = cx * p.inv_scale; qc[1] = cy * p.inv_scale; qc[2] = cz * p.inv_scale; }   // exact == cx / scale
         else { qc[0] = cx / p.scale; qc[1] = cy / p.scale; qc[2] = cz / p.scale; }                                 // :576 true division
@@ -121,9 +149,9 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
             const float cfy = fy < -2.f ? -2.f : (fy > (float)p.H ? (float)p.H : fy);
             const int x0 = (int)cfx, y0 = (int)cfy;
             if (TAPS) {
-                if (p.tap_idx && q == 0 && valid) {
-                    p.tap_idx[(gp * 3 + pl) * 2 + 0] = x0;
-                    p.tap_idx[(gp * 3 + pl) * 2 + 1] = y0;
+                if (p.tap_idx && gc4 == 0 && gvalid) {
+                    p.tap_idx[(ggp * 3 + pl) * 2 + 0] = x0;
+                    p.tap_idx[(ggp * 3 + pl) * 2 + 1] = y0;
                 }
             }
             const bool vx0 = x0 >= 0 && x0 < p.W, vx1 = x0 + 1 >= 0 && x0 + 1 < p.W;
@@ -133,14 +161,14 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
             wgt[pl][1] = (vx1 && vy0) ? ts * tw : 0.f;    // ne
             wgt[pl][2] = (vx0 && vy1) ? tn * te : 0.f;    // sw
             wgt[pl][3] = (vx1 && vy1) ? tn * tw : 0.f;    // se
-            const float* base = bplanes + pl * plane_elems + q * FQ;
+            const float* base = bplanes + pl * plane_elems;
             const int xa = min(max(x0, 0), p.W - 1), xb = min(max(x0 + 1, 0), p.W - 1);
             const int ya = min(max(y0, 0), p.H - 1), yb = min(max(y0 + 1, 0), p.H - 1);
             const int ra = ya * p.W, rb = yb * p.W;         // 32-bit element offsets inside one plane (< 2^31)
-            load_vec<FQ>(base + (ra + xa) * F, tap[pl][0]);
-            load_vec<FQ>(base + (ra + xb) * F, tap[pl][1]);
-            load_vec<FQ>(base + (rb + xa) * F, tap[pl][2]);
-            load_vec<FQ>(base + (rb + xb) * F, tap[pl][3]);
+            load_texel<FQ>(base + (ra + xa) * F, gc4, tap[pl][0]);
+            load_texel<FQ>(base + (ra + xb) * F, gc4, tap[pl][1]);
+            load_texel<FQ>(base + (rb + xa) * F, gc4, tap[pl][2]);
+            load_texel<FQ>(base + (rb + xb) * F, gc4, tap[pl][3]);
         }
         float g[FQ];
 #pragma unroll
@@ -150,6 +178,11 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
             for (int pl = 0; pl < 3; pl++)
                 pa[pl] = fmaf_(tap[pl][3][s], wgt[pl][3], fmaf_(tap[pl][2][s], wgt[pl][2], fmaf_(tap[pl][1][s], wgt[pl][1], tap[pl][0][s] * wgt[pl][0])));
             g[s] = div3((pa[0] + pa[1]) + pa[2]);          // x.mean(dim=1)
+        }
+        if (FQ % 4 == 0) {                                 // gather layout -> MFMA layout: lane (q, pt) takes from lane 4*pt + q
+            const int src = (pt * 4 + q) * 4;
+#pragma unroll
+            for (int s = 0; s < FQ; s++) g[s] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(g[s])));
         }
 
         // layer 1 on the matrix cores: h^T[hid x 16 pts] = W0s * g^T
@@ -193,20 +226,24 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
         const int nb = gridDim.x, per = nb / 8;
         const int lb = (nb % 8 == 0) ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
         const int wvi = threadIdx.x >> 6;
-        const int dy = pt >> 2, dx = pt & 3;
+        auto ray_of = [&](int b, int py, int px, int tpt, bool& ok) {       // pixel tpt of this wave's 4x4 quadrant -> ray index
+            const int y = py * 8 + (wvi >> 1) * 4 + (tpt >> 2), x = px * 8 + (wvi & 1) * 4 + (tpt & 3);
+            ok = y < p.ray_h && x < p.ray_w;
+            return b * (int)p.R + (ok ? y * p.ray_w + x : 0);                   // B*R*S < 2^31 (checked on the host)
+        };
         for (int patch = lb; patch < npatch; patch += nb) {
             const int px = patch % pX, py = (patch / pX) % pY, b = patch / (pX * pY);       // uniform
-            const int y = py * 8 + (wvi >> 1) * 4 + dy, x = px * 8 + (wvi & 1) * 4 + dx;
-            const bool rvalid = y < p.ray_h && x < p.ray_w;
-            const int ray = b * (int)p.R + (rvalid ? y * p.ray_w + x : 0);                   // B*R*S < 2^31 (checked on the host)
-            const float ox = p.ray_o[ray * 3 + 0], oy = p.ray_o[ray * 3 + 1], oz = p.ray_o[ray * 3 + 2];
-            const float dxr = p.ray_d[ray * 3 + 0], dyr = p.ray_d[ray * 3 + 1], dzr = p.ray_d[ray * 3 + 2];
+            bool gok, sok;
+            const int gray = ray_of(b, py, px, gpt, gok);      // the ray this lane gathers for
+            const int sray = ray_of(b, py, px, pt, sok);       // the ray this lane stores for (q == 0 lanes)
+            const float ox = p.ray_o[gray * 3 + 0], oy = p.ray_o[gray * 3 + 1], oz = p.ray_o[gray * 3 + 2];
+            const float dxr = p.ray_d[gray * 3 + 0], dyr = p.ray_d[gray * 3 + 1], dzr = p.ray_d[gray * 3 + 2];
             const float* bplanes = p.planes + (int64_t)b * 3 * plane_elems;
-            const float* tp = p.t + (int64_t)ray * p.S;
-            const int gp0 = ray * p.S;
+            const float* tp = p.t + (int64_t)gray * p.S;
             for (int k = 0; k < p.S; k++) {
                 const float tt = tp[k];
-                eval_tile(ox + tt * dxr, oy + tt * dyr, oz + tt * dzr, bplanes, gp0 + k, rvalid);   // tri_plane_renderer.py:141 (unfused mul, add)
+                eval_tile(ox + tt * dxr, oy + tt * dyr, oz + tt * dzr, bplanes, (int64_t)gray * p.S + k, gok,      // :141 (unfused mul, add)
+                          (int64_t)sray * p.S + k, sok);
             }
         }
         return;
@@ -215,9 +252,11 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t tile = wave0; tile < ntiles; tile += nwaves) {
-        const int64_t gp = tile * 16 + pt;
+        const int64_t gp = tile * 16 + pt;                 // stored by this lane (MFMA layout)
         const bool valid = gp < p.total;
-        const int64_t gpc = valid ? gp : p.total - 1;
+        const int64_t ggp = tile * 16 + gpt;               // gathered by this lane
+        const bool gvalid = ggp < p.total;
+        const int64_t gpc = gvalid ? ggp : p.total - 1;
         const int b = (int)(gpc / p.P);
         float cx, cy, cz;
         if (p.coords) {
@@ -229,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
             cy = p.ray_o[ray * 3 + 1] + tt * p.ray_d[ray * 3 + 1];
             cz = p.ray_o[ray * 3 + 2] + tt * p.ray_d[ray * 3 + 2];
         }
-        eval_tile(cx, cy, cz, p.planes + (int64_t)b * 3 * plane_elems, gp, valid);
+        eval_tile(cx, cy, cz, p.planes + (int64_t)b * 3 * plane_elems, ggp, gvalid, gp, valid);
     }
 }
 
