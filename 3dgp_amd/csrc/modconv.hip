@@ -137,66 +137,126 @@ __device__ __forceinline__ void epilogue_store(const EpiParams& e, float v, int 
 //   layout 1 (channel-last planes):           lane = channel (32 consecutive features = one 128-B texel line), 16 pixels
 //                                             per lane, pixel coordinates fetched from the owning lane by shuffle.
 // Side inputs (demod, bias, noise, skip taps) are loaded in batches of 8 before the math so their latencies overlap.
-__device__ __forceinline__ void epilogue_tile(const EpiParams& e, const float* ct, int obase, int pb, int poy, int pox, int pok, float* part) {
+// `side`: per-block LDS cache of the per-channel side inputs, [0..BM) = bias, then NSB slabs of BM demod coefficients for the
+// samples b0 .. b0+NSB-1 a block tile can touch (side == nullptr: tile spans more samples -> read them from global memory).
+struct SideCache { const float* lds; int b0, bm, m0; };
+__device__ __forceinline__ float side_bias(const EpiParams& e, const SideCache& sc, int o, bool ok) {
+    if (!e.bias || !ok) return 0.f;
+    return sc.lds ? sc.lds[o - sc.m0] : e.bias[o];
+}
+__device__ __forceinline__ float side_demod(const EpiParams& e, const SideCache& sc, int b, int o, bool ok) {
+    if (!e.dcoef || !ok) return 1.f;
+    return sc.lds ? sc.lds[(1 + b - sc.b0) * sc.bm + (o - sc.m0)] : e.dcoef[b * e.Cout + o];
+}
+
+// One 32(channels) x 32(pixels) accumulator tile parked in the per-wave LDS tile `ct` (row stride CT_LD = 36 floats, so
+// 4 consecutive entries are a 16-B aligned float4).  Stores are 16 B per lane wherever the geometry allows it -- 4-byte
+// per-lane stores top out near 1.6 TB/s on this chip, which made the output stage 15-25 % of every conv launch:
+//   NCHW / raw split-K partials, `vec`: ct is channel-major; lane = (channel row l>>3 of the pass, pixel quad l&7) stores
+//         float4 = 4 consecutive x of one channel (a 32-pixel subtile is made of whole rows of >= 4 pixels);
+//   NCHW scalar fallback: sub-pixel phases of the x2 layers (stride-2 scatter) and the op-level ToRGB with an NCHW skip;
+//   channel-last planes (CL, ToRGB): ct is PIXEL-major; lane = (pixel l>>3 of the pass, channel quad l&7) stores float4 =
+//         4 consecutive features of one texel; the x2-upsampled skip is 4 float4 taps per lane, all 4 passes in flight.
+constexpr int CT_LD = 36;
+template <bool CL>
+__device__ __forceinline__ void epilogue_tile(const EpiParams& e, const SideCache& sc, const float* ct, int obase, int pb, int poy, int pox, int pok,
+                                              float* part, bool vec) {
     const int l = lane_id(), l32 = l & 31, half = l >> 5;
     const int h2 = e.Hout / 2, w2 = e.Wout / 2;
     const bool raw = part != nullptr;
-    if (raw || e.out_layout == 0) {
+    if (!CL || raw || e.out_layout == 0) {
         float* dst = raw ? part : e.y;
-        const int pix = (pb * e.Cout * e.Hout + poy) * e.Wout + pox;          // + o * Hout * Wout   (tensor < 2^31 elements)
         const int cstride = e.Hout * e.Wout;
+        if (vec && (raw || !e.skip)) {
+            const int g = l & 7, cr = l >> 3;
+            const int b4 = __shfl(pb, 4 * g, 64), oy4 = __shfl(poy, 4 * g, 64), ox4 = __shfl(pox, 4 * g, 64), ok4 = __shfl(pok, 4 * g, 64);
+            float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!raw && e.noise && ok4) nz = *(const float4*)(e.noise + b4 * e.noise_bstride + (int64_t)oy4 * e.Wout + ox4);
+            const int pix = (b4 * e.Cout * e.Hout + oy4) * e.Wout + ox4;      // tensor < 2^31 elements (checked on the host)
+#pragma unroll
+            for (int pass = 0; pass < 4; pass++) {
+                const int row = pass * 8 + cr, o = obase + row;
+                if (ok4 && o < e.Cout) {
+                    float4 v = *(const float4*)&ct[row * CT_LD + 4 * g];
+                    if (!raw) {
+                        const float d = side_demod(e, sc, b4, o, true), bb = side_bias(e, sc, o, true);
+                        v.x = finish_act(e, (v.x * d + nz.x) + bb); v.y = finish_act(e, (v.y * d + nz.y) + bb);
+                        v.z = finish_act(e, (v.z * d + nz.z) + bb); v.w = finish_act(e, (v.w * d + nz.w) + bb);
+                    }
+                    *(float4*)(dst + pix + o * cstride) = v;
+                }
+            }
+            return;
+        }
+        const int pix = (pb * e.Cout * e.Hout + poy) * e.Wout + pox;
         const float nz = (!raw && e.noise && pok) ? e.noise[pb * e.noise_bstride + (int64_t)poy * e.Wout + pox] : 0.f;
         SkipTaps st;
         if (!raw && e.skip) st = skip_taps(h2, w2, poy, pox, e.fir);
 #pragma unroll 1
         for (int g = 0; g < 2; g++) {
-            float dv[8], bv[8], sk[8];
+            float sk[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const int o = obase + (g * 8 + q) * 2 + half;
-                const bool ok = pok && o < e.Cout;
-                dv[q] = (!raw && e.dcoef && ok) ? e.dcoef[pb * e.Cout + o] : 1.f;
-                bv[q] = (!raw && e.bias && ok) ? e.bias[o] : 0.f;
-                sk[q] = (!raw && e.skip && ok) ? skip_eval(e.skip + ((int64_t)pb * e.Cout + o) * h2 * w2, st, 1) : 0.f;
+                sk[q] = (!raw && e.skip && pok && o < e.Cout) ? skip_eval(e.skip + ((int64_t)pb * e.Cout + o) * h2 * w2, st, 1) : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const int sel = (g * 8 + q) * 2 + half;
                 const int o = obase + sel;
                 if (pok && o < e.Cout) {
-                    float v = ct[sel * 33 + l32];
-                    if (!raw) v = finish_act(e, ((v * dv[q] + nz) + bv[q]) + sk[q]);
+                    float v = ct[sel * CT_LD + l32];
+                    if (!raw) v = finish_act(e, ((v * side_demod(e, sc, pb, o, true) + nz) + side_bias(e, sc, o, true)) + sk[q]);
                     dst[pix + o * cstride] = v;
                 }
             }
         }
     } else {
-        const int o = obase + l32;
-        const bool okc = o < e.Cout;
+        // channel-last planes; ct is pixel-major here (the kernel wrote it transposed)
+        const int cg = l & 7, pr = l >> 3;
+        const int o = obase + 4 * cg;
+        const bool okc = o < e.Cout;                                            // Cout and out_feat are multiples of 4 (host check)
         const int pl = o / e.out_feat, f = o % e.out_feat;
         const int planes = e.Cout / e.out_feat;
-        const float bias = (e.bias && okc) ? e.bias[o] : 0.f;
-#pragma unroll 1
-        for (int g = 0; g < 2; g++) {
-            float sk[8], dv[8], nz[8];
-            int addr[8], okp[8];
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e.bias && okc) bias4 = make_float4(side_bias(e, sc, o, true), side_bias(e, sc, o + 1, true), side_bias(e, sc, o + 2, true), side_bias(e, sc, o + 3, true));
+        float4 sk[4];
+        int addr[4], bq[4];
+        float nzq[4];
+        bool okp[4];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int sel = (g * 8 + q) * 2 + half;
-                const int b = __shfl(pb, sel, 64), oy = __shfl(poy, sel, 64), ox = __shfl(pox, sel, 64);
-                okp[q] = __shfl(pok, sel, 64) && okc;
-                const int plane = b * planes + pl;
-                addr[q] = ((plane * e.Hout + oy) * e.Wout + ox) * e.out_feat + f;
-                dv[q] = (e.dcoef && okp[q]) ? e.dcoef[b * e.Cout + o] : 1.f;
-                nz[q] = (e.noise && okp[q]) ? e.noise[b * e.noise_bstride + (int64_t)oy * e.Wout + ox] : 0.f;
-                sk[q] = (e.skip && okp[q]) ? skip_eval(e.skip + (int64_t)plane * h2 * w2 * e.out_feat + f, skip_taps(h2, w2, oy, ox, e.fir), e.out_feat) : 0.f;
+        for (int pass = 0; pass < 4; pass++) {
+            const int px = pass * 8 + pr;
+            const int b = __shfl(pb, px, 64), oy = __shfl(poy, px, 64), ox = __shfl(pox, px, 64);
+            okp[pass] = __shfl(pok, px, 64) && okc;
+            bq[pass] = b;
+            const int plane = b * planes + pl;
+            addr[pass] = ((plane * e.Hout + oy) * e.Wout + ox) * e.out_feat + f;
+            nzq[pass] = (e.noise && okp[pass]) ? e.noise[b * e.noise_bstride + (int64_t)oy * e.Wout + ox] : 0.f;
+            sk[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e.skip && okp[pass]) {
+                const SkipTaps t = skip_taps(h2, w2, oy, ox, e.fir);
+                const float* sp = e.skip + (int64_t)plane * h2 * w2 * e.out_feat + f;
+                const float4 a = *(const float4*)(sp + (int64_t)t.i00 * e.out_feat), bb = *(const float4*)(sp + (int64_t)t.i01 * e.out_feat);
+                const float4 c = *(const float4*)(sp + (int64_t)t.i10 * e.out_feat), d = *(const float4*)(sp + (int64_t)t.i11 * e.out_feat);
+                sk[pass].x = fmaf_(t.w11, d.x, fmaf_(t.w10, c.x, fmaf_(t.w01, bb.x, t.w00 * a.x)));
+                sk[pass].y = fmaf_(t.w11, d.y, fmaf_(t.w10, c.y, fmaf_(t.w01, bb.y, t.w00 * a.y)));
+                sk[pass].z = fmaf_(t.w11, d.z, fmaf_(t.w10, c.z, fmaf_(t.w01, bb.z, t.w00 * a.z)));
+                sk[pass].w = fmaf_(t.w11, d.w, fmaf_(t.w10, c.w, fmaf_(t.w01, bb.w, t.w00 * a.w)));
             }
+        }
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                if (okp[q]) {
-                    const float v = ct[l32 * 33 + (g * 8 + q) * 2 + half];
-                    e.y[addr[q]] = finish_act(e, ((v * dv[q] + nz[q]) + bias) + sk[q]);
-                }
+        for (int pass = 0; pass < 4; pass++) {
+            if (okp[pass]) {
+                const int px = pass * 8 + pr;
+                float4 v = *(const float4*)&ct[px * CT_LD + 4 * cg];
+                const float d0 = side_demod(e, sc, bq[pass], o, true), d1 = side_demod(e, sc, bq[pass], o + 1, true);
+                const float d2 = side_demod(e, sc, bq[pass], o + 2, true), d3 = side_demod(e, sc, bq[pass], o + 3, true);
+                v.x = finish_act(e, ((v.x * d0 + nzq[pass]) + bias4.x) + sk[pass].x);
+                v.y = finish_act(e, ((v.y * d1 + nzq[pass]) + bias4.y) + sk[pass].y);
+                v.z = finish_act(e, ((v.z * d2 + nzq[pass]) + bias4.z) + sk[pass].z);
+                v.w = finish_act(e, ((v.w * d3 + nzq[pass]) + bias4.w) + sk[pass].w);
+                *(float4*)(e.y + addr[pass]) = v;
             }
         }
     }
@@ -222,7 +282,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     constexpr int KH = KCS / 2;             // k-steps (of 2 channels) per tap; even
     static_assert(KH % 2 == 0, "KCS must be a multiple of 4");
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][As | Xs], then the tap-offset table
-    int* toff_tab = (int*)(smem + 2 * BUF_SZ);                      // [MAXT + 2]
+    int* toff_tab = (int*)(smem + 2 * BUF_SZ);                      // [MAXT + 2 (+ pad to 16)]
+    float* side = smem + 2 * BUF_SZ + 16;                           // [1 + NSB][BM]: bias, demod coefficients of the tile's samples
 
     const int phase_id = blockIdx.z % p.nphases, ks = blockIdx.z / p.nphases;
     const Phase& ph = p.ph[phase_id];
@@ -243,6 +304,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     const int wm = wv / WN, wn = wv % WN;
 
     if (tid < MAXT + 2) toff_tab[tid] = tid < ph.ntaps ? (ph.tap_off_y[tid] + 1) * PC + (ph.tap_off_x[tid] + 1) : 0;
+    // per-channel side inputs of the epilogue -> LDS now, so the output stage has no dependent global loads
+    constexpr int NSB = 4;
+    const int sb0 = vr0 / ph.gridH, sb1 = min(p.B - 1, (vr0 + TR - 1) / ph.gridH);
+    const bool side_ok = (sb1 - sb0 + 1) <= NSB && p.ksplit == 1;
+    if (side_ok) {
+        for (int i = tid; i < (2 + sb1 - sb0) * BM; i += 256) {
+            const int slab = i / BM, o = m0 + i % BM;
+            float v = slab == 0 ? 0.f : 1.f;
+            if (o < p.e.Cout) {
+                if (slab == 0) { if (p.e.bias) v = p.e.bias[o]; }
+                else if (p.e.dcoef) v = p.e.dcoef[(sb0 + slab - 1) * p.e.Cout + o];
+            }
+            side[i] = v;
+        }
+    }
 
     // ---- per-thread patch positions (fixed across the K loop) -------------------------------------
     constexpr int NPOS = (XS_MAX + 255) / 256;
@@ -414,18 +490,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     // ---- epilogue: accumulators -> per-wave 32x33 LDS tile -> epilogue_tile() ---------------------------------------
     // The loop over the wave's tiles stays rolled; the accumulator tile is selected with a compile-time-indexed if-chain
     // so the accumulators never need dynamic register indexing.
-    float* ct = smem + wv * (32 * 33);
+    float* ct = smem + wv * (32 * CT_LD);
+    const bool ct_pixel_major = (MAXT == 1) && p.ksplit == 1 && p.e.out_layout == 1;       // channel-last epilogue reads float4 of channels
+    const bool vec = ph.ox_mul == 1 && (p.e.Wout & 3) == 0;                               // 4 consecutive lanes = 4 consecutive x of one row
     const EpiParams& e = p.e;
+    SideCache scache;
+    scache.lds = side_ok ? side : nullptr; scache.b0 = sb0; scache.bm = BM; scache.m0 = m0;
     float* part = (p.ksplit > 1) ? p.partial + (int64_t)ks * e.B * e.Cout * e.Hout * e.Wout : nullptr;
 #pragma unroll 1
-    for (int tile = 0; tile < MTW * NTW; tile++) {
+    for (int tile = 0; tile < ((p.dbg & 16) ? 0 : MTW * NTW); tile++) {
         int pb = 0, pm = 0, pn = 0, pk = 0;
 #pragma unroll
         for (int k = 0; k < MTW * NTW; k++) {
             if (tile == k) {
                 constexpr int dummy = 0; (void)dummy;
 #pragma unroll
-                for (int r = 0; r < 16; r++) ct[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l32] = acc[k % MTW][k / MTW][r];
+                for (int r = 0; r < 16; r++) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    ct[ct_pixel_major ? l32 * CT_LD + row : row * CT_LD + l32] = acc[k % MTW][k / MTW][r];
+                }
                 pb = px_b[k / MTW]; pm = px_m[k / MTW]; pn = px_n[k / MTW]; pk = px_ok[k / MTW] ? 1 : 0;
             }
         }
@@ -434,7 +517,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         const int pok = (pk && poy < e.Hout && pox < e.Wout) ? 1 : 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        epilogue_tile(e, ct, m0 + (wm * MTW + m) * 32, pb, poy, pox, pok, part);
+        if (!(p.dbg & 32)) epilogue_tile<MAXT == 1>(e, scache, ct, m0 + (wm * MTW + m) * 32, pb, poy, pox, pok, part, vec);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -628,7 +711,7 @@ template <int MTW, int NTW, int WM, int WN, int KCS, int MAXT>
 int launch_conv(ConvParams& p, float* partial, int64_t partial_floats, hipStream_t s) {
     constexpr int BM = 32 * MTW * WM, NT = NTW * WN, BN = 32 * NT;
     constexpr int XS_MAX = (BN / 4 + 2) * (4 + 2) > (BN / 32 + 2) * (32 + 2) ? (BN / 4 + 2) * (4 + 2) : (BN / 32 + 2) * (32 + 2);
-    const size_t lds = (size_t)(2 * (MAXT * KCS * BM + KCS * XS_MAX + 64) + MAXT + 2 + 14) * sizeof(float);
+    const size_t lds = (size_t)(2 * (MAXT * KCS * BM + KCS * XS_MAX + 64) + 16 + 5 * BM) * sizeof(float);
     static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<MTW, NTW, WM, WN, KCS, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -709,7 +792,8 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
     TDGP_CHECK(!skip || (up == 1 && k == 1 && fir4x4 && (H % 2) == 0 && (W % 2) == 0), TDGP_EINVAL, "modconv2d: skip needs k=1, up=1, even H/W and the filter");
     TDGP_CHECK(!demodulate || styles, TDGP_EINVAL, "modconv2d: demodulate needs styles");
     TDGP_CHECK(act >= 1 && act <= 9, TDGP_EUNSUPPORTED, "modconv2d: unknown activation %d", act);
-    TDGP_CHECK(out_layout == 0 || (out_layout == 1 && out_feat >= 1 && (Cout % out_feat) == 0 && up == 1), TDGP_EINVAL, "modconv2d: bad output layout");
+    TDGP_CHECK(out_layout == 0 || (out_layout == 1 && out_feat >= 4 && (out_feat % 4) == 0 && (Cout % out_feat) == 0 && up == 1 && k == 1), TDGP_EINVAL,
+               "modconv2d: the channel-last plane layout is a ToRGB (k=1, up=1) output");
     TDGP_CHECK((int64_t)B * Cin * H * W <= INT32_MAX && (int64_t)B * Cout * (H * up + 1) * (W * up + 1) <= INT32_MAX, TDGP_EINVAL, "modconv2d: tensor too large");
     const WsLayout wl = ws_layout(B, Cin, Cout, H, W, k, up);
     TDGP_CHECK(workspace && workspace_bytes >= wl.total, TDGP_EWORKSPACE, "modconv2d: workspace %lld < %lld bytes", (long long)workspace_bytes,
