@@ -252,20 +252,31 @@ __global__ __launch_bounds__(256) void sample_importance_kernel(const float* __r
     if (cdf_o) for (int i = l; i < Wn - 1; i += 64) cdf_o[r * (Wn - 1) + i] = sc.cdf[i];
 }
 
-// stable rank of every element of key[0..M) under (key, index) order -> pos[]; brute force from LDS broadcasts
-__device__ __forceinline__ void stable_ranks(const float* key, int M, int* rank /* per-lane, MAXS/64 entries */) {
+// stable rank of every element of key[0..M) under (key, index) order -> rank[]; brute force from LDS broadcasts.
+// NS = ceil(M / 64) value slots per lane actually in use (compile time, so no work is spent on empty slots).
+template <int NS>
+__device__ __forceinline__ void stable_ranks_n(const float* key, int M, int* rank) {
     const int l = lane_id();
-    float k[MAXS / 64];
+    float k[NS];
 #pragma unroll
-    for (int c = 0; c < MAXS / 64; c++) { const int i = l + 64 * c; k[c] = i < M ? key[i] : 0.f; rank[c] = 0; }
+    for (int c = 0; c < NS; c++) { const int i = l + 64 * c; k[c] = i < M ? key[i] : 0.f; rank[c] = 0; }
+#pragma unroll 4
     for (int m = 0; m < M; m++) {
         const float km = key[m];                   // same address on every lane: LDS broadcast
 #pragma unroll
-        for (int c = 0; c < MAXS / 64; c++) {
+        for (int c = 0; c < NS; c++) {
             const int i = l + 64 * c;
             rank[c] += (km < k[c] || (km == k[c] && m < i)) ? 1 : 0;
         }
     }
+}
+__device__ __forceinline__ void stable_ranks(const float* key, int M, int* rank /* per-lane, MAXS/64 entries */) {
+#pragma unroll
+    for (int c = 0; c < MAXS / 64; c++) rank[c] = 0;
+    if (M <= 64) stable_ranks_n<1>(key, M, rank);
+    else if (M <= 128) stable_ranks_n<2>(key, M, rank);
+    else if (M <= 192) stable_ranks_n<3>(key, M, rank);
+    else stable_ranks_n<4>(key, M, rank);
 }
 
 // fused: coarse march (s-space) -> importance sampling -> fine depths (t-space), WRITTEN IN ASCENDING DEPTH ORDER.
