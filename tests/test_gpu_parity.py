@@ -437,3 +437,107 @@ def test_e2e_vs_oracle_bigger(tdgp, oracle):
     # bounded at 1e-3 (= abs error <= 1e-6 of the image range on near-zero pixels).
     assert_image_parity(N(out.img), dict(img=oimg), 'img vs oracle', pix_tol=1e-3)
     assert_image_parity(N(out.depth), dict(depth=odepth), 'depth vs oracle', 'depth', pix_tol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ full size (BASELINE configs[2])
+
+@pytest.fixture(scope='module')
+def full_c3(tdgp):
+    """ImageNet 256^2 / 64 ray steps / cmax 512 generator with synthetic weights, one forward with intermediates."""
+    cfg = tdgp.config.config_c3()
+    sd = tdgp.weights.random_state_dict(cfg, seed=0, exercise_all=True)
+    G = tdgp.generator.Generator(cfg)
+    G.load_numpy_state_dict(sd)
+    G = G.to(DEV)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=2, seed=7)
+    ws = G.mapping(T(inp['z']), T(inp['c']))
+    planes = G.synthesis.tri_plane_decoder(ws, noise_mode='const', hwc=True)
+    cam = {k: T(v) for k, v in inp['camera'].items()}
+    return dict(cfg=cfg, sd=sd, G=G, inp=inp, ws=ws, planes=planes, cam=cam)
+
+
+def test_full_size_backbone_vs_oracle(tdgp, oracle, full_c3):
+    """All eight blocks at their real shapes (512 -> 64 channels, 4^2 -> 512^2, every tile configuration, split-K layers,
+    sub-pixel phases with odd 2^k+1 grids) against the CPU oracle: one sample, ~10 s of host time."""
+    cfg, sd = full_c3['cfg'], full_c3['sd']
+    ws1 = N(full_c3['ws'])[:1]
+    oracle.set_threads(min(64, __import__('os').cpu_count() or 1))
+    ref = oracle.synthesis_backbone(sd, cfg.to_dict(), ws1, 'const')                     # [1, 96, 512, 512]
+    got = N(full_c3['planes'].t[:1].permute(0, 1, 4, 2, 3).reshape(1, 96, 512, 512))
+    assert_close(got, ref, 1e-5, 'tri-planes 512^2', 1.0)
+
+
+def test_full_size_renderer_strip_vs_oracle(tdgp, oracle, full_c3):
+    """256^2 x (64 + 64) samples: the HIP renderer on the real 100 MB tri-planes; a strip of 3 x 256 rays is re-rendered by the
+    oracle from the same planes and must agree (rays are independent, so a strip is a full-fidelity check)."""
+    cfg, G, inp = full_c3['cfg'], full_c3['G'], full_c3['inp']
+    out = G.synthesis(full_c3['ws'], camera_params=full_c3['cam'], noise_mode='const', render_opts=dict(return_depth=True),
+                      u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']))
+    img, depth = N(out.img), N(out.depth)
+    assert img.shape == (2, 3, 256, 256) and np.isfinite(img).all()
+    from oracle.pipeline import render_options
+    sd = full_c3['sd']
+    mlp = tuple(sd[f'synthesis.tri_plane_mlp.model.{i}.{n}'] for i in (0, 1) for n in ('weight', 'bias'))
+    planes_nchw = N(full_c3['planes'].t.permute(0, 1, 4, 2, 3).reshape(2, 96, 512, 512))
+    c2w = oracle.cam2world(inp['camera']['angles'], inp['camera']['radius'], inp['camera']['look_at'])
+    ro, rd = oracle.sample_rays(c2w, inp['camera']['fov'], 256, 256)
+    R, S = 256 * 256, cfg.num_ray_steps
+    rows = [0, 131, 255]
+    sel = np.concatenate([np.arange(r * 256, (r + 1) * 256) for r in rows])
+    u1 = inp['u_coarse'].reshape(2, R, S)[:, sel]
+    u2 = inp['u_fine'].reshape(2, R, S)[:, sel].reshape(-1, S)
+    orgb, odepth, _, _ = oracle.importance_render(planes_nchw, mlp, ro[:, sel], rd[:, sel], render_options(cfg.to_dict()), u1, u2)
+    got = img.reshape(2, 3, R)[:, :, sel].transpose(0, 2, 1)
+    scale = np.abs(orgb).max()
+    assert np.abs(got - orgb).max() / scale < 1e-5, np.abs(got - orgb).max() / scale
+    assert np.abs(depth.reshape(2, R)[:, sel] - odepth[..., 0]).max() < 1e-5
+
+
+def test_full_size_properties(tdgp, full_c3):
+    """Size-independent properties at 256^2 / 64 steps: ray independence (a sub-batch of rays renders bit-identically),
+    batch consistency, sorted merge order, and sum(weights) + final transmittance == 1 for the classical marcher."""
+    G, inp, cfg = full_c3['G'], full_c3['inp'], full_c3['cfg']
+    R, S = 256 * 256, cfg.num_ray_steps
+    syn = G.synthesis
+    c2w = tdgp.renderer.compute_cam2world_matrix(full_c3['cam'])
+    ro, rd = tdgp.renderer.sample_rays(c2w, full_c3['cam']['fov'], (256, 256))
+    opts = syn.rendering_options(syn._default_render_options)
+    u1, u2 = T(inp['u_coarse']), T(inp['u_fine'])
+    (rgb, depth, wsum, fT), inter = syn.renderer(full_c3['planes'], syn.tri_plane_mlp, ro, rd, dict(opts, u_coarse=u1, u_fine=u2, ray_grid_w=256),
+                                                 return_intermediates=True)
+    # sum of compositing weights + final transmittance telescopes to 1 (up to the 1e-10 the reference adds per step)
+    assert float((wsum[..., 0] + fT - 1).abs().max()) < 1e-4
+    # merged depths ascending: gather t by the reported permutation
+    t_all = torch.cat([inter['tdist_coarse'], torch.gather(inter['tdist_fine'], 2, torch.argsort(inter['fine_perm'].reshape(2, R, S).long(), dim=2))], dim=2)
+    t_sorted = torch.gather(t_all, 2, inter['perm'].long())
+    assert bool((t_sorted[:, :, 1:] >= t_sorted[:, :, :-1]).all())
+    # ray independence + layout independence: rows 64..127 alone, linear point order (no image tiling) -> identical pixels
+    sl = slice(64 * 256, 128 * 256)
+    rgb_s, depth_s, _, _ = syn.renderer(full_c3['planes'], syn.tri_plane_mlp, ro[:, sl].contiguous(), rd[:, sl].contiguous(),
+                                        dict(opts, u_coarse=u1.reshape(2, R, S)[:, sl].contiguous(), u_fine=u2.reshape(2, R, S)[:, sl].reshape(-1, S).contiguous(),
+                                             ray_grid_w=0))
+    np.testing.assert_array_equal(N(rgb[:, sl]), N(rgb_s))
+    np.testing.assert_array_equal(N(depth[:, sl]), N(depth_s))
+    # batch consistency of the whole forward: sample 1 alone == sample 1 inside the batch of 2 (split-K factors may differ -> 1e-5)
+    cam1 = {k: v[1:2] for k, v in full_c3['cam'].items()}
+    img_b = syn(full_c3['ws'], camera_params=full_c3['cam'], noise_mode='const', u_coarse=u1, u_fine=u2)
+    img_1 = syn(full_c3['ws'][1:2], camera_params=cam1, noise_mode='const', u_coarse=u1[1:2], u_fine=u2.reshape(2, R, S)[1:2].reshape(-1, S))
+    assert float((img_b[1:2] - img_1).abs().max() / img_b.abs().max()) < 1e-5
+    # determinism
+    img_b2 = syn(full_c3['ws'], camera_params=full_c3['cam'], noise_mode='const', u_coarse=u1, u_fine=u2)
+    assert torch.equal(img_b, img_b2)
+
+
+def test_compat_plugins(tdgp, oracle):
+    """The pybind-signature plugin objects of 3dgp_amd/compat.py (bias_act.cpp:32 / upfirdn2d.cpp:16 argument orders)."""
+    rs = np.random.RandomState(2)
+    x = rs.randn(2, 6, 9, 9).astype(np.float32)
+    b = rs.randn(6).astype(np.float32)
+    empty = torch.empty([0], device=DEV)
+    y = tdgp.compat.BiasActPlugin.bias_act(T(x), T(b), empty, empty, empty, 0, 1, 3, 0.2, float(np.sqrt(2)), -1.0)
+    assert_close(N(y), oracle.bias_act(x, b, act='lrelu'), 1e-6)
+    f = oracle.setup_filter([1, 3, 3, 1])
+    y = tdgp.compat.Upfirdn2dPlugin.upfirdn2d(T(x), T(f), 2, 2, 1, 1, 2, 1, 2, 1, False, 4.0)
+    assert_close(N(y), oracle.upsample2d(x, f), 2e-6, 'upsample2d via plugin', 1.0)
+    with pytest.raises(RuntimeError):
+        tdgp.compat.BiasActPlugin.bias_act(T(x), T(b), empty, empty, empty, 1, 1, 3, 0.2, 1.0, -1.0)     # grad != 0: not on this path
