@@ -523,6 +523,218 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// x2 layers: stride-2 transposed 3x3 convolution (conv2d_resample.py:108-125, unflipped weights)
+//     Z[2i+a, 2j+e] += w[a,e] * x[i,j]
+// as ONE implicit GEMM over a LINEARISED input grid.  Grid point v' = m*(W+1) + n, m in [0,H], n in [0,W], with x := 0
+// on column W and row H.  The four output parities (py,px) of grid point (m,n) are
+//     Z[2m+py, 2n+px] = sum_{a = py (mod 2), e = px (mod 2)} w[a,e] * x[m - (a==2), n - (e==2)]
+// and in linear space the four distinct taps are the offsets {0, -1, -(W+1), -(W+2)}: the zero column doubles as the
+// left AND right padding (n-1 at n = 0 wraps onto column W of the previous row), the zero row separates samples.  So
+//   * a block tile is BN CONSECUTIVE grid points -- no 2-D tile edges, no "+1" column of wasted tiles (the old four-phase
+//     launch lost 11-50 % of its lanes to the (W+1)-wide phase grids), no tap masks in the MFMA loop;
+//   * the activation patch is two runs of BN+1 values per channel (the dy = 0 and dy = -1 rows);
+//   * all 9 taps of a channel pair are multiplied in one pass: 9 A fragments x 4 B fragments feed the 4 parity
+//     accumulators of each 32x32 tile (taps per parity 4/2/2/1), so x is staged once instead of once per phase;
+//   * the epilogue interleaves the px = 0/1 accumulators through LDS and writes Z as dense 16-B-per-lane rows.
+// Z layout (workspace): [ksplit][B][Cout][py][2*GS], entry 2*v' + px; GS = (H+1)*(W+1) rounded up to 32 so a 32-point
+// subtile never straddles samples and every row segment stays 16-B aligned.  Seen as an image, parity plane py holds Z rows
+// 2m+py with row pitch 2(W+1); the pad column 2W+1 and the pad row 2H+1 come out as exact zeros.
+// -------------------------------------------------------------------------------------------------
+struct UpParams {
+    const float* x; const float* wp; const float* styles; float* z;
+    int B, Cin, Cout, CoutP, H, W, G1, GS, ksplit;
+    int64_t zslice;
+};
+
+constexpr int UP_CT_W = 68;     // epilogue LDS tile: 32 channels x 64 floats (+4 pad)
+
+template <int MTW, int NTW, int WM, int WN, int KCS>
+__global__ __launch_bounds__(64 * WM * WN) void upconv_mfma_kernel(UpParams p) {
+    constexpr int NTH = 64 * WM * WN;
+    constexpr int BM = 32 * MTW * WM, BN = 32 * NTW * WN;
+    constexpr int XP = BN + 4, XCH = 2 * XP;            // per channel: [dy = -1 run | dy = 0 run], BN + 1 used of each
+    constexpr int AS_SZ = 9 * KCS * BM, XS_SZ = KCS * XCH, BUF_SZ = AS_SZ + XS_SZ;
+    constexpr int KH = KCS / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int v0 = blockIdx.x * BN, m0 = blockIdx.y * BM, ks = blockIdx.z;
+    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, l32 = l & 31, half = l >> 5;
+    const int wm = wv / WN, wn = wv % WN;
+
+    // ---- activation patch slots of this thread (fixed across the K loop) ---------------------------------------------
+    constexpr int NE = 2 * (BN + 1);
+    constexpr int NPOS = (NE + NTH - 1) / NTH;
+    int pos_off[NPOS], pos_sb[NPOS], pos_lds[NPOS];
+#pragma unroll
+    for (int k = 0; k < NPOS; k++) {
+        const int e = tid + k * NTH;
+        pos_off[k] = -1; pos_sb[k] = 0; pos_lds[k] = -1;
+        if (e < NE) {
+            const int seg = e / (BN + 1), idx = e % (BN + 1);
+            const int g = v0 + idx - 1 - (seg == 0 ? p.G1 : 0);
+            pos_lds[k] = seg * XP + idx;
+            if (g >= 0) {
+                const int b = g / p.GS, vp = g - b * p.GS;
+                const int m = vp / p.G1, n = vp - m * p.G1;
+                if (b < p.B && m < p.H && n < p.W) {
+                    pos_off[k] = ((b * p.Cin) * p.H + m) * p.W + n;
+                    pos_sb[k] = b * p.Cin;
+                }
+            }
+        }
+    }
+    const int chw = p.H * p.W;
+
+    f32x16 acc[4][MTW][NTW];            // [py*2+px]
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int m = 0; m < MTW; m++)
+#pragma unroll
+            for (int n = 0; n < NTW; n++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[q][m][n][r] = 0.f;
+
+    constexpr int G = KCS / KC3;
+    const int nchunks_packed = (p.Cin + KC3 - 1) / KC3;
+    const int niter = (nchunks_packed + G - 1) / G;
+    const int it_per = (niter + p.ksplit - 1) / p.ksplit;
+    const int it0 = ks * it_per, it1 = min(niter, it0 + it_per);
+
+    constexpr int AROWS = 9 * KCS;
+    constexpr int NA = (AROWS * (BM / 4) + NTH - 1) / NTH;
+    float4 a_reg[NA];
+    float x_reg[NPOS][KCS], s_reg[NPOS][KCS];
+    int a_goff[NA], a_loff[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int e = tid + i * NTH;
+        a_goff[i] = -1; a_loff[i] = -1;
+        if (e < AROWS * (BM / 4)) {
+            const int row = e / (BM / 4), j4 = e % (BM / 4);
+            const int t = row / KCS, ci = row % KCS;
+            const int g = ci / KC3, c4 = ci % KC3;
+            const int o = m0 + j4 * 4;
+            a_loff[i] = row * BM + j4 * 4;
+            if (o < p.CoutP) a_goff[i] = ((g * 9 + t) * KC3 + c4) * p.CoutP + o;
+        }
+    }
+    const int a_gstride = G * 9 * KC3 * p.CoutP;
+
+    auto load_stage = [&](int it) {
+        const float* wp_it = p.wp + (int64_t)it * a_gstride;
+#pragma unroll
+        for (int i = 0; i < NA; i++) a_reg[i] = a_goff[i] >= 0 ? *(const float4*)(wp_it + a_goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c0 = it * KCS;
+        const float* x_it = p.x + (int64_t)c0 * chw;
+#pragma unroll
+        for (int k = 0; k < NPOS; k++) {
+            const int off = pos_off[k];
+#pragma unroll
+            for (int ci = 0; ci < KCS; ci++) {
+                const bool ok = off >= 0 && c0 + ci < p.Cin;
+                x_reg[k][ci] = ok ? x_it[off + ci * chw] : 0.f;
+                s_reg[k][ci] = (ok && p.styles) ? p.styles[pos_sb[k] + c0 + ci] : 1.f;
+            }
+        }
+    };
+    auto store_stage = [&](float* As, float* Xs) {
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+            if (a_loff[i] >= 0) *(float4*)(As + a_loff[i]) = a_reg[i];
+#pragma unroll
+        for (int k = 0; k < NPOS; k++)
+            if (pos_lds[k] >= 0) {
+#pragma unroll
+                for (int ci = 0; ci < KCS; ci++) Xs[ci * XCH + pos_lds[k]] = x_reg[k][ci] * s_reg[k][ci];
+            }
+    };
+
+    if (it0 < it1) {
+        load_stage(it0);
+        store_stage(smem, smem + AS_SZ);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int it = it0; it < it1; it++) {
+        const bool more = it + 1 < it1;
+        if (more) load_stage(it + 1);
+        const float* As = smem + cur * BUF_SZ + half * BM + (wm * MTW) * 32 + l32;
+        const float* Xs = smem + cur * BUF_SZ + AS_SZ + half * XCH + (wn * NTW) * 32 + l32;
+        float fa[2][9][MTW], fb[2][4][NTW];             // fb index = seg*2 + dxi  (seg 0: dy = -1, dxi 0: dx = -1)
+        auto load_frag = [&](int buf, int kk) {
+#pragma unroll
+            for (int t = 0; t < 9; t++)
+#pragma unroll
+                for (int m = 0; m < MTW; m++) fa[buf][t][m] = As[(t * KCS + 2 * kk) * BM + m * 32];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int n = 0; n < NTW; n++) fb[buf][q][n] = Xs[2 * kk * XCH + (q >> 1) * XP + (q & 1) + n * 32];
+        };
+        load_frag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < KH; kk++) {
+            const int cb = kk & 1;
+            if (kk + 1 < KH) load_frag(cb ^ 1, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ds_reads above this step's MFMAs
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int a = t / 3, e = t % 3;
+                const int q = (a & 1) * 2 + (e & 1);                    // output parity of this tap
+                const int f = (a == 2 ? 0 : 2) + (e == 2 ? 0 : 1);     // which shifted run it reads
+#pragma unroll
+                for (int m = 0; m < MTW; m++)
+#pragma unroll
+                    for (int n = 0; n < NTW; n++) acc[q][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][t][m], fb[cb][f][n], acc[q][m][n], 0, 0, 0);
+            }
+        }
+        if (more) store_stage(smem + (cur ^ 1) * BUF_SZ, smem + (cur ^ 1) * BUF_SZ + AS_SZ);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: per (channel tile, point subtile, py): interleave px = 0/1 in a per-wave LDS tile, store 16 B per lane -----
+    float* ct = smem + wv * (32 * UP_CT_W);
+    float* zout = p.z + (int64_t)ks * p.zslice;
+#pragma unroll 1
+    for (int tile = 0; tile < 2 * MTW * NTW; tile++) {
+#pragma unroll
+        for (int k = 0; k < 2 * MTW * NTW; k++) {
+            if (tile == k) {
+                constexpr int dummy = 0; (void)dummy;
+                const int py = k / (MTW * NTW), mm = (k / NTW) % MTW, nn = k % NTW;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    *(float2*)&ct[row * UP_CT_W + 2 * l32] = make_float2(acc[py * 2][mm][nn][r], acc[py * 2 + 1][mm][nn][r]);
+                }
+            }
+        }
+        const int py = tile / (MTW * NTW), mm = (tile / NTW) % MTW, nn = tile % NTW;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int g0 = v0 + (wn * NTW + nn) * 32;
+        const int b = g0 / p.GS, vp0 = g0 - b * p.GS;
+        if (b < p.B) {
+            const int q = l & 15, cr = l >> 4;
+            const int obase = m0 + (wm * MTW + mm) * 32;
+#pragma unroll
+            for (int pass = 0; pass < 8; pass++) {
+                const int ch = pass * 4 + cr, o = obase + ch;
+                if (o < p.Cout) {
+                    const float4 v = *(const float4*)&ct[ch * UP_CT_W + 4 * q];
+                    *(float4*)(zout + (((int64_t)b * p.Cout + o) * 2 + py) * (2 * p.GS) + 2 * vp0 + 4 * q) = v;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Split-K reduction: y = epilogue(sum_ks partial[ks]) ; one thread per output element, ks summed in order (deterministic).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, EpiParams e) {
     const int64_t slice = (int64_t)e.B * e.Cout * e.Hout * e.Wout;
@@ -539,24 +751,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 // -------------------------------------------------------------------------------------------------
-// FIR (4x4, pad 1, gain folded into the taps) + demod + noise + bias + activation on the transposed-conv
-// intermediate Z [B,C,ZH,ZW] -> y [B,C,ZH-1,ZW-1].   (conv2d_resample.py:126 + networks_stylegan2.py:86-87,144)
-// One thread produces 4 consecutive outputs of a row from a 4x7 register window.
+// FIR (4x4, pad 1, gain folded into the taps) + demod + noise + bias + activation on the transposed-conv intermediate
+// (upconv_mfma_kernel's parity-planar Z, split-K slices summed on the fly) -> y [B,C,2H,2W].
+// (conv2d_resample.py:126 + networks_stylegan2.py:86-87,144)
+// Block = one 16x64 output tile of one (b,c) plane: the (16+3) x (64+4) input window is staged in LDS with aligned 8-byte
+// loads, each thread then produces 4 consecutive outputs from a 4x7 window.  HBM traffic = Z read once + y written once.
 // -------------------------------------------------------------------------------------------------
 struct FirParams {
     const float* z; const float* dcoef; const float* noise; const float* bias; float* y;
-    int64_t noise_bstride;
+    int64_t noise_bstride, zslice;
     float fir[16];
-    int B, C, ZH, ZW, OH, OW;
+    int B, C, ZROWS, P2, GS2, ksplit, OH, OW;      // ZROWS = 2H+2 rows of pitch P2 = 2(W+1), alternating between the parity planes
     int act; float alpha, gain, clamp;
 };
 
-// Block = one 16x64 output tile of one (b,c) plane: the (16+3)x(64+3) input tile is staged in LDS with coalesced row
-// loads, each thread then produces 4 consecutive outputs from a 4x7 window.  HBM traffic = Z read once + y written once.
-constexpr int FIR_TH = 16, FIR_TW = 64;
+constexpr int FIR_TH = 32, FIR_TW = 64;
 __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
-    __shared__ float zt[(FIR_TH + 3) * (FIR_TW + 4)];
-    constexpr int ZP = FIR_TW + 4;
+    constexpr int ZP = FIR_TW + 4;                  // window columns ox0-2 .. ox0+65
+    __shared__ __attribute__((aligned(16))) float zt[(FIR_TH + 3) * ZP];
     const int tilesX = (p.OW + FIR_TW - 1) / FIR_TW, tilesY = (p.OH + FIR_TH - 1) / FIR_TH;
     const int64_t ntiles = (int64_t)p.B * p.C * tilesY * tilesX;
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -566,44 +778,61 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
         const int c = (int)(r % p.C);
         const int b = (int)(r / p.C);
         const int oy0 = ty * FIR_TH, ox0 = tx * FIR_TW;
-        const float* zp = p.z + ((int64_t)b * p.C + c) * p.ZH * p.ZW;
+        const float* zp = p.z + ((int64_t)b * p.C + c) * 2 * p.GS2;
+        const int nrows = min(FIR_TH, p.OH - oy0) + 3;
         __syncthreads();
-        for (int i = threadIdx.x; i < (FIR_TH + 3) * (FIR_TW + 3); i += 256) {
-            const int ry = i / (FIR_TW + 3), rx = i % (FIR_TW + 3);
-            const int zy = oy0 - 1 + ry, zx = ox0 - 1 + rx;
-            zt[ry * ZP + rx] = (zy >= 0 && zy < p.ZH && zx >= 0 && zx < p.ZW) ? zp[(int64_t)zy * p.ZW + zx] : 0.f;
+        for (int i = threadIdx.x; i < nrows * (ZP / 2); i += 256) {
+            const int ry = i / (ZP / 2), j = i % (ZP / 2);
+            const int zy = oy0 - 1 + ry, zx = ox0 - 2 + 2 * j;
+            float2 v = make_float2(0.f, 0.f);
+            if (zy >= 0 && zy < p.ZROWS && zx >= 0 && zx < p.P2) {
+                const float* q = zp + (zy & 1) * p.GS2 + (zy >> 1) * p.P2 + zx;
+                v = *(const float2*)q;
+                for (int k0 = 1; k0 < p.ksplit; k0 += 8) {      // split-K slices, summed in order (deterministic); 8 loads in flight
+                    float2 w[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) w[k] = (k0 + k < p.ksplit) ? *(const float2*)(q + (k0 + k) * p.zslice) : make_float2(0.f, 0.f);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { v.x += w[k].x; v.y += w[k].y; }
+                }
+            }
+            *(float2*)&zt[ry * ZP + 2 * j] = v;
         }
         __syncthreads();
-        const int ly = threadIdx.x >> 4, lx = (threadIdx.x & 15) * 4;
-        const int oy = oy0 + ly;
-        if (oy < p.OH && ox0 + lx < p.OW) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const int lx = (threadIdx.x & 15) * 4;
+        const float d = p.dcoef ? p.dcoef[b * p.C + c] : 1.f;
+        const float bv = p.bias ? p.bias[c] : 0.f;
 #pragma unroll
-            for (int ky = 0; ky < 4; ky++) {
-                float win[7];
+        for (int hrow = 0; hrow < FIR_TH / 16; hrow++) {
+            const int ly = (threadIdx.x >> 4) + hrow * 16;
+            const int oy = oy0 + ly;
+            if (oy < p.OH && ox0 + lx < p.OW) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 7; j++) win[j] = zt[(ly + ky) * ZP + lx + j];
+                for (int ky = 0; ky < 4; ky++) {
+                    float win[7];
 #pragma unroll
-                for (int o = 0; o < 4; o++)
+                    for (int j = 0; j < 7; j++) win[j] = zt[(ly + ky) * ZP + lx + j + 1];
 #pragma unroll
-                    for (int kx = 0; kx < 4; kx++) acc[o] = fmaf_(p.fir[ky * 4 + kx], win[o + kx], acc[o]);
+                    for (int o = 0; o < 4; o++)
+#pragma unroll
+                        for (int kx = 0; kx < 4; kx++) acc[o] = fmaf_(p.fir[ky * 4 + kx], win[o + kx], acc[o]);
+                }
+                float* yp = p.y + (((int64_t)b * p.C + c) * p.OH + oy) * p.OW + ox0 + lx;
+                float out[4];
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    float v = acc[o] * d;
+                    if (p.noise && ox0 + lx + o < p.OW) v = v + p.noise[b * p.noise_bstride + (int64_t)oy * p.OW + ox0 + lx + o];
+                    v = v + bv;
+                    v = act_apply(v, p.act, p.alpha) * p.gain;
+                    if (p.clamp >= 0.f) v = v < -p.clamp ? -p.clamp : (v > p.clamp ? p.clamp : v);
+                    out[o] = v;
+                }
+                if (ox0 + lx + 3 < p.OW && (p.OW & 3) == 0) *(float4*)yp = make_float4(out[0], out[1], out[2], out[3]);
+                else
+                    for (int o = 0; o < 4 && ox0 + lx + o < p.OW; o++) yp[o] = out[o];
             }
-            const float d = p.dcoef ? p.dcoef[b * p.C + c] : 1.f;
-            const float bv = p.bias ? p.bias[c] : 0.f;
-            float* yp = p.y + (((int64_t)b * p.C + c) * p.OH + oy) * p.OW + ox0 + lx;
-            float out[4];
-#pragma unroll
-            for (int o = 0; o < 4; o++) {
-                float v = acc[o] * d;
-                if (p.noise && ox0 + lx + o < p.OW) v = v + p.noise[b * p.noise_bstride + (int64_t)oy * p.OW + ox0 + lx + o];
-                v = v + bv;
-                v = act_apply(v, p.act, p.alpha) * p.gain;
-                if (p.clamp >= 0.f) v = v < -p.clamp ? -p.clamp : (v > p.clamp ? p.clamp : v);
-                out[o] = v;
-            }
-            if (ox0 + lx + 3 < p.OW && (p.OW & 3) == 0) *(float4*)yp = make_float4(out[0], out[1], out[2], out[3]);
-            else
-                for (int o = 0; o < 4 && ox0 + lx + o < p.OW; o++) yp[o] = out[o];
         }
     }
 }
@@ -731,6 +960,56 @@ int launch_conv(ConvParams& p, float* partial, int64_t partial_floats, hipStream
     return 0;
 }
 
+// x2 layers: tile configuration, split-K factor and Z geometry -- shared by the workspace query and the launch.
+struct UpPlan { int cfg, BM, BN, KCS, G1, GS, ksplit; int64_t zslice; };
+inline UpPlan up_plan(int B, int Cin, int Cout, int H, int W) {
+    UpPlan u;
+    u.cfg = Cout > 64 ? 0 : 1;
+    { const char* ev = getenv("TDGP_UP_CFG"); if (ev) u.cfg = atoi(ev); }
+    static const int cfgs[6][3] = {{128, 64, 4}, {64, 128, 4}, {128, 128, 4}, {128, 64, 8}, {64, 128, 8}, {64, 128, 4}};
+    u.BM = cfgs[u.cfg][0]; u.BN = cfgs[u.cfg][1]; u.KCS = cfgs[u.cfg][2];
+    u.G1 = W + 1;
+    u.GS = round_up((H + 1) * (W + 1), 32);
+    u.zslice = (int64_t)B * Cout * 4 * u.GS;
+    const int blocks = cdiv(B * u.GS, u.BN) * cdiv(Cout, u.BM);
+    const int niter = cdiv(cdiv(Cin, KC3), u.KCS / KC3);
+    int ks;
+    if (blocks < 256) {
+        ks = pick_ksplit(blocks, niter);
+        const int64_t cap = ((int64_t)64 << 20) / 4;             // low-resolution layers: at most 64 MiB of slices
+        while (ks > 1 && ks * u.zslice > cap) ks--;
+    } else {
+        // Tail balancing.  512 block slots (2 per CU); a launch of n blocks runs n / 512 full rounds plus a tail that costs ~0.7
+        // of a round when <= 256 blocks are left (one block per CU runs faster) -- e.g. 560 blocks are 1.7 rounds for 1.09
+        // rounds of work.  Splitting K by ks shrinks the rounds; each extra slice costs one more pass over Z (~4 TB/s, mostly
+        // served by the 256 MB MALL).  Times in microseconds at ~85 TFLOP/s of block throughput.
+        const double flop = 2.0 * Cin * Cout * 9.0 * H * W * B;
+        double best = 1e30; ks = 1;
+        for (int k = 1; k <= 4 && niter / k >= 16; k++) {
+            const int n = blocks * k, full = n / 512, rem = n % 512;
+            const double rounds = full + (rem == 0 ? 0.0 : (rem <= 256 ? 0.7 : 1.0));
+            const double t = rounds * (flop / n) / (85e12 / 512) * 1e6 + (k - 1) * (double)u.zslice * 4.0 / 4e12 * 1e6;
+            if (t < best * 0.97) { best = t; ks = k; }
+        }
+    }
+    u.ksplit = ks;
+    return u;
+}
+
+template <int MTW, int NTW, int WM, int WN, int KCS>
+void launch_upconv(const UpParams& u, hipStream_t s) {
+    constexpr int BM = 32 * MTW * WM, BN = 32 * NTW * WN, NW = WM * WN;
+    constexpr int stage = 2 * (9 * KCS * BM + KCS * 2 * (BN + 4)), epi = NW * 32 * UP_CT_W;
+    const size_t lds = (size_t)(stage > epi ? stage : epi) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)upconv_mfma_kernel<MTW, NTW, WM, WN, KCS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(cdiv(u.B * u.GS, BN), cdiv(u.Cout, BM), u.ksplit);
+    TDGP_LAUNCH("upconv_mfma_kernel", (upconv_mfma_kernel<MTW, NTW, WM, WN, KCS>), grid, dim3(64 * NW), lds, s, u);
+}
+
 inline int pick_tw_log2(int gridW) {
     int tw = 4, lg = 2;
     while (tw < 32 && tw < gridW) { tw <<= 1; lg++; }
@@ -744,8 +1023,16 @@ WsLayout ws_layout(int B, int Cin, int Cout, int H, int W, int k, int up) {
     auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
     w.dco = 0;
     w.z = al((int64_t)B * Cout * sizeof(float));
-    const int64_t out_elems = (up == 2) ? (int64_t)B * Cout * (2 * H + 1) * (2 * W + 1) : (int64_t)B * Cout * H * W;
-    w.partial = w.z + (up == 2 ? al(out_elems * (int64_t)sizeof(float)) : 0);
+    if (up == 2) {
+        // the parity-planar transposed-conv intermediate (x its split-K slices); the FIR kernel reduces the slices itself
+        const UpPlan u = up_plan(B, Cin, Cout, H, W);
+        w.partial = w.z + al(u.zslice * u.ksplit * (int64_t)sizeof(float));
+        w.partial_floats = 0;
+        w.total = w.partial;
+        return w;
+    }
+    const int64_t out_elems = (int64_t)B * Cout * H * W;
+    w.partial = w.z;
     // split-K is only chosen for launches with < 256 blocks: bound its buffer at 32 slices and 64 MiB
     int64_t pf = out_elems * 32;
     const int64_t cap = ((int64_t)64 << 20) / 4;
@@ -843,38 +1130,24 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
             else launch_conv<2, 2, 1, 4, 16, 1>(p, partial, wl.partial_floats, s);
         }
     } else {
-        // transposed conv, stride 2, UNFLIPPED weights (conv2d_resample.py:108-125): Z[2i+a, 2j+e] += w[a,e] * x[i,j]
-        const int ZH = 2 * H + 1, ZW = 2 * W + 1;
-        e.dcoef = nullptr; e.noise = nullptr; e.noise_bstride = 0; e.bias = nullptr; e.skip = nullptr; e.y = z;
-        e.Hout = ZH; e.Wout = ZW; e.out_layout = 0; e.out_feat = 1;
-        e.act = 1; e.alpha = 0.f; e.gain = 1.f; e.clamp = -1.f;
-        p.nphases = 4;
-        for (int py = 0; py < 2; py++)
-            for (int px = 0; px < 2; px++) {
-                Phase& ph = p.ph[py * 2 + px];
-                ph.ntaps = 0;
-                // row taps: py=0 -> (a=0, dy=0), (a=2, dy=-1); py=1 -> (a=1, dy=0); same for columns
-                for (int a = 0; a < 3; a++) {
-                    if ((a & 1) != py) continue;
-                    for (int ee = 0; ee < 3; ee++) {
-                        if ((ee & 1) != px) continue;
-                        const int t = ph.ntaps++;
-                        ph.tap_w[t] = a * 3 + ee;
-                        ph.tap_off_y[t] = (a == 2) ? -1 : 0;
-                        ph.tap_off_x[t] = (ee == 2) ? -1 : 0;
-                    }
-                }
-                ph.gridH = (py == 0) ? H + 1 : H;
-                ph.gridW = (px == 0) ? W + 1 : W;
-                ph.oy_mul = 2; ph.oy_add = py; ph.ox_mul = 2; ph.ox_add = px;
-            }
-        p.tw_log2 = pick_tw_log2(W + 1 > 32 ? 32 : W + 1);
-        if (Cout > 64) launch_conv<2, 2, 2, 2, 8, 4>(p, partial, wl.partial_floats, s);
-        else launch_conv<2, 2, 1, 4, 8, 4>(p, partial, wl.partial_floats, s);
+        // transposed conv, stride 2, UNFLIPPED weights (conv2d_resample.py:108-125) -> parity-planar Z -> FIR + output stage
+        const UpPlan pl = up_plan(B, Cin, Cout, H, W);
+        UpParams u;
+        u.x = x; u.wp = wp; u.styles = styles; u.z = z;
+        u.B = B; u.Cin = Cin; u.Cout = Cout; u.CoutP = pi.CoutP; u.H = H; u.W = W; u.G1 = pl.G1; u.GS = pl.GS; u.ksplit = pl.ksplit; u.zslice = pl.zslice;
+        switch (pl.cfg) {
+        case 0: launch_upconv<2, 1, 2, 2, 4>(u, s); break;
+        case 1: launch_upconv<2, 1, 1, 4, 4>(u, s); break;
+        case 2: launch_upconv<2, 1, 2, 4, 4>(u, s); break;
+        case 3: launch_upconv<2, 1, 2, 2, 8>(u, s); break;
+        case 4: launch_upconv<2, 1, 1, 4, 8>(u, s); break;
+        default: launch_upconv<1, 2, 2, 2, 4>(u, s); break;
+        }
         FirParams f;
         f.z = z; f.dcoef = dco; f.noise = noise; f.noise_bstride = noise_bstride; f.bias = bias; f.y = y;
         for (int i = 0; i < 16; i++) f.fir[i] = e.fir[i];
-        f.B = B; f.C = Cout; f.ZH = ZH; f.ZW = ZW; f.OH = 2 * H; f.OW = 2 * W;
+        f.B = B; f.C = Cout; f.ZROWS = 2 * H + 2; f.P2 = 2 * (W + 1); f.GS2 = 2 * pl.GS; f.ksplit = pl.ksplit; f.zslice = pl.zslice;
+        f.OH = 2 * H; f.OW = 2 * W;
         f.act = act; f.alpha = alpha; f.gain = gain; f.clamp = clamp;
         const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, FIR_TH) * cdiv(f.OW, FIR_TW);
         TDGP_LAUNCH("fir_act_kernel", fir_act_kernel, dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
