@@ -53,31 +53,25 @@ def algorithmic_flops(cfg):
     return dict(conv_mfma_kernel=(conv, launches), upconv_mfma_kernel=(up, up_launches), triplane_field_kernel=(field, 2))
 
 
-def cpu_baseline(tdgp, cfg, strip_rays=8192):
-    """Time the CPU oracle on ONE image of the same workload: the whole backbone + a strip of rays (scaled to the full
-    image).  Bounded to ~10-30 s of host time."""
+def cpu_baseline(tdgp, cfg, n_img=8, budget_s=25.0):
+    """Time the CPU oracle on the same workload: whole generator forwards (mapping, backbone, all 256^2 rays), one image at
+    a time, until `n_img` images or ~`budget_s` seconds of host time (whichever first; at least one image)."""
     import oracle as O
-    from oracle.pipeline import render_options
-    cores = os.cpu_count() or 1
+    # 2-socket hosts: the OpenMP loops of the oracle stop scaling (and then slow down) past a few dozen threads
+    cores = int(os.environ.get('TDGP_ORACLE_THREADS', min(os.cpu_count() or 1, 32)))
     O.set_threads(cores)
     sd = tdgp.weights.random_state_dict(cfg, seed=0)
-    inp = tdgp.weights.synthetic_inputs(cfg, batch=1, seed=0)
-    t0 = time.time()
-    ws = O.mapping_forward(sd, cfg.to_dict(), inp['z'], inp['c'])
-    planes = O.synthesis_backbone(sd, cfg.to_dict(), ws, 'const')
-    t_backbone = time.time() - t0
-    R = cfg.img_resolution ** 2
-    strip = min(strip_rays, R)
-    c2w = O.cam2world(inp['camera']['angles'], inp['camera']['radius'], inp['camera']['look_at'])
-    ro, rd = O.sample_rays(c2w, inp['camera']['fov'], cfg.img_resolution, cfg.img_resolution)
-    mlp = tuple(sd[f'synthesis.tri_plane_mlp.model.{i}.{n}'] for i in (0, 1) for n in ('weight', 'bias'))
-    t0 = time.time()
-    O.importance_render(planes, mlp, ro[:, :strip], rd[:, :strip], render_options(cfg.to_dict()), inp['u_coarse'][:, :strip], inp['u_fine'][:strip])
-    t_strip = time.time() - t0
-    t_img = t_backbone + t_strip * (R / strip)
-    return dict(value=round(1.0 / t_img, 5), unit='img/s', cores=cores, kind='port',
-                sample=f'1 image: full tri-plane backbone ({t_backbone:.2f} s) + {strip} of {R} rays rendered ({t_strip:.2f} s) scaled to the image; '
-                       f'OpenMP oracle (oracle/tdgp_oracle.c), {cores} threads')
+    done, t_total = 0, 0.0
+    while done < n_img and (done == 0 or t_total * (done + 1) / done < budget_s):
+        inp = tdgp.weights.synthetic_inputs(cfg, batch=1, seed=done)
+        t0 = time.time()
+        img, _ = O.generator_forward(sd, cfg.to_dict(), inp['z'], inp['c'], inp['camera'], inp['u_coarse'], inp['u_fine'])
+        t_total += time.time() - t0
+        assert np.isfinite(img).all()
+        done += 1
+    return dict(value=round(done / t_total, 5), unit='img/s', cores=cores, kind='port',
+                sample=f'{done} whole images (mapping + tri-plane backbone + all {cfg.img_resolution ** 2} rays x {cfg.num_ray_steps}+{cfg.num_ray_steps} '
+                       f'samples) in {t_total:.1f} s; OpenMP C oracle (oracle/tdgp_oracle.c), {cores} threads')
 
 
 def main():
@@ -151,6 +145,14 @@ def main():
                        avg_ms=round(v['avg_ms'], 5)) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])}
     dominant = next(iter(kernels))
     flops = algorithmic_flops(cfg)
+    # HBM bytes per launch from the committed PMC passes (tools/profile_bench.sh -> tools/pmc_traffic.py); counters cannot be
+    # collected from inside this process, so `traffic` is only filled when that measurement was taken on this very workload.
+    traffic = None
+    tpath = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get('config') == args.config and tj.get('batch_per_gpu') == args.batch and dominant in tj.get('kernels', {}):
+            traffic = tj['kernels'][dominant]['hbm_bytes_per_launch']
     roofline = None
     if dominant in flops:
         fl_img, launches_img = flops[dominant]
@@ -158,7 +160,7 @@ def main():
         fl_per_launch = fl_img * args.batch / k['launches_per_step']
         achieved = fl_per_launch / (k['avg_ms'] * 1e-3) / 1e12
         roofline = dict(kernel=dominant, bound='mfma', achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                        frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
                         flop_per_launch=fl_per_launch, avg_launch_ms=k['avg_ms'], launches_per_step=k['launches_per_step'])
 
     if rank == 0:
