@@ -15,17 +15,29 @@
 //   * layer 1 runs on the matrix cores as h^T[hid x 16pts] = W0s[hid x F] * g^T[F x 16pts] with
 //     v_mfma_f32_16x16x4_f32: B operand = g (exactly the per-lane data the gather produced: k-slot = q),
 //     A operand = W0s pre-arranged in registers; FQ k-steps per 16-row tile of hid, exact fp32;
-//   * the accumulator layout then gives each lane 4*MT hidden units of ITS point, so bias + lrelu are
-//     lane-local, and layer 2 (hid -> 4) is 4*4*MT lane-local FMAs + two cross-lane adds (xor 16, 32);
-//   * lanes q == 0 store (r,g,b,sigma) as one float4: 16 lanes * 16 B = 256 B contiguous per tile.
-// Roofline: 2*(F*hid + 4*hid) = 4608 MFMA/VALU flop and 12 taps * F * 4 = 1536 B of L1/L2-served gathers per
+//   * the accumulator layout then gives each lane 4*MT hidden units of ITS point, so lrelu is lane-local (the bias is
+//     the accumulator's initial value), and layer 2 (hid -> 4) is 4*MT 16-block v_mfma_f32_4x4x1 steps + two cross-lane adds;
+//   * ray walk: a wave marches the S samples of a 4x4-pixel quad; the taps of sample k+1 are in flight while sample k runs
+//     its MLP, and results are parked in LDS and flushed as 128-B runs per ray (8 samples x 16 B).
+// Roofline: 2*(F*hid + 4*hid) = 4608 MLP flop + 768 blend flop and 12 taps * F * 4 = 1536 B of L1/L2-served gathers per
 // point; the tri-plane of one image (100.7 MB at 512^2 x 96) is read from HBM once and then lives in
 // L2 / Infinity Cache.  Output traffic 16 B per point.
+// Measured (r01): with the tap loads compiled out the kernel runs at 0.87x of its full time, and that time equals the SUM of
+// its VALU and MFMA issue cycles (~316 VALU x 4 + 48 MFMA = ~2400 cycles per 16-point tile): fp32 MFMA and (packed) fp32
+// VALU have the same 64 flop/clk/SIMD rate on this chip and do not overlap, so every VALU instruction in the loop costs
+// matrix time -- the blend uses v_pk_fma_f32 and the remaining lever is the per-point address arithmetic.
 #include "common.h"
+
+// Compile-time ablations for timing experiments (tools/scratch/build_variant.sh): 1 = no tap loads, 2 = no layer-1 MFMAs,
+// 4 = no stores, 8 = no blend.  Always 0 in the shipped library.
+#ifndef TDGP_FIELD_ABL
+#define TDGP_FIELD_ABL 0
+#endif
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));     // v_pk_{mul,add,fma}_f32: two fp32 lanes per VALU slot, IEEE per element
 
 struct FieldParams {
     const float* planes;   // [B,3,H,W,F]
@@ -66,26 +78,33 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ p, float* v) 
     }
 }
 
-// The FQ floats this lane owns of one texel (F = 4*FQ floats): piece c4 of every 64-B group (FQ % 4 == 0), else a contiguous run.
+// The FQ floats this lane owns of one texel (F = 4*FQ floats), as FQ/2 register pairs: piece c4 of every 64-B group
+// (FQ % 4 == 0), else a contiguous run.
 template <int FQ>
-__device__ __forceinline__ void load_texel(const float* __restrict__ texel, int c4, float* v) {
+__device__ __forceinline__ void load_texel(const float* __restrict__ texel, int c4, f32x2* v) {
+    static_assert(FQ % 2 == 0, "feat_dim must be a multiple of 8");
     if constexpr (FQ % 4 == 0) {
 #pragma unroll
         for (int j = 0; j < FQ / 4; j++) {
             const float4 t = *(const float4*)(texel + 16 * j + 4 * c4);
-            v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+            v[2 * j] = (f32x2){t.x, t.y}; v[2 * j + 1] = (f32x2){t.z, t.w};
         }
     } else {
-        load_vec<FQ>(texel + c4 * FQ, v);
+#pragma unroll
+        for (int j = 0; j < FQ / 2; j++) {
+            const float2 t = *(const float2*)(texel + c4 * FQ + 2 * j);
+            v[j] = (f32x2){t.x, t.y};
+        }
     }
 }
 
 // correctly rounded x / 3 without the hardware division sequence (Markstein: q1 = fma(fma(-3,q0,x), r, q0))
-__device__ __forceinline__ float div3(float x) {
-    const float r = 0.333333343267440796f;        // RN(1/3)
-    float q0 = x * r;
-    float rem = fmaf_(-3.0f, q0, x);
-    return fmaf_(rem, r, q0);
+__device__ __forceinline__ f32x2 div3(f32x2 x) {
+    const f32x2 r = {0.333333343267440796f, 0.333333343267440796f};        // RN(1/3)
+    const f32x2 m3 = {-3.0f, -3.0f};
+    const f32x2 q0 = x * r;
+    const f32x2 rem = __builtin_elementwise_fma(m3, q0, x);
+    return __builtin_elementwise_fma(rem, r, q0);
 }
 
 // Channel held in value slot s of the lane that serves k-slot q.  A texel (F floats) is fetched by 4 adjacent lanes as
@@ -99,18 +118,19 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
     constexpr int HID = MT * 16;
     // MFMA A operands, one float per lane per k-step, stored [step][lane] (conflict-free ds_read_b32, shared by the 4 waves):
     //   layer 1: a0s[mt*FQ + s][lane]  = W0[mt*16 + (lane&15)][feat_of(s, lane>>4)] / sqrt(F)
-    //   layer 2: a1s[mt*4 + r][lane]   = (lane&15) < 4 ? W1[lane&15][mt*16 + 4*(lane>>4) + r] * sqrt(2)/sqrt(HID) : 0
+    //   layer 2: a1s[mt*4 + r][lane]   = W1[lane&3][mt*16 + 4*(lane>>4) + r] * sqrt(2)/sqrt(HID)     (16-block 4x4x1 MFMA, see below)
     __shared__ float a0s[MT * FQ * 64];
     __shared__ float a1s[MT * 4 * 64];
     __shared__ float b0s[HID];
+    __shared__ float4 obuf_all[4 * 16 * 9];      // per wave: [16 rays][8 samples (+1 pad)] parked outputs of the ray walk
     const float sqrt2 = 1.41421353816986083984375f;    // (float)sqrt(2): lrelu gain, folded into the layer-2 weights
     for (int i = threadIdx.x; i < MT * FQ * 64; i += blockDim.x) {
         const int ln = i & 63, ms = i >> 6, mt = ms / FQ, sidx = ms % FQ;
         a0s[i] = p.w0[(mt * 16 + (ln & 15)) * F + feat_of(sidx, ln >> 4, FQ)] * p.g0;
     }
     for (int i = threadIdx.x; i < MT * 4 * 64; i += blockDim.x) {
-        const int ln = i & 63, ms = i >> 6, mt = ms >> 2, r = ms & 3, o = ln & 15;
-        a1s[i] = o < 4 ? (p.w1[o * HID + mt * 16 + 4 * (ln >> 4) + r] * p.g1) * sqrt2 : 0.f;
+        const int ln = i & 63, ms = i >> 6, mt = ms >> 2, r = ms & 3;
+        a1s[i] = (p.w1[(ln & 3) * HID + mt * 16 + 4 * (ln >> 4) + r] * p.g1) * sqrt2;
     }
     for (int i = threadIdx.x; i < HID; i += blockDim.x) b0s[i] = p.b0[i];
     __syncthreads();
@@ -118,6 +138,9 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
     const int l = lane_id();
     const int pt = l & 15, q = l >> 4;
     const float sx = (float)(p.W - 1) / 2.f, sy = (float)(p.H - 1) / 2.f;
+    f32x4 bias0[MT];                  // layer-1 bias of the hidden units this lane owns (accumulator rows 4*q + r of tile mt)
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) bias0[mt] = (f32x4){b0s[mt * 16 + 4 * q], b0s[mt * 16 + 4 * q + 1], b0s[mt * 16 + 4 * q + 2], b0s[mt * 16 + 4 * q + 3]};
     const int plane_elems = p.H * p.W * F;
 
     // Two lane layouts per 16-point tile:
@@ -128,16 +151,18 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
     // The blended features hop from one to the other with FQ ds_bpermute_b32 (piece index c4 becomes k-slot q).
     const int gpt = (FQ % 4 == 0) ? (l >> 2) : pt, gc4 = (FQ % 4 == 0) ? (l & 3) : q;
 
-    // ---- one 16-point tile.  (cx,cy,cz,gvalid,ggp) describe the point of THIS lane in the gather layout; (gp,valid) the point
-    // whose result this lane stores (MFMA layout, q == 0 lanes).  `bplanes` = planes of the sample ------------------------------
-    auto eval_tile = [&](float cx, float cy, float cz, const float* __restrict__ bplanes, int64_t ggp, bool gvalid, int64_t gp, bool valid) {
+    // ---- one 16-point tile, in three stages so the ray walk can software-pipeline them:
+    //   issue_taps : coordinates -> tap addresses + weights, all 12 taps put in flight (3 planes x 4 taps x FQ floats per lane);
+    //   blend      : bilinear blend + plane mean -> g, moved to the MFMA layout;
+    //   mlp_store  : both MLP layers on the matrix cores, (r,g,b,sigma) stored by the q == 0 lanes.
+    // (cx,cy,cz,gvalid,ggp) describe the point of THIS lane in the gather layout; (gp,valid) the point whose result this lane
+    // stores (MFMA layout).  `bplanes` = planes of the sample.
+    f32x2 tap[3][4][FQ / 2];
+    float wgt[3][4];
+    auto issue_taps = [&](float cx, float cy, float cz, const float* __restrict__ bplanes, int64_t ggp, bool gvalid) {
         float qc[3];
         if (p.scale_is_pow2) { qc[0] = cx * p.inv_scale; qc[1] = cy * p.inv_scale; qc[2] = cz * p.inv_scale; }   // exact == cx / scale
         else { qc[0] = cx / p.scale; qc[1] = cy / p.scale; qc[2] = cz / p.scale; }                                 // :576 true division
-
-        // All 12 taps of the tile are put in flight before any of them is consumed (3 planes x 4 taps x FQ floats per lane).
-        float tap[3][4][FQ];
-        float wgt[3][4];
 #pragma unroll
         for (int pl = 0; pl < 3; pl++) {
             const float u = qc[pl == 2 ? 1 : 0];          // planes (x,y), (x,z), (y,z): width <- first coordinate (:577-581)
@@ -165,55 +190,84 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
             const int xa = min(max(x0, 0), p.W - 1), xb = min(max(x0 + 1, 0), p.W - 1);
             const int ya = min(max(y0, 0), p.H - 1), yb = min(max(y0 + 1, 0), p.H - 1);
             const int ra = ya * p.W, rb = yb * p.W;         // 32-bit element offsets inside one plane (< 2^31)
+            if (TDGP_FIELD_ABL & 1) {
+#pragma unroll
+                for (int s = 0; s < FQ / 2; s++) {
+                    tap[pl][0][s] = (f32x2){(float)(ra + xa + s), 1.f}; tap[pl][1][s] = (f32x2){(float)(ra + xb), 2.f};
+                    tap[pl][2][s] = (f32x2){(float)(rb + xa), 3.f}; tap[pl][3][s] = (f32x2){(float)(rb + xb), 4.f};
+                }
+            } else {
             load_texel<FQ>(base + (ra + xa) * F, gc4, tap[pl][0]);
             load_texel<FQ>(base + (ra + xb) * F, gc4, tap[pl][1]);
             load_texel<FQ>(base + (rb + xa) * F, gc4, tap[pl][2]);
             load_texel<FQ>(base + (rb + xb) * F, gc4, tap[pl][3]);
+            }
         }
-        float g[FQ];
+    };
+    auto blend = [&](float* g) {
+        // two channels per VALU slot (v_pk_fma_f32): the same fma chain per element as the scalar form
 #pragma unroll
-        for (int s = 0; s < FQ; s++) {
-            float pa[3];
+        for (int s = 0; s < FQ / 2; s++) {
+            f32x2 pa[3];
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++)
-                pa[pl] = fmaf_(tap[pl][3][s], wgt[pl][3], fmaf_(tap[pl][2][s], wgt[pl][2], fmaf_(tap[pl][1][s], wgt[pl][1], tap[pl][0][s] * wgt[pl][0])));
-            g[s] = div3((pa[0] + pa[1]) + pa[2]);          // x.mean(dim=1)
+            for (int pl = 0; pl < 3; pl++) {
+                const f32x2 w0 = {wgt[pl][0], wgt[pl][0]}, w1 = {wgt[pl][1], wgt[pl][1]}, w2 = {wgt[pl][2], wgt[pl][2]}, w3 = {wgt[pl][3], wgt[pl][3]};
+                pa[pl] = __builtin_elementwise_fma(tap[pl][3][s], w3, __builtin_elementwise_fma(tap[pl][2][s], w2, __builtin_elementwise_fma(tap[pl][1][s], w1, tap[pl][0][s] * w0)));
+            }
+            const f32x2 m = div3((pa[0] + pa[1]) + pa[2]);          // x.mean(dim=1)
+            g[2 * s] = m.x; g[2 * s + 1] = m.y;
         }
         if (FQ % 4 == 0) {                                 // gather layout -> MFMA layout: lane (q, pt) takes from lane 4*pt + q
             const int src = (pt * 4 + q) * 4;
 #pragma unroll
             for (int s = 0; s < FQ; s++) g[s] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(g[s])));
         }
-
+    };
+    auto mlp = [&](const float* g) -> float4 {
         // layer 1 on the matrix cores: h^T[hid x 16 pts] = W0s * g^T
         f32x4 acc[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; mt++) acc[mt] = bias0[mt];           // addmm(b, x, W^T): the bias is the initial accumulator
+        if (!(TDGP_FIELD_ABL & 2))
 #pragma unroll
         for (int s = 0; s < FQ; s++)
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0s[(mt * FQ + s) * 64 + l], g[s], acc[mt], 0, 0, 0);
 
-        // bias + lrelu(0.2) lane-locally (each lane owns 4*MT hidden units of ITS point), then layer 2 on the matrix cores as
-        // out^T[16 (4 used) x 16 pts] = W1s * h^T: k-slot = lane quarter, exactly the layout layer 1 left behind; rows 0..3
-        // of the result (r,g,b,sigma) land in the four accumulator registers of the q == 0 lanes.
-        f32x4 o4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // bias + lrelu(0.2) lane-locally (each lane owns 4*MT hidden units of ITS point).  Layer 2 (hid -> 4) as sixteen 4x4x1
+        // block MFMAs: the instruction multiplies 16 independent (4x1)*(1x4) blocks, block = lane >> 2.  With lane = 16*q + pt the
+        // block is (q, pt >> 2): B = the lane's own hidden unit of point pt, A = W1[lane & 3][that unit], so after the 4*MT steps
+        // lane (q, pt) holds the (r,g,b,sigma) partial sums of ITS point over the hidden units of quarter q; two cross-lane adds
+        // finish them.  8 MFMA cycles per step instead of 32 for a 16x16x4 tile that would be 3/4 padding.
+        f32x4 o4[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float v = acc[mt][r] + b0s[mt * 16 + 4 * q + r];
+                const float v = acc[mt][r];
                 const float h = fmaxf(v, 0.2f * v);                      // leaky_relu(v, 0.2); the sqrt(2) gain lives in a1s
-                o4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1s[(mt * 4 + r) * 64 + l], h, o4, 0, 0, 0);
+                o4[r & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1s[(mt * 4 + r) * 64 + l], h, o4[r & 1], 0, 0, 0);
             }
-        if (q == 0 && valid) {
-            float o[4] = {p.b1[0] + o4[0], p.b1[1] + o4[1], p.b1[2] + o4[2], p.b1[3] + o4[3]};
-            if (p.marcher == 1) {
+        float o[4];
 #pragma unroll
-                for (int c = 0; c < 3; c++) o[c] = (1.0f / (1.0f + expf(-o[c]))) * (1.f + 2.f * 0.001f) - 0.001f;
-            }
-            ((float4*)p.rgbs)[gp] = make_float4(o[0], o[1], o[2], o[3]);
+        for (int c = 0; c < 4; c++) {
+            float v = o4[0][c] + o4[1][c];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            o[c] = p.b1[c] + v;
         }
+        if (p.marcher == 1) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) o[c] = (1.0f / (1.0f + expf(-o[c]))) * (1.f + 2.f * 0.001f) - 0.001f;
+        }
+        return make_float4(o[0], o[1], o[2], o[3]);        // (r,g,b,sigma) of point pt, valid in every lane of its column
+    };
+    auto eval_tile = [&](float cx, float cy, float cz, const float* __restrict__ bplanes, int64_t ggp, bool gvalid, int64_t gp, bool valid) {
+        float g[FQ];
+        issue_taps(cx, cy, cz, bplanes, ggp, gvalid);
+        blend(g);
+        const float4 o = mlp(g);
+        if (q == 0 && valid && (!(TDGP_FIELD_ABL & 4) || o.x == 123.f)) ((float4*)p.rgbs)[gp] = o;
     };
 
     if (p.ray_w > 0) {
@@ -226,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
         const int nb = gridDim.x, per = nb / 8;
         const int lb = (nb % 8 == 0) ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
         const int wvi = threadIdx.x >> 6;
+        float4* obuf = obuf_all + wvi * (16 * 9);
         auto ray_of = [&](int b, int py, int px, int tpt, bool& ok) {       // pixel tpt of this wave's 4x4 quadrant -> ray index
             const int y = py * 8 + (wvi >> 1) * 4 + (tpt >> 2), x = px * 8 + (wvi & 1) * 4 + (tpt & 3);
             ok = y < p.ray_h && x < p.ray_w;
@@ -233,17 +288,46 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
         };
         for (int patch = lb; patch < npatch; patch += nb) {
             const int px = patch % pX, py = (patch / pX) % pY, b = patch / (pX * pY);       // uniform
-            bool gok, sok;
+            bool gok;
             const int gray = ray_of(b, py, px, gpt, gok);      // the ray this lane gathers for
-            const int sray = ray_of(b, py, px, pt, sok);       // the ray this lane stores for (q == 0 lanes)
+            bool fok;
+            const int fray = ray_of(b, py, px, l >> 2, fok);   // the ray whose parked results this lane flushes
             const float ox = p.ray_o[gray * 3 + 0], oy = p.ray_o[gray * 3 + 1], oz = p.ray_o[gray * 3 + 2];
             const float dxr = p.ray_d[gray * 3 + 0], dyr = p.ray_d[gray * 3 + 1], dzr = p.ray_d[gray * 3 + 2];
             const float* bplanes = p.planes + (int64_t)b * 3 * plane_elems;
             const float* tp = p.t + (int64_t)gray * p.S;
+            // Software pipeline over the samples of the patch's rays: the taps of sample k+1 are put in flight right after sample
+            // k has been blended (its tap registers are free again), so they travel while the matrix cores run sample k's MLP.
+            float tt = tp[0];
+            float tn = p.S > 1 ? tp[1] : 0.f;
+            issue_taps(ox + tt * dxr, oy + tt * dyr, oz + tt * dzr, bplanes, (int64_t)gray * p.S, gok);          // :141 (unfused mul, add)
             for (int k = 0; k < p.S; k++) {
-                const float tt = tp[k];
-                eval_tile(ox + tt * dxr, oy + tt * dyr, oz + tt * dzr, bplanes, (int64_t)gray * p.S + k, gok,      // :141 (unfused mul, add)
-                          (int64_t)sray * p.S + k, sok);
+                float g[FQ];
+                blend(g);
+                if (k + 1 < p.S) {
+                    tt = tn;
+                    tn = k + 2 < p.S ? tp[k + 2] : 0.f;
+                    issue_taps(ox + tt * dxr, oy + tt * dyr, oz + tt * dzr, bplanes, (int64_t)gray * p.S + k + 1, gok);
+                }
+                const float4 o = mlp(g);
+                // Results are parked in a per-wave LDS tile [16 rays][8 samples] and flushed as 128-B runs per ray: stored
+                // directly, the 16 points of a step sit S*16 B apart -- sixteen 16-B fragments of sixteen different lines (the
+                // PMC write traffic was 3.3x the payload).
+                if (q == 0) obuf[pt * 9 + (k & 7)] = o;
+                if ((k & 7) == 7 || k + 1 == p.S) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int k0 = k & ~7, nk = (k & 7) + 1;
+                    const int fr = l >> 2, j = (l & 3) * 2;
+                    const float4 v0 = obuf[fr * 9 + j], v1 = obuf[fr * 9 + j + 1];
+                    float4* dst = (float4*)p.rgbs + (int64_t)fray * p.S + k0 + j;
+                    if (fok && !(TDGP_FIELD_ABL & 4)) {
+                        if (j < nk) dst[0] = v0;
+                        if (j + 1 < nk) dst[1] = v1;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
         return;
