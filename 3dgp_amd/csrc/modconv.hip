@@ -60,7 +60,6 @@ struct ConvParams {
     int B, Cin, Cout, CoutP, Hin, Win, T, KC;
     int tw_log2;
     int nphases, ksplit;
-    int dbg;            // TDGP_CONV_DBG ablations: bit0 skip the MFMA loop, bit1 skip re-staging (timing experiments only)
     Phase ph[4];
 };
 
@@ -379,7 +378,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     const int it_per = (niter + p.ksplit - 1) / p.ksplit;          // split-K: this block reduces iterations [it0, it1)
     const int it0 = ks * it_per, it1 = min(niter, it0 + it_per);
 
-    constexpr int NA = (MAXT * KCS * (BM / 4) + 255) / 256;     // float4 of the A tile per thread
+    constexpr int NA = (MAXT == 9 ? (MAXT * BM + 255) / 256 : (MAXT * KCS * (BM / 4) + 255) / 256);     // float4 of the A tile per thread
     float4 a_reg[NA];
     float x_reg[NPOS][KCS], s_reg[NPOS][KCS];
     // Everything about a thread's staging slots that does not depend on the K iteration is computed once: global offsets
@@ -389,7 +388,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     for (int i = 0; i < NA; i++) {
         const int e = tid + i * 256;
         a_goff[i] = -1; a_loff[i] = 0;
-        if (e < arows * (BM / 4)) {
+        if constexpr (MAXT == 9) {
+            // 3x3 weights are packed [chunk][tap][CoutP][4 channels]: a slot is the 4 channels of one out-channel column
+            static_assert(MAXT != 9 || KCS == KC3, "the generic 3x3 path stages one packed chunk per iteration");
+            if (e < ph.ntaps * BM) {
+                const int t = e / BM, col = e % BM;
+                a_loff[i] = t * KCS * BM + col;
+                if (m0 + col < p.CoutP) a_goff[i] = (ph.tap_w[t] * p.CoutP + m0 + col) * 4;
+            }
+        } else if (e < arows * (BM / 4)) {
             const int row = e / (BM / 4), j4 = e % (BM / 4);
             const int t = row / KCS, ci = row % KCS;
             const int g = ci / p.KC, c8 = ci % p.KC;
@@ -419,8 +426,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     };
     auto store_stage = [&](float* As, float* Xs) {
 #pragma unroll
-        for (int i = 0; i < NA; i++)
-            if (tid + i * 256 < arows * (BM / 4)) *(float4*)(As + a_loff[i]) = a_reg[i];
+        for (int i = 0; i < NA; i++) {
+            if constexpr (MAXT == 9) {
+                if (tid + i * 256 < ph.ntaps * BM) {            // [col][4 ch] -> k-major rows
+                    float* d = As + a_loff[i];
+                    d[0] = a_reg[i].x; d[BM] = a_reg[i].y; d[2 * BM] = a_reg[i].z; d[3 * BM] = a_reg[i].w;
+                }
+            } else {
+                if (tid + i * 256 < arows * (BM / 4)) *(float4*)(As + a_loff[i]) = a_reg[i];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NPOS; k++) {
             const int pos = tid + k * 256;
@@ -438,7 +453,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     __syncthreads();
     int cur = 0;
     for (int it = it0; it < it1; it++) {
-        const bool more = it + 1 < it1 && !(p.dbg & 2);
+        const bool more = it + 1 < it1;
         if (more) load_stage(it + 1);
         const float* As = smem + cur * BUF_SZ + (wm * MTW) * 32 + l32 + half * BM;
         const float* Xs = smem + cur * BUF_SZ + AS_SZ;
@@ -447,13 +462,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         bool fk[2][NTW];                                  // tap-row validity of the staged B values (applied at use, not at load)
         int toff_cur = toff_tab[0], toff_nxt = toff_tab[1];
         auto load_frag = [&](int buf, int row2, int kk, int toff, int t) {
-            if (p.dbg & 4) {      // ablation: no LDS reads at all
-#pragma unroll
-                for (int m = 0; m < MTW; m++) fa[buf][m] = (float)(row2 + m);
-#pragma unroll
-                for (int n = 0; n < NTW; n++) { fb[buf][n] = (float)(kk + toff); fk[buf][n] = true; }
-                return;
-            }
 #pragma unroll
             for (int m = 0; m < MTW; m++) fa[buf][m] = As[row2 * 2 * BM + m * 32];
 #pragma unroll
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
                 fk[buf][n] = (px_mask[n] >> t) & 1;
             }
         };
-        const int ntaps = (p.dbg & 1) ? 0 : ph.ntaps;
+        const int ntaps = ph.ntaps;
         load_frag(0, 0, 0, toff_cur, 0);
         for (int t = 0; t < ntaps; t++) {
 #pragma unroll
@@ -483,7 +491,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
             toff_nxt = toff_tab[t + 2];
         }
         if (more) store_stage(smem + (cur ^ 1) * BUF_SZ, smem + (cur ^ 1) * BUF_SZ + AS_SZ);
-        if (!(p.dbg & 8)) __syncthreads();             // cur fully read, cur^1 fully written
+        __syncthreads();             // cur fully read, cur^1 fully written
         cur ^= 1;
     }
 
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     scache.lds = side_ok ? side : nullptr; scache.b0 = sb0; scache.bm = BM; scache.m0 = m0;
     float* part = (p.ksplit > 1) ? p.partial + (int64_t)ks * e.B * e.Cout * e.Hout * e.Wout : nullptr;
 #pragma unroll 1
-    for (int tile = 0; tile < ((p.dbg & 16) ? 0 : MTW * NTW); tile++) {
+    for (int tile = 0; tile < MTW * NTW; tile++) {
         int pb = 0, pm = 0, pn = 0, pk = 0;
 #pragma unroll
         for (int k = 0; k < MTW * NTW; k++) {
@@ -517,14 +525,215 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         const int pok = (pk && poy < e.Hout && pox < e.Wout) ? 1 : 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (!(p.dbg & 32)) epilogue_tile<MAXT == 1>(e, scache, ct, m0 + (wm * MTW + m) * 32, pb, poy, pox, pok, part, vec);
+        epilogue_tile<MAXT == 1>(e, scache, ct, m0 + (wm * MTW + m) * 32, pb, poy, pox, pok, part, vec);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
 }
 
 // -------------------------------------------------------------------------------------------------
-// x2 layers: stride-2 transposed 3x3 convolution (conv2d_resample.py:108-125, unflipped weights)
+// Fast paths of the 3x3 layers.  Measured on this chip (tools/scratch/ubench_overlap.hip): fp32 MFMA and fp32 VALU do NOT
+// overlap -- an MFMA-only loop runs at 149-155 TFLOP/s, a v_pk_fma-only loop of the same cycle count takes the same time, and
+// the two together take the SUM (or more), whether interleaved in one wave or split across the waves of a SIMD.  Every VALU
+// instruction inside the K loop therefore costs matrix time (4 cycles of 64 for a 32x32x2 step), and the generic kernel above
+// spends ~35 VALU per 8 MFMA on tap masks, LDS address arithmetic and fragment moves.  The two kernels below are built so the
+// loop body is MFMA + ds_read_b64 with immediate offsets and nothing else:
+//   * weights packed [chunk][tap][Cout][4 channels] and staged as-is: a lane's A operand for BOTH k-steps of a 4-channel chunk
+//     is one aligned 8-byte LDS read (k-step kk multiplies channels {kk, kk+2}: lane half h holds channels 2h, 2h+1);
+//   * activations staged [position][4 channels] (one 16-B LDS write per position), read the same way;
+//   * taps and k-steps fully unrolled: every LDS address is base register + compile-time offset;
+//   * no masks: padding is materialised as zeros in the staged patch (zero rows between samples / the linearised grid).
+// -------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- 3x3, stride 1, W % 32 == 0 ------------------------------------------------------------------------------------------
+// Pixel tile = NT "virtual rows" x 32 columns, virtual row vi = b*(H+1) + m where row m == H of every sample is a ZERO row:
+// it is the bottom padding of sample b and the top padding of sample b+1, so a tile may straddle samples without any per-lane
+// tap mask (cost: 1/(H+1) of the rows compute nothing useful).  Left/right padding = the zero halo columns of the patch.
+struct Conv3Params {
+    const float* x; const float* wp; const float* styles; float* partial;
+    EpiParams e;
+    int B, Cin, Cout, CoutP, H, W, ksplit;
+};
+
+template <int MTW, int NTW, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
+    constexpr int BM = 32 * MTW * WM, NT = NTW * WN, PR = NT + 2, PC = 34, PSZ = PR * PC;
+    constexpr int AS_SZ = 9 * BM * 4, XS_SZ = PSZ * 4, BUF_SZ = AS_SZ + XS_SZ;          // floats
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* side = smem + 2 * BUF_SZ;                                // [1 + NSB][BM]: bias, demod coefficients of the tile's samples
+
+    const int H1 = p.H + 1;
+    const int tilesX = p.W >> 5, VR = p.B * H1;
+    const int ty = blockIdx.x / tilesX, tx = blockIdx.x % tilesX;
+    const int vr0 = ty * NT, n0 = tx * 32, m0 = blockIdx.y * BM, ks = blockIdx.z;
+    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, l32 = l & 31, half = l >> 5;
+    const int wm = wv / WN, wn = wv % WN;
+
+    constexpr int NSB = 4;
+    const int sb0 = vr0 / H1, sb1 = min(p.B - 1, (vr0 + NT - 1) / H1);
+    const bool side_ok = (sb1 - sb0 + 1) <= NSB && p.ksplit == 1;
+    if (side_ok) {
+        for (int i = tid; i < (2 + sb1 - sb0) * BM; i += 256) {
+            const int slab = i / BM, o = m0 + i % BM;
+            float v = slab == 0 ? 0.f : 1.f;
+            if (o < p.e.Cout) {
+                if (slab == 0) { if (p.e.bias) v = p.e.bias[o]; }
+                else if (p.e.dcoef) v = p.e.dcoef[(sb0 + slab - 1) * p.e.Cout + o];
+            }
+            side[i] = v;
+        }
+    }
+
+    // ---- patch slots of this thread: position (row, col) of the halo'd patch, 4 channels per K iteration ----------------
+    constexpr int NPOS = (PSZ + 255) / 256;
+    int pos_off[NPOS], pos_sb[NPOS];
+#pragma unroll
+    for (int k = 0; k < NPOS; k++) {
+        const int pos = tid + k * 256;
+        pos_off[k] = -1; pos_sb[k] = 0;
+        if (pos < PSZ) {
+            const int pr = pos / PC, pc = pos % PC;
+            const int vi = vr0 - 1 + pr, ix = n0 - 1 + pc;
+            if (vi >= 0 && ix >= 0 && ix < p.W) {
+                const int b = vi / H1, m = vi - b * H1;
+                if (b < p.B && m < p.H) { pos_off[k] = ((b * p.Cin) * p.H + m) * p.W + ix; pos_sb[k] = b * p.Cin; }
+            }
+        }
+    }
+    const int chw = p.H * p.W;
+    const bool cin4 = (p.Cin & 3) == 0;
+
+    f32x16 acc[MTW][NTW];
+#pragma unroll
+    for (int m = 0; m < MTW; m++)
+#pragma unroll
+        for (int n = 0; n < NTW; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+
+    const int niter = (p.Cin + 3) >> 2;
+    const int it_per = (niter + p.ksplit - 1) / p.ksplit;
+    const int it0 = ks * it_per, it1 = min(niter, it0 + it_per);
+
+    constexpr int NA = (9 * BM + 255) / 256;
+    float4 a_reg[NA], x_reg[NPOS], s_reg[NPOS];
+    int a_goff[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int e = tid + i * 256;
+        a_goff[i] = -1;
+        if (e < 9 * BM) {
+            const int t = e / BM, col = e % BM;
+            if (m0 + col < p.CoutP) a_goff[i] = (t * p.CoutP + m0 + col) * 4;
+        }
+    }
+    const int a_gstride = 9 * p.CoutP * 4;
+
+    auto load_stage = [&](int it) {
+        const float* wp_it = p.wp + (int64_t)it * a_gstride;
+#pragma unroll
+        for (int i = 0; i < NA; i++) a_reg[i] = a_goff[i] >= 0 ? *(const float4*)(wp_it + a_goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c0 = it * 4;
+        const float* x_it = p.x + (int64_t)c0 * chw;
+#pragma unroll
+        for (int k = 0; k < NPOS; k++) {
+            const int off = pos_off[k];
+            float xv[4], sv[4];
+#pragma unroll
+            for (int ci = 0; ci < 4; ci++) {
+                const bool ok = off >= 0 && c0 + ci < p.Cin;
+                xv[ci] = ok ? x_it[off + ci * chw] : 0.f;
+                sv[ci] = 1.f;
+            }
+            if (p.styles && off >= 0) {
+                if (cin4) { const float4 t = *(const float4*)(p.styles + pos_sb[k] + c0); sv[0] = t.x; sv[1] = t.y; sv[2] = t.z; sv[3] = t.w; }
+                else {
+#pragma unroll
+                    for (int ci = 0; ci < 4; ci++) sv[ci] = c0 + ci < p.Cin ? p.styles[pos_sb[k] + c0 + ci] : 1.f;
+                }
+            }
+            x_reg[k] = make_float4(xv[0], xv[1], xv[2], xv[3]); s_reg[k] = make_float4(sv[0], sv[1], sv[2], sv[3]);
+        }
+    };
+    auto store_stage = [&](float* As, float* Xs) {
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+            if (tid + i * 256 < 9 * BM) *(float4*)(As + (tid + i * 256) * 4) = a_reg[i];
+#pragma unroll
+        for (int k = 0; k < NPOS; k++)
+            if (tid + k * 256 < PSZ)        // modulation rides on the staging
+                *(float4*)(Xs + (tid + k * 256) * 4) = make_float4(x_reg[k].x * s_reg[k].x, x_reg[k].y * s_reg[k].y, x_reg[k].z * s_reg[k].z, x_reg[k].w * s_reg[k].w);
+    };
+
+    if (it0 < it1) {
+        load_stage(it0);
+        store_stage(smem, smem + AS_SZ);
+    }
+    __syncthreads();
+    const int a_lane = ((wm * MTW) * 32 + l32) * 4 + 2 * half;                   // + (t*BM + m*32)*4
+    const int b_lane = (((wn * NTW) + 1) * PC + l32 + 1) * 4 + 2 * half;        // centre tap of subtile 0; + (n*PC + dy*PC + dx)*4
+    int cur = 0;
+    for (int it = it0; it < it1; it++) {
+        const bool more = it + 1 < it1;
+        if (more) load_stage(it + 1);
+        const float* As = smem + cur * BUF_SZ + a_lane;
+        const float* Xs = smem + cur * BUF_SZ + AS_SZ + b_lane;
+        f32x2 fa[2][MTW], fb[2][NTW];
+        auto load_frag = [&](int buf, int t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+#pragma unroll
+            for (int m = 0; m < MTW; m++) fa[buf][m] = *(const f32x2*)(As + (t * BM + m * 32) * 4);
+#pragma unroll
+            for (int n = 0; n < NTW; n++) fb[buf][n] = *(const f32x2*)(Xs + ((n + dy) * PC + dx) * 4);
+        };
+        load_frag(0, 0);
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int cb = t & 1;
+            if (t + 1 < 9) load_frag(cb ^ 1, t + 1);
+            __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ds_reads above this tap's MFMAs
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                for (int m = 0; m < MTW; m++)
+#pragma unroll
+                    for (int n = 0; n < NTW; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][m][kk], fb[cb][n][kk], acc[m][n], 0, 0, 0);
+        }
+        if (more) store_stage(smem + (cur ^ 1) * BUF_SZ, smem + (cur ^ 1) * BUF_SZ + AS_SZ);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: accumulators -> per-wave LDS tile -> epilogue_tile() (16-B stores, fused demod/noise/bias/act) ------------
+    float* ct = smem + wv * (32 * CT_LD);
+    const EpiParams& e = p.e;
+    SideCache scache;
+    scache.lds = side_ok ? side : nullptr; scache.b0 = sb0; scache.bm = BM; scache.m0 = m0;
+    float* part = (p.ksplit > 1) ? p.partial + (int64_t)ks * e.B * e.Cout * e.Hout * e.Wout : nullptr;
+#pragma unroll 1
+    for (int tile = 0; tile < MTW * NTW; tile++) {
+#pragma unroll
+        for (int k = 0; k < MTW * NTW; k++) {
+            if (tile == k) {
+                constexpr int dummy = 0; (void)dummy;
+#pragma unroll
+                for (int r = 0; r < 16; r++) ct[((r & 3) + 8 * (r >> 2) + 4 * half) * CT_LD + l32] = acc[k % MTW][k / MTW][r];
+            }
+        }
+        const int m = tile % MTW, n = tile / MTW;
+        const int vi = vr0 + wn * NTW + n;
+        const int pb = vi / H1, poy = vi - pb * H1;
+        const int pok = (vi < VR && poy < p.H) ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        epilogue_tile<false>(e, scache, ct, m0 + (wm * MTW + m) * 32, pb, poy, n0 + l32, pok, part, true);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- x2 layers: stride-2 transposed 3x3 convolution (conv2d_resample.py:108-125, unflipped weights) --------------------
 //     Z[2i+a, 2j+e] += w[a,e] * x[i,j]
 // as ONE implicit GEMM over a LINEARISED input grid.  Grid point v' = m*(W+1) + n, m in [0,H], n in [0,W], with x := 0
 // on column W and row H.  The four output parities (py,px) of grid point (m,n) are
@@ -533,14 +742,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 // left AND right padding (n-1 at n = 0 wraps onto column W of the previous row), the zero row separates samples.  So
 //   * a block tile is BN CONSECUTIVE grid points -- no 2-D tile edges, no "+1" column of wasted tiles (the old four-phase
 //     launch lost 11-50 % of its lanes to the (W+1)-wide phase grids), no tap masks in the MFMA loop;
-//   * the activation patch is two runs of BN+1 values per channel (the dy = 0 and dy = -1 rows);
+//   * the activation patch is two runs of BN+1 positions (the dy = -1 and dy = 0 rows);
 //   * all 9 taps of a channel pair are multiplied in one pass: 9 A fragments x 4 B fragments feed the 4 parity
 //     accumulators of each 32x32 tile (taps per parity 4/2/2/1), so x is staged once instead of once per phase;
 //   * the epilogue interleaves the px = 0/1 accumulators through LDS and writes Z as dense 16-B-per-lane rows.
 // Z layout (workspace): [ksplit][B][Cout][py][2*GS], entry 2*v' + px; GS = (H+1)*(W+1) rounded up to 32 so a 32-point
 // subtile never straddles samples and every row segment stays 16-B aligned.  Seen as an image, parity plane py holds Z rows
 // 2m+py with row pitch 2(W+1); the pad column 2W+1 and the pad row 2H+1 come out as exact zeros.
-// -------------------------------------------------------------------------------------------------
 struct UpParams {
     const float* x; const float* wp; const float* styles; float* z;
     int B, Cin, Cout, CoutP, H, W, G1, GS, ksplit;
@@ -549,20 +757,19 @@ struct UpParams {
 
 constexpr int UP_CT_W = 68;     // epilogue LDS tile: 32 channels x 64 floats (+4 pad)
 
-template <int MTW, int NTW, int WM, int WN, int KCS>
-__global__ __launch_bounds__(64 * WM * WN) void upconv_mfma_kernel(UpParams p) {
+template <int MTW, int NTW, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int BM = 32 * MTW * WM, BN = 32 * NTW * WN;
-    constexpr int XP = BN + 4, XCH = 2 * XP;            // per channel: [dy = -1 run | dy = 0 run], BN + 1 used of each
-    constexpr int AS_SZ = 9 * KCS * BM, XS_SZ = KCS * XCH, BUF_SZ = AS_SZ + XS_SZ;
-    constexpr int KH = KCS / 2;
+    constexpr int XP = BN + 2;                            // positions per run (BN + 1 used)
+    constexpr int AS_SZ = 9 * BM * 4, XS_SZ = 2 * XP * 4, BUF_SZ = AS_SZ + XS_SZ;          // floats
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int v0 = blockIdx.x * BN, m0 = blockIdx.y * BM, ks = blockIdx.z;
     const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, l32 = l & 31, half = l >> 5;
     const int wm = wv / WN, wn = wv % WN;
 
-    // ---- activation patch slots of this thread (fixed across the K loop) ---------------------------------------------
+    // ---- activation patch slots of this thread (fixed across the K loop): run 0 = grid points v-(W+1) (dy = -1), run 1 = dy = 0
     constexpr int NE = 2 * (BN + 1);
     constexpr int NPOS = (NE + NTH - 1) / NTH;
     int pos_off[NPOS], pos_sb[NPOS], pos_lds[NPOS];
@@ -573,7 +780,7 @@ __global__ __launch_bounds__(64 * WM * WN) void upconv_mfma_kernel(UpParams p) {
         if (e < NE) {
             const int seg = e / (BN + 1), idx = e % (BN + 1);
             const int g = v0 + idx - 1 - (seg == 0 ? p.G1 : 0);
-            pos_lds[k] = seg * XP + idx;
+            pos_lds[k] = (seg * XP + idx) * 4;
             if (g >= 0) {
                 const int b = g / p.GS, vp = g - b * p.GS;
                 const int m = vp / p.G1, n = vp - m * p.G1;
@@ -585,6 +792,7 @@ __global__ __launch_bounds__(64 * WM * WN) void upconv_mfma_kernel(UpParams p) {
         }
     }
     const int chw = p.H * p.W;
+    const bool cin4 = (p.Cin & 3) == 0;
 
     f32x16 acc[4][MTW][NTW];            // [py*2+px]
 #pragma unroll
@@ -596,59 +804,58 @@ __global__ __launch_bounds__(64 * WM * WN) void upconv_mfma_kernel(UpParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[q][m][n][r] = 0.f;
 
-    constexpr int G = KCS / KC3;
-    const int nchunks_packed = (p.Cin + KC3 - 1) / KC3;
-    const int niter = (nchunks_packed + G - 1) / G;
+    const int niter = (p.Cin + 3) >> 2;
     const int it_per = (niter + p.ksplit - 1) / p.ksplit;
     const int it0 = ks * it_per, it1 = min(niter, it0 + it_per);
 
-    constexpr int AROWS = 9 * KCS;
-    constexpr int NA = (AROWS * (BM / 4) + NTH - 1) / NTH;
-    float4 a_reg[NA];
-    float x_reg[NPOS][KCS], s_reg[NPOS][KCS];
-    int a_goff[NA], a_loff[NA];
+    constexpr int NA = (9 * BM + NTH - 1) / NTH;
+    float4 a_reg[NA], x_reg[NPOS], s_reg[NPOS];
+    int a_goff[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
         const int e = tid + i * NTH;
-        a_goff[i] = -1; a_loff[i] = -1;
-        if (e < AROWS * (BM / 4)) {
-            const int row = e / (BM / 4), j4 = e % (BM / 4);
-            const int t = row / KCS, ci = row % KCS;
-            const int g = ci / KC3, c4 = ci % KC3;
-            const int o = m0 + j4 * 4;
-            a_loff[i] = row * BM + j4 * 4;
-            if (o < p.CoutP) a_goff[i] = ((g * 9 + t) * KC3 + c4) * p.CoutP + o;
+        a_goff[i] = -1;
+        if (e < 9 * BM) {
+            const int t = e / BM, col = e % BM;
+            if (m0 + col < p.CoutP) a_goff[i] = (t * p.CoutP + m0 + col) * 4;
         }
     }
-    const int a_gstride = G * 9 * KC3 * p.CoutP;
+    const int a_gstride = 9 * p.CoutP * 4;
 
     auto load_stage = [&](int it) {
         const float* wp_it = p.wp + (int64_t)it * a_gstride;
 #pragma unroll
         for (int i = 0; i < NA; i++) a_reg[i] = a_goff[i] >= 0 ? *(const float4*)(wp_it + a_goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int c0 = it * KCS;
+        const int c0 = it * 4;
         const float* x_it = p.x + (int64_t)c0 * chw;
 #pragma unroll
         for (int k = 0; k < NPOS; k++) {
             const int off = pos_off[k];
+            float xv[4], sv[4];
 #pragma unroll
-            for (int ci = 0; ci < KCS; ci++) {
+            for (int ci = 0; ci < 4; ci++) {
                 const bool ok = off >= 0 && c0 + ci < p.Cin;
-                x_reg[k][ci] = ok ? x_it[off + ci * chw] : 0.f;
-                s_reg[k][ci] = (ok && p.styles) ? p.styles[pos_sb[k] + c0 + ci] : 1.f;
+                xv[ci] = ok ? x_it[off + ci * chw] : 0.f;
+                sv[ci] = 1.f;
             }
+            if (p.styles && off >= 0) {
+                if (cin4) { const float4 t = *(const float4*)(p.styles + pos_sb[k] + c0); sv[0] = t.x; sv[1] = t.y; sv[2] = t.z; sv[3] = t.w; }
+                else {
+#pragma unroll
+                    for (int ci = 0; ci < 4; ci++) sv[ci] = c0 + ci < p.Cin ? p.styles[pos_sb[k] + c0 + ci] : 1.f;
+                }
+            }
+            x_reg[k] = make_float4(xv[0], xv[1], xv[2], xv[3]); s_reg[k] = make_float4(sv[0], sv[1], sv[2], sv[3]);
         }
     };
     auto store_stage = [&](float* As, float* Xs) {
 #pragma unroll
         for (int i = 0; i < NA; i++)
-            if (a_loff[i] >= 0) *(float4*)(As + a_loff[i]) = a_reg[i];
+            if (tid + i * NTH < 9 * BM) *(float4*)(As + (tid + i * NTH) * 4) = a_reg[i];
 #pragma unroll
         for (int k = 0; k < NPOS; k++)
-            if (pos_lds[k] >= 0) {
-#pragma unroll
-                for (int ci = 0; ci < KCS; ci++) Xs[ci * XCH + pos_lds[k]] = x_reg[k][ci] * s_reg[k][ci];
-            }
+            if (pos_lds[k] >= 0)
+                *(float4*)(Xs + pos_lds[k]) = make_float4(x_reg[k].x * s_reg[k].x, x_reg[k].y * s_reg[k].y, x_reg[k].z * s_reg[k].z, x_reg[k].w * s_reg[k].w);
     };
 
     if (it0 < it1) {
@@ -656,40 +863,38 @@ __global__ __launch_bounds__(64 * WM * WN) void upconv_mfma_kernel(UpParams p) {
         store_stage(smem, smem + AS_SZ);
     }
     __syncthreads();
+    const int a_lane = ((wm * MTW) * 32 + l32) * 4 + 2 * half;
+    const int b_lane = ((wn * NTW) * 32 + l32) * 4 + 2 * half;      // + (run*XP + dxi + n*32)*4, run 0: dy = -1, dxi 0: dx = -1
     int cur = 0;
     for (int it = it0; it < it1; it++) {
         const bool more = it + 1 < it1;
         if (more) load_stage(it + 1);
-        const float* As = smem + cur * BUF_SZ + half * BM + (wm * MTW) * 32 + l32;
-        const float* Xs = smem + cur * BUF_SZ + AS_SZ + half * XCH + (wn * NTW) * 32 + l32;
-        float fa[2][9][MTW], fb[2][4][NTW];             // fb index = seg*2 + dxi  (seg 0: dy = -1, dxi 0: dx = -1)
-        auto load_frag = [&](int buf, int kk) {
+        const float* As = smem + cur * BUF_SZ + a_lane;
+        const float* Xs = smem + cur * BUF_SZ + AS_SZ + b_lane;
+        f32x2 fa[2][MTW], fb[4][NTW];               // fb index = run*2 + dxi
 #pragma unroll
-            for (int t = 0; t < 9; t++)
+        for (int q = 0; q < 4; q++)
 #pragma unroll
-                for (int m = 0; m < MTW; m++) fa[buf][t][m] = As[(t * KCS + 2 * kk) * BM + m * 32];
+            for (int n = 0; n < NTW; n++) fb[q][n] = *(const f32x2*)(Xs + ((q >> 1) * XP + (q & 1) + n * 32) * 4);
+        auto load_a = [&](int buf, int t) {
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-#pragma unroll
-                for (int n = 0; n < NTW; n++) fb[buf][q][n] = Xs[2 * kk * XCH + (q >> 1) * XP + (q & 1) + n * 32];
+            for (int m = 0; m < MTW; m++) fa[buf][m] = *(const f32x2*)(As + (t * BM + m * 32) * 4);
         };
-        load_frag(0, 0);
+        load_a(0, 0);
 #pragma unroll
-        for (int kk = 0; kk < KH; kk++) {
-            const int cb = kk & 1;
-            if (kk + 1 < KH) load_frag(cb ^ 1, kk + 1);
-            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ds_reads above this step's MFMAs
+        for (int t = 0; t < 9; t++) {
+            const int cb = t & 1;
+            if (t + 1 < 9) load_a(cb ^ 1, t + 1);
+            __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ds_reads above this tap's MFMAs
+            const int a = t / 3, e = t % 3;
+            const int q = (a & 1) * 2 + (e & 1);                    // output parity of this tap
+            const int f = (a == 2 ? 0 : 2) + (e == 2 ? 0 : 1);     // which shifted run it reads
 #pragma unroll
-            for (int t = 0; t < 9; t++) {
-                constexpr int dummy = 0; (void)dummy;
-                const int a = t / 3, e = t % 3;
-                const int q = (a & 1) * 2 + (e & 1);                    // output parity of this tap
-                const int f = (a == 2 ? 0 : 2) + (e == 2 ? 0 : 1);     // which shifted run it reads
+            for (int kk = 0; kk < 2; kk++)
 #pragma unroll
                 for (int m = 0; m < MTW; m++)
 #pragma unroll
-                    for (int n = 0; n < NTW; n++) acc[q][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][t][m], fb[cb][f][n], acc[q][m][n], 0, 0, 0);
-            }
+                    for (int n = 0; n < NTW; n++) acc[q][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][m][kk], fb[f][n][kk], acc[q][m][n], 0, 0, 0);
         }
         if (more) store_stage(smem + (cur ^ 1) * BUF_SZ, smem + (cur ^ 1) * BUF_SZ + AS_SZ);
         __syncthreads();
@@ -860,16 +1065,25 @@ __global__ __launch_bounds__(1024) void demod_kernel(const float* __restrict__ s
     }
 }
 
-// weight [Cout,Cin,k,k] -> packed [nchunks][T][KC][CoutP] (zero padded) followed by wsq [Cin][CoutP]
+// weight [Cout,Cin,k,k] -> packed (zero padded) [nchunks][9][CoutP][4] for 3x3, [nchunks][1][16][CoutP] for 1x1, followed by wsq [Cin][CoutP]
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wsq, int Cout, int Cin, int T,
                                                   int KC, int CoutP, int nchunks) {
     const int64_t total = (int64_t)nchunks * T * KC * CoutP;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int o = (int)(i % CoutP);
-        int64_t r = i / CoutP;
-        const int c8 = (int)(r % KC); r /= KC;
-        const int t = (int)(r % T);
-        const int cc = (int)(r / T);
+        int o, c8, t, cc;
+        if (T == 9) {               // [chunk][tap][CoutP][KC]: the KC channels of a column are one 16-B vector
+            c8 = (int)(i % KC);
+            int64_t r = i / KC;
+            o = (int)(r % CoutP); r /= CoutP;
+            t = (int)(r % T);
+            cc = (int)(r / T);
+        } else {                    // [chunk][tap][KC][CoutP]
+            o = (int)(i % CoutP);
+            int64_t r = i / CoutP;
+            c8 = (int)(r % KC); r /= KC;
+            t = (int)(r % T);
+            cc = (int)(r / T);
+        }
         const int c = cc * KC + c8;
         wp[i] = (o < Cout && c < Cin) ? w[((int64_t)o * Cin + c) * T + t] : 0.f;
     }
@@ -960,54 +1174,84 @@ int launch_conv(ConvParams& p, float* partial, int64_t partial_floats, hipStream
     return 0;
 }
 
+// Split-K for launches that already fill the chip: tail balancing.  512 block slots (2 blocks per CU); a launch of n blocks
+// runs n / 512 full rounds plus a tail that costs ~0.7 of a round when <= 256 blocks are left (one block per CU runs faster)
+// -- e.g. 560 blocks are 1.7 rounds for 1.09 rounds of work.  Splitting K by ks shrinks the rounds; each extra slice costs
+// one more pass over the partial sums (~4 TB/s, mostly served by the 256 MB MALL).  Times in microseconds at ~100 TFLOP/s of
+// block throughput.
+inline int tail_ksplit(int blocks, int niter, double flop, int64_t slice_floats, int max_ks) {
+    double best = 1e30;
+    int ks = 1;
+    for (int k = 1; k <= max_ks && k <= 4 && niter / k >= 16; k++) {
+        const int n = blocks * k, full = n / 512, rem = n % 512;
+        const double rounds = full + (rem == 0 ? 0.0 : (rem <= 256 ? 0.7 : 1.0));
+        const double t = rounds * (flop / n) / (100e12 / 512) * 1e6 + (k - 1) * (double)slice_floats * 4.0 / 4e12 * 1e6;
+        if (t < best * 0.97) { best = t; ks = k; }
+    }
+    return ks;
+}
+
 // x2 layers: tile configuration, split-K factor and Z geometry -- shared by the workspace query and the launch.
-struct UpPlan { int cfg, BM, BN, KCS, G1, GS, ksplit; int64_t zslice; };
+struct UpPlan { int cfg, BM, BN, G1, GS, ksplit; int64_t zslice; };
 inline UpPlan up_plan(int B, int Cin, int Cout, int H, int W) {
     UpPlan u;
     u.cfg = Cout > 64 ? 0 : 1;
-    { const char* ev = getenv("TDGP_UP_CFG"); if (ev) u.cfg = atoi(ev); }
-    static const int cfgs[6][3] = {{128, 64, 4}, {64, 128, 4}, {128, 128, 4}, {128, 64, 8}, {64, 128, 8}, {64, 128, 4}};
-    u.BM = cfgs[u.cfg][0]; u.BN = cfgs[u.cfg][1]; u.KCS = cfgs[u.cfg][2];
+    u.BM = Cout > 64 ? 128 : 64; u.BN = Cout > 64 ? 64 : 128;
     u.G1 = W + 1;
     u.GS = round_up((H + 1) * (W + 1), 32);
     u.zslice = (int64_t)B * Cout * 4 * u.GS;
     const int blocks = cdiv(B * u.GS, u.BN) * cdiv(Cout, u.BM);
-    const int niter = cdiv(cdiv(Cin, KC3), u.KCS / KC3);
+    const int niter = cdiv(Cin, 4);
     int ks;
     if (blocks < 256) {
         ks = pick_ksplit(blocks, niter);
         const int64_t cap = ((int64_t)64 << 20) / 4;             // low-resolution layers: at most 64 MiB of slices
         while (ks > 1 && ks * u.zslice > cap) ks--;
     } else {
-        // Tail balancing.  512 block slots (2 per CU); a launch of n blocks runs n / 512 full rounds plus a tail that costs ~0.7
-        // of a round when <= 256 blocks are left (one block per CU runs faster) -- e.g. 560 blocks are 1.7 rounds for 1.09
-        // rounds of work.  Splitting K by ks shrinks the rounds; each extra slice costs one more pass over Z (~4 TB/s, mostly
-        // served by the 256 MB MALL).  Times in microseconds at ~85 TFLOP/s of block throughput.
-        const double flop = 2.0 * Cin * Cout * 9.0 * H * W * B;
-        double best = 1e30; ks = 1;
-        for (int k = 1; k <= 4 && niter / k >= 16; k++) {
-            const int n = blocks * k, full = n / 512, rem = n % 512;
-            const double rounds = full + (rem == 0 ? 0.0 : (rem <= 256 ? 0.7 : 1.0));
-            const double t = rounds * (flop / n) / (85e12 / 512) * 1e6 + (k - 1) * (double)u.zslice * 4.0 / 4e12 * 1e6;
-            if (t < best * 0.97) { best = t; ks = k; }
-        }
+        ks = tail_ksplit(blocks, niter, 2.0 * Cin * Cout * 9.0 * H * W * B, u.zslice, 4);
     }
     u.ksplit = ks;
     return u;
 }
 
-template <int MTW, int NTW, int WM, int WN, int KCS>
+template <int MTW, int NTW, int WM, int WN>
 void launch_upconv(const UpParams& u, hipStream_t s) {
     constexpr int BM = 32 * MTW * WM, BN = 32 * NTW * WN, NW = WM * WN;
-    constexpr int stage = 2 * (9 * KCS * BM + KCS * 2 * (BN + 4)), epi = NW * 32 * UP_CT_W;
+    constexpr int stage = 2 * (9 * BM * 4 + 2 * (BN + 2) * 4), epi = NW * 32 * UP_CT_W;
     const size_t lds = (size_t)(stage > epi ? stage : epi) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)upconv_mfma_kernel<MTW, NTW, WM, WN, KCS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)upconv_mfma_kernel<MTW, NTW, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(cdiv(u.B * u.GS, BN), cdiv(u.Cout, BM), u.ksplit);
-    TDGP_LAUNCH("upconv_mfma_kernel", (upconv_mfma_kernel<MTW, NTW, WM, WN, KCS>), grid, dim3(64 * NW), lds, s, u);
+    TDGP_LAUNCH("upconv_mfma_kernel", (upconv_mfma_kernel<MTW, NTW, WM, WN>), grid, dim3(64 * NW), lds, s, u);
+}
+
+// 3x3 stride-1 fast path (W % 32 == 0)
+template <int MTW, int NTW, int WM, int WN>
+int launch_conv3(Conv3Params& p, float* partial, int64_t partial_floats, hipStream_t s) {
+    constexpr int BM = 32 * MTW * WM, NT = NTW * WN;
+    constexpr int stage = 2 * (9 * BM * 4 + (NT + 2) * 34 * 4) + 5 * BM, epi = 4 * 32 * CT_LD;
+    const size_t lds = (size_t)(stage > epi ? stage : epi) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<MTW, NTW, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int gx = (p.W >> 5) * cdiv(p.B * (p.H + 1), NT), gy = cdiv(p.Cout, BM);
+    const int niter = cdiv(p.Cin, 4);
+    const int64_t slice = (int64_t)p.B * p.Cout * p.H * p.W;
+    const int max_ks = (int)min((int64_t)32, partial_floats / slice);
+    int ks = gx * gy < 256 ? pick_ksplit(gx * gy, niter) : tail_ksplit(gx * gy, niter, 2.0 * p.Cin * p.Cout * 9.0 * p.H * p.W * p.B, 2 * slice, max_ks);
+    if (ks > max_ks) ks = max_ks;
+    if (ks < 1) ks = 1;
+    p.ksplit = ks;
+    p.partial = partial;
+    TDGP_LAUNCH("conv_mfma_kernel", (conv3_mfma_kernel<MTW, NTW, WM, WN>), dim3(gx, gy, ks), dim3(256), lds, s, p);
+    if (ks > 1)
+        TDGP_LAUNCH("splitk_reduce_kernel", splitk_reduce_kernel, dim3((int)min((int64_t)2048, cdiv64(slice, 256))), dim3(256), 0, s, partial, ks, p.e);
+    return 0;
 }
 
 inline int pick_tw_log2(int gridW) {
@@ -1098,7 +1342,6 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
     ConvParams p;
     p.x = x; p.wp = wp; p.styles = styles; p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutP = pi.CoutP; p.Hin = H; p.Win = W;
     p.T = pi.T; p.KC = pi.KC; p.ksplit = 1; p.partial = nullptr;
-    { const char* dv = getenv("TDGP_CONV_DBG"); p.dbg = dv ? atoi(dv) : 0; }
     EpiParams& e = p.e;
     e.B = B; e.Cout = Cout;
     for (int i = 0; i < 16; i++) e.fir[i] = 0.f;
@@ -1121,7 +1364,13 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         }
         ph.gridH = H; ph.gridW = W; ph.oy_mul = 1; ph.oy_add = 0; ph.ox_mul = 1; ph.ox_add = 0;
         p.tw_log2 = pick_tw_log2(W);
-        if (k == 3) {
+        if (k == 3 && (W & 31) == 0) {
+            Conv3Params c;
+            c.x = x; c.wp = wp; c.styles = styles; c.partial = nullptr; c.e = e;
+            c.B = B; c.Cin = Cin; c.Cout = Cout; c.CoutP = pi.CoutP; c.H = H; c.W = W; c.ksplit = 1;
+            if (Cout > 64) launch_conv3<2, 2, 2, 2>(c, partial, wl.partial_floats, s);
+            else launch_conv3<2, 2, 1, 4>(c, partial, wl.partial_floats, s);
+        } else if (k == 3) {
             if (Cout > 64) launch_conv<2, 2, 2, 2, 4, 9>(p, partial, wl.partial_floats, s);
             else launch_conv<2, 2, 1, 4, 4, 9>(p, partial, wl.partial_floats, s);
         } else {
@@ -1135,14 +1384,8 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         UpParams u;
         u.x = x; u.wp = wp; u.styles = styles; u.z = z;
         u.B = B; u.Cin = Cin; u.Cout = Cout; u.CoutP = pi.CoutP; u.H = H; u.W = W; u.G1 = pl.G1; u.GS = pl.GS; u.ksplit = pl.ksplit; u.zslice = pl.zslice;
-        switch (pl.cfg) {
-        case 0: launch_upconv<2, 1, 2, 2, 4>(u, s); break;
-        case 1: launch_upconv<2, 1, 1, 4, 4>(u, s); break;
-        case 2: launch_upconv<2, 1, 2, 4, 4>(u, s); break;
-        case 3: launch_upconv<2, 1, 2, 2, 8>(u, s); break;
-        case 4: launch_upconv<2, 1, 1, 4, 8>(u, s); break;
-        default: launch_upconv<1, 2, 2, 2, 4>(u, s); break;
-        }
+        if (pl.cfg == 0) launch_upconv<2, 1, 2, 2>(u, s);
+        else launch_upconv<2, 1, 1, 4>(u, s);
         FirParams f;
         f.z = z; f.dcoef = dco; f.noise = noise; f.noise_bstride = noise_bstride; f.bias = bias; f.y = y;
         for (int i = 0; i < 16; i++) f.fir[i] = e.fir[i];
