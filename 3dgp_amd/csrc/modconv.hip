@@ -30,8 +30,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int KC3 = 4;    // packed channel chunk for 3x3 weights
-constexpr int KC1 = 16;   // packed channel chunk for 1x1 weights
+constexpr int KC3 = 4;    // packed channel chunk: weights live as [chunk][tap][Cout][4 channels]
 
 struct Phase {
     int ntaps;
@@ -57,7 +56,7 @@ struct ConvParams {
     const float* x; const float* wp; const float* styles;
     float* partial;     // split-K: raw partial sums [ksplit][B,Cout,Hout,Wout]
     EpiParams e;
-    int B, Cin, Cout, CoutP, Hin, Win, T, KC;
+    int B, Cin, Cout, CoutP, Hin, Win, T;
     int tw_log2;
     int nphases, ksplit;
     Phase ph[4];
@@ -263,7 +262,7 @@ __device__ __forceinline__ void epilogue_tile(const EpiParams& e, const SideCach
 
 // -------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution.  Block = 256 threads = WM x WN waves, wave tile = (MTW*32) x (NTW*32).
-// KCS = channels staged per K iteration (a multiple of the packed chunk p.KC), MAXT = max taps per phase.
+// KCS = channels staged per K iteration (a multiple of the packed chunk of 4), MAXT = max taps per phase.
 //
 // K loop: double-buffered LDS, ONE barrier per iteration.
 //   issue global loads of chunk it+1 (packed weights as 16-B vectors, the halo'd activation patch as scalars)
@@ -371,14 +370,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
 
-    const int G = KCS / p.KC;                       // packed chunks per staged iteration
-    const int nchunks_packed = (p.Cin + p.KC - 1) / p.KC;
+    const int G = KCS / KC3;                        // packed chunks per staged iteration
+    const int nchunks_packed = (p.Cin + KC3 - 1) / KC3;
     const int niter = (nchunks_packed + G - 1) / G;
     const int arows = ph.ntaps * KCS;
     const int it_per = (niter + p.ksplit - 1) / p.ksplit;          // split-K: this block reduces iterations [it0, it1)
     const int it0 = ks * it_per, it1 = min(niter, it0 + it_per);
 
-    constexpr int NA = (MAXT == 9 ? (MAXT * BM + 255) / 256 : (MAXT * KCS * (BM / 4) + 255) / 256);     // float4 of the A tile per thread
+    // A tile of one iteration: ntaps x G packed chunks x BM columns, one float4 (the 4 channels of a column) per slot
+    constexpr int GC = KCS / KC3;
+    constexpr int NA = (MAXT * GC * BM + 255) / 256;
     float4 a_reg[NA];
     float x_reg[NPOS][KCS], s_reg[NPOS][KCS];
     // Everything about a thread's staging slots that does not depend on the K iteration is computed once: global offsets
@@ -388,24 +389,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     for (int i = 0; i < NA; i++) {
         const int e = tid + i * 256;
         a_goff[i] = -1; a_loff[i] = 0;
-        if constexpr (MAXT == 9) {
-            // 3x3 weights are packed [chunk][tap][CoutP][4 channels]: a slot is the 4 channels of one out-channel column
-            static_assert(MAXT != 9 || KCS == KC3, "the generic 3x3 path stages one packed chunk per iteration");
-            if (e < ph.ntaps * BM) {
-                const int t = e / BM, col = e % BM;
-                a_loff[i] = t * KCS * BM + col;
-                if (m0 + col < p.CoutP) a_goff[i] = (ph.tap_w[t] * p.CoutP + m0 + col) * 4;
-            }
-        } else if (e < arows * (BM / 4)) {
-            const int row = e / (BM / 4), j4 = e % (BM / 4);
-            const int t = row / KCS, ci = row % KCS;
-            const int g = ci / p.KC, c8 = ci % p.KC;
-            const int o = m0 + j4 * 4;
-            a_loff[i] = row * BM + j4 * 4;
-            if (o < p.CoutP) a_goff[i] = ((g * p.T + ph.tap_w[t]) * p.KC + c8) * p.CoutP + o;
+        if (e < ph.ntaps * GC * BM) {
+            const int col = e % BM, tg = e / BM, g = tg % GC, t = tg / GC;
+            a_loff[i] = (t * KCS + g * KC3) * BM + col;
+            if (m0 + col < p.CoutP) a_goff[i] = ((g * p.T + ph.tap_w[t]) * p.CoutP + m0 + col) * 4;
         }
     }
-    const int a_gstride = G * p.T * p.KC * p.CoutP;
+    const int a_gstride = GC * p.T * p.CoutP * 4;
 
     auto load_stage = [&](int it) {
         const float* wp_it = p.wp + (int64_t)it * a_gstride;
@@ -426,16 +416,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     };
     auto store_stage = [&](float* As, float* Xs) {
 #pragma unroll
-        for (int i = 0; i < NA; i++) {
-            if constexpr (MAXT == 9) {
-                if (tid + i * 256 < ph.ntaps * BM) {            // [col][4 ch] -> k-major rows
-                    float* d = As + a_loff[i];
-                    d[0] = a_reg[i].x; d[BM] = a_reg[i].y; d[2 * BM] = a_reg[i].z; d[3 * BM] = a_reg[i].w;
-                }
-            } else {
-                if (tid + i * 256 < arows * (BM / 4)) *(float4*)(As + a_loff[i]) = a_reg[i];
+        for (int i = 0; i < NA; i++)
+            if (tid + i * 256 < ph.ntaps * GC * BM) {           // [col][4 ch] -> k-major rows
+                float* d = As + a_loff[i];
+                d[0] = a_reg[i].x; d[BM] = a_reg[i].y; d[2 * BM] = a_reg[i].z; d[3 * BM] = a_reg[i].w;
             }
-        }
 #pragma unroll
         for (int k = 0; k < NPOS; k++) {
             const int pos = tid + k * 256;
@@ -940,6 +925,163 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
     }
 }
 
+// ---- ToRGB: 1x1 modulated conv without demodulation, Cout <= 96, channel-last plane output with the fused x2 skip ---------
+// (networks_stylegan2.py:252-273).  12 kFLOP against 736 B per pixel at 64 channels: the layer sits on the ridge between the
+// matrix cores and HBM, so the kernel is built to keep both busy -- one block = 128 consecutive pixels (1x1: no halo, tiles
+// are linear over B*H*W), 64 channels per K iteration held in registers one iteration ahead, activations fetched as 16-B
+// vectors along x and transposed in registers to the [pixel][4 channels] LDS layout while the style scale is applied,
+// weights [chunk][Cout][4], fragments = 8-byte LDS reads with immediate offsets, no VALU in the MFMA loop.
+struct RgbParams {
+    const float* x; const float* wp; const float* styles;
+    EpiParams e;
+    int B, Cin, Cout, CoutP, HW, W;
+    int64_t P;          // B*H*W
+};
+
+template <int MT>
+__global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
+    constexpr int BM = 32 * MT, BN = 128, NCH = 16;                 // 16 packed chunks = 64 channels per iteration
+    constexpr int AS_SZ = NCH * BM * 4, XS_SZ = NCH * BN * 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Xs = smem + AS_SZ;
+    float* side = smem + AS_SZ + XS_SZ;                             // [BM] bias
+    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, l32 = l & 31, half = l >> 5;
+    const int64_t px0 = (int64_t)blockIdx.x * BN;
+
+    for (int i = tid; i < BM; i += 256) side[i] = (i < p.Cout && p.e.bias) ? p.e.bias[i] : 0.f;
+
+    // two 4-channel x 4-pixel micro-tiles per thread and iteration
+    int x_off[2], x_sb[2];
+    const int cq = tid >> 5, pq = tid & 31;                        // micro-tile k: channels 4*(cq + 8k) .. +3 of the iteration, pixels 4*pq .. +3
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int64_t pix = px0 + 4 * pq;
+        x_off[k] = -1; x_sb[k] = 0;
+        if (pix < p.P) {
+            const int b = (int)(pix / p.HW), inner = (int)(pix - (int64_t)b * p.HW);
+            x_sb[k] = b * p.Cin + 4 * (cq + 8 * k);
+            x_off[k] = x_sb[k] * p.HW + inner;
+        }
+    }
+    const bool cin4 = (p.Cin & 3) == 0;
+
+    constexpr int NA = (NCH * BM + 255) / 256;
+    int a_goff[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int e = tid + i * 256;
+        a_goff[i] = -1;
+        if (e < NCH * BM) {
+            const int chunk = e / BM, col = e % BM;
+            if (col < p.CoutP) a_goff[i] = (chunk * p.CoutP + col) * 4;
+        }
+    }
+    const int a_gstride = NCH * p.CoutP * 4;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+
+    float4 a_reg[NA], xr[2][4], sr[2];
+    auto load_stage = [&](int it) {
+        const float* wp_it = p.wp + (int64_t)it * a_gstride;
+#pragma unroll
+        for (int i = 0; i < NA; i++) a_reg[i] = a_goff[i] >= 0 ? *(const float4*)(wp_it + a_goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c0 = it * 64;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int cb = c0 + 4 * (cq + 8 * k);                  // first channel of the micro-tile
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                xr[k][j] = (x_off[k] >= 0 && cb + j < p.Cin) ? *(const float4*)(p.x + x_off[k] + (int64_t)(c0 + j) * p.HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sr[k] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (p.styles && x_off[k] >= 0) {
+                if (cin4) { if (cb < p.Cin) sr[k] = *(const float4*)(p.styles + x_sb[k] + c0); }
+                else {
+                    float sv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) sv[j] = cb + j < p.Cin ? p.styles[x_sb[k] + c0 + j] : 1.f;
+                    sr[k] = make_float4(sv[0], sv[1], sv[2], sv[3]);
+                }
+            }
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+            if (tid + i * 256 < NCH * BM) *(float4*)(As + (tid + i * 256) * 4) = a_reg[i];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            // 4x4 register transpose: xr[k][j] = channel j over 4 pixels  ->  per pixel, 4 channels (x style)
+            // Pixel 4*pq + j lands in slot j*32 + pq: consecutive lanes write consecutive 16-B slots (conflict-free), and wave j's
+            // MFMA column l32 (slot j*32 + l32) is pixel 4*l32 + j -- a permutation the channel-last epilogue does not care about.
+            float* d = Xs + (((cq + 8 * k) * BN) + pq) * 4;
+            *(float4*)(d + 0 * 128) = make_float4(xr[k][0].x * sr[k].x, xr[k][1].x * sr[k].y, xr[k][2].x * sr[k].z, xr[k][3].x * sr[k].w);
+            *(float4*)(d + 1 * 128) = make_float4(xr[k][0].y * sr[k].x, xr[k][1].y * sr[k].y, xr[k][2].y * sr[k].z, xr[k][3].y * sr[k].w);
+            *(float4*)(d + 2 * 128) = make_float4(xr[k][0].z * sr[k].x, xr[k][1].z * sr[k].y, xr[k][2].z * sr[k].z, xr[k][3].z * sr[k].w);
+            *(float4*)(d + 3 * 128) = make_float4(xr[k][0].w * sr[k].x, xr[k][1].w * sr[k].y, xr[k][2].w * sr[k].z, xr[k][3].w * sr[k].w);
+        }
+    };
+
+    const int niter = (p.Cin + 63) >> 6;
+    const float* Al = As + l32 * 4 + 2 * half;
+    const float* Xl = Xs + (wv * 32 + l32) * 4 + 2 * half;
+    load_stage(0);
+    for (int it = 0; it < niter; it++) {
+        __syncthreads();                        // the previous iteration's fragments have been read
+        store_stage();
+        __syncthreads();
+        if (it + 1 < niter) load_stage(it + 1);
+        f32x2 fa[2][MT], fb[2];
+        auto load_frag = [&](int buf, int ch) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) fa[buf][m] = *(const f32x2*)(Al + (ch * BM + m * 32) * 4);
+            fb[buf] = *(const f32x2*)(Xl + ch * BN * 4);
+        };
+        load_frag(0, 0);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            const int cb = ch & 1;
+            if (ch + 1 < NCH) load_frag(cb ^ 1, ch + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                for (int m = 0; m < MT; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][m][kk], fb[cb][kk], acc[m], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: bias + FIR-upsampled skip, channel-last float4 stores (epilogue_tile<true>, pixel-major LDS tile) --------
+    float* ct = Xs + wv * (32 * CT_LD);
+    const int64_t pix = px0 + 4 * l32 + wv;
+    const int pok = pix < p.P ? 1 : 0;
+    const int64_t pc = pok ? pix : 0;
+    const int pb = (int)(pc / p.HW), inner = (int)(pc - (int64_t)pb * p.HW);
+    const int poy = inner / p.W, pox = inner - poy * p.W;
+    SideCache scache;
+    scache.lds = side; scache.b0 = 0; scache.bm = BM; scache.m0 = 0;
+#pragma unroll 1
+    for (int tile = 0; tile < MT; tile++) {
+#pragma unroll
+        for (int k = 0; k < MT; k++) {
+            if (tile == k) {
+                constexpr int dummy = 0; (void)dummy;
+#pragma unroll
+                for (int r = 0; r < 16; r++) ct[l32 * CT_LD + (r & 3) + 8 * (r >> 2) + 4 * half] = acc[k][r];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        epilogue_tile<true>(p.e, scache, ct, tile * 32, pb, poy, pox, pok, nullptr, false);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Split-K reduction: y = epilogue(sum_ks partial[ks]) ; one thread per output element, ks summed in order (deterministic).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, EpiParams e) {
     const int64_t slice = (int64_t)e.B * e.Cout * e.Hout * e.Wout;
@@ -1065,25 +1207,16 @@ __global__ __launch_bounds__(1024) void demod_kernel(const float* __restrict__ s
     }
 }
 
-// weight [Cout,Cin,k,k] -> packed (zero padded) [nchunks][9][CoutP][4] for 3x3, [nchunks][1][16][CoutP] for 1x1, followed by wsq [Cin][CoutP]
+// weight [Cout,Cin,k,k] -> packed (zero padded) [nchunks][k*k][CoutP][4] followed by wsq [Cin][CoutP]
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wsq, int Cout, int Cin, int T,
                                                   int KC, int CoutP, int nchunks) {
     const int64_t total = (int64_t)nchunks * T * KC * CoutP;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int o, c8, t, cc;
-        if (T == 9) {               // [chunk][tap][CoutP][KC]: the KC channels of a column are one 16-B vector
-            c8 = (int)(i % KC);
-            int64_t r = i / KC;
-            o = (int)(r % CoutP); r /= CoutP;
-            t = (int)(r % T);
-            cc = (int)(r / T);
-        } else {                    // [chunk][tap][KC][CoutP]
-            o = (int)(i % CoutP);
-            int64_t r = i / CoutP;
-            c8 = (int)(r % KC); r /= KC;
-            t = (int)(r % T);
-            cc = (int)(r / T);
-        }
+        const int c8 = (int)(i % KC);               // [chunk][tap][CoutP][KC]: the KC channels of a column are one 16-B vector
+        int64_t r = i / KC;
+        const int o = (int)(r % CoutP); r /= CoutP;
+        const int t = (int)(r % T);
+        const int cc = (int)(r / T);
         const int c = cc * KC + c8;
         wp[i] = (o < Cout && c < Cin) ? w[((int64_t)o * Cin + c) * T + t] : 0.f;
     }
@@ -1121,9 +1254,9 @@ struct PackInfo { int T, KC, CoutP, nchunks; int64_t wp_floats, wsq_floats; };
 inline PackInfo pack_info(int Cout, int Cin, int k) {
     PackInfo pi;
     pi.T = k * k;
-    pi.KC = (k == 1) ? KC1 : KC3;
+    pi.KC = KC3;
     pi.CoutP = round_up(Cout, 4);
-    pi.nchunks = round_up((Cin + pi.KC - 1) / pi.KC, 2);      // zero-padded to whole K iterations (G <= 2 packed chunks each)
+    pi.nchunks = round_up((Cin + pi.KC - 1) / pi.KC, k == 1 ? 16 : 2);      // zero-padded to whole K iterations (1x1 kernels stage up to 16 chunks)
     pi.wp_floats = (int64_t)pi.nchunks * pi.T * pi.KC * pi.CoutP;
     pi.wsq_floats = (int64_t)Cin * pi.CoutP;
     return pi;
@@ -1161,7 +1294,7 @@ int launch_conv(ConvParams& p, float* partial, int64_t partial_floats, hipStream
         attr_set = true;
     }
     const int gx = px_tiles(p, NT), gy = cdiv(p.Cout, BM);
-    const int niter = cdiv(cdiv(p.Cin, p.KC), KCS / p.KC);
+    const int niter = cdiv(cdiv(p.Cin, KC3), KCS / KC3);
     const int64_t slice = (int64_t)p.e.B * p.e.Cout * p.e.Hout * p.e.Wout;
     int ks = pick_ksplit(gx * gy * p.nphases, niter);
     while (ks > 1 && ks * slice > partial_floats) ks--;          // never exceed the caller's workspace
@@ -1226,6 +1359,18 @@ void launch_upconv(const UpParams& u, hipStream_t s) {
     }
     dim3 grid(cdiv(u.B * u.GS, BN), cdiv(u.Cout, BM), u.ksplit);
     TDGP_LAUNCH("upconv_mfma_kernel", (upconv_mfma_kernel<MTW, NTW, WM, WN>), grid, dim3(64 * NW), lds, s, u);
+}
+
+template <int MT>
+void launch_torgb(const RgbParams& r, hipStream_t s) {
+    constexpr int BM = 32 * MT;
+    const size_t lds = (size_t)(16 * BM * 4 + 16 * 128 * 4 + BM) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)torgb_mfma_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    TDGP_LAUNCH("torgb_mfma_kernel", (torgb_mfma_kernel<MT>), dim3((unsigned)cdiv64(r.P, 128)), dim3(256), lds, s, r);
 }
 
 // 3x3 stride-1 fast path (W % 32 == 0)
@@ -1341,7 +1486,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
 
     ConvParams p;
     p.x = x; p.wp = wp; p.styles = styles; p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutP = pi.CoutP; p.Hin = H; p.Win = W;
-    p.T = pi.T; p.KC = pi.KC; p.ksplit = 1; p.partial = nullptr;
+    p.T = pi.T; p.ksplit = 1; p.partial = nullptr;
     EpiParams& e = p.e;
     e.B = B; e.Cout = Cout;
     for (int i = 0; i < 16; i++) e.fir[i] = 0.f;
@@ -1373,6 +1518,13 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         } else if (k == 3) {
             if (Cout > 64) launch_conv<2, 2, 2, 2, 4, 9>(p, partial, wl.partial_floats, s);
             else launch_conv<2, 2, 1, 4, 4, 9>(p, partial, wl.partial_floats, s);
+        } else if (out_layout == 1 && Cout <= 96 && !demodulate && !noise && ((H * W) & 3) == 0) {
+            RgbParams r;
+            r.x = x; r.wp = wp; r.styles = styles; r.e = e;
+            r.B = B; r.Cin = Cin; r.Cout = Cout; r.CoutP = pi.CoutP; r.HW = H * W; r.W = W; r.P = (int64_t)B * H * W;
+            if (Cout <= 32) launch_torgb<1>(r, s);
+            else if (Cout <= 64) launch_torgb<2>(r, s);
+            else launch_torgb<3>(r, s);
         } else {
             if (Cout > 64 && Cout <= 96) launch_conv<3, 1, 1, 4, 32, 1>(p, partial, wl.partial_floats, s);
             else if (Cout > 64) launch_conv<2, 2, 2, 2, 16, 1>(p, partial, wl.partial_floats, s);

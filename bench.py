@@ -35,10 +35,10 @@ PEAK_HBM_GBS = 8000.0
 
 
 def algorithmic_flops(cfg):
-    """Algorithmic FLOP per image of the MFMA kernels: 2 * MAC of every conv launch (stride-1 3x3 + ToRGB in
-    conv_mfma_kernel, the x2 layers in upconv_mfma_kernel); 5376 per field point."""
+    """Algorithmic FLOP per image of the MFMA kernels: 2 * MAC of every conv launch (stride-1 3x3 layers in
+    conv_mfma_kernel, the x2 layers in upconv_mfma_kernel, ToRGB in torgb_mfma_kernel); 5376 per field point."""
     ch = cfg.channels
-    conv = up = 0
+    conv = up = rgb = 0
     launches = up_launches = 0
     for i, r in enumerate(cfg.block_resolutions):
         c = ch[r]
@@ -46,11 +46,12 @@ def algorithmic_flops(cfg):
             up += 2 * ch[r // 2] * c * 9 * (r // 2) ** 2          # stride-2 transposed conv: 9 taps per INPUT pixel
             up_launches += 1
         conv += 2 * c * c * 9 * r * r                              # conv1
-        conv += 2 * c * cfg.plane_channels * r * r                 # ToRGB 1x1
-        launches += 2
+        rgb += 2 * c * cfg.plane_channels * r * r                  # ToRGB 1x1
+        launches += 1
     pts = 2 * cfg.img_resolution ** 2 * cfg.num_ray_steps          # coarse + fine
     field = pts * (2 * (cfg.feat_dim * cfg.mlp_hid + 4 * cfg.mlp_hid) + 3 * 4 * 2 * cfg.feat_dim)   # MLP 4608 + bilerp 768 @ (32,64)
-    return dict(conv_mfma_kernel=(conv, launches), upconv_mfma_kernel=(up, up_launches), triplane_field_kernel=(field, 2))
+    return dict(conv_mfma_kernel=(conv, launches), upconv_mfma_kernel=(up, up_launches), torgb_mfma_kernel=(rgb, launches),
+                triplane_field_kernel=(field, 2))
 
 
 def cpu_baseline(tdgp, cfg, n_img=8, budget_s=25.0):

@@ -369,7 +369,9 @@ def test_e2e_tiny(tdgp, oracle):
     planes = G.synthesis.tri_plane_decoder(ws, noise_mode='const')
     assert_close(N(planes), g['planes'], 5e-6, 'planes (NCHW)', 1.0)
     hwc = G.synthesis.tri_plane_decoder(ws, noise_mode='const', hwc=True).t
-    np.testing.assert_array_equal(N(hwc.permute(0, 1, 4, 2, 3).reshape(planes.shape)), N(planes))
+    # the channel-last planes come from the fused ToRGB kernel, the NCHW ones from the generic 1x1 path: same algebra, different
+    # K-step grouping inside the matrix cores -> equal to fp32 rounding, not bit for bit
+    assert_close(N(hwc.permute(0, 1, 4, 2, 3).reshape(planes.shape)), N(planes), 2e-6, 'planes channel-last vs NCHW', 1.0)
     out = G.synthesis(ws, camera_params=_cam(g), noise_mode='const', render_opts=dict(return_depth=True), u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
     ex_img, ex_depth = _exact(oracle, tdgp, cfg, 21, g)
     assert_image_parity(N(out.img), g, 'img', exact=ex_img)

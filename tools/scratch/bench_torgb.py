@@ -12,8 +12,10 @@ def run(B,cin,H,skip,layout,reps=5):
     torch.cuda.synchronize(); t._lib.profile_enable(True)
     for _ in range(reps): y = mc.modconv_forward(x,pk,s,**kw)
     torch.cuda.synchronize(); r = t._lib.profile_report(); t._lib.profile_enable(False)
-    return round(r['conv_mfma_kernel']['avg_ms']*1e3,1)
-for H,cin in ((512,64),(256,128)):
+    return {k: round(v['avg_ms']*1e3,1) for k, v in r.items()}
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+for H,cin in ((512,64),(256,128),(128,256),(64,512),(32,512)):
     for skip in (0,1):
-        for layout in (0,1):
-            print(os.environ.get('TDGP_CONV_DBG','0'), 'H',H,'cin',cin,'skip',skip,'layout',layout, run(4,cin,H,skip,layout),'us')
+        r = run(B,cin,H,skip,1)
+        byt = B*H*H*4*(cin + 96 + (24 if skip else 0))
+        print('H',H,'cin',cin,'skip',skip, r, 'GB/s', round(byt/list(r.values())[0]/1e3), 'TF', round(2*B*H*H*cin*96/list(r.values())[0]/1e6,1))
