@@ -5,7 +5,44 @@ Field names follow the keys the reference's hot path actually reads (SURVEY.md s
 `src/train.py:156-273`.  Only what the generator forward consumes is kept.
 """
 import math
-from dataclasses import dataclass, asdict
+from dataclasses import dataclass, field, asdict
+from typing import Optional
+
+
+@dataclass
+class DepthAdaptorConfig:
+    """configs/model/3dgp.yaml:40-50 (the keys DepthAdaptor.forward reads)."""
+    kernel_size: int = 5
+    hid_dim: int = 64
+    num_hid_layers: int = 3
+    out_strategy: str = 'random'
+    near_plane_offset_max_fraction: float = 0.25
+    near_plane_offset_bias: float = -3.0
+
+
+@dataclass
+class CameraRanges:
+    """The entries of configs/camera/base.yaml the camera adaptor reads: (min, max) of each prior."""
+    yaw: tuple = (-1.57079633, 1.57079633)
+    pitch: tuple = (0.392699082, 2.74889357)
+    fov: tuple = (10.0, 45.0)
+    look_at_yaw: tuple = (-3.14159265, 3.14159265)
+    look_at_pitch: tuple = (0.0, 3.14159265)
+    look_at_radius: tuple = (0.0, 0.0)
+
+
+@dataclass
+class CameraAdaptorConfig:
+    """configs/model/3dgp.yaml:52-75; z_dim / c_dim are filled in from the generator."""
+    hid_dim: int = 256
+    embed_dim: int = 16
+    lr_multiplier: float = 0.1
+    residual: bool = False
+    adjust_angles: bool = True
+    adjust_radius: bool = False
+    adjust_fov: bool = True
+    adjust_look_at: bool = True
+    camera: CameraRanges = field(default_factory=CameraRanges)
 
 
 @dataclass
@@ -32,6 +69,11 @@ class GeneratorConfig:
     density_bias: float = 0.0
     img_resolution: int = 256
     max_batch_res: int = 128        # kept for API parity (run_batchwise chunking is a no-op for results)
+    # enabled in every 3dgp training config (model/base.yaml:32-35); None = module absent, as when
+    # `training.use_depth` / `training.learn_camera_dist` are off.  The section-8a hot path (and bench.py's metric) is the
+    # generator forward without them.
+    depth_adaptor: Optional[DepthAdaptorConfig] = None
+    camera_adaptor: Optional[CameraAdaptorConfig] = None
 
     def to_dict(self):
         return asdict(self)
@@ -89,3 +131,15 @@ def config_mid():
     """Mid-sized golden configuration: exercises MFMA tile edges (channels 64/32, 64^2 planes)."""
     return GeneratorConfig(z_dim=64, w_dim=64, c_dim=10, cbase=2048, cmax=64, tri_plane_res=64, feat_dim=32,
                            mlp_hid=64, num_ray_steps=16, img_resolution=32)
+
+
+def configs_adaptor_goldens():
+    """The two adaptor configurations behind tests/golden/adaptors.npz (tools/gen_goldens.py:gen_adaptors)."""
+    a = config_tiny()
+    a.depth_adaptor = DepthAdaptorConfig(hid_dim=16)
+    a.camera_adaptor = CameraAdaptorConfig(hid_dim=32, embed_dim=8)
+    b = config_mid()            # c_dim 10, 32^2 images -> the W % 32 == 0 fast path of the 5x5 kernel
+    b.depth_adaptor = DepthAdaptorConfig(hid_dim=64, num_hid_layers=2, out_strategy='mean', near_plane_offset_max_fraction=0.4)
+    b.camera_adaptor = CameraAdaptorConfig(hid_dim=64, embed_dim=16, residual=True, adjust_angles=True, adjust_radius=True, adjust_fov=False,
+                                           adjust_look_at=True, camera=CameraRanges(look_at_radius=(0.0, 0.2)))
+    return [('a', a), ('b', b)]

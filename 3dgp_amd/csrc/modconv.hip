@@ -33,11 +33,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KC3 = 4;    // packed channel chunk: weights live as [chunk][tap][Cout][4 channels]
 
 struct Phase {
-    int ntaps;
-    int tap_w[9];       // tap index in the packed weight layout
-    int tap_off_y[9];   // dy in {-1,0,1}
-    int tap_off_x[9];
-    int gridH, gridW;   // pixels computed by this phase
+    int ntaps, halo;    // halo = k/2
+    int tap_w[25];      // tap index in the packed weight layout
+    int tap_off_y[25];  // dy in [-halo, halo]
+    int tap_off_x[25];
+    int gridH, gridW;   // output pixels
     int oy_mul, oy_add, ox_mul, ox_add;
 };
 
@@ -59,7 +59,7 @@ struct ConvParams {
     int B, Cin, Cout, CoutP, Hin, Win, T;
     int tw_log2;
     int nphases, ksplit;
-    Phase ph[4];
+    Phase ph[1];
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float alpha) {
@@ -275,19 +275,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     constexpr int BM = 32 * MTW * WM;
     constexpr int NT = NTW * WN;            // 32-pixel subtiles per block
     constexpr int BN = 32 * NT;
-    constexpr int XS_MAX = (BN / 4 + 2) * (4 + 2) > (BN / 32 + 2) * (32 + 2) ? (BN / 4 + 2) * (4 + 2) : (BN / 32 + 2) * (32 + 2);
+    constexpr int HALO = MAXT == 25 ? 2 : 1;      // largest halo this instantiation is launched with
+    constexpr int XS_MAX = (BN / 4 + 2 * HALO) * (4 + 2 * HALO) > (BN / 32 + 2 * HALO) * (32 + 2 * HALO) ? (BN / 4 + 2 * HALO) * (4 + 2 * HALO) : (BN / 32 + 2 * HALO) * (32 + 2 * HALO);
     constexpr int AS_SZ = MAXT * KCS * BM, XS_SZ = KCS * XS_MAX, BUF_SZ = AS_SZ + XS_SZ + 64;   // +64: fragment prefetch past the last row
     constexpr int KH = KCS / 2;             // k-steps (of 2 channels) per tap; even
     static_assert(KH % 2 == 0, "KCS must be a multiple of 4");
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][As | Xs], then the tap-offset table
-    int* toff_tab = (int*)(smem + 2 * BUF_SZ);                      // [MAXT + 2 (+ pad to 16)]
-    float* side = smem + 2 * BUF_SZ + 16;                           // [1 + NSB][BM]: bias, demod coefficients of the tile's samples
+    int* toff_tab = (int*)(smem + 2 * BUF_SZ);                      // [MAXT + 2 (+ pad to 32)]
+    float* side = smem + 2 * BUF_SZ + 32;                           // [1 + NSB][BM]: bias, demod coefficients of the tile's samples
 
     const int phase_id = blockIdx.z % p.nphases, ks = blockIdx.z / p.nphases;
     const Phase& ph = p.ph[phase_id];
     const int TW = 1 << p.tw_log2, RPS = 32 >> p.tw_log2;
     const int TR = NT * RPS;                        // virtual rows per block tile
-    const int PR = TR + 2, PC = TW + 2;
+    const int R = ph.halo;
+    const int PR = TR + 2 * R, PC = TW + 2 * R;
     const int PSZ = PR * PC;
     const int tilesX = (ph.gridW + TW - 1) / TW;
     const int VR = p.B * ph.gridH;
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     const int l32 = l & 31, half = l >> 5;
     const int wm = wv / WN, wn = wv % WN;
 
-    if (tid < MAXT + 2) toff_tab[tid] = tid < ph.ntaps ? (ph.tap_off_y[tid] + 1) * PC + (ph.tap_off_x[tid] + 1) : 0;
+    if (tid < MAXT + 2) toff_tab[tid] = tid < ph.ntaps ? (ph.tap_off_y[tid] + R) * PC + (ph.tap_off_x[tid] + R) : 0;
     // per-channel side inputs of the epilogue -> LDS now, so the output stage has no dependent global loads
     constexpr int NSB = 4;
     const int sb0 = vr0 / ph.gridH, sb1 = min(p.B - 1, (vr0 + TR - 1) / ph.gridH);
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
         pos_off[k] = -1; pos_sb[k] = 0;
         if (pos < PSZ) {
             const int pr = pos / PC, pc = pos % PC;
-            const int vi = vr0 - 1 + pr, ix = n0 - 1 + pc;
+            const int vi = vr0 - R + pr, ix = n0 - R + pc;
             if (vi >= 0 && ix >= 0 && ix < p.Win) {
                 const int bb = vi / ph.gridH, iy = vi % ph.gridH;
                 if (bb < p.B && iy < p.Hin) {
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     const int chw = p.Hin * p.Win;
 
     // ---- per-lane pixel info for its NTW subtiles ------------------------------------------------
-    int px_base[NTW];           // LDS offset of the pixel inside the patch (tap (0,0) -> + PC + 1)
+    int px_base[NTW];           // LDS offset of the pixel's (-halo,-halo) tap inside the patch
     int px_mask[NTW];           // bit t: tap t reads a row of the same sample
     int px_b[NTW], px_m[NTW], px_n[NTW];
     bool px_ok[NTW];
@@ -531,24 +533,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 // -------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// ---- 3x3, stride 1, W % 32 == 0 ------------------------------------------------------------------------------------------
-// Pixel tile = NT "virtual rows" x 32 columns, virtual row vi = b*(H+1) + m where row m == H of every sample is a ZERO row:
-// it is the bottom padding of sample b and the top padding of sample b+1, so a tile may straddle samples without any per-lane
-// tap mask (cost: 1/(H+1) of the rows compute nothing useful).  Left/right padding = the zero halo columns of the patch.
+// ---- KS x KS (3x3 / 5x5), stride 1, W % 32 == 0 -----------------------------------------------------------------------------
+// Pixel tile = NT "virtual rows" x 32 columns, virtual row vi = b*(H+R) + m (R = KS/2) where rows m >= H of every sample are
+// ZERO rows: they are the bottom padding of sample b and the top padding of sample b+1, so a tile may straddle samples without
+// any per-lane tap mask (cost: R/(H+R) of the rows compute nothing useful).  Left/right padding = the zero halo columns.
 struct Conv3Params {
     const float* x; const float* wp; const float* styles; float* partial;
     EpiParams e;
     int B, Cin, Cout, CoutP, H, W, ksplit;
 };
 
-template <int MTW, int NTW, int WM, int WN>
+template <int KS, int MTW, int NTW, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
-    constexpr int BM = 32 * MTW * WM, NT = NTW * WN, PR = NT + 2, PC = 34, PSZ = PR * PC;
-    constexpr int AS_SZ = 9 * BM * 4, XS_SZ = PSZ * 4, BUF_SZ = AS_SZ + XS_SZ;          // floats
+    constexpr int R = KS / 2, T = KS * KS;
+    constexpr int BM = 32 * MTW * WM, NT = NTW * WN, PR = NT + 2 * R, PC = 32 + 2 * R, PSZ = PR * PC;
+    constexpr int AS_SZ = T * BM * 4, XS_SZ = PSZ * 4, BUF_SZ = AS_SZ + XS_SZ;          // floats
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* side = smem + 2 * BUF_SZ;                                // [1 + NSB][BM]: bias, demod coefficients of the tile's samples
 
-    const int H1 = p.H + 1;
+    const int H1 = p.H + R;
     const int tilesX = p.W >> 5, VR = p.B * H1;
     const int ty = blockIdx.x / tilesX, tx = blockIdx.x % tilesX;
     const int vr0 = ty * NT, n0 = tx * 32, m0 = blockIdx.y * BM, ks = blockIdx.z;
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
         pos_off[k] = -1; pos_sb[k] = 0;
         if (pos < PSZ) {
             const int pr = pos / PC, pc = pos % PC;
-            const int vi = vr0 - 1 + pr, ix = n0 - 1 + pc;
+            const int vi = vr0 - R + pr, ix = n0 - R + pc;
             if (vi >= 0 && ix >= 0 && ix < p.W) {
                 const int b = vi / H1, m = vi - b * H1;
                 if (b < p.B && m < p.H) { pos_off[k] = ((b * p.Cin) * p.H + m) * p.W + ix; pos_sb[k] = b * p.Cin; }
@@ -601,19 +604,19 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
     const int it_per = (niter + p.ksplit - 1) / p.ksplit;
     const int it0 = ks * it_per, it1 = min(niter, it0 + it_per);
 
-    constexpr int NA = (9 * BM + 255) / 256;
+    constexpr int NA = (T * BM + 255) / 256;
     float4 a_reg[NA], x_reg[NPOS], s_reg[NPOS];
     int a_goff[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
         const int e = tid + i * 256;
         a_goff[i] = -1;
-        if (e < 9 * BM) {
+        if (e < T * BM) {
             const int t = e / BM, col = e % BM;
             if (m0 + col < p.CoutP) a_goff[i] = (t * p.CoutP + m0 + col) * 4;
         }
     }
-    const int a_gstride = 9 * p.CoutP * 4;
+    const int a_gstride = T * p.CoutP * 4;
 
     auto load_stage = [&](int it) {
         const float* wp_it = p.wp + (int64_t)it * a_gstride;
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
     auto store_stage = [&](float* As, float* Xs) {
 #pragma unroll
         for (int i = 0; i < NA; i++)
-            if (tid + i * 256 < 9 * BM) *(float4*)(As + (tid + i * 256) * 4) = a_reg[i];
+            if (tid + i * 256 < T * BM) *(float4*)(As + (tid + i * 256) * 4) = a_reg[i];
 #pragma unroll
         for (int k = 0; k < NPOS; k++)
             if (tid + k * 256 < PSZ)        // modulation rides on the staging
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
     }
     __syncthreads();
     const int a_lane = ((wm * MTW) * 32 + l32) * 4 + 2 * half;                   // + (t*BM + m*32)*4
-    const int b_lane = (((wn * NTW) + 1) * PC + l32 + 1) * 4 + 2 * half;        // centre tap of subtile 0; + (n*PC + dy*PC + dx)*4
+    const int b_lane = (((wn * NTW) + R) * PC + l32 + R) * 4 + 2 * half;        // centre tap of subtile 0; + (n*PC + dy*PC + dx)*4
     int cur = 0;
     for (int it = it0; it < it1; it++) {
         const bool more = it + 1 < it1;
@@ -666,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
         const float* Xs = smem + cur * BUF_SZ + AS_SZ + b_lane;
         f32x2 fa[2][MTW], fb[2][NTW];
         auto load_frag = [&](int buf, int t) {
-            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            const int dy = t / KS - R, dx = t % KS - R;
 #pragma unroll
             for (int m = 0; m < MTW; m++) fa[buf][m] = *(const f32x2*)(As + (t * BM + m * 32) * 4);
 #pragma unroll
@@ -674,9 +677,9 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
         };
         load_frag(0, 0);
 #pragma unroll
-        for (int t = 0; t < 9; t++) {
+        for (int t = 0; t < T; t++) {
             const int cb = t & 1;
-            if (t + 1 < 9) load_frag(cb ^ 1, t + 1);
+            if (t + 1 < T) load_frag(cb ^ 1, t + 1);
             __builtin_amdgcn_sched_barrier(0);          // keep the prefetch ds_reads above this tap's MFMAs
 #pragma unroll
             for (int kk = 0; kk < 2; kk++)
@@ -1286,8 +1289,9 @@ inline int pick_ksplit(int blocks, int niter) {
 template <int MTW, int NTW, int WM, int WN, int KCS, int MAXT>
 int launch_conv(ConvParams& p, float* partial, int64_t partial_floats, hipStream_t s) {
     constexpr int BM = 32 * MTW * WM, NT = NTW * WN, BN = 32 * NT;
-    constexpr int XS_MAX = (BN / 4 + 2) * (4 + 2) > (BN / 32 + 2) * (32 + 2) ? (BN / 4 + 2) * (4 + 2) : (BN / 32 + 2) * (32 + 2);
-    const size_t lds = (size_t)(2 * (MAXT * KCS * BM + KCS * XS_MAX + 64) + 16 + 5 * BM) * sizeof(float);
+    constexpr int HALO = MAXT == 25 ? 2 : 1;
+    constexpr int XS_MAX = (BN / 4 + 2 * HALO) * (4 + 2 * HALO) > (BN / 32 + 2 * HALO) * (32 + 2 * HALO) ? (BN / 4 + 2 * HALO) * (4 + 2 * HALO) : (BN / 32 + 2 * HALO) * (32 + 2 * HALO);
+    const size_t lds = (size_t)(2 * (MAXT * KCS * BM + KCS * XS_MAX + 64) + 32 + 5 * BM) * sizeof(float);
     static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<MTW, NTW, WM, WN, KCS, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1373,27 +1377,27 @@ void launch_torgb(const RgbParams& r, hipStream_t s) {
     TDGP_LAUNCH("torgb_mfma_kernel", (torgb_mfma_kernel<MT>), dim3((unsigned)cdiv64(r.P, 128)), dim3(256), lds, s, r);
 }
 
-// 3x3 stride-1 fast path (W % 32 == 0)
-template <int MTW, int NTW, int WM, int WN>
+// KS x KS stride-1 fast path (W % 32 == 0)
+template <int KS, int MTW, int NTW, int WM, int WN>
 int launch_conv3(Conv3Params& p, float* partial, int64_t partial_floats, hipStream_t s) {
-    constexpr int BM = 32 * MTW * WM, NT = NTW * WN;
-    constexpr int stage = 2 * (9 * BM * 4 + (NT + 2) * 34 * 4) + 5 * BM, epi = 4 * 32 * CT_LD;
+    constexpr int BM = 32 * MTW * WM, NT = NTW * WN, R = KS / 2;
+    constexpr int stage = 2 * (KS * KS * BM * 4 + (NT + 2 * R) * (32 + 2 * R) * 4) + 5 * BM, epi = 4 * 32 * CT_LD;
     const size_t lds = (size_t)(stage > epi ? stage : epi) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<MTW, NTW, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<KS, MTW, NTW, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int gx = (p.W >> 5) * cdiv(p.B * (p.H + 1), NT), gy = cdiv(p.Cout, BM);
+    const int gx = (p.W >> 5) * cdiv(p.B * (p.H + R), NT), gy = cdiv(p.Cout, BM);
     const int niter = cdiv(p.Cin, 4);
     const int64_t slice = (int64_t)p.B * p.Cout * p.H * p.W;
     const int max_ks = (int)min((int64_t)32, partial_floats / slice);
-    int ks = gx * gy < 256 ? pick_ksplit(gx * gy, niter) : tail_ksplit(gx * gy, niter, 2.0 * p.Cin * p.Cout * 9.0 * p.H * p.W * p.B, 2 * slice, max_ks);
+    int ks = gx * gy < 256 ? pick_ksplit(gx * gy, niter) : tail_ksplit(gx * gy, niter, 2.0 * p.Cin * p.Cout * KS * KS * p.H * p.W * p.B, 2 * slice, max_ks);
     if (ks > max_ks) ks = max_ks;
     if (ks < 1) ks = 1;
     p.ksplit = ks;
     p.partial = partial;
-    TDGP_LAUNCH("conv_mfma_kernel", (conv3_mfma_kernel<MTW, NTW, WM, WN>), dim3(gx, gy, ks), dim3(256), lds, s, p);
+    TDGP_LAUNCH("conv_mfma_kernel", (conv3_mfma_kernel<KS, MTW, NTW, WM, WN>), dim3(gx, gy, ks), dim3(256), lds, s, p);
     if (ks > 1)
         TDGP_LAUNCH("splitk_reduce_kernel", splitk_reduce_kernel, dim3((int)min((int64_t)2048, cdiv64(slice, 256))), dim3(256), 0, s, partial, ks, p.e);
     return 0;
@@ -1434,7 +1438,7 @@ WsLayout ws_layout(int B, int Cin, int Cout, int H, int W, int k, int up) {
 }  // namespace
 
 TDGP_API int64_t tdgp_modconv_pack_bytes(int Cout, int Cin, int k) {
-    if (Cout < 1 || Cin < 1 || (k != 1 && k != 3)) return -1;
+    if (Cout < 1 || Cin < 1 || (k != 1 && k != 3 && k != 5)) return -1;
     const PackInfo pi = pack_info(Cout, Cin, k);
     return (pi.wp_floats + pi.wsq_floats) * (int64_t)sizeof(float);
 }
@@ -1442,7 +1446,7 @@ TDGP_API int64_t tdgp_modconv_pack_bytes(int Cout, int Cin, int k) {
 TDGP_API int tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int Cin, int k, tdgp_stream_t stream) {
     TDGP_CHECK(weight && wpack, TDGP_EINVAL, "modconv_pack: null pointer");
     TDGP_CHECK(Cout >= 1 && Cin >= 1, TDGP_EINVAL, "modconv_pack: bad channel counts");
-    TDGP_CHECK(k == 1 || k == 3, TDGP_EUNSUPPORTED, "modconv_pack: kernel size %d not on the generator path (1 or 3)", k);
+    TDGP_CHECK(k == 1 || k == 3 || k == 5, TDGP_EUNSUPPORTED, "modconv_pack: kernel size %d not on the generator path (1, 3 or 5)", k);
     const PackInfo pi = pack_info(Cout, Cin, k);
     float* wp = (float*)wpack;
     TDGP_LAUNCH("pack_kernel", pack_kernel, dim3((int)min((int64_t)4096, cdiv64(pi.wp_floats, 256))), dim3(256), 0, (hipStream_t)stream, weight, wp,
@@ -1462,7 +1466,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                             void* workspace, int64_t workspace_bytes, tdgp_stream_t stream) {
     TDGP_CHECK(x && wpack && y, TDGP_EINVAL, "modconv2d: null pointer");
     TDGP_CHECK(B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, TDGP_EINVAL, "modconv2d: bad shape");
-    TDGP_CHECK(k == 1 || k == 3, TDGP_EUNSUPPORTED, "modconv2d: kernel size %d not supported (1 or 3)", k);
+    TDGP_CHECK(k == 1 || k == 3 || k == 5, TDGP_EUNSUPPORTED, "modconv2d: kernel size %d not supported (1, 3 or 5)", k);
     TDGP_CHECK(up == 1 || (up == 2 && k == 3), TDGP_EUNSUPPORTED, "modconv2d: up=%d with k=%d not supported", up, k);
     TDGP_CHECK(up == 1 || fir4x4, TDGP_EINVAL, "modconv2d: up=2 needs the 4x4 resample filter");
     TDGP_CHECK(!skip || (up == 1 && k == 1 && fir4x4 && (H % 2) == 0 && (W % 2) == 0), TDGP_EINVAL, "modconv2d: skip needs k=1, up=1, even H/W and the filter");
@@ -1501,23 +1505,31 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         e.act = act; e.alpha = alpha; e.gain = gain; e.clamp = clamp;
         p.nphases = 1;
         Phase& ph = p.ph[0];
-        ph.ntaps = k * k;
+        ph.ntaps = k * k; ph.halo = k / 2;
         for (int t = 0; t < k * k; t++) {
             ph.tap_w[t] = t;
-            ph.tap_off_y[t] = (k == 3) ? t / 3 - 1 : 0;      // correlation, padding k/2 (conv2d_resample.py:132-134)
-            ph.tap_off_x[t] = (k == 3) ? t % 3 - 1 : 0;
+            ph.tap_off_y[t] = t / k - k / 2;                 // correlation, padding k/2 (conv2d_resample.py:132-134)
+            ph.tap_off_x[t] = t % k - k / 2;
         }
         ph.gridH = H; ph.gridW = W; ph.oy_mul = 1; ph.oy_add = 0; ph.ox_mul = 1; ph.ox_add = 0;
         p.tw_log2 = pick_tw_log2(W);
-        if (k == 3 && (W & 31) == 0) {
+        if (k >= 3 && (W & 31) == 0) {
             Conv3Params c;
             c.x = x; c.wp = wp; c.styles = styles; c.partial = nullptr; c.e = e;
             c.B = B; c.Cin = Cin; c.Cout = Cout; c.CoutP = pi.CoutP; c.H = H; c.W = W; c.ksplit = 1;
-            if (Cout > 64) launch_conv3<2, 2, 2, 2>(c, partial, wl.partial_floats, s);
-            else launch_conv3<2, 2, 1, 4>(c, partial, wl.partial_floats, s);
+            if (k == 3) {
+                if (Cout > 64) launch_conv3<3, 2, 2, 2, 2>(c, partial, wl.partial_floats, s);
+                else launch_conv3<3, 2, 2, 1, 4>(c, partial, wl.partial_floats, s);
+            } else {
+                if (Cout > 64) launch_conv3<5, 2, 2, 2, 2>(c, partial, wl.partial_floats, s);
+                else launch_conv3<5, 2, 2, 1, 4>(c, partial, wl.partial_floats, s);
+            }
         } else if (k == 3) {
             if (Cout > 64) launch_conv<2, 2, 2, 2, 4, 9>(p, partial, wl.partial_floats, s);
             else launch_conv<2, 2, 1, 4, 4, 9>(p, partial, wl.partial_floats, s);
+        } else if (k == 5) {
+            if (Cout > 64) launch_conv<2, 2, 2, 2, 4, 25>(p, partial, wl.partial_floats, s);
+            else launch_conv<2, 2, 1, 4, 4, 25>(p, partial, wl.partial_floats, s);
         } else if (out_layout == 1 && Cout <= 96 && !demodulate && !noise && ((H * W) & 3) == 0) {
             RgbParams r;
             r.x = x; r.wp = wp; r.styles = styles; r.e = e;

@@ -280,7 +280,7 @@ class SynthesisBlocksSequence(torch.nn.Module):
 
 
 class SynthesisNetwork(torch.nn.Module):
-    """networks_epigraf.py:134-261 (eval; adaptors disabled)."""
+    """networks_epigraf.py:134-261 (eval).  The depth / camera adaptors exist when the configuration carries them."""
 
     def __init__(self, cfg: GeneratorConfig, img_resolution, img_channels=3):
         super().__init__()
@@ -291,6 +291,9 @@ class SynthesisNetwork(torch.nn.Module):
         self.num_ws = self.tri_plane_decoder.num_ws
         self.test_resolution = img_resolution
         self.renderer = _renderer.ImportanceRenderer(ray_marcher_type=cfg.ray_marcher_type)
+        from . import adaptors as _adaptors          # (adaptors imports this module)
+        self.depth_adaptor = _adaptors.DepthAdaptor(cfg.depth_adaptor, min_depth=cfg.ray_start, max_depth=cfg.ray_end) if cfg.depth_adaptor is not None else None
+        self.camera_adaptor = _adaptors.CameraAdaptor(cfg.camera_adaptor, cfg.z_dim, cfg.c_dim) if cfg.camera_adaptor is not None else None
         self._default_render_options = dict(max_batch_res=cfg.max_batch_res, return_depth=False, return_depth_adapted=False, return_weights=False,
                                             concat_depth=False, cut_quantile=0.0, density_bias=cfg.density_bias)
 
@@ -315,8 +318,8 @@ class SynthesisNetwork(torch.nn.Module):
         if self.training:
             raise NotImplementedError('the HIP path implements the eval-mode forward (training is SURVEY.md 8f rank 4)')
         render_opts = {**self._default_render_options, **render_opts}
-        if render_opts['return_depth_adapted'] or render_opts['concat_depth']:
-            raise NotImplementedError('depth adaptor outputs need the DepthAdaptor (SURVEY.md 8f rank 1)')
+        if (render_opts['return_depth_adapted'] or render_opts['concat_depth']) and self.depth_adaptor is None:
+            raise RuntimeError('return_depth_adapted / concat_depth need cfg.depth_adaptor')
         B = ws.shape[0]
         planes = self.tri_plane_decoder(ws[:, :self.tri_plane_decoder.num_ws], hwc=True, **block_kwargs)
         h = w = self.test_resolution
@@ -331,8 +334,21 @@ class SynthesisNetwork(torch.nn.Module):
         img = torch.empty([B, self.img_channels, h, w], dtype=torch.float32, device=ws.device)
         with torch.cuda.device(ws.device):
             _lib.call('tdgp_rays_to_image', rgb.data_ptr(), img.data_ptr(), B, h * w, _lib.stream_of(rgb))
-        if render_opts['return_depth']:
-            return TensorGroup(img=img, depth=depth.reshape(B, 1, h, w))
+        depth = depth.reshape(B, 1, h, w)
+        depth_adapted = None
+        if self.depth_adaptor is not None:                                  # networks_epigraf.py:246-253
+            depth_adapted = self.depth_adaptor(depth, ws[:, 0])
+            if render_opts['concat_depth']:
+                img = torch.cat([img, depth_adapted], dim=1)
+            else:
+                img = img + 0.0 * depth_adapted.max()
+        if render_opts['return_depth'] or render_opts['return_depth_adapted']:
+            out = TensorGroup(img=img)
+            if render_opts['return_depth']:
+                out.depth = depth
+            if render_opts['return_depth_adapted']:
+                out.depth_adapted = depth_adapted
+            return out
         return img
 
 

@@ -55,8 +55,8 @@ class PackedConv:
     def __init__(self, weight):
         _lib.require_cuda(weight, 'weight')
         cout, cin, kh, kw = weight.shape
-        if kh != kw or kh not in (1, 3):
-            raise NotImplementedError(f'modulated_conv2d: {kh}x{kw} kernels are not on the generator path (1x1 / 3x3)')
+        if kh != kw or kh not in (1, 3, 5):
+            raise NotImplementedError(f'modulated_conv2d: {kh}x{kw} kernels are not on the generator path (1x1 / 3x3 / 5x5)')
         self.cout, self.cin, self.k = int(cout), int(cin), int(kh)
         nbytes = _lib.load().tdgp_modconv_pack_bytes(self.cout, self.cin, self.k)
         self.buf = torch.empty(nbytes // 4, dtype=torch.float32, device=weight.device)

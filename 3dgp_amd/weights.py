@@ -61,6 +61,39 @@ def state_dict_spec(cfg: GeneratorConfig):
     for i in range(cfg.map_depth):
         spec[f'mapping.fc{i}.weight'] = (feats[i + 1], feats[i])
         spec[f'mapping.fc{i}.bias'] = (feats[i + 1],)
+    da = cfg.depth_adaptor
+    if da is not None:                     # networks_depth_adaptor.py:28-40
+        pfx = 'synthesis.depth_adaptor'
+        dims = [1] + [da.hid_dim] * da.num_hid_layers
+        for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+            spec[f'{pfx}.layers.{i}.weight'] = (cout, cin, da.kernel_size, da.kernel_size)
+            spec[f'{pfx}.layers.{i}.bias'] = (cout,)
+            spec[f'{pfx}.layers.{i}.resample_filter'] = (4, 4)
+        if da.num_hid_layers > 0:
+            spec[f'{pfx}.head.weight'] = (1, dims[-1], 1, 1)
+            spec[f'{pfx}.head.bias'] = (1,)
+            spec[f'{pfx}.head.resample_filter'] = (4, 4)
+        spec[f'{pfx}.progress_coef'] = (1,)
+        spec[f'{pfx}.near_plane_offset_raw'] = (1,)
+    ca = cfg.camera_adaptor
+    if ca is not None:                     # networks_camera_adaptor.py:24-64
+        for name, nin, use_z in (('origin_adaptor', 4, False), ('look_at_adaptor', 8, True)):
+            pfx = f'synthesis.camera_adaptor.{name}'
+            spec[f'{pfx}.project_params.weight'] = (ca.hid_dim, nin)
+            spec[f'{pfx}.project_params.bias'] = (ca.hid_dim,)
+            main_in = ca.hid_dim
+            if use_z:
+                spec[f'{pfx}.project_z.weight'] = (ca.embed_dim, cfg.z_dim)
+                spec[f'{pfx}.project_z.bias'] = (ca.embed_dim,)
+                main_in += ca.embed_dim
+            if cfg.c_dim > 0:
+                spec[f'{pfx}.project_c.weight'] = (ca.embed_dim, cfg.c_dim)
+                spec[f'{pfx}.project_c.bias'] = (ca.embed_dim,)
+                main_in += ca.embed_dim
+            spec[f'{pfx}.main.0.weight'] = (ca.hid_dim, main_in)
+            spec[f'{pfx}.main.0.bias'] = (ca.hid_dim,)
+            spec[f'{pfx}.main.1.weight'] = (4, ca.hid_dim)
+            spec[f'{pfx}.main.1.bias'] = (4,)
     return spec
 
 
@@ -82,6 +115,14 @@ def random_state_dict(cfg: GeneratorConfig, seed=0, exercise_all=False):
         leaf = name.rsplit('.', 1)[-1]
         if leaf == 'resample_filter':
             v = resample_filter()
+        elif leaf == 'progress_coef':
+            v = np.zeros(shape)
+        elif leaf == 'near_plane_offset_raw':
+            v = np.full(shape, cfg.depth_adaptor.near_plane_offset_bias + (0.5 * g.randn() if exercise_all else 0.0))
+        elif name.startswith('synthesis.camera_adaptor') and leaf == 'weight':
+            v = g.randn(*shape) / cfg.camera_adaptor.lr_multiplier      # weight_init / lr_multiplier, layers.py:36
+        elif name.startswith('synthesis.camera_adaptor') and leaf == 'bias':
+            v = (0.1 * g.randn(*shape) / cfg.camera_adaptor.lr_multiplier) if exercise_all else np.zeros(shape)
         elif name.startswith('mapping.fc') and leaf == 'weight':
             v = g.randn(*shape) / 0.01                       # weight_init / lr_multiplier, layers.py:36
         elif leaf in ('weight', 'const', 'noise_const'):

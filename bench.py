@@ -48,9 +48,18 @@ def algorithmic_flops(cfg):
         conv += 2 * c * c * 9 * r * r                              # conv1
         rgb += 2 * c * cfg.plane_channels * r * r                  # ToRGB 1x1
         launches += 1
+    da = cfg.depth_adaptor
+    if da is not None:                                             # --depth-adaptor: 5x5 Conv2dLayers + the 1x1 head of the last layer
+        dims = [1] + [da.hid_dim] * da.num_hid_layers
+        for cin, cout in zip(dims[:-1], dims[1:]):
+            conv += 2 * cin * cout * da.kernel_size ** 2 * cfg.img_resolution ** 2
+        conv += 2 * dims[-1] * cfg.img_resolution ** 2
+        launches_da = da.num_hid_layers + 1
+    else:
+        launches_da = 0
     pts = 2 * cfg.img_resolution ** 2 * cfg.num_ray_steps          # coarse + fine
     field = pts * (2 * (cfg.feat_dim * cfg.mlp_hid + 4 * cfg.mlp_hid) + 3 * 4 * 2 * cfg.feat_dim)   # MLP 4608 + bilerp 768 @ (32,64)
-    return dict(conv_mfma_kernel=(conv, launches), upconv_mfma_kernel=(up, up_launches), torgb_mfma_kernel=(rgb, launches),
+    return dict(conv_mfma_kernel=(conv, launches + launches_da), upconv_mfma_kernel=(up, up_launches), torgb_mfma_kernel=(rgb, launches),
                 triplane_field_kernel=(field, 2))
 
 
@@ -66,7 +75,9 @@ def cpu_baseline(tdgp, cfg, n_img=8, budget_s=25.0):
     while done < n_img and (done == 0 or t_total * (done + 1) / done < budget_s):
         inp = tdgp.weights.synthetic_inputs(cfg, batch=1, seed=done)
         t0 = time.time()
-        img, _ = O.generator_forward(sd, cfg.to_dict(), inp['z'], inp['c'], inp['camera'], inp['u_coarse'], inp['u_fine'])
+        img, depth = O.generator_forward(sd, cfg.to_dict(), inp['z'], inp['c'], inp['camera'], inp['u_coarse'], inp['u_fine'])
+        if cfg.depth_adaptor is not None:
+            O.depth_adaptor_forward(sd, cfg.to_dict(), depth, inp['z'])
         t_total += time.time() - t0
         assert np.isfinite(img).all()
         done += 1
@@ -83,6 +94,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
     ap.add_argument('--config', default='c3', choices=['c1', 'c2', 'c3', 'c4'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--depth-adaptor', action='store_true', help='also run the DepthAdaptor inside G.forward (SURVEY 8f rank 1; off = the 8a hot path)')
     ap.add_argument('--profile-steps', type=int, default=2)
     args = ap.parse_args()
 
@@ -96,6 +108,8 @@ def main():
     tdgp._lib.load()                       # the HIP library must be there: no fallback
 
     cfg = getattr(tdgp.config, f'config_{args.config}')()
+    if args.depth_adaptor:
+        cfg.depth_adaptor = tdgp.config.DepthAdaptorConfig()
     G = tdgp.generator.Generator(cfg)
     G.load_numpy_state_dict(tdgp.weights.random_state_dict(cfg, seed=0))        # random-init weights, identical on every rank
     G = G.to(dev)
@@ -152,7 +166,7 @@ def main():
     tpath = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
-        if tj.get('config') == args.config and tj.get('batch_per_gpu') == args.batch and dominant in tj.get('kernels', {}):
+        if tj.get('config') == args.config and tj.get('batch_per_gpu') == args.batch and not args.depth_adaptor and dominant in tj.get('kernels', {}):
             traffic = tj['kernels'][dominant]['hbm_bytes_per_launch']
     roofline = None
     if dominant in flops:
@@ -174,7 +188,7 @@ def main():
             'config': {'workload': f'BASELINE configs[2]: ImageNet 256x256, {cfg.num_ray_steps}(+{cfg.num_ray_steps}) ray steps, cmax {cfg.cmax}, '
                                    f'c_dim {cfg.c_dim}, tri-plane {cfg.tri_plane_res}^2 x {cfg.plane_channels}, full HIP path' if args.config == 'c3'
                        else args.config, 'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'img_resolution': cfg.img_resolution,
-                       'num_ray_steps': cfg.num_ray_steps, 'parallelism': f'dp{world} (batch-sharded, weights replicated)'},
+                       'num_ray_steps': cfg.num_ray_steps, 'depth_adaptor': bool(args.depth_adaptor), 'parallelism': f'dp{world} (batch-sharded, weights replicated)'},
             'roofline': roofline, 'kernels': kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

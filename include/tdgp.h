@@ -78,7 +78,7 @@ int tdgp_upfirdn2d(const void* x, const float* f, void* y, int N, int C, int inH
  *
  * Weights are static across calls, so they are packed once:
  *   tdgp_modconv_pack_bytes  -> bytes of the packed buffer for (Cout,Cin,k)
- *   tdgp_modconv_pack        -> wpack (MFMA-friendly k-major layout + sum_k w^2 per (o,c))
+ *   tdgp_modconv_pack        -> wpack ([Cin/4][k*k][Cout][4 channels], zero padded, + sum_taps w^2 per (c,o))
  * Forward:
  *   y[b,o] = act( d[b,o] * conv(x[b]*s[b,:], W)[o] + noise + bias[o] ) * gain  (+ skip term)
  *   d[b,o] = rsqrt(sum_c s[b,c]^2 * wsq[o,c] + 1e-8) if demodulate else 1
@@ -92,6 +92,8 @@ int tdgp_upfirdn2d(const void* x, const float* f, void* y, int N, int C, int inH
  * out_layout: 0 = NCHW, 1 = plane-major channel-last [B, Cout/feat, H, W, feat] (the renderer's layout;
  *       `feat` = out_feat).
  * workspace: tdgp_modconv2d_workspace_bytes(...) bytes (0 allowed when it returns 0).
+ * k in {1, 3, 5} with padding k/2; up=2 needs k=3.  styles = NULL: plain convolution -- this is how the 5x5
+ *       `Conv2dLayer`s of the depth adaptor run (src/training/layers.py:221-236: conv2d_resample + bias_act).
  * --------------------------------------------------------------------------------------------- */
 int64_t tdgp_modconv_pack_bytes(int Cout, int Cin, int k);
 int     tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int Cin, int k, tdgp_stream_t stream);

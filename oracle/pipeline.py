@@ -181,3 +181,100 @@ def generator_forward(sd, cfg, z, c, camera, u_coarse, u_fine, noise_mode='const
     """Generator.forward, networks_epigraf.py:288-291."""
     ws = mapping_forward(sd, cfg, z, c, truncation_psi)
     return synthesis_forward(sd, cfg, ws, camera, u_coarse, u_fine, noise_mode)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SURVEY.md 8f rank 1: depth / camera adaptors (forward, eval)
+# ---------------------------------------------------------------------------------------------------------------------
+def conv2d_layer(x, weight, bias, act='linear'):
+    """Conv2dLayer.forward with up = down = 1 (layers.py:221-236): correlation with padding k // 2, bias_act with the
+    activation's default gain.  The plain convolution is the modulated-conv restatement with unit styles, no demodulation."""
+    weight = np.asarray(weight, dtype=np.float32)
+    cout, cin, k, _ = weight.shape
+    w = (weight * np.float32(1 / np.sqrt(cin * k * k))).astype(np.float32)
+    y = O.modulated_conv2d(x, w, np.ones((x.shape[0], cin), dtype=np.float32), up=1, demodulate=False)
+    return O.bias_act(y, bias, act=act)
+
+
+def _sigmoid32(x):
+    x = np.asarray(x, dtype=np.float32)
+    with np.errstate(over='ignore'):
+        return (np.float32(1.0) / (np.float32(1.0) + np.exp(-x, dtype=np.float32))).astype(np.float32)
+
+
+def depth_adaptor_forward(sd, cfg, depth, w, return_all=False):
+    """DepthAdaptor.forward in eval mode (networks_depth_adaptor.py:49-99).  depth [B,1,h,w], w [B,w_dim] (only its batch
+    size is used, :44).  Returns the adapted depth [B,1,h,w] (and the stacked per-layer heads [B,n,1,h,w])."""
+    da, pfx = cfg['depth_adaptor'], 'synthesis.depth_adaptor'
+    f32 = np.float32
+    B = depth.shape[0]
+    raw = np.repeat(np.asarray(sd[pfx + '.near_plane_offset_raw'], dtype=f32), B)
+    off = (_sigmoid32(raw) * f32(da['near_plane_offset_max_fraction'])) * f32(cfg['ray_end'] - cfg['ray_start'])     # :46
+    near = (f32(cfg['ray_start']) + off).reshape(B, 1, 1, 1)
+    mid = f32(0.5) * (f32(cfg['ray_end']) + near)
+    rng = f32(cfg['ray_end']) - near
+    x = ((np.asarray(depth, dtype=f32) - mid) / (rng + f32(1e-12)) * f32(2.0)).astype(f32)
+    outs = [x]
+    for i in range(da['num_hid_layers']):
+        x = conv2d_layer(x, sd[f'{pfx}.layers.{i}.weight'], sd[f'{pfx}.layers.{i}.bias'], 'lrelu')
+        outs.append(conv2d_layer(x, sd[pfx + '.head.weight'], sd[pfx + '.head.bias'], 'linear'))
+    stack = np.stack(outs, axis=1)
+    if da['out_strategy'] in ('last', 'random'):
+        res = stack[:, -1] + f32(0.0) * stack.max()
+    elif da['out_strategy'] == 'mean':
+        res = stack.mean(axis=1, dtype=f32)
+    else:
+        raise NotImplementedError(da['out_strategy'])
+    return (res, stack) if return_all else res
+
+
+def _params_adaptor(sd, pfx, lr, x, z=None, c=None):
+    """ParamsAdaptor.forward (networks_camera_adaptor.py:44-52)."""
+    fc = lambda name, v, act: O.fc(v, sd[f'{pfx}.{name}.weight'], sd[f'{pfx}.{name}.bias'], act=act, lr_multiplier=lr)     # noqa: E731
+    x = fc('project_params', x, 'softplus')
+    if z is not None and f'{pfx}.project_z.weight' in sd:
+        x = np.concatenate([x, O.normalize_2nd_moment(fc('project_z', z, 'softplus'))], axis=1)
+    if c is not None and f'{pfx}.project_c.weight' in sd:
+        x = np.concatenate([x, O.normalize_2nd_moment(fc('project_c', c, 'softplus'))], axis=1)
+    return fc('main.1', fc('main.0', x, 'softplus'), 'linear')
+
+
+def camera_adaptor_forward(sd, cfg, camera, z, c=None):
+    """CameraAdaptor.forward (networks_camera_adaptor.py:74-134): prior camera parameters -> posterior."""
+    ca, pfx = cfg['camera_adaptor'], 'synthesis.camera_adaptor'
+    cam, f32, eps = ca['camera'], np.float32, np.float32(1e-8)
+    col = lambda a: np.asarray(a, dtype=f32).reshape(len(a), -1)        # noqa: E731
+    yaw, pitch, roll = (col(camera['angles'])[:, [i]] for i in range(3))
+    fov, radius = col(camera['fov']), col(camera['radius'])
+    la_yaw, la_pitch, la_radius = (col(camera['look_at'])[:, [i]] for i in range(3))
+    nrm = lambda v, r: (v - f32(r[0])) / (f32(r[1] - r[0]) + eps)       # noqa: E731
+    n_yaw, n_pitch, n_fov = nrm(yaw, cam['yaw']), nrm(pitch, cam['pitch']), nrm(fov, cam['fov'])
+    n_la = [nrm(la_yaw, cam['look_at_yaw']), nrm(la_pitch, cam['look_at_pitch']), nrm(la_radius, cam['look_at_radius'])]
+    lr = ca['lr_multiplier']
+    origin_new = _params_adaptor(sd, pfx + '.origin_adaptor', lr, np.concatenate([n_yaw, n_pitch, roll, radius], axis=1), c=c)
+    la_in = np.concatenate([origin_new[:, :3], n_fov, origin_new[:, [3]]] + n_la, axis=1)
+    la_new = _params_adaptor(sd, pfx + '.look_at_adaptor', lr, la_in, z=z, c=c)
+    new = [origin_new[:, [0]], origin_new[:, [1]], origin_new[:, [2]], la_new[:, [0]], origin_new[:, [3]], la_new[:, [1]], la_new[:, [2]], la_new[:, [3]]]
+    if ca['residual']:
+        old = [n_yaw, n_pitch, roll, n_fov, radius] + n_la
+        new = [o + n for o, n in zip(old, new)]
+    rng = lambda r: f32(r[1] - r[0])                                     # noqa: E731
+    d_yaw = _sigmoid32(new[0]) * rng(cam['yaw']) + f32(cam['yaw'][0])
+    d_pitch = _sigmoid32(new[1]) * f32(cam['pitch'][1] - cam['pitch'][0] - 2e-5) + f32(cam['pitch'][0]) + f32(1e-5)
+    d_roll = new[2] * f32(0.0)
+    d_fov = _sigmoid32(new[3]) * rng(cam['fov']) + f32(cam['fov'][0])
+    d_radius = new[4]
+    d_la_yaw = _sigmoid32(new[5]) * rng(cam['look_at_yaw']) + f32(cam['look_at_yaw'][0])
+    d_la_pitch = _sigmoid32(new[6]) * rng(cam['look_at_pitch']) + f32(cam['look_at_pitch'][0])
+    d_la_radius = _sigmoid32(new[7]) * f32(cam['look_at_radius'][1] - cam['look_at_pitch'][0]) + f32(cam['look_at_pitch'][0])   # sic (:95)
+    out = dict(angles=np.concatenate([d_yaw, d_pitch, d_roll], axis=1), fov=d_fov[:, 0], radius=d_radius[:, 0],
+               look_at=np.concatenate([d_la_yaw, d_la_pitch, d_la_radius], axis=1))
+    if not ca['adjust_angles']:
+        out['angles'] = col(camera['angles']) + f32(0.0) * out['angles']
+    if not ca['adjust_radius']:
+        out['radius'] = col(camera['radius'])[:, 0] + f32(0.0) * out['radius']
+    if not ca['adjust_fov']:
+        out['fov'] = col(camera['fov'])[:, 0] + f32(0.0) * out['fov']
+    if not ca['adjust_look_at']:
+        out['look_at'] = col(camera['look_at']) + f32(0.0) * out['look_at']
+    return {k: v.astype(f32) for k, v in out.items()}

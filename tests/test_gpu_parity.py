@@ -543,3 +543,34 @@ def test_compat_plugins(tdgp, oracle):
     assert_close(N(y), oracle.upsample2d(x, f), 2e-6, 'upsample2d via plugin', 1.0)
     with pytest.raises(RuntimeError):
         tdgp.compat.BiasActPlugin.bias_act(T(x), T(b), empty, empty, empty, 1, 1, 3, 0.2, 1.0, -1.0)     # grad != 0: not on this path
+
+
+# ------------------------------------------------------------------------------------------------ adaptors
+@pytest.mark.parametrize('idx', [0, 1])
+def test_adaptors(tdgp, oracle, idx):
+    """DepthAdaptor (5x5 convolutions on the MFMA kernels: generic path at 16^2, mask-free fast path at 32^2) and CameraAdaptor
+    against the reference goldens; then the depth adaptor inside SynthesisNetwork.forward against the oracle on the HIP depth."""
+    from oracle import pipeline as P
+    g = load_golden('adaptors')
+    tag, cfg = tdgp.config.configs_adaptor_goldens()[idx]
+    G = _gen(tdgp, cfg, 51)
+    da, ca = G.synthesis.depth_adaptor, G.synthesis.camera_adaptor
+    outs = da(T(g[f'{tag}_depth']), T(g[f'{tag}_w']), all_outs=True)
+    assert_close(N(outs), g[f'{tag}_outs'], 5e-6, 'per-layer heads', 1.0)
+    assert_close(N(da(T(g[f'{tag}_depth']), T(g[f'{tag}_w']))), g[f'{tag}_depth_adapted'], 5e-6, 'depth_adapted', 1.0)
+    cam = {k: T(g[f'{tag}_cam_{k}']) for k in ('angles', 'fov', 'radius', 'look_at')}
+    new = ca(cam, T(g[f'{tag}_z']), T(g[f'{tag}_c']) if cfg.c_dim > 0 else None)
+    for k in ('angles', 'fov', 'radius', 'look_at'):
+        assert_close(N(new[k]), g[f'{tag}_new_{k}'], 5e-6, k, 1.0)
+    # inside the generator: render_opts as networks_epigraf.py:255-259
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=2, seed=54)
+    out = G(T(inp['z']), T(inp['c']), {k: T(v) for k, v in inp['camera'].items()}, noise_mode='const', u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']),
+            render_opts=dict(return_depth=True, return_depth_adapted=True))
+    sd = tdgp.weights.random_state_dict(cfg, seed=51, exercise_all=True)
+    ws = N(G.mapping(T(inp['z']), T(inp['c'])))
+    ref = P.depth_adaptor_forward(sd, cfg.to_dict(), N(out.depth), ws[:, 0])
+    assert_close(N(out.depth_adapted), ref, 5e-6, 'depth_adapted in G.forward', 1.0)
+    cat = G(T(inp['z']), T(inp['c']), {k: T(v) for k, v in inp['camera'].items()}, noise_mode='const', u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']),
+            render_opts=dict(concat_depth=True))
+    assert cat.shape == (2, 4, cfg.img_resolution, cfg.img_resolution)
+    assert torch.equal(cat[:, :3], out.img) and torch.equal(cat[:, 3:], out.depth_adapted)

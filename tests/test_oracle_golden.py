@@ -187,3 +187,29 @@ def test_e2e_tiny_mip(oracle, tdgp):
     g, img, depth, _ = _e2e(oracle, tdgp, 'e2e_tiny_mip', cfg, 41)
     assert_image_parity(img, g, 'img')
     assert_image_parity(depth, g, 'depth', 'depth')
+
+
+# ------------------------------------------------------------------------------------------------ adaptors
+@pytest.mark.parametrize('idx', [0, 1])
+def test_depth_adaptor(oracle, tdgp, idx):
+    """DepthAdaptor.forward (eval): normalisation, 5x5 Conv2dLayers, 1x1 heads, 'random'(= last) and 'mean' strategies."""
+    from oracle import pipeline as P
+    g = load_golden('adaptors')
+    tag, cfg = tdgp.config.configs_adaptor_goldens()[idx]
+    sd = tdgp.weights.random_state_dict(cfg, seed=51, exercise_all=True)
+    res, stack = P.depth_adaptor_forward(sd, cfg.to_dict(), g[f'{tag}_depth'], g[f'{tag}_w'], return_all=True)
+    assert_close(stack, g[f'{tag}_outs'], 3e-6, 'per-layer heads', 1.0)
+    assert_close(res, g[f'{tag}_depth_adapted'], 3e-6, 'depth_adapted', 1.0)
+
+
+@pytest.mark.parametrize('idx', [0, 1])
+def test_camera_adaptor(oracle, tdgp, idx):
+    """CameraAdaptor.forward: normalise -> origin / look-at ParamsAdaptors -> denormalise -> adjust_for_prior (residual on/off)."""
+    from oracle import pipeline as P
+    g = load_golden('adaptors')
+    tag, cfg = tdgp.config.configs_adaptor_goldens()[idx]
+    sd = tdgp.weights.random_state_dict(cfg, seed=51, exercise_all=True)
+    cam = {k: g[f'{tag}_cam_{k}'] for k in ('angles', 'fov', 'radius', 'look_at')}
+    new = P.camera_adaptor_forward(sd, cfg.to_dict(), cam, g[f'{tag}_z'], g[f'{tag}_c'] if cfg.c_dim > 0 else None)
+    for k in ('angles', 'fov', 'radius', 'look_at'):
+        assert_close(new[k], g[f'{tag}_new_{k}'], 2e-6, k, 1.0)

@@ -411,8 +411,59 @@ def gen_e2e(tag, cfg, batch, seed, keep_intermediates):
     save(tag, **arrays)
 
 
+def ref_camera_cfg(r):
+    mm = lambda t: EasyDict(min=t[0], max=t[1])   # noqa: E731
+    return EasyDict(origin=EasyDict(angles=EasyDict(yaw=mm(r.yaw), pitch=mm(r.pitch))), fov=mm(r.fov),
+                    look_at=EasyDict(angles=EasyDict(yaw=mm(r.look_at_yaw), pitch=mm(r.look_at_pitch)), radius=mm(r.look_at_radius)))
+
+
+def gen_adaptors():
+    """DepthAdaptor / CameraAdaptor forward (networks_depth_adaptor.py, networks_camera_adaptor.py), eval mode."""
+    from src.training.networks_depth_adaptor import DepthAdaptor
+    from src.training.networks_camera_adaptor import CameraAdaptor
+    arrays = {}
+    for tag, cfg in tdgp.config.configs_adaptor_goldens():
+        sd = tdgp.weights.random_state_dict(cfg, seed=51, exercise_all=True)
+        da, ca = cfg.depth_adaptor, cfg.camera_adaptor
+        rda = DepthAdaptor(EasyDict(kernel_size=da.kernel_size, hid_dim=da.hid_dim, num_hid_layers=da.num_hid_layers, out_strategy=da.out_strategy,
+                                    near_plane_offset_max_fraction=da.near_plane_offset_max_fraction, near_plane_offset_bias=da.near_plane_offset_bias,
+                                    selection_start_p=0.1, anneal_kimg=10000), min_depth=cfg.ray_start, max_depth=cfg.ray_end).eval()
+        pfx = 'synthesis.depth_adaptor.'
+        rda.load_state_dict({k[len(pfx):]: T(v) for k, v in sd.items() if k.startswith(pfx)}, strict=True)
+        g = np.random.RandomState(52)
+        B, h = 2, cfg.img_resolution
+        depth = g.uniform(cfg.ray_start, cfg.ray_end, (B, 1, h, h)).astype(np.float32)
+        w = g.randn(B, cfg.w_dim).astype(np.float32)
+        with torch.no_grad():
+            x = rda.normalize(T(depth), T(w))
+            heads = [x]
+            for layer in rda.layers:
+                x = layer(x)
+                heads.append(rda.head(x))
+            out = rda(T(depth), T(w))
+        arrays.update({f'{tag}_depth': depth, f'{tag}_w': w, f'{tag}_outs': npy(torch.stack(heads).transpose(0, 1)), f'{tag}_depth_adapted': npy(out)})
+
+        rca = CameraAdaptor(EasyDict(camera=ref_camera_cfg(ca.camera), residual=ca.residual, lr_multiplier=ca.lr_multiplier, z_dim=cfg.z_dim, c_dim=cfg.c_dim,
+                                     hid_dim=ca.hid_dim, embed_dim=ca.embed_dim,
+                                     adjust=EasyDict(angles=ca.adjust_angles, radius=ca.adjust_radius, fov=ca.adjust_fov, look_at=ca.adjust_look_at))).eval()
+        pfx = 'synthesis.camera_adaptor.'
+        rca.load_state_dict({k[len(pfx):]: T(v) for k, v in sd.items() if k.startswith(pfx)}, strict=True)
+        inp = tdgp.weights.synthetic_inputs(cfg, batch=5, seed=53)
+        cam = TensorGroup(**{k: T(v) for k, v in inp['camera'].items()})
+        with torch.no_grad():
+            new = rca(cam, T(inp['z']), T(inp['c']) if cfg.c_dim > 0 else None)
+        arrays.update({f'{tag}_z': inp['z'], f'{tag}_c': inp['c'], **{f'{tag}_cam_{k}': v for k, v in inp['camera'].items()},
+                       **{f'{tag}_new_{k}': npy(new[k]) for k in ('angles', 'fov', 'radius', 'look_at')}})
+    save('adaptors', **arrays)
+
+
 def main():
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:                      # regenerate selected files only: python tools/gen_goldens.py adaptors
+        for name in sys.argv[1:]:
+            globals()['gen_' + name]()
+        return
+    gen_adaptors()
     gen_bias_act()
     gen_upfirdn2d()
     gen_modconv()
