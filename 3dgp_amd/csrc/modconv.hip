@@ -532,6 +532,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 //   * no masks: padding is materialised as zeros in the staged patch (zero rows between samples / the linearised grid).
 // -------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Staging loads go through buffer instructions: address = descriptor base (SGPRs) + per-lane byte offset (a VGPR that never
+// changes) + per-iteration byte offset (an SGPR, advanced on the scalar unit) -- no vector ALU work per K iteration at all,
+// and an offset at or beyond the descriptor's size returns 0, which is how halo positions, padded out-channel columns and
+// unused slots are masked (offset kOOB) without branches or selects.
+constexpr uint32_t kOOB = 0xFFFFFFF0u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
 
 // ---- KS x KS (3x3 / 5x5), stride 1, W % 32 == 0 -----------------------------------------------------------------------------
 // Pixel tile = NT "virtual rows" x 32 columns, virtual row vi = b*(H+R) + m (R = KS/2) where rows m >= H of every sample are
@@ -541,6 +558,7 @@ struct Conv3Params {
     const float* x; const float* wp; const float* styles; float* partial;
     EpiParams e;
     int B, Cin, Cout, CoutP, H, W, ksplit;
+    uint32_t x_bytes, wp_bytes, st_bytes;       // sizes for the buffer descriptors
 };
 
 template <int KS, int MTW, int NTW, int WM, int WN>
@@ -573,24 +591,26 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
         }
     }
 
-    // ---- patch slots of this thread: position (row, col) of the halo'd patch, 4 channels per K iteration ----------------
+    // ---- patch slots of this thread: position (row, col) of the halo'd patch, 4 channels per K iteration; byte offsets into
+    // x / styles for the buffer loads, kOOB (-> 0) for halo positions outside the image, zero rows and unused slots
     constexpr int NPOS = (PSZ + 255) / 256;
-    int pos_off[NPOS], pos_sb[NPOS];
+    uint32_t pos_xo[NPOS], pos_so[NPOS];
 #pragma unroll
     for (int k = 0; k < NPOS; k++) {
         const int pos = tid + k * 256;
-        pos_off[k] = -1; pos_sb[k] = 0;
+        pos_xo[k] = kOOB; pos_so[k] = kOOB;
         if (pos < PSZ) {
             const int pr = pos / PC, pc = pos % PC;
             const int vi = vr0 - R + pr, ix = n0 - R + pc;
             if (vi >= 0 && ix >= 0 && ix < p.W) {
                 const int b = vi / H1, m = vi - b * H1;
-                if (b < p.B && m < p.H) { pos_off[k] = ((b * p.Cin) * p.H + m) * p.W + ix; pos_sb[k] = b * p.Cin; }
+                if (b < p.B && m < p.H) { pos_xo[k] = (uint32_t)(((b * p.Cin) * p.H + m) * p.W + ix) * 4u; pos_so[k] = (uint32_t)(b * p.Cin) * 4u; }
             }
         }
     }
-    const int chw = p.H * p.W;
+    const uint32_t chw4 = (uint32_t)(p.H * p.W) * 4u;
     const bool cin4 = (p.Cin & 3) == 0;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.wp, p.wp_bytes), rs = make_rsrc(p.styles ? p.styles : p.x, p.styles ? p.st_bytes : 0);
 
     f32x16 acc[MTW][NTW];
 #pragma unroll
@@ -606,42 +626,33 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
 
     constexpr int NA = (T * BM + 255) / 256;
     float4 a_reg[NA], x_reg[NPOS], s_reg[NPOS];
-    int a_goff[NA];
+    uint32_t a_vo[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
         const int e = tid + i * 256;
-        a_goff[i] = -1;
+        a_vo[i] = kOOB;
         if (e < T * BM) {
             const int t = e / BM, col = e % BM;
-            if (m0 + col < p.CoutP) a_goff[i] = (t * p.CoutP + m0 + col) * 4;
+            if (m0 + col < p.CoutP) a_vo[i] = (uint32_t)(t * p.CoutP + m0 + col) * 16u;
         }
     }
-    const int a_gstride = T * p.CoutP * 4;
+    const uint32_t a_gstride4 = (uint32_t)(T * p.CoutP) * 16u;
 
     auto load_stage = [&](int it) {
-        const float* wp_it = p.wp + (int64_t)it * a_gstride;
+        const uint32_t a_so = (uint32_t)it * a_gstride4;
 #pragma unroll
-        for (int i = 0; i < NA; i++) a_reg[i] = a_goff[i] >= 0 ? *(const float4*)(wp_it + a_goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int c0 = it * 4;
-        const float* x_it = p.x + (int64_t)c0 * chw;
+        for (int i = 0; i < NA; i++) a_reg[i] = buf_load4(rw, a_vo[i], a_so);
+        const uint32_t c0 = (uint32_t)it * 4u;
 #pragma unroll
         for (int k = 0; k < NPOS; k++) {
-            const int off = pos_off[k];
-            float xv[4], sv[4];
-#pragma unroll
-            for (int ci = 0; ci < 4; ci++) {
-                const bool ok = off >= 0 && c0 + ci < p.Cin;
-                xv[ci] = ok ? x_it[off + ci * chw] : 0.f;
-                sv[ci] = 1.f;
+            // channels beyond Cin (Cin % 4 != 0 only) read a neighbouring channel or 0; their packed weights are 0
+            x_reg[k] = make_float4(buf_load1(rx, pos_xo[k], c0 * chw4), buf_load1(rx, pos_xo[k], (c0 + 1) * chw4), buf_load1(rx, pos_xo[k], (c0 + 2) * chw4),
+                                   buf_load1(rx, pos_xo[k], (c0 + 3) * chw4));
+            if (p.styles) {
+                if (cin4) s_reg[k] = buf_load4(rs, pos_so[k], c0 * 4u);
+                else s_reg[k] = make_float4(buf_load1(rs, pos_so[k], c0 * 4u), buf_load1(rs, pos_so[k], c0 * 4u + 4u), buf_load1(rs, pos_so[k], c0 * 4u + 8u),
+                                            buf_load1(rs, pos_so[k], c0 * 4u + 12u));
             }
-            if (p.styles && off >= 0) {
-                if (cin4) { const float4 t = *(const float4*)(p.styles + pos_sb[k] + c0); sv[0] = t.x; sv[1] = t.y; sv[2] = t.z; sv[3] = t.w; }
-                else {
-#pragma unroll
-                    for (int ci = 0; ci < 4; ci++) sv[ci] = c0 + ci < p.Cin ? p.styles[pos_sb[k] + c0 + ci] : 1.f;
-                }
-            }
-            x_reg[k] = make_float4(xv[0], xv[1], xv[2], xv[3]); s_reg[k] = make_float4(sv[0], sv[1], sv[2], sv[3]);
         }
     };
     auto store_stage = [&](float* As, float* Xs) {
@@ -650,8 +661,10 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
             if (tid + i * 256 < T * BM) *(float4*)(As + (tid + i * 256) * 4) = a_reg[i];
 #pragma unroll
         for (int k = 0; k < NPOS; k++)
-            if (tid + k * 256 < PSZ)        // modulation rides on the staging
-                *(float4*)(Xs + (tid + k * 256) * 4) = make_float4(x_reg[k].x * s_reg[k].x, x_reg[k].y * s_reg[k].y, x_reg[k].z * s_reg[k].z, x_reg[k].w * s_reg[k].w);
+            if (tid + k * 256 < PSZ) {       // modulation rides on the staging
+                if (p.styles) *(float4*)(Xs + (tid + k * 256) * 4) = make_float4(x_reg[k].x * s_reg[k].x, x_reg[k].y * s_reg[k].y, x_reg[k].z * s_reg[k].z, x_reg[k].w * s_reg[k].w);
+                else *(float4*)(Xs + (tid + k * 256) * 4) = x_reg[k];
+            }
     };
 
     if (it0 < it1) {
@@ -741,8 +754,12 @@ struct UpParams {
     const float* x; const float* wp; const float* styles; float* z;
     int B, Cin, Cout, CoutP, H, W, G1, GS, ksplit;
     int64_t zslice;
+    uint32_t x_bytes, wp_bytes, st_bytes;       // sizes for the buffer descriptors
 };
 
+#ifndef TDGP_UP_ABL
+#define TDGP_UP_ABL 0      // timing experiments (tools/scratch/build_variant.sh): 1 no Z stores, 2 no global staging loads, 4 no LDS fragment reads, 8 no barriers
+#endif
 constexpr int UP_CT_W = 68;     // epilogue LDS tile: 32 channels x 64 floats (+4 pad)
 
 template <int MTW, int NTW, int WM, int WN>
@@ -760,11 +777,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
     // ---- activation patch slots of this thread (fixed across the K loop): run 0 = grid points v-(W+1) (dy = -1), run 1 = dy = 0
     constexpr int NE = 2 * (BN + 1);
     constexpr int NPOS = (NE + NTH - 1) / NTH;
-    int pos_off[NPOS], pos_sb[NPOS], pos_lds[NPOS];
+    uint32_t pos_xo[NPOS], pos_so[NPOS];        // byte offsets into x / styles (kOOB -> the load returns 0)
+    int pos_lds[NPOS];
 #pragma unroll
     for (int k = 0; k < NPOS; k++) {
         const int e = tid + k * NTH;
-        pos_off[k] = -1; pos_sb[k] = 0; pos_lds[k] = -1;
+        pos_xo[k] = kOOB; pos_so[k] = kOOB; pos_lds[k] = -1;
         if (e < NE) {
             const int seg = e / (BN + 1), idx = e % (BN + 1);
             const int g = v0 + idx - 1 - (seg == 0 ? p.G1 : 0);
@@ -773,14 +791,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
                 const int b = g / p.GS, vp = g - b * p.GS;
                 const int m = vp / p.G1, n = vp - m * p.G1;
                 if (b < p.B && m < p.H && n < p.W) {
-                    pos_off[k] = ((b * p.Cin) * p.H + m) * p.W + n;
-                    pos_sb[k] = b * p.Cin;
+                    pos_xo[k] = (uint32_t)(((b * p.Cin) * p.H + m) * p.W + n) * 4u;
+                    pos_so[k] = (uint32_t)(b * p.Cin) * 4u;
                 }
             }
         }
     }
-    const int chw = p.H * p.W;
+    const uint32_t chw4 = (uint32_t)(p.H * p.W) * 4u;
     const bool cin4 = (p.Cin & 3) == 0;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.wp, p.wp_bytes), rs = make_rsrc(p.styles ? p.styles : p.x, p.styles ? p.st_bytes : 0);
 
     f32x16 acc[4][MTW][NTW];            // [py*2+px]
 #pragma unroll
@@ -796,67 +815,56 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
     const int it_per = (niter + p.ksplit - 1) / p.ksplit;
     const int it0 = ks * it_per, it1 = min(niter, it0 + it_per);
 
+    // Staging pipeline, two stages deep: the global loads of K iteration i+2 are issued while iteration i multiplies, into the
+    // second of two register sets, so a load has two full iterations (~2 x 2300 cycles) to land before its LDS write.  With a
+    // single set the loads of iteration i+1 had one iteration, and the vmcnt wait in front of the LDS write cost a third of the
+    // kernel (ablation without the loads: 125-130 TFLOP/s against 82-88).
     constexpr int NA = (9 * BM + NTH - 1) / NTH;
-    float4 a_reg[NA], x_reg[NPOS], s_reg[NPOS];
-    int a_goff[NA];
+    float4 a_reg[2][NA], x_reg[2][NPOS], s_reg[2][NPOS];
+    uint32_t a_vo[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
         const int e = tid + i * NTH;
-        a_goff[i] = -1;
+        a_vo[i] = kOOB;
         if (e < 9 * BM) {
             const int t = e / BM, col = e % BM;
-            if (m0 + col < p.CoutP) a_goff[i] = (t * p.CoutP + m0 + col) * 4;
+            if (m0 + col < p.CoutP) a_vo[i] = (uint32_t)(t * p.CoutP + m0 + col) * 16u;
         }
     }
-    const int a_gstride = 9 * p.CoutP * 4;
+    const uint32_t a_gstride4 = (uint32_t)(9 * p.CoutP) * 16u;
 
-    auto load_stage = [&](int it) {
-        const float* wp_it = p.wp + (int64_t)it * a_gstride;
+    auto load_stage = [&](int it, int set) {
+        const uint32_t a_so = (uint32_t)it * a_gstride4;
 #pragma unroll
-        for (int i = 0; i < NA; i++) a_reg[i] = a_goff[i] >= 0 ? *(const float4*)(wp_it + a_goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int c0 = it * 4;
-        const float* x_it = p.x + (int64_t)c0 * chw;
+        for (int i = 0; i < NA; i++) a_reg[set][i] = buf_load4(rw, a_vo[i], a_so);
+        const uint32_t c0 = (uint32_t)it * 4u;
 #pragma unroll
         for (int k = 0; k < NPOS; k++) {
-            const int off = pos_off[k];
-            float xv[4], sv[4];
-#pragma unroll
-            for (int ci = 0; ci < 4; ci++) {
-                const bool ok = off >= 0 && c0 + ci < p.Cin;
-                xv[ci] = ok ? x_it[off + ci * chw] : 0.f;
-                sv[ci] = 1.f;
+            // channels beyond Cin (Cin % 4 != 0 only) read a neighbouring channel or 0; their packed weights are 0
+            x_reg[set][k] = make_float4(buf_load1(rx, pos_xo[k], c0 * chw4), buf_load1(rx, pos_xo[k], (c0 + 1) * chw4), buf_load1(rx, pos_xo[k], (c0 + 2) * chw4),
+                                        buf_load1(rx, pos_xo[k], (c0 + 3) * chw4));
+            if (p.styles) {
+                if (cin4) s_reg[set][k] = buf_load4(rs, pos_so[k], c0 * 4u);
+                else s_reg[set][k] = make_float4(buf_load1(rs, pos_so[k], c0 * 4u), buf_load1(rs, pos_so[k], c0 * 4u + 4u), buf_load1(rs, pos_so[k], c0 * 4u + 8u),
+                                                 buf_load1(rs, pos_so[k], c0 * 4u + 12u));
             }
-            if (p.styles && off >= 0) {
-                if (cin4) { const float4 t = *(const float4*)(p.styles + pos_sb[k] + c0); sv[0] = t.x; sv[1] = t.y; sv[2] = t.z; sv[3] = t.w; }
-                else {
-#pragma unroll
-                    for (int ci = 0; ci < 4; ci++) sv[ci] = c0 + ci < p.Cin ? p.styles[pos_sb[k] + c0 + ci] : 1.f;
-                }
-            }
-            x_reg[k] = make_float4(xv[0], xv[1], xv[2], xv[3]); s_reg[k] = make_float4(sv[0], sv[1], sv[2], sv[3]);
         }
     };
-    auto store_stage = [&](float* As, float* Xs) {
+    auto store_stage = [&](int set, float* As, float* Xs) {
 #pragma unroll
         for (int i = 0; i < NA; i++)
-            if (tid + i * NTH < 9 * BM) *(float4*)(As + (tid + i * NTH) * 4) = a_reg[i];
+            if (tid + i * NTH < 9 * BM) *(float4*)(As + (tid + i * NTH) * 4) = a_reg[set][i];
 #pragma unroll
         for (int k = 0; k < NPOS; k++)
-            if (pos_lds[k] >= 0)
-                *(float4*)(Xs + pos_lds[k]) = make_float4(x_reg[k].x * s_reg[k].x, x_reg[k].y * s_reg[k].y, x_reg[k].z * s_reg[k].z, x_reg[k].w * s_reg[k].w);
+            if (pos_lds[k] >= 0) {
+                if (p.styles) *(float4*)(Xs + pos_lds[k]) = make_float4(x_reg[set][k].x * s_reg[set][k].x, x_reg[set][k].y * s_reg[set][k].y,
+                                                                        x_reg[set][k].z * s_reg[set][k].z, x_reg[set][k].w * s_reg[set][k].w);
+                else *(float4*)(Xs + pos_lds[k]) = x_reg[set][k];
+            }
     };
-
-    if (it0 < it1) {
-        load_stage(it0);
-        store_stage(smem, smem + AS_SZ);
-    }
-    __syncthreads();
     const int a_lane = ((wm * MTW) * 32 + l32) * 4 + 2 * half;
     const int b_lane = ((wn * NTW) * 32 + l32) * 4 + 2 * half;      // + (run*XP + dxi + n*32)*4, run 0: dy = -1, dxi 0: dx = -1
-    int cur = 0;
-    for (int it = it0; it < it1; it++) {
-        const bool more = it + 1 < it1;
-        if (more) load_stage(it + 1);
+    auto mma = [&](int cur) {
         const float* As = smem + cur * BUF_SZ + a_lane;
         const float* Xs = smem + cur * BUF_SZ + AS_SZ + b_lane;
         f32x2 fa[2][MTW], fb[4][NTW];               // fb index = run*2 + dxi
@@ -884,10 +892,47 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
 #pragma unroll
                     for (int n = 0; n < NTW; n++) acc[q][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][m][kk], fb[f][n][kk], acc[q][m][n], 0, 0, 0);
         }
-        if (more) store_stage(smem + (cur ^ 1) * BUF_SZ, smem + (cur ^ 1) * BUF_SZ + AS_SZ);
+    };
+
+    float* const L0 = smem;
+    float* const L1 = smem + BUF_SZ;
+    if (it0 < it1) load_stage(it0, 0);
+    if (it0 + 1 < it1) load_stage(it0 + 1, 1);
+    if (it0 < it1) store_stage(0, L0, L0 + AS_SZ);
+    if (it0 + 2 < it1) load_stage(it0 + 2, 0);
+    __syncthreads();
+#if TDGP_UP_ABL & 16
+    long long tseg[4] = {0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define TSEG(i) { const long long tn = __builtin_readcyclecounter(); tseg[i] += tn - tprev; tprev = tn; }
+#else
+#define TSEG(i)
+#endif
+    for (int it = it0; it < it1; it += 2) {
+        // even half: L0 holds iteration `it`; set 1 = iteration it+1, set 0 = iteration it+2 (both in flight)
+        mma(0);
+        TSEG(0)
+        if (it + 1 < it1) store_stage(1, L1, L1 + AS_SZ);
+        TSEG(1)
+        if (it + 3 < it1) load_stage(it + 3, 1);
+        TSEG(2)
         __syncthreads();
-        cur ^= 1;
+        TSEG(3)
+        if (it + 1 >= it1) break;
+        // odd half: L1 holds iteration it+1; set 0 = iteration it+2, set 1 = iteration it+3
+        mma(1);
+        TSEG(0)
+        if (it + 2 < it1) store_stage(0, L0, L0 + AS_SZ);
+        TSEG(1)
+        if (it + 4 < it1) load_stage(it + 4, 0);
+        TSEG(2)
+        __syncthreads();
+        TSEG(3)
     }
+#if TDGP_UP_ABL & 16
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 700) && blockIdx.y == 0 && blockIdx.z == 0)
+        printf("upconv blk %d iters %d: mma %lld store %lld load-issue %lld barrier %lld cycles\n", (int)blockIdx.x, it1 - it0, tseg[0], tseg[1], tseg[2], tseg[3]);
+#endif
+#undef TSEG
 
     // ---- epilogue: per (channel tile, point subtile, py): interleave px = 0/1 in a per-wave LDS tile, store 16 B per lane -----
     float* ct = smem + wv * (32 * UP_CT_W);
@@ -911,7 +956,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
         __builtin_amdgcn_wave_barrier();
         const int g0 = v0 + (wn * NTW + nn) * 32;
         const int b = g0 / p.GS, vp0 = g0 - b * p.GS;
-        if (b < p.B) {
+        if (b < p.B && (!(TDGP_UP_ABL & 1) || acc[0][0][0][0] == 123.f)) {
             const int q = l & 15, cr = l >> 4;
             const int obase = m0 + (wm * MTW + mm) * 32;
 #pragma unroll
@@ -939,6 +984,7 @@ struct RgbParams {
     EpiParams e;
     int B, Cin, Cout, CoutP, HW, W;
     int64_t P;          // B*H*W
+    uint32_t x_bytes, wp_bytes, st_bytes;       // sizes for the buffer descriptors
 };
 
 template <int MT>
@@ -954,33 +1000,36 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
 
     for (int i = tid; i < BM; i += 256) side[i] = (i < p.Cout && p.e.bias) ? p.e.bias[i] : 0.f;
 
-    // two 4-channel x 4-pixel micro-tiles per thread and iteration
-    int x_off[2], x_sb[2];
+    // two 4-channel x 4-pixel micro-tiles per thread and iteration (byte offsets for the buffer loads; kOOB -> 0)
+    uint32_t x_vo[2], s_vo[2];
     const int cq = tid >> 5, pq = tid & 31;                        // micro-tile k: channels 4*(cq + 8k) .. +3 of the iteration, pixels 4*pq .. +3
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const int64_t pix = px0 + 4 * pq;
-        x_off[k] = -1; x_sb[k] = 0;
+        x_vo[k] = kOOB; s_vo[k] = kOOB;
         if (pix < p.P) {
             const int b = (int)(pix / p.HW), inner = (int)(pix - (int64_t)b * p.HW);
-            x_sb[k] = b * p.Cin + 4 * (cq + 8 * k);
-            x_off[k] = x_sb[k] * p.HW + inner;
+            const int sb = b * p.Cin + 4 * (cq + 8 * k);
+            s_vo[k] = (uint32_t)sb * 4u;
+            x_vo[k] = (uint32_t)(sb * p.HW + inner) * 4u;
         }
     }
+    const uint32_t hw4 = (uint32_t)p.HW * 4u;
     const bool cin4 = (p.Cin & 3) == 0;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.wp, p.wp_bytes), rs = make_rsrc(p.styles ? p.styles : p.x, p.styles ? p.st_bytes : 0);
 
     constexpr int NA = (NCH * BM + 255) / 256;
-    int a_goff[NA];
+    uint32_t a_vo[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
         const int e = tid + i * 256;
-        a_goff[i] = -1;
+        a_vo[i] = kOOB;
         if (e < NCH * BM) {
             const int chunk = e / BM, col = e % BM;
-            if (col < p.CoutP) a_goff[i] = (chunk * p.CoutP + col) * 4;
+            if (col < p.CoutP) a_vo[i] = (uint32_t)(chunk * p.CoutP + col) * 16u;
         }
     }
-    const int a_gstride = NCH * p.CoutP * 4;
+    const uint32_t a_gstride4 = (uint32_t)(NCH * p.CoutP) * 16u;
 
     f32x16 acc[MT];
 #pragma unroll
@@ -990,25 +1039,20 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
 
     float4 a_reg[NA], xr[2][4], sr[2];
     auto load_stage = [&](int it) {
-        const float* wp_it = p.wp + (int64_t)it * a_gstride;
+        const uint32_t a_so = (uint32_t)it * a_gstride4;
 #pragma unroll
-        for (int i = 0; i < NA; i++) a_reg[i] = a_goff[i] >= 0 ? *(const float4*)(wp_it + a_goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const int c0 = it * 64;
+        for (int i = 0; i < NA; i++) a_reg[i] = buf_load4(rw, a_vo[i], a_so);
+        const uint32_t c0 = (uint32_t)it * 64u;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const int cb = c0 + 4 * (cq + 8 * k);                  // first channel of the micro-tile
+            // micro-tile channels beyond Cin: the x loads fall into the next sample (finite) or beyond the buffer (0) and meet zero weights
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                xr[k][j] = (x_off[k] >= 0 && cb + j < p.Cin) ? *(const float4*)(p.x + x_off[k] + (int64_t)(c0 + j) * p.HW) : make_float4(0.f, 0.f, 0.f, 0.f);
-            sr[k] = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (p.styles && x_off[k] >= 0) {
-                if (cin4) { if (cb < p.Cin) sr[k] = *(const float4*)(p.styles + x_sb[k] + c0); }
-                else {
-                    float sv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) sv[j] = cb + j < p.Cin ? p.styles[x_sb[k] + c0 + j] : 1.f;
-                    sr[k] = make_float4(sv[0], sv[1], sv[2], sv[3]);
-                }
+            for (int j = 0; j < 4; j++) xr[k][j] = buf_load4(rx, x_vo[k], (c0 + j) * hw4);
+            if (p.styles) {
+                if (cin4) sr[k] = buf_load4(rs, s_vo[k], c0 * 4u);
+                else sr[k] = make_float4(buf_load1(rs, s_vo[k], c0 * 4u), buf_load1(rs, s_vo[k], c0 * 4u + 4u), buf_load1(rs, s_vo[k], c0 * 4u + 8u), buf_load1(rs, s_vo[k], c0 * 4u + 12u));
+            } else {
+                sr[k] = make_float4(1.f, 1.f, 1.f, 1.f);
             }
         }
     };
@@ -1474,7 +1518,8 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
     TDGP_CHECK(act >= 1 && act <= 9, TDGP_EUNSUPPORTED, "modconv2d: unknown activation %d", act);
     TDGP_CHECK(out_layout == 0 || (out_layout == 1 && out_feat >= 4 && (out_feat % 4) == 0 && (Cout % out_feat) == 0 && up == 1 && k == 1), TDGP_EINVAL,
                "modconv2d: the channel-last plane layout is a ToRGB (k=1, up=1) output");
-    TDGP_CHECK((int64_t)B * Cin * H * W <= INT32_MAX && (int64_t)B * Cout * (H * up + 1) * (W * up + 1) <= INT32_MAX, TDGP_EINVAL, "modconv2d: tensor too large");
+    TDGP_CHECK((int64_t)B * Cin * H * W < ((int64_t)1 << 30) && (int64_t)B * Cout * (H * up + 1) * (W * up + 1) <= INT32_MAX, TDGP_EINVAL,
+               "modconv2d: tensor too large (activations are addressed through 4 GiB buffer descriptors)");
     const WsLayout wl = ws_layout(B, Cin, Cout, H, W, k, up);
     TDGP_CHECK(workspace && workspace_bytes >= wl.total, TDGP_EWORKSPACE, "modconv2d: workspace %lld < %lld bytes", (long long)workspace_bytes,
                (long long)wl.total);
@@ -1517,6 +1562,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
             Conv3Params c;
             c.x = x; c.wp = wp; c.styles = styles; c.partial = nullptr; c.e = e;
             c.B = B; c.Cin = Cin; c.Cout = Cout; c.CoutP = pi.CoutP; c.H = H; c.W = W; c.ksplit = 1;
+            c.x_bytes = (uint32_t)((int64_t)B * Cin * H * W * 4); c.wp_bytes = (uint32_t)(pi.wp_floats * 4); c.st_bytes = (uint32_t)((int64_t)B * Cin * 4);
             if (k == 3) {
                 if (Cout > 64) launch_conv3<3, 2, 2, 2, 2>(c, partial, wl.partial_floats, s);
                 else launch_conv3<3, 2, 2, 1, 4>(c, partial, wl.partial_floats, s);
@@ -1534,6 +1580,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
             RgbParams r;
             r.x = x; r.wp = wp; r.styles = styles; r.e = e;
             r.B = B; r.Cin = Cin; r.Cout = Cout; r.CoutP = pi.CoutP; r.HW = H * W; r.W = W; r.P = (int64_t)B * H * W;
+            r.x_bytes = (uint32_t)((int64_t)B * Cin * H * W * 4); r.wp_bytes = (uint32_t)(pi.wp_floats * 4); r.st_bytes = (uint32_t)((int64_t)B * Cin * 4);
             if (Cout <= 32) launch_torgb<1>(r, s);
             else if (Cout <= 64) launch_torgb<2>(r, s);
             else launch_torgb<3>(r, s);
@@ -1548,6 +1595,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         UpParams u;
         u.x = x; u.wp = wp; u.styles = styles; u.z = z;
         u.B = B; u.Cin = Cin; u.Cout = Cout; u.CoutP = pi.CoutP; u.H = H; u.W = W; u.G1 = pl.G1; u.GS = pl.GS; u.ksplit = pl.ksplit; u.zslice = pl.zslice;
+        u.x_bytes = (uint32_t)((int64_t)B * Cin * H * W * 4); u.wp_bytes = (uint32_t)(pi.wp_floats * 4); u.st_bytes = (uint32_t)((int64_t)B * Cin * 4);
         if (pl.cfg == 0) launch_upconv<2, 1, 2, 2>(u, s);
         else launch_upconv<2, 1, 1, 4>(u, s);
         FirParams f;
