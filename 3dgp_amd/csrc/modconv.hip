@@ -103,11 +103,22 @@ __device__ __forceinline__ float skip_eval(const float* __restrict__ img, const 
     return fmaf_(t.w11, d, fmaf_(t.w10, c, fmaf_(t.w01, b, t.w00 * a)));
 }
 
+// ACT = 0: activation / clamp decided at run time (every bias_act form); ACT = 1 (linear) / 3 (lrelu): the two forms of the
+// generator path with no clamp, specialised at compile time.  It matters more than its instruction count suggests: fp32 VALU
+// and MFMA share the issue port, and a wave in its output stage gets one VALU instruction in per 64-cycle MFMA of its
+// co-resident waves, so every instruction saved here is ~60 cycles of epilogue latency.
+template <int ACT = 0>
 __device__ __forceinline__ float finish_act(const EpiParams& e, float v) {
-    v = act_apply(v, e.act, e.alpha) * e.gain;
-    if (e.clamp >= 0.f) v = v < -e.clamp ? -e.clamp : (v > e.clamp ? e.clamp : v);
-    return v;
+    if constexpr (ACT == 1) return v * e.gain;
+    else if constexpr (ACT == 3) return (v > 0.f ? v : v * e.alpha) * e.gain;
+    else {
+        v = act_apply(v, e.act, e.alpha) * e.gain;
+        if (e.clamp >= 0.f) v = v < -e.clamp ? -e.clamp : (v > e.clamp ? e.clamp : v);
+        return v;
+    }
 }
+// which specialisation a launch can use
+__device__ __forceinline__ int epi_variant(const EpiParams& e) { return (e.clamp < 0.f && (e.act == 1 || e.act == 3)) ? e.act : 0; }
 
 // demod * acc + noise + bias (+ FIR-upsampled skip) -> activation * gain -> clamp -> store (NCHW or channel-last planes);
 // element-at-a-time form used by the split-K reduction.
@@ -156,7 +167,7 @@ __device__ __forceinline__ float side_demod(const EpiParams& e, const SideCache&
 //   channel-last planes (CL, ToRGB): ct is PIXEL-major; lane = (pixel l>>3 of the pass, channel quad l&7) stores float4 =
 //         4 consecutive features of one texel; the x2-upsampled skip is 4 float4 taps per lane, all 4 passes in flight.
 constexpr int CT_LD = 36;
-template <bool CL>
+template <bool CL, int ACT = 0>
 __device__ __forceinline__ void epilogue_tile(const EpiParams& e, const SideCache& sc, const float* ct, int obase, int pb, int poy, int pox, int pok,
                                               float* part, bool vec) {
     const int l = lane_id(), l32 = l & 31, half = l >> 5;
@@ -178,8 +189,8 @@ __device__ __forceinline__ void epilogue_tile(const EpiParams& e, const SideCach
                     float4 v = *(const float4*)&ct[row * CT_LD + 4 * g];
                     if (!raw) {
                         const float d = side_demod(e, sc, b4, o, true), bb = side_bias(e, sc, o, true);
-                        v.x = finish_act(e, (v.x * d + nz.x) + bb); v.y = finish_act(e, (v.y * d + nz.y) + bb);
-                        v.z = finish_act(e, (v.z * d + nz.z) + bb); v.w = finish_act(e, (v.w * d + nz.w) + bb);
+                        v.x = finish_act<ACT>(e, (v.x * d + nz.x) + bb); v.y = finish_act<ACT>(e, (v.y * d + nz.y) + bb);
+                        v.z = finish_act<ACT>(e, (v.z * d + nz.z) + bb); v.w = finish_act<ACT>(e, (v.w * d + nz.w) + bb);
                     }
                     *(float4*)(dst + pix + o * cstride) = v;
                 }
@@ -204,7 +215,7 @@ __device__ __forceinline__ void epilogue_tile(const EpiParams& e, const SideCach
                 const int o = obase + sel;
                 if (pok && o < e.Cout) {
                     float v = ct[sel * CT_LD + l32];
-                    if (!raw) v = finish_act(e, ((v * side_demod(e, sc, pb, o, true) + nz) + side_bias(e, sc, o, true)) + sk[q]);
+                    if (!raw) v = finish_act<ACT>(e, ((v * side_demod(e, sc, pb, o, true) + nz) + side_bias(e, sc, o, true)) + sk[q]);
                     dst[pix + o * cstride] = v;
                 }
             }
@@ -250,10 +261,10 @@ __device__ __forceinline__ void epilogue_tile(const EpiParams& e, const SideCach
                 float4 v = *(const float4*)&ct[px * CT_LD + 4 * cg];
                 const float d0 = side_demod(e, sc, bq[pass], o, true), d1 = side_demod(e, sc, bq[pass], o + 1, true);
                 const float d2 = side_demod(e, sc, bq[pass], o + 2, true), d3 = side_demod(e, sc, bq[pass], o + 3, true);
-                v.x = finish_act(e, ((v.x * d0 + nzq[pass]) + bias4.x) + sk[pass].x);
-                v.y = finish_act(e, ((v.y * d1 + nzq[pass]) + bias4.y) + sk[pass].y);
-                v.z = finish_act(e, ((v.z * d2 + nzq[pass]) + bias4.z) + sk[pass].z);
-                v.w = finish_act(e, ((v.w * d3 + nzq[pass]) + bias4.w) + sk[pass].w);
+                v.x = finish_act<ACT>(e, ((v.x * d0 + nzq[pass]) + bias4.x) + sk[pass].x);
+                v.y = finish_act<ACT>(e, ((v.y * d1 + nzq[pass]) + bias4.y) + sk[pass].y);
+                v.z = finish_act<ACT>(e, ((v.z * d2 + nzq[pass]) + bias4.z) + sk[pass].z);
+                v.w = finish_act<ACT>(e, ((v.w * d3 + nzq[pass]) + bias4.w) + sk[pass].w);
                 *(float4*)(e.y + addr[pass]) = v;
             }
         }
@@ -712,6 +723,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
     SideCache scache;
     scache.lds = side_ok ? side : nullptr; scache.b0 = sb0; scache.bm = BM; scache.m0 = m0;
     float* part = (p.ksplit > 1) ? p.partial + (int64_t)ks * e.B * e.Cout * e.Hout * e.Wout : nullptr;
+    const int evar = epi_variant(e);
 #pragma unroll 1
     for (int tile = 0; tile < MTW * NTW; tile++) {
 #pragma unroll
@@ -728,7 +740,9 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
         const int pok = (vi < VR && poy < p.H) ? 1 : 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        epilogue_tile<false>(e, scache, ct, m0 + (wm * MTW + m) * 32, pb, poy, n0 + l32, pok, part, true);
+        if (evar == 3) epilogue_tile<false, 3>(e, scache, ct, m0 + (wm * MTW + m) * 32, pb, poy, n0 + l32, pok, part, true);
+        else if (evar == 1) epilogue_tile<false, 1>(e, scache, ct, m0 + (wm * MTW + m) * 32, pb, poy, n0 + l32, pok, part, true);
+        else epilogue_tile<false, 0>(e, scache, ct, m0 + (wm * MTW + m) * 32, pb, poy, n0 + l32, pok, part, true);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -1111,6 +1125,7 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
     const int poy = inner / p.W, pox = inner - poy * p.W;
     SideCache scache;
     scache.lds = side; scache.b0 = 0; scache.bm = BM; scache.m0 = 0;
+    const int evar = epi_variant(p.e);
 #pragma unroll 1
     for (int tile = 0; tile < MT; tile++) {
 #pragma unroll
@@ -1123,7 +1138,8 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        epilogue_tile<true>(p.e, scache, ct, tile * 32, pb, poy, pox, pok, nullptr, false);
+        if (evar == 1) epilogue_tile<true, 1>(p.e, scache, ct, tile * 32, pb, poy, pox, pok, nullptr, false);
+        else epilogue_tile<true, 0>(p.e, scache, ct, tile * 32, pb, poy, pox, pok, nullptr, false);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
