@@ -56,6 +56,7 @@ struct FieldParams {
     int marcher;
     int ray_h, ray_w;      // > 0: rays form a [B, ray_h, ray_w] image -> waves walk 4x4-pixel tiles (cache locality); 0: linear point order
     int64_t R;             // rays per sample
+    uint32_t planes_bytes; // B*3*H*W*F*4 when it fits a buffer descriptor (< 4 GiB), else 0
 };
 
 template <int N>
@@ -98,6 +99,12 @@ __device__ __forceinline__ void load_texel(const float* __restrict__ texel, int 
     }
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 // correctly rounded x / 3 without the hardware division sequence (Markstein: q1 = fma(fma(-3,q0,x), r, q0))
 __device__ __forceinline__ f32x2 div3(f32x2 x) {
     const f32x2 r = {0.333333343267440796f, 0.333333343267440796f};        // RN(1/3)
@@ -123,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
     __shared__ float a1s[MT * 4 * 64];
     __shared__ float b0s[HID];
     __shared__ float4 obuf_all[4 * 16 * 9];      // per wave: [16 rays][8 samples (+1 pad)] parked outputs of the ray walk
+    __shared__ uint4 atab_all[(FQ % 4 == 0) ? 4 * 6 * 64 : 1];   // per wave: tap table of 4 samples x 16 rays, [3 planes x {weights, texel offsets}][sample*16 + ray]
     const float sqrt2 = 1.41421353816986083984375f;    // (float)sqrt(2): lrelu gain, folded into the layer-2 weights
     for (int i = threadIdx.x; i < MT * FQ * 64; i += blockDim.x) {
         const int ln = i & 63, ms = i >> 6, mt = ms / FQ, sidx = ms % FQ;
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const float v = acc[mt][r];
-                const float h = fmaxf(v, 0.2f * v);                      // leaky_relu(v, 0.2); the sqrt(2) gain lives in a1s
+                const float h = __builtin_amdgcn_fmed3f(v, 0.2f * v, __builtin_inff());     // leaky_relu(v, 0.2) = max(v, 0.2 v) in ONE v_med3 (fmaxf costs a canonicalising extra max); the sqrt(2) gain lives in a1s
                 o4[r & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1s[(mt * 4 + r) * 64 + l], h, o4[r & 1], 0, 0, 0);
             }
         float o[4];
@@ -286,6 +294,113 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
             ok = y < p.ray_h && x < p.ray_w;
             return b * (int)p.R + (ok ? y * p.ray_w + x : 0);                   // B*R*S < 2^31 (checked on the host)
         };
+        if constexpr (FQ % 4 == 0) {
+          if (p.planes_bytes != 0) {
+            // Table-driven walk.  The four lanes that gather for one point would each repeat that point's coordinate -> tap
+            // arithmetic (~135 VALU instructions per 16-point tile, a third of the kernel's vector work, and vector work is paid
+            // in matrix time on this chip).  Instead the wave does it ONCE for four consecutive samples with lane = (ray, sample),
+            // parks (4 weights, 4 texel byte offsets) x 3 planes per point in LDS, and each tile then reads its rows back (6
+            // conflict-free 16-B LDS reads) and issues buffer loads: descriptor = all planes, scalar offset = the sample's plane,
+            // lane offset = texel * F * 4 + piece * 16.
+            uint4* atab = atab_all + wvi * (6 * 64);
+            const uint32_t c4off = (uint32_t)gc4 * 16u;
+            const uint32_t plane_bytes = (uint32_t)plane_elems * 4u;
+            const __amdgpu_buffer_rsrc_t rpl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.planes), 0, p.planes_bytes, 0x00020000);
+            const int wslot = gc4 * 16 + gpt;                           // table slot this lane WRITES (sample j = gc4 of the group, ray gpt)
+            for (int patch = lb; patch < npatch; patch += nb) {
+                const int px = patch % pX, py = (patch / pX) % pY, b = patch / (pX * pY);       // uniform
+                bool gok, fok;
+                const int gray = ray_of(b, py, px, gpt, gok);      // the ray this lane computes addresses / gathers for
+                const int fray = ray_of(b, py, px, l >> 2, fok);   // the ray whose parked results this lane flushes
+                const float ox = p.ray_o[gray * 3 + 0], oy = p.ray_o[gray * 3 + 1], oz = p.ray_o[gray * 3 + 2];
+                const float dxr = p.ray_d[gray * 3 + 0], dyr = p.ray_d[gray * 3 + 1], dzr = p.ray_d[gray * 3 + 2];
+                const uint32_t soff_b = (uint32_t)b * 3u * plane_bytes;
+                const float* tp = p.t + (int64_t)gray * p.S;
+                float t_grp = tp[min(gc4, p.S - 1)];
+                auto address_phase = [&](int k0) {
+                    const int ks = min(k0 + gc4, p.S - 1);
+                    const float tt = t_grp;
+                    t_grp = tp[min(k0 + 4 + gc4, p.S - 1)];           // next group's depth, in flight during this group
+                    const float cx = ox + tt * dxr, cy = oy + tt * dyr, cz = oz + tt * dzr;     // :141 (unfused mul, add)
+                    float qc[3];
+                    if (p.scale_is_pow2) { qc[0] = cx * p.inv_scale; qc[1] = cy * p.inv_scale; qc[2] = cz * p.inv_scale; }
+                    else { qc[0] = cx / p.scale; qc[1] = cy / p.scale; qc[2] = cz / p.scale; }
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++) {
+                        const float u = qc[pl == 2 ? 1 : 0], v = qc[pl == 0 ? 1 : 2];
+                        const float ix = (u + 1.0f) * sx, iy = (v + 1.0f) * sy;
+                        const float fx = floorf(ix), fy = floorf(iy);
+                        const float tw = ix - fx, te = 1.0f - tw, tn = iy - fy, ts = 1.0f - tn;
+                        const float cfx = fx < -2.f ? -2.f : (fx > (float)p.W ? (float)p.W : fx);
+                        const float cfy = fy < -2.f ? -2.f : (fy > (float)p.H ? (float)p.H : fy);
+                        const int x0 = (int)cfx, y0 = (int)cfy;
+                        if (TAPS) {
+                            if (p.tap_idx && gok && k0 + gc4 < p.S) {
+                                p.tap_idx[(((int64_t)gray * p.S + ks) * 3 + pl) * 2 + 0] = x0;
+                                p.tap_idx[(((int64_t)gray * p.S + ks) * 3 + pl) * 2 + 1] = y0;
+                            }
+                        }
+                        const bool vx0 = (unsigned)x0 < (unsigned)p.W, vx1 = (unsigned)(x0 + 1) < (unsigned)p.W;
+                        const bool vy0 = (unsigned)y0 < (unsigned)p.H, vy1 = (unsigned)(y0 + 1) < (unsigned)p.H;
+                        const float4 w4 = make_float4((vx0 && vy0) ? ts * te : 0.f, (vx1 && vy0) ? ts * tw : 0.f, (vx0 && vy1) ? tn * te : 0.f, (vx1 && vy1) ? tn * tw : 0.f);
+                        const int xa = min(max(x0, 0), p.W - 1), xb = min(max(x0 + 1, 0), p.W - 1);
+                        const int ya = min(max(y0, 0), p.H - 1), yb = min(max(y0 + 1, 0), p.H - 1);
+                        const int ra = ya * p.W, rb = yb * p.W;
+                        atab[(pl * 2 + 0) * 64 + wslot] = make_uint4(__float_as_uint(w4.x), __float_as_uint(w4.y), __float_as_uint(w4.z), __float_as_uint(w4.w));
+                        atab[(pl * 2 + 1) * 64 + wslot] = make_uint4((uint32_t)(ra + xa) * (F * 4u), (uint32_t)(ra + xb) * (F * 4u), (uint32_t)(rb + xa) * (F * 4u),
+                                                                     (uint32_t)(rb + xb) * (F * 4u));
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                };
+                auto issue_from_table = [&](int j) {                   // sample j of the current group: this lane's point is ray gpt
+                    const int rslot = j * 16 + gpt;
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++) {
+                        const uint4 w4 = atab[(pl * 2 + 0) * 64 + rslot], o4 = atab[(pl * 2 + 1) * 64 + rslot];
+                        wgt[pl][0] = __uint_as_float(w4.x); wgt[pl][1] = __uint_as_float(w4.y); wgt[pl][2] = __uint_as_float(w4.z); wgt[pl][3] = __uint_as_float(w4.w);
+                        const uint32_t so = soff_b + (uint32_t)pl * plane_bytes;
+                        const uint32_t ov[4] = {o4.x + c4off, o4.y + c4off, o4.z + c4off, o4.w + c4off};
+#pragma unroll
+                        for (int t = 0; t < 4; t++)
+#pragma unroll
+                            for (int jj = 0; jj < FQ / 4; jj++) {
+                                float4 v = make_float4((float)(ov[t] + jj), 1.f, 2.f, 3.f);
+                                if (!(TDGP_FIELD_ABL & 1)) v = buf_load4(rpl, ov[t] + 64u * jj, so);
+                                tap[pl][t][2 * jj] = (f32x2){v.x, v.y}; tap[pl][t][2 * jj + 1] = (f32x2){v.z, v.w};
+                            }
+                    }
+                };
+                address_phase(0);
+                issue_from_table(0);
+                for (int k = 0; k < p.S; k++) {
+                    float g[FQ];
+                    blend(g);
+                    if (k + 1 < p.S) {
+                        if (((k + 1) & 3) == 0) address_phase(k + 1);
+                        issue_from_table((k + 1) & 3);
+                    }
+                    const float4 o = mlp(g);
+                    if (q == 0) obuf[pt * 9 + (k & 7)] = o;
+                    if ((k & 7) == 7 || k + 1 == p.S) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const int k0 = k & ~7, nk = (k & 7) + 1;
+                        const int fr = l >> 2, j = (l & 3) * 2;
+                        const float4 v0 = obuf[fr * 9 + j], v1 = obuf[fr * 9 + j + 1];
+                        float4* dst = (float4*)p.rgbs + (int64_t)fray * p.S + k0 + j;
+                        if (fok && !(TDGP_FIELD_ABL & 4)) {
+                            if (j < nk) dst[0] = v0;
+                            if (j + 1 < nk) dst[1] = v1;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+            return;
+          }
+        }
         for (int patch = lb; patch < npatch; patch += nb) {
             const int px = patch % pX, py = (patch / pX) % pY, b = patch / (pX * pY);       // uniform
             bool gok;
@@ -425,6 +540,7 @@ TDGP_API int tdgp_triplane_field(const float* planes_hwc, const float* coords, c
     TDGP_CHECK((int64_t)B * P <= INT32_MAX / 4 && (int64_t)3 * H * W * F <= INT32_MAX, TDGP_EINVAL, "triplane_field: tensor too large");
     p.g0 = (float)(1.0 / sqrt((double)F)); p.g1 = (float)(1.0 / sqrt((double)hid));    // weight_gain, layers.py:39
     p.marcher = marcher;
+    { const int64_t pb = (int64_t)B * 3 * H * W * F * 4; p.planes_bytes = pb < ((int64_t)1 << 32) - 65536 ? (uint32_t)pb : 0u; }
     p.R = coords ? 0 : P / S; p.ray_w = 0; p.ray_h = 0;
     if (!coords && ray_w > 0) {
         TDGP_CHECK((p.R % ray_w) == 0, TDGP_EINVAL, "triplane_field: ray_w=%d does not divide the %lld rays", ray_w, (long long)p.R);
