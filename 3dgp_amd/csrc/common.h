@@ -75,22 +75,37 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
     hi = __shfl(hi, src, 64);
     return __hiloint2double(hi, lo);
 }
+// fp64 cross-lane helpers on the DPP path (gfx9 row shifts / row broadcasts, wave shift, v_readlane): a scan is 12 VALU
+// moves with no LDS round trip.  The ds_bpermute versions they replace put twelve DEPENDENT ~120-cycle shuffles on the
+// critical path of every scan, which is what the per-ray kernels (4-8 waves per SIMD, nothing else to overlap) were
+// waiting for.
+template <int CTRL, int RMASK>
+__device__ __forceinline__ double dpp_f64(double keep, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(keep), __double2loint(v), CTRL, RMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), __double2hiint(v), CTRL, RMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 // inclusive prefix (sum or product) over the 64 lanes of a wave, fp64
 template <bool PROD>
 __device__ __forceinline__ double wave_scan_f64(double v) {
-    const int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        double o = shfl_up_f64(v, d);
-        if (l >= d) v = PROD ? v * o : v + o;
-    }
+    const double id = PROD ? 1.0 : 0.0;
+#define TDGP_SCAN_STEP(CTRL, RMASK) { const double o = dpp_f64<CTRL, RMASK>(id, v); v = PROD ? v * o : v + o; }
+    TDGP_SCAN_STEP(0x111, 0xf)      // row_shr:1   (Hillis-Steele inside each row of 16 lanes)
+    TDGP_SCAN_STEP(0x112, 0xf)      // row_shr:2
+    TDGP_SCAN_STEP(0x114, 0xf)      // row_shr:4
+    TDGP_SCAN_STEP(0x118, 0xf)      // row_shr:8
+    TDGP_SCAN_STEP(0x142, 0xa)      // row_bcast:15 -> rows 1 and 3 take the total of the row before
+    TDGP_SCAN_STEP(0x143, 0xc)      // row_bcast:31 -> rows 2 and 3 take the total of rows 0-1
+#undef TDGP_SCAN_STEP
     return v;
 }
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
-    return v;
+// value of lane 63 in every lane (wave-uniform)
+__device__ __forceinline__ double wave_last_f64(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
+// lane i takes lane i-1's value, lane 0 takes `first`
+__device__ __forceinline__ double wave_shr1_f64(double v, double first) { return dpp_f64<0x138, 0xf>(first, v); }
+__device__ __forceinline__ double wave_sum_f64(double v) { return wave_last_f64(wave_scan_f64<false>(v)); }
 
 // torch's thresholded softplus (beta 1, threshold 20), evaluated in fp64 and rounded once.
 __device__ __forceinline__ float softplus20(float x) { return x > 20.f ? x : (float)log1p(exp((double)x)); }

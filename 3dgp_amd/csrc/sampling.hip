@@ -13,19 +13,27 @@
 // integer decisions (searchsorted index, sort permutation) identical to the CPU oracle.
 #include "common.h"
 
+#ifndef TDGP_RAY_ABL
+#define TDGP_RAY_ABL 0      // 1: per-phase cycle counts of one wave, printed (timing experiments only)
+#endif
+
 namespace {
 
 constexpr int MAXS = 256;          // max samples per ray in one pass (2*S for the merged pass)
 constexpr int RAYS_PER_BLOCK = 4;
 
-struct WaveScratch {
-    float z[MAXS];      // depths (s- or t-space)
-    float sig[MAXS];    // densities
-    float w[MAXS + 4];  // weights / pdf scratch
-    float cdf[MAXS];
-    float bins[MAXS];
-    float col[3][MAXS]; // colours (merged pass)
+// Per-wave LDS scratch.  MS = capacity in samples; the fused kernels pick 128 when the ray fits (4.1 KB per wave -> 8 waves
+// per SIMD instead of 4: these kernels are chains of dependent LDS / cross-lane steps, occupancy is what hides them).
+template <int MS>
+struct WaveScratchT {
+    float z[MS];        // depths (s- or t-space)
+    float sig[MS];      // densities
+    float w[MS + 4];    // weights / pdf scratch
+    float cdf[MS];
+    float bins[MS];
+    float col[3][MS];   // colours (merged pass)
 };
+using WaveScratch = WaveScratchT<MAXS>;
 
 __device__ __forceinline__ void wave_sync() {
     // all LDS traffic of a wave is issued in order; this only stops the compiler from reordering across it
@@ -53,11 +61,10 @@ __device__ void march_classical_lds(const float* z, const float* sig, float* w, 
             fac = (1.0f - alpha) + 1e-10f;
         }
         double incl = wave_scan_f64<true>((double)fac) * carry;
-        double excl = shfl_up_f64(incl, 1);
-        if (l == 0) excl = carry;
+        const double excl = wave_shr1_f64(incl, carry);
         float wi = alpha * (float)excl;
         if (i < S) { w[i] = wi; wsum += (double)wi; }
-        carry = shfl_f64(incl, 63);
+        carry = wave_last_f64(incl);
     }
     wsum = wave_sum_f64(wsum);
     wagg = (float)wsum;
@@ -87,11 +94,10 @@ __device__ void march_mip_lds(const float* z, const float* sig, float* w, int S,
             fac = (1.0f - alpha) + 1e-10f;
         }
         double incl = wave_scan_f64<true>((double)fac) * carry;
-        double excl = shfl_up_f64(incl, 1);
-        if (l == 0) excl = carry;
+        const double excl = wave_shr1_f64(incl, carry);
         float wi = alpha * (float)excl;
         if (i < M) { w[i] = wi; wsum += (double)wi; }
-        carry = shfl_f64(incl, 63);
+        carry = wave_last_f64(incl);
     }
     wsum = wave_sum_f64(wsum);
     wagg = (float)wsum;
@@ -104,8 +110,8 @@ __device__ void march_mip_lds(const float* z, const float* sig, float* w, int S,
 // tri_plane_renderer.py:237-295.  Clobbers sc.w / sc.cdf / sc.bins.
 // Lane j produces sample j (strided by 64).  `emit(j, sample, ind, below, above)` consumes the results.
 // ------------------------------------------------------------------------------------------------
-template <typename Emit>
-__device__ void importance_lds(WaveScratch& sc, int S, int Wn, const float* u, int N, int mip, Emit emit) {
+template <typename SC, typename Emit>
+__device__ void importance_lds(SC& sc, int S, int Wn, const float* u, int N, int mip, Emit emit) {
     const int l = lane_id();
     const float eps = 1e-5f;
     float* w = sc.w;
@@ -147,7 +153,7 @@ __device__ void importance_lds(WaveScratch& sc, int S, int Wn, const float* u, i
         float pdf = (i < ns) ? (w[1 + i] + eps) / totf : 0.f;
         double incl = wave_scan_f64<false>((double)pdf) + carry;
         if (i < ns) sc.cdf[i + 1] = (float)incl;
-        carry = shfl_f64(incl, 63);
+        carry = wave_last_f64(incl);
     }
     wave_sync();
     for (int j = l; j < N; j += 64) {
@@ -279,27 +285,54 @@ __device__ __forceinline__ void stable_ranks(const float* key, int M, int* rank 
     else stable_ranks_n<4>(key, M, rank);
 }
 
+// Bitonic sort of one (key, index) pair per lane across the 64 lanes of a wave, ascending by (key, index): 21 compare-exchange
+// stages, each two ds_bpermute (LDS pipe) + ~5 VALU -- a third of the vector work of the brute-force rank above for 64 keys.
+// Indices are unique, so the order is total and the result is the stable sort.
+__device__ __forceinline__ void wave_bitonic_sort(float& key, int& idx) {
+    const int l = lane_id();
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const float pk = __shfl_xor(key, j, 64);
+            const int pi = __shfl_xor(idx, j, 64);
+            const bool keep_min = ((l & j) == 0) == ((l & k) == 0);        // lower lane of an ascending pair / upper lane of a descending one
+            const bool partner_less = pk < key || (pk == key && pi < idx);
+            if (partner_less == keep_min) { key = pk; idx = pi; }
+        }
+    }
+}
+
 // fused: coarse march (s-space) -> importance sampling -> fine depths (t-space), WRITTEN IN ASCENDING DEPTH ORDER.
 // The reference leaves the fine samples in draw order and sorts coarse+fine together later (unify_samples); sorting the
 // fine list here (stable, by (t, draw index)) changes nothing in that final order but makes the j-th fine sample of
 // neighbouring rays neighbours in space (texture locality of the second field pass) and turns the later merge into a
 // merge of two sorted lists.  fine_perm[pos] = draw index of the sample stored at pos.
+template <int MS>
 __global__ __launch_bounds__(256) void importance_from_coarse_kernel(const float* __restrict__ rgbs, const float* __restrict__ sdist,
                                                                     const float* __restrict__ u_fine, float* __restrict__ tfine,
                                                                     float* __restrict__ sfine, int32_t* __restrict__ inds,
                                                                     int32_t* __restrict__ fine_perm, int64_t rays, int S, int N,
                                                                     int marcher, int flags, float density_bias, float t_near, float t_far) {
-    __shared__ WaveScratch scratch[RAYS_PER_BLOCK];
+    __shared__ WaveScratchT<MS> scratch[RAYS_PER_BLOCK];
     const int wv = threadIdx.x >> 6, l = lane_id();
     const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
     if (r >= rays) return;
-    WaveScratch& sc = scratch[wv];
+    WaveScratchT<MS>& sc = scratch[wv];
+#if TDGP_RAY_ABL & 1
+    long long tph[6], t0_ = __builtin_readcyclecounter();
+#define TPH(i) { const long long t_ = __builtin_readcyclecounter(); tph[i] = t_ - t0_; t0_ = t_; }
+#else
+#define TPH(i)
+#endif
     for (int i = l; i < S; i += 64) { sc.z[i] = sdist[r * S + i]; sc.sig[i] = rgbs[(r * S + i) * 4 + 3]; }
     wave_sync();
+    TPH(0)
     float fT, wagg;
     int Wn = S;
     if (marcher == 0) march_classical_lds(sc.z, sc.sig, sc.w, S, flags, fT, wagg);
     else { march_mip_lds(sc.z, sc.sig, sc.w, S, flags, density_bias, fT, wagg); Wn = (flags & 1) ? S : S - 1; }
+    TPH(1)
     float* tkey = sc.col[0];
     importance_lds(sc, S, Wn, u_fine + r * N, N, marcher, [&](int j, float smp, int ind, int, int) {
         tkey[j] = s2t(smp, t_near, t_far);
@@ -307,6 +340,22 @@ __global__ __launch_bounds__(256) void importance_from_coarse_kernel(const float
         if (inds) inds[r * N + j] = ind;
     });
     wave_sync();
+    TPH(2)
+    if (N <= 64) {                  // one sample per lane: sort across the lanes, store coalesced
+        float key = l < N ? tkey[l] : INFINITY;
+        int idx = l;
+        wave_bitonic_sort(key, idx);
+        TPH(3)
+        if (l < N) {
+            tfine[r * N + l] = key;
+            if (fine_perm) fine_perm[r * N + l] = idx;
+        }
+        TPH(4)
+#if TDGP_RAY_ABL & 1
+        if (l == 0 && (r == 1000 || r == 200000)) printf("importance ray %lld: load %lld march %lld importance %lld sort %lld store %lld\n", (long long)r, tph[0], tph[1], tph[2], tph[3], tph[4]);
+#endif
+        return;
+    }
     int rank[MAXS / 64];
     stable_ranks(tkey, N, rank);
 #pragma unroll
@@ -346,23 +395,28 @@ __global__ __launch_bounds__(256) void unify_kernel(const float* __restrict__ d1
 }
 
 // fused: merge coarse + fine by depth (stable), march in t-space, composite.
+template <int MS>
 __global__ __launch_bounds__(256) void merge_composite_kernel(const float* __restrict__ rgbs1, const float* __restrict__ t1, int S1,
                                                              const float* __restrict__ rgbs2, const float* __restrict__ t2, int S2,
                                                              float* __restrict__ rgb, float* __restrict__ depth_o, float* __restrict__ wsum_o,
                                                              float* __restrict__ final_T, int32_t* __restrict__ perm, const int32_t* __restrict__ perm2, int64_t rays,
                                                              int marcher, int flags, float density_bias) {
-    __shared__ WaveScratch scratch[RAYS_PER_BLOCK];
+    __shared__ WaveScratchT<MS> scratch[RAYS_PER_BLOCK];
     const int wv = threadIdx.x >> 6, l = lane_id();
     const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
     if (r >= rays) return;
-    WaveScratch& sc = scratch[wv];
+    WaveScratchT<MS>& sc = scratch[wv];
     const int M = S1 + S2;
+#if TDGP_RAY_ABL & 1
+    long long tph[6], t0_ = __builtin_readcyclecounter();
+#endif
     // keys -> sc.cdf (scratch), ranks, scatter into sorted sc.z / sc.sig / sc.col
     for (int i = l; i < M; i += 64) sc.cdf[i] = i < S1 ? t1[r * S1 + i] : t2[r * S2 + (i - S1)];
     wave_sync();
     // both lists already ascending (stratified coarse samples; fine samples sorted by importance_from_coarse)?  Then the
     // stable merge position is the element's own index plus a binary search in the OTHER list; otherwise (arbitrary caller
     // data, or the ~1e-10-probability ulp inversion of s -> t) fall back to the brute-force stable rank.
+    TPH(0)
     bool bad = false;
     for (int i = l; i < M; i += 64)
         if (i + 1 < M && i + 1 != S1 && sc.cdf[i + 1] < sc.cdf[i]) bad = true;
@@ -388,6 +442,7 @@ __global__ __launch_bounds__(256) void merge_composite_kernel(const float* __res
             }
         }
     }
+    TPH(1)
 #pragma unroll
     for (int cc = 0; cc < MAXS / 64; cc++) {
         const int i = l + 64 * cc;
@@ -399,10 +454,12 @@ __global__ __launch_bounds__(256) void merge_composite_kernel(const float* __res
         if (perm) perm[r * M + pos] = i < S1 ? i : S1 + (perm2 ? perm2[r * S2 + (i - S1)] : i - S1);
     }
     wave_sync();
+    TPH(2)
     float fT, wagg;
     const int Mm = (marcher == 0) ? M : ((flags & 1) ? M : M - 1);
     if (marcher == 0) march_classical_lds(sc.z, sc.sig, sc.w, M, flags, fT, wagg);
     else march_mip_lds(sc.z, sc.sig, sc.w, M, flags, density_bias, fT, wagg);
+    TPH(3)
     double acc[4] = {0.0, 0.0, 0.0, 0.0}, wacc = 0.0;
     for (int i = l; i < Mm; i += 64) {
         const float wi = sc.w[i];
@@ -425,6 +482,10 @@ __global__ __launch_bounds__(256) void merge_composite_kernel(const float* __res
             out[c] = out[c] * 2.0f - 1.0f;
         }
     }
+    TPH(4)
+#if TDGP_RAY_ABL & 1
+    if (l == 0 && (r == 1000 || r == 200000)) printf("merge ray %lld: load %lld rank %lld gather %lld march %lld composite %lld\n", (long long)r, tph[0], tph[1], tph[2], tph[3], tph[4]);
+#endif
     if (l == 0) {
         rgb[r * 3 + 0] = out[0]; rgb[r * 3 + 1] = out[1]; rgb[r * 3 + 2] = out[2];
         depth_o[r] = out[3];
@@ -492,8 +553,12 @@ TDGP_API int tdgp_importance_from_coarse(const float* rgbs_coarse, const float* 
     TDGP_CHECK(S >= 4 && S <= MAXS && N >= 1, TDGP_EUNSUPPORTED, "importance_from_coarse: bad S=%d N=%d", S, N);
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "importance_from_coarse: unknown ray marcher %d", marcher);
     if (rays == 0) return TDGP_OK;
-    TDGP_LAUNCH("importance_from_coarse_kernel", importance_from_coarse_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, sdist, u_fine,
-                       tdist_fine, sdist_fine, inds, fine_perm, rays, S, N, marcher, flags, density_bias, t_near, t_far);
+    if (S <= 128 && N <= 128)
+        TDGP_LAUNCH("importance_from_coarse_kernel", importance_from_coarse_kernel<128>, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, sdist,
+                           u_fine, tdist_fine, sdist_fine, inds, fine_perm, rays, S, N, marcher, flags, density_bias, t_near, t_far);
+    else
+        TDGP_LAUNCH("importance_from_coarse_kernel", importance_from_coarse_kernel<MAXS>, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, sdist,
+                           u_fine, tdist_fine, sdist_fine, inds, fine_perm, rays, S, N, marcher, flags, density_bias, t_near, t_far);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }
@@ -505,8 +570,12 @@ TDGP_API int tdgp_merge_composite(const float* rgbs_coarse, const float* t_coars
     TDGP_CHECK(S1 >= 1 && S2 >= 1 && S1 + S2 <= MAXS, TDGP_EUNSUPPORTED, "merge_composite: S1+S2=%d > %d", S1 + S2, MAXS);
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "merge_composite: unknown ray marcher %d", marcher);
     if (rays == 0) return TDGP_OK;
-    TDGP_LAUNCH("merge_composite_kernel", merge_composite_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, t_coarse, S1, rgbs_fine,
-                       t_fine, S2, rgb, depth, wsum, final_T, perm, fine_perm, rays, marcher, flags, density_bias);
+    if (S1 + S2 <= 128)
+        TDGP_LAUNCH("merge_composite_kernel", merge_composite_kernel<128>, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, t_coarse, S1,
+                           rgbs_fine, t_fine, S2, rgb, depth, wsum, final_T, perm, fine_perm, rays, marcher, flags, density_bias);
+    else
+        TDGP_LAUNCH("merge_composite_kernel", merge_composite_kernel<MAXS>, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, t_coarse, S1,
+                           rgbs_fine, t_fine, S2, rgb, depth, wsum, final_T, perm, fine_perm, rays, marcher, flags, density_bias);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }
