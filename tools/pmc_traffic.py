@@ -16,6 +16,10 @@ import os
 import re
 
 
+# device function name -> the label the library's event timing (and bench.py) pools it under
+ALIAS = {'conv3_mfma_kernel': 'conv_mfma_kernel'}
+
+
 def table(path):
     rows = {}
     for line in open(path):
@@ -35,7 +39,8 @@ def main():
     fam = collections.defaultdict(lambda: dict(launches=0, fetch_bytes=0.0, write_bytes=0.0))
     for key, fn in (('fetch_bytes', 'pmc_FETCH_SIZE.md'), ('write_bytes', 'pmc_WRITE_SIZE.md')):
         for name, (calls, kib) in table(os.path.join(a.indir, fn)).items():
-            f = fam[name.split('<')[0].strip()]
+            base = name.split('<')[0].strip()
+            f = fam[ALIAS.get(base, base)]
             f[key] += calls * kib * 1024.0
             if key == 'fetch_bytes':
                 f['launches'] += calls
