@@ -8,6 +8,8 @@ The directory name starts with a digit, so import it with ``importlib.import_mod
   ops                  bias_act / upfirdn2d / conv2d_resample / modulated_conv2d with the reference's signatures
   renderer             camera, rays, tri-plane field, importance sampling, ray marchers
   generator            Generator / SynthesisNetwork / MappingNetwork with the reference's state-dict names
+  adaptors             DepthAdaptor / CameraAdaptor / Conv2dLayer
+  metrics              FeatureStats, Frechet distance, camera priors, generator feature loop (host side)
   compat               `src.*` module aliases so reference-style call sites resolve to this package
   distributed          batch-sharded multi-GPU generation (one process per GPU, RCCL all-gather of features)
 """
@@ -17,7 +19,7 @@ from .config import GeneratorConfig  # noqa: F401
 
 def __getattr__(name):
     # torch-dependent submodules are imported on first use
-    if name in ('_lib', 'ops', 'renderer', 'generator', 'compat', 'distributed', 'build'):
+    if name in ('_lib', 'ops', 'renderer', 'generator', 'adaptors', 'metrics', 'compat', 'distributed', 'build'):
         import importlib
         return importlib.import_module(f'{__name__}.{name}')
     raise AttributeError(name)

@@ -1,0 +1,212 @@
+"""FID-side aggregation and camera priors of the generator harness (host side).
+
+Reference: `src/metrics/metric_utils.py:104-169` (FeatureStats), `:288-320` (compute_feature_stats_for_generator),
+`src/metrics/frechet_inception_distance.py:20-39` (compute_fid), `src/training/rendering_utils.py:72-156` (camera priors).
+
+These are host-side pieces: fp64 mean / covariance accumulation in numpy, `scipy.linalg.sqrtm` for the Frechet distance, the
+camera prior samplers (torch RNG in the reference's draw order, scipy for the truncated normal).  The device work they drive is
+the generator forward (HIP) and ONE all-gather per feature block (`distributed.FeatureGatherer`, RCCL) instead of the
+reference's `world` sequential broadcasts.  The Inception detector itself is a URL-fetched TorchScript pickle
+(`frechet_inception_distance.py:22`) and is not reproduced: `detector` is any callable `uint8 images [N,3,H,W] -> features [N,F]`.
+"""
+import numpy as np
+import torch
+
+from .generator import TensorGroup
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# camera priors (configs/camera/base.yaml), rendering_utils.py:72-156
+# ----------------------------------------------------------------------------------------------------------------------
+def camera_base():
+    """configs/camera/base.yaml as a nested dict."""
+    return dict(
+        ray=dict(start=0.75, end=1.25),
+        fov=dict(dist='uniform', min=10.0, max=45.0),
+        origin=dict(radius=dict(dist='normal', mean=1.0, std=0.0),
+                    angles=dict(dist='truncnorm', yaw=dict(min=-1.57079633, max=1.57079633, mean=0.0, std=0.4),
+                                pitch=dict(min=0.392699082, max=2.74889357, mean=1.57, std=0.2))),
+        look_at=dict(radius=dict(dist='uniform', min=0.0, max=0.0),
+                     angles=dict(dist='spherical_uniform', yaw=dict(min=-3.14159265, max=3.14159265), pitch=dict(min=0.0, max=3.14159265))),
+        cube_scale=0.5)
+
+
+def _g(cfg, path):
+    for k in path.split('.'):
+        cfg = cfg[k] if isinstance(cfg, dict) else getattr(cfg, k)
+    return cfg
+
+
+def sample_truncnorm(mean, std, lo, hi, batch_size, device):
+    """rendering_utils.py:136-142 (scipy's sampler on numpy's global RNG, like the reference)."""
+    from scipy.stats import truncnorm
+    x = truncnorm.rvs(a=(lo - mean) / std, b=(hi - mean) / std, loc=mean, scale=std, size=(batch_size,))
+    return torch.from_numpy(x).float().to(device)
+
+
+def sample_camera_angles(cfg, batch_size, device):
+    """rendering_utils.py:72-109: yaw / pitch / roll = 0 from the configured distribution; pitch clamped to (1e-5, pi - 1e-5)."""
+    dist = _g(cfg, 'dist')
+    rand = lambda: torch.rand((batch_size, 1), device=device)         # noqa: E731
+    randn = lambda: torch.randn((batch_size, 1), device=device)       # noqa: E731
+    if dist == 'uniform':
+        yaw = rand() * (_g(cfg, 'yaw.max') - _g(cfg, 'yaw.min')) + _g(cfg, 'yaw.min')
+        pitch = rand() * (_g(cfg, 'pitch.max') - _g(cfg, 'pitch.min')) + _g(cfg, 'pitch.min')
+    elif dist == 'normal':
+        yaw = randn() * _g(cfg, 'yaw.std') + _g(cfg, 'yaw.mean')
+        pitch = randn() * _g(cfg, 'pitch.std') + _g(cfg, 'pitch.mean')
+    elif dist == 'truncnorm':
+        yaw = sample_truncnorm((_g(cfg, 'yaw.max') + _g(cfg, 'yaw.min')) * 0.5, _g(cfg, 'yaw.std'), _g(cfg, 'yaw.min'), _g(cfg, 'yaw.max'), batch_size, device).unsqueeze(1)
+        pitch = sample_truncnorm((_g(cfg, 'pitch.max') + _g(cfg, 'pitch.min')) * 0.5, _g(cfg, 'pitch.std'), _g(cfg, 'pitch.min'), _g(cfg, 'pitch.max'), batch_size,
+                                 device).unsqueeze(1)
+    elif dist == 'spherical_uniform':
+        yaw_range, yaw_center = _g(cfg, 'yaw.max') - _g(cfg, 'yaw.min'), 0.5 * (_g(cfg, 'yaw.max') + _g(cfg, 'yaw.min'))
+        pitch_range, pitch_center = _g(cfg, 'pitch.max') - _g(cfg, 'pitch.min'), 0.5 * (_g(cfg, 'pitch.max') + _g(cfg, 'pitch.min'))
+        yaw = (rand() - 0.5) * yaw_range + yaw_center
+        v = (rand() - 0.5) * pitch_range + pitch_center
+        v = torch.clamp(v / np.pi, 1e-5, 1 - 1e-5)
+        pitch = torch.arccos(1 - 2 * v)
+    else:
+        raise NotImplementedError(f'Unknown distribution: {dist}')
+    pitch = torch.clamp(pitch, 1e-5, np.pi - 1e-5)
+    return torch.cat([yaw, pitch, torch.zeros_like(yaw)], dim=1)
+
+
+def sample_bounded_scalar(cfg, batch_size, device):
+    """rendering_utils.py:122-132."""
+    dist = _g(cfg, 'dist')
+    if dist == 'normal':
+        assert _g(cfg, 'std') == 0.0, 'Scalar must be bounded'
+        return torch.empty(batch_size, device=device, dtype=torch.float32).fill_(_g(cfg, 'mean'))
+    if dist == 'truncnorm':
+        return sample_truncnorm(_g(cfg, 'mean'), _g(cfg, 'std'), _g(cfg, 'min'), _g(cfg, 'max'), batch_size, device)
+    if dist == 'uniform':
+        return torch.rand(batch_size, device=device) * (_g(cfg, 'max') - _g(cfg, 'min')) + _g(cfg, 'min')
+    raise NotImplementedError(f'Unknown distribution: {dist}')
+
+
+def sample_camera_params(cfg, batch_size, device='cpu', origin_angles=None):
+    """rendering_utils.py:146-152; draw order: origin angles, fov, radius, look-at (angles, radius)."""
+    origin_angles = sample_camera_angles(_g(cfg, 'origin.angles'), batch_size, device) if origin_angles is None else origin_angles
+    fov = sample_bounded_scalar(_g(cfg, 'fov'), batch_size, device)
+    radius = sample_bounded_scalar(_g(cfg, 'origin.radius'), batch_size, device)
+    la_angles = sample_camera_angles(_g(cfg, 'look_at.angles'), batch_size, device)
+    la_radius = sample_bounded_scalar(_g(cfg, 'look_at.radius'), batch_size, device)
+    look_at = torch.cat([la_angles[:, [0, 1]], la_radius.unsqueeze(1)], dim=1)
+    return TensorGroup(angles=origin_angles, fov=fov, radius=radius, look_at=look_at)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# feature statistics + Frechet distance
+# ----------------------------------------------------------------------------------------------------------------------
+class FeatureStats:
+    """metric_utils.py:104-169: running fp64 sum / outer-product sum of feature rows (and, optionally, the rows themselves)."""
+
+    def __init__(self, capture_all=False, capture_mean_cov=False, max_items=None):
+        self.capture_all, self.capture_mean_cov, self.max_items = capture_all, capture_mean_cov, max_items
+        self.num_items = 0
+        self.num_features = None
+        self.all_features = None
+        self.raw_mean = None
+        self.raw_cov = None
+
+    def set_num_features(self, num_features):
+        if self.num_features is not None:
+            assert num_features == self.num_features
+        else:
+            self.num_features = num_features
+            self.all_features = []
+            self.raw_mean = np.zeros([num_features], dtype=np.float64)
+            self.raw_cov = np.zeros([num_features, num_features], dtype=np.float64)
+
+    def is_full(self):
+        return (self.max_items is not None) and (self.num_items >= self.max_items)
+
+    def append(self, x):
+        x = np.asarray(x, dtype=np.float32)
+        assert x.ndim == 2
+        if (self.max_items is not None) and (self.num_items + x.shape[0] > self.max_items):
+            if self.num_items >= self.max_items:
+                return
+            x = x[:self.max_items - self.num_items]
+        self.set_num_features(x.shape[1])
+        self.num_items += x.shape[0]
+        if self.capture_all:
+            self.all_features.append(x)
+        if self.capture_mean_cov:
+            x64 = x.astype(np.float64)
+            self.raw_mean += x64.sum(axis=0)
+            self.raw_cov += x64.T @ x64
+
+    def append_torch(self, x, num_gpus=1, rank=0, gatherer=None):
+        """Rows of every rank, interleaved (item i of the gathered block came from rank i % world, :154).  `gatherer`: a
+        `distributed.FeatureGatherer` (one all-gather); created on demand when num_gpus > 1."""
+        assert isinstance(x, torch.Tensor) and x.ndim == 2
+        assert 0 <= rank < num_gpus
+        if num_gpus > 1:
+            if gatherer is None:
+                from .distributed import FeatureGatherer
+                gatherer = FeatureGatherer(side_stream=False)
+            x = gatherer.gather(x)
+        self.append(x.cpu().numpy())
+
+    def get_all(self):
+        assert self.capture_all
+        return np.concatenate(self.all_features, axis=0)
+
+    def get_mean_cov(self):
+        assert self.capture_mean_cov
+        mean = self.raw_mean / self.num_items
+        cov = self.raw_cov / self.num_items
+        return mean, cov - np.outer(mean, mean)
+
+    def save(self, path):
+        """Neutral container (npz) instead of the reference's pickle of __dict__."""
+        np.savez(path, capture_all=self.capture_all, capture_mean_cov=self.capture_mean_cov, max_items=-1 if self.max_items is None else self.max_items,
+                 num_items=self.num_items, raw_mean=self.raw_mean, raw_cov=self.raw_cov,
+                 all_features=self.get_all() if self.capture_all and self.all_features else np.zeros([0, self.num_features or 0], np.float32))
+
+    @staticmethod
+    def load(path):
+        d = np.load(path)
+        obj = FeatureStats(capture_all=bool(d['capture_all']), capture_mean_cov=bool(d['capture_mean_cov']), max_items=None if int(d['max_items']) < 0 else int(d['max_items']))
+        obj.set_num_features(int(d['raw_mean'].shape[0]))
+        obj.num_items = int(d['num_items'])
+        obj.raw_mean, obj.raw_cov = d['raw_mean'].astype(np.float64), d['raw_cov'].astype(np.float64)
+        if obj.capture_all and d['all_features'].size:
+            obj.all_features = [d['all_features']]
+        return obj
+
+
+def frechet_distance(mu_gen, sigma_gen, mu_real, sigma_real):
+    """frechet_inception_distance.py:35-38."""
+    import scipy.linalg
+    m = np.square(mu_gen - mu_real).sum()
+    s, _ = scipy.linalg.sqrtm(np.dot(sigma_gen, sigma_real), disp=False)
+    return float(np.real(m + np.trace(sigma_gen + sigma_real - s * 2)))
+
+
+def compute_feature_stats_for_generator(G, detector, max_items, batch_size=64, batch_gen=4, camera_cfg=None, c_sampler=None, num_gpus=1, rank=0,
+                                        device='cuda', gatherer=None, G_kwargs=None, **stats_kwargs):
+    """metric_utils.py:288-320: generate `batch_size` images per iteration in chunks of `batch_gen`, run the detector, gather the
+    feature block across ranks, accumulate.  `c_sampler(batch) -> c [batch, c_dim]` (the reference draws dataset labels);
+    cameras come from the prior (`camera_cfg`, default camera/base.yaml) and pass through G's camera adaptor when it has one."""
+    assert batch_size % batch_gen == 0
+    camera_cfg = camera_base() if camera_cfg is None else camera_cfg
+    G_kwargs = {} if G_kwargs is None else G_kwargs
+    stats = FeatureStats(max_items=max_items, **stats_kwargs)
+    while not stats.is_full():
+        images = []
+        for _ in range(batch_size // batch_gen):
+            z = torch.randn([batch_gen, G.z_dim], device=device)
+            c = c_sampler(batch_gen).to(device) if c_sampler is not None else torch.zeros([batch_gen, G.c_dim], device=device)
+            camera_params = sample_camera_params(camera_cfg, batch_gen, device)
+            if getattr(G.synthesis, 'camera_adaptor', None) is not None:
+                camera_params = G.synthesis.camera_adaptor(camera_params, z, c)
+            img = G(z, c, camera_params, **G_kwargs)
+            images.append((img * 127.5 + 128).clamp(0, 255).to(torch.uint8))
+        images = torch.cat(images)
+        if images.shape[1] == 1:
+            images = images.repeat([1, 3, 1, 1])
+        stats.append_torch(detector(images), num_gpus=num_gpus, rank=rank, gatherer=gatherer)
+    return stats

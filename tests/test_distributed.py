@@ -5,6 +5,7 @@ import os
 import socket
 
 import pytest
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -40,6 +41,12 @@ def _worker(rank, world, port, q):
     # async form returns the same block
     g.gather_async(feats)
     ok = ok and torch.equal(g.wait(), ref)
+    # FeatureStats.append_torch (metric_utils.py:145-155): every rank accumulates the same interleaved block, max_items truncates
+    M = importlib.import_module('3dgp_amd').metrics
+    st = M.FeatureStats(capture_all=True, capture_mean_cov=True, max_items=13)
+    st.append_torch(feats, num_gpus=world, rank=rank, gatherer=g)
+    st.append_torch(feats + 100, num_gpus=world, rank=rank)            # gatherer built on demand; only 3 of these 10 rows fit
+    ok = ok and st.num_items == 13 and st.is_full() and bool((st.get_all() == torch.cat([ref, ref[:3] + 100]).numpy()).all())
     q.put((rank, bool(ok), D.rank_seed(3, rank, world)))
     dist.barrier()
     dist.destroy_process_group()

@@ -457,6 +457,30 @@ def gen_adaptors():
     save('adaptors', **arrays)
 
 
+def gen_metrics():
+    """FeatureStats accumulation (metric_utils.py:104-169) and the camera prior sampler (rendering_utils.py:146-152)."""
+    from src.metrics.metric_utils import FeatureStats
+    arrays = {}
+    g = np.random.RandomState(61)
+    feats = [g.randn(70, 16).astype(np.float32) * 3 + 1 for _ in range(3)]
+    st = FeatureStats(capture_all=True, capture_mean_cov=True, max_items=200)
+    for f in feats:
+        st.append(f)
+    mean, cov = st.get_mean_cov()
+    arrays.update(fs_feats=np.stack(feats), fs_mean=mean, fs_cov=cov, fs_num_items=np.array(st.num_items), fs_all=st.get_all())
+    cam = tdgp.metrics.camera_base()
+    to_easy = lambda d: EasyDict({k: to_easy(v) if isinstance(v, dict) else v for k, v in d.items()})      # noqa: E731
+    for tag, mod in (('base', {}), ('uniform', dict(origin=dict(radius=cam['origin']['radius'], angles=dict(dist='uniform', yaw=dict(min=-1.57, max=1.57),
+                                                                                                  pitch=dict(min=0.785398163, max=2.35619449))),
+                                                    look_at=dict(radius=dict(dist='uniform', min=0.0, max=0.2), angles=cam['look_at']['angles'])))):
+        cfg = {**cam, **mod}
+        torch.manual_seed(62)
+        np.random.seed(62)
+        cp = ref_ru.sample_camera_params(to_easy(cfg), 6, 'cpu')
+        arrays.update({f'cam_{tag}_{k}': npy(cp[k]) for k in ('angles', 'fov', 'radius', 'look_at')})
+    save('metrics', **arrays)
+
+
 def main():
     torch.set_num_threads(8)
     if len(sys.argv) > 1:                      # regenerate selected files only: python tools/gen_goldens.py adaptors
@@ -464,6 +488,7 @@ def main():
             globals()['gen_' + name]()
         return
     gen_adaptors()
+    gen_metrics()
     gen_bias_act()
     gen_upfirdn2d()
     gen_modconv()
