@@ -165,3 +165,36 @@ def synthetic_inputs(cfg: GeneratorConfig, batch, seed=0):
     u_fine = g.rand(batch * R, S).astype(np.float32)
     camera = dict(angles=angles, fov=fov, radius=radius, look_at=la.astype(np.float32))
     return dict(z=z, c=c, camera=camera, u_coarse=u_coarse, u_fine=u_fine)
+
+
+def config_from_json(d):
+    """The dict written by tools/export_reference_checkpoint.py (or GeneratorConfig.to_dict()) -> GeneratorConfig."""
+    from .config import CameraAdaptorConfig, CameraRanges, DepthAdaptorConfig
+    d = dict(d)
+    da, ca = d.pop('depth_adaptor', None), d.pop('camera_adaptor', None)
+    cfg = GeneratorConfig(**d)
+    if da is not None:
+        cfg.depth_adaptor = DepthAdaptorConfig(**da)
+    if ca is not None:
+        ca = dict(ca)
+        cam = ca.pop('camera', None)
+        cfg.camera_adaptor = CameraAdaptorConfig(**ca)
+        if cam is not None:
+            cfg.camera_adaptor.camera = CameraRanges(**{k: tuple(v) for k, v in cam.items()})
+    return cfg
+
+
+def load_exported(path):
+    """(GeneratorConfig, state dict) from the directory written by tools/export_reference_checkpoint.py.  Tensors the forward
+    does not read (optimizer state is never there; `*.w_avg`-like buffers are) are kept; `Generator.load_numpy_state_dict` is
+    strict about the keys of `state_dict_spec(cfg)` only."""
+    import json
+    import os
+    cfg = config_from_json(json.load(open(os.path.join(path, 'generator.json'))))
+    with np.load(os.path.join(path, 'generator.npz')) as z:
+        sd = OrderedDict((k, z[k]) for k in z.files)
+    spec = state_dict_spec(cfg)
+    missing = [k for k in spec if k not in sd]
+    if missing:
+        raise KeyError(f'exported checkpoint lacks {len(missing)} tensors the generator forward reads, e.g. {missing[:3]}')
+    return cfg, OrderedDict((k, sd[k]) for k in spec)
