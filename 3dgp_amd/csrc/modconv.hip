@@ -750,20 +750,20 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
 
 // ---- x2 layers: stride-2 transposed 3x3 convolution (conv2d_resample.py:108-125, unflipped weights) --------------------
 //     Z[2i+a, 2j+e] += w[a,e] * x[i,j]
-// as ONE implicit GEMM over a LINEARISED input grid.  Grid point v' = m*(W+1) + n, m in [0,H], n in [0,W], with x := 0
-// on column W and row H.  The four output parities (py,px) of grid point (m,n) are
+// as ONE implicit GEMM over a LINEARISED input grid.  Grid point v' = m*G1 + n, m in [0,H], n in [0,G1), G1 = W+2, with x := 0
+// on columns >= W and row H (one zero column would do; two make the Z row pitch a multiple of 4 floats for the FIR's 16-B loads).  The four output parities (py,px) of grid point (m,n) are
 //     Z[2m+py, 2n+px] = sum_{a = py (mod 2), e = px (mod 2)} w[a,e] * x[m - (a==2), n - (e==2)]
-// and in linear space the four distinct taps are the offsets {0, -1, -(W+1), -(W+2)}: the zero column doubles as the
-// left AND right padding (n-1 at n = 0 wraps onto column W of the previous row), the zero row separates samples.  So
+// and in linear space the four distinct taps are the offsets {0, -1, -G1, -G1-1}: the zero columns double as the
+// left AND right padding (n-1 at n = 0 wraps onto the last column of the previous row), the zero row separates samples.  So
 //   * a block tile is BN CONSECUTIVE grid points -- no 2-D tile edges, no "+1" column of wasted tiles (the old four-phase
 //     launch lost 11-50 % of its lanes to the (W+1)-wide phase grids), no tap masks in the MFMA loop;
 //   * the activation patch is two runs of BN+1 positions (the dy = -1 and dy = 0 rows);
 //   * all 9 taps of a channel pair are multiplied in one pass: 9 A fragments x 4 B fragments feed the 4 parity
 //     accumulators of each 32x32 tile (taps per parity 4/2/2/1), so x is staged once instead of once per phase;
 //   * the epilogue interleaves the px = 0/1 accumulators through LDS and writes Z as dense 16-B-per-lane rows.
-// Z layout (workspace): [ksplit][B][Cout][py][2*GS], entry 2*v' + px; GS = (H+1)*(W+1) rounded up to 32 so a 32-point
+// Z layout (workspace): [ksplit][B][Cout][py][2*GS], entry 2*v' + px; GS = (H+1)*G1 rounded up to 32 so a 32-point
 // subtile never straddles samples and every row segment stays 16-B aligned.  Seen as an image, parity plane py holds Z rows
-// 2m+py with row pitch 2(W+1); the pad column 2W+1 and the pad row 2H+1 come out as exact zeros.
+// 2m+py with row pitch 2*G1; the pad columns 2W+1.. and the pad row 2H+1 come out as exact zeros.
 struct UpParams {
     const float* x; const float* wp; const float* styles; float* z;
     int B, Cin, Cout, CoutP, H, W, G1, GS, ksplit;
@@ -1164,20 +1164,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // FIR (4x4, pad 1, gain folded into the taps) + demod + noise + bias + activation on the transposed-conv intermediate
 // (upconv_mfma_kernel's parity-planar Z, split-K slices summed on the fly) -> y [B,C,2H,2W].
 // (conv2d_resample.py:126 + networks_stylegan2.py:86-87,144)
-// Block = one 16x64 output tile of one (b,c) plane: the (16+3) x (64+4) input window is staged in LDS with aligned 8-byte
-// loads, each thread then produces 4 consecutive outputs from a 4x7 window.  HBM traffic = Z read once + y written once.
+// Block = one 32x64 output tile of one (b,c) plane: the (32+3) x (64+8) input window is staged in LDS with aligned 16-byte
+// loads, each thread then produces 2 x 4 consecutive outputs from 4x7 windows.  HBM traffic = Z read once + y written once.
 // -------------------------------------------------------------------------------------------------
 struct FirParams {
     const float* z; const float* dcoef; const float* noise; const float* bias; float* y;
     int64_t noise_bstride, zslice;
     float fir[16];
-    int B, C, ZROWS, P2, GS2, ksplit, OH, OW;      // ZROWS = 2H+2 rows of pitch P2 = 2(W+1), alternating between the parity planes
+    int B, C, ZROWS, P2, GS2, ksplit, OH, OW;      // ZROWS = 2H+2 rows of pitch P2 = 2*G1 (a multiple of 4), alternating between the parity planes
     int act; float alpha, gain, clamp;
 };
 
 constexpr int FIR_TH = 32, FIR_TW = 64;
 __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
-    constexpr int ZP = FIR_TW + 4;                  // window columns ox0-2 .. ox0+65
+    constexpr int ZP = FIR_TW + 8;                  // window columns ox0-4 .. ox0+67, fetched as aligned 16-B vectors (P2 % 4 == 0)
     __shared__ __attribute__((aligned(16))) float zt[(FIR_TH + 3) * ZP];
     const int tilesX = (p.OW + FIR_TW - 1) / FIR_TW, tilesY = (p.OH + FIR_TH - 1) / FIR_TH;
     const int64_t ntiles = (int64_t)p.B * p.C * tilesY * tilesX;
@@ -1191,22 +1191,22 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
         const float* zp = p.z + ((int64_t)b * p.C + c) * 2 * p.GS2;
         const int nrows = min(FIR_TH, p.OH - oy0) + 3;
         __syncthreads();
-        for (int i = threadIdx.x; i < nrows * (ZP / 2); i += 256) {
-            const int ry = i / (ZP / 2), j = i % (ZP / 2);
-            const int zy = oy0 - 1 + ry, zx = ox0 - 2 + 2 * j;
-            float2 v = make_float2(0.f, 0.f);
+        for (int i = threadIdx.x; i < nrows * (ZP / 4); i += 256) {
+            const int ry = i / (ZP / 4), j = i % (ZP / 4);
+            const int zy = oy0 - 1 + ry, zx = ox0 - 4 + 4 * j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (zy >= 0 && zy < p.ZROWS && zx >= 0 && zx < p.P2) {
                 const float* q = zp + (zy & 1) * p.GS2 + (zy >> 1) * p.P2 + zx;
-                v = *(const float2*)q;
-                for (int k0 = 1; k0 < p.ksplit; k0 += 8) {      // split-K slices, summed in order (deterministic); 8 loads in flight
-                    float2 w[8];
+                v = *(const float4*)q;
+                for (int k0 = 1; k0 < p.ksplit; k0 += 4) {      // split-K slices, summed in order (deterministic); 4 loads in flight
+                    float4 w[4];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) w[k] = (k0 + k < p.ksplit) ? *(const float2*)(q + (k0 + k) * p.zslice) : make_float2(0.f, 0.f);
+                    for (int k = 0; k < 4; k++) w[k] = (k0 + k < p.ksplit) ? *(const float4*)(q + (k0 + k) * p.zslice) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int k = 0; k < 8; k++) { v.x += w[k].x; v.y += w[k].y; }
+                    for (int k = 0; k < 4; k++) { v.x += w[k].x; v.y += w[k].y; v.z += w[k].z; v.w += w[k].w; }
                 }
             }
-            *(float2*)&zt[ry * ZP + 2 * j] = v;
+            *(float4*)&zt[ry * ZP + 4 * j] = v;
         }
         __syncthreads();
         const int lx = (threadIdx.x & 15) * 4;
@@ -1222,7 +1222,7 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
                 for (int ky = 0; ky < 4; ky++) {
                     float win[7];
 #pragma unroll
-                    for (int j = 0; j < 7; j++) win[j] = zt[(ly + ky) * ZP + lx + j + 1];
+                    for (int j = 0; j < 7; j++) win[j] = zt[(ly + ky) * ZP + lx + j + 3];
 #pragma unroll
                     for (int o = 0; o < 4; o++)
 #pragma unroll
@@ -1394,8 +1394,8 @@ inline UpPlan up_plan(int B, int Cin, int Cout, int H, int W) {
     UpPlan u;
     u.cfg = Cout > 64 ? 0 : 1;
     u.BM = Cout > 64 ? 128 : 64; u.BN = Cout > 64 ? 64 : 128;
-    u.G1 = W + 1;
-    u.GS = round_up((H + 1) * (W + 1), 32);
+    u.G1 = W + 2;                  // grid pitch: W + 1 would do (one zero column); W + 2 makes the Z row pitch 2*G1 a multiple of 4 floats -> 16-B FIR loads
+    u.GS = round_up((H + 1) * (W + 2), 32);
     u.zslice = (int64_t)B * Cout * 4 * u.GS;
     const int blocks = cdiv(B * u.GS, u.BN) * cdiv(Cout, u.BM);
     const int niter = cdiv(Cin, 4);
@@ -1617,7 +1617,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         FirParams f;
         f.z = z; f.dcoef = dco; f.noise = noise; f.noise_bstride = noise_bstride; f.bias = bias; f.y = y;
         for (int i = 0; i < 16; i++) f.fir[i] = e.fir[i];
-        f.B = B; f.C = Cout; f.ZROWS = 2 * H + 2; f.P2 = 2 * (W + 1); f.GS2 = 2 * pl.GS; f.ksplit = pl.ksplit; f.zslice = pl.zslice;
+        f.B = B; f.C = Cout; f.ZROWS = 2 * H + 2; f.P2 = 2 * pl.G1; f.GS2 = 2 * pl.GS; f.ksplit = pl.ksplit; f.zslice = pl.zslice;
         f.OH = 2 * H; f.OW = 2 * W;
         f.act = act; f.alpha = alpha; f.gain = gain; f.clamp = clamp;
         const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, FIR_TH) * cdiv(f.OW, FIR_TW);
