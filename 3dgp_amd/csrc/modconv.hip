@@ -572,12 +572,21 @@ struct Conv3Params {
     uint32_t x_bytes, wp_bytes, st_bytes;       // sizes for the buffer descriptors
 };
 
+#ifndef TDGP_C3_ABL
+#define TDGP_C3_ABL 0      // 16: per-phase cycle counts of one wave, printed (timing experiments only)
+#endif
 template <int KS, int MTW, int NTW, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
     constexpr int R = KS / 2, T = KS * KS;
     constexpr int BM = 32 * MTW * WM, NT = NTW * WN, PR = NT + 2 * R, PC = 32 + 2 * R, PSZ = PR * PC;
     constexpr int AS_SZ = T * BM * 4, XS_SZ = PSZ * 4, BUF_SZ = AS_SZ + XS_SZ;          // floats
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#if TDGP_C3_ABL & 16
+    long long tq[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define TQ(i) { const long long tn_ = __builtin_readcyclecounter(); tq[i] += tn_ - tprev; tprev = tn_; }
+#else
+#define TQ(i)
+#endif
     float* side = smem + 2 * BUF_SZ;                                // [1 + NSB][BM]: bias, demod coefficients of the tile's samples
 
     const int H1 = p.H + R;
@@ -636,7 +645,10 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
     const int it0 = ks * it_per, it1 = min(niter, it0 + it_per);
 
     constexpr int NA = (T * BM + 255) / 256;
-    float4 a_reg[NA], x_reg[NPOS], s_reg[NPOS];
+    // Staging registers: weights one K iteration ahead (they come from L2), activations TWO iterations ahead in alternating
+    // register sets -- at 64 channels the activation tensor streams from HBM, and with one iteration (4600 cycles) of flight
+    // time the LDS write waited ~8000 cycles per iteration for its loads (per-phase cycle counts, TDGP_C3_ABL=16).
+    float4 a_reg[NA], x_reg[2][NPOS], s_reg[2][NPOS];
     uint32_t a_vo[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
@@ -649,46 +661,40 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
     }
     const uint32_t a_gstride4 = (uint32_t)(T * p.CoutP) * 16u;
 
-    auto load_stage = [&](int it) {
+    auto load_a = [&](int it) {
         const uint32_t a_so = (uint32_t)it * a_gstride4;
 #pragma unroll
         for (int i = 0; i < NA; i++) a_reg[i] = buf_load4(rw, a_vo[i], a_so);
+    };
+    auto load_x = [&](int it, int set) {
         const uint32_t c0 = (uint32_t)it * 4u;
 #pragma unroll
         for (int k = 0; k < NPOS; k++) {
             // channels beyond Cin (Cin % 4 != 0 only) read a neighbouring channel or 0; their packed weights are 0
-            x_reg[k] = make_float4(buf_load1(rx, pos_xo[k], c0 * chw4), buf_load1(rx, pos_xo[k], (c0 + 1) * chw4), buf_load1(rx, pos_xo[k], (c0 + 2) * chw4),
-                                   buf_load1(rx, pos_xo[k], (c0 + 3) * chw4));
+            x_reg[set][k] = make_float4(buf_load1(rx, pos_xo[k], c0 * chw4), buf_load1(rx, pos_xo[k], (c0 + 1) * chw4), buf_load1(rx, pos_xo[k], (c0 + 2) * chw4),
+                                        buf_load1(rx, pos_xo[k], (c0 + 3) * chw4));
             if (p.styles) {
-                if (cin4) s_reg[k] = buf_load4(rs, pos_so[k], c0 * 4u);
-                else s_reg[k] = make_float4(buf_load1(rs, pos_so[k], c0 * 4u), buf_load1(rs, pos_so[k], c0 * 4u + 4u), buf_load1(rs, pos_so[k], c0 * 4u + 8u),
-                                            buf_load1(rs, pos_so[k], c0 * 4u + 12u));
+                if (cin4) s_reg[set][k] = buf_load4(rs, pos_so[k], c0 * 4u);
+                else s_reg[set][k] = make_float4(buf_load1(rs, pos_so[k], c0 * 4u), buf_load1(rs, pos_so[k], c0 * 4u + 4u), buf_load1(rs, pos_so[k], c0 * 4u + 8u),
+                                                 buf_load1(rs, pos_so[k], c0 * 4u + 12u));
             }
         }
     };
-    auto store_stage = [&](float* As, float* Xs) {
+    auto store_stage = [&](int set, float* As, float* Xs) {
 #pragma unroll
         for (int i = 0; i < NA; i++)
             if (tid + i * 256 < T * BM) *(float4*)(As + (tid + i * 256) * 4) = a_reg[i];
 #pragma unroll
         for (int k = 0; k < NPOS; k++)
             if (tid + k * 256 < PSZ) {       // modulation rides on the staging
-                if (p.styles) *(float4*)(Xs + (tid + k * 256) * 4) = make_float4(x_reg[k].x * s_reg[k].x, x_reg[k].y * s_reg[k].y, x_reg[k].z * s_reg[k].z, x_reg[k].w * s_reg[k].w);
-                else *(float4*)(Xs + (tid + k * 256) * 4) = x_reg[k];
+                if (p.styles) *(float4*)(Xs + (tid + k * 256) * 4) = make_float4(x_reg[set][k].x * s_reg[set][k].x, x_reg[set][k].y * s_reg[set][k].y,
+                                                                                x_reg[set][k].z * s_reg[set][k].z, x_reg[set][k].w * s_reg[set][k].w);
+                else *(float4*)(Xs + (tid + k * 256) * 4) = x_reg[set][k];
             }
     };
-
-    if (it0 < it1) {
-        load_stage(it0);
-        store_stage(smem, smem + AS_SZ);
-    }
-    __syncthreads();
     const int a_lane = ((wm * MTW) * 32 + l32) * 4 + 2 * half;                   // + (t*BM + m*32)*4
     const int b_lane = (((wn * NTW) + R) * PC + l32 + R) * 4 + 2 * half;        // centre tap of subtile 0; + (n*PC + dy*PC + dx)*4
-    int cur = 0;
-    for (int it = it0; it < it1; it++) {
-        const bool more = it + 1 < it1;
-        if (more) load_stage(it + 1);
+    auto mma = [&](int cur) {
         const float* As = smem + cur * BUF_SZ + a_lane;
         const float* Xs = smem + cur * BUF_SZ + AS_SZ + b_lane;
         f32x2 fa[2][MTW], fb[2][NTW];
@@ -712,9 +718,37 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
 #pragma unroll
                     for (int n = 0; n < NTW; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][m][kk], fb[cb][n][kk], acc[m][n], 0, 0, 0);
         }
-        if (more) store_stage(smem + (cur ^ 1) * BUF_SZ, smem + (cur ^ 1) * BUF_SZ + AS_SZ);
+    };
+
+    float* const L0 = smem;
+    float* const L1 = smem + BUF_SZ;
+    if (it0 < it1) { load_a(it0); load_x(it0, 0); }
+    if (it0 + 1 < it1) load_x(it0 + 1, 1);
+    if (it0 < it1) store_stage(0, L0, L0 + AS_SZ);
+    __syncthreads();
+    TQ(0)
+    for (int it = it0; it < it1; it += 2) {
+        // even half: L0 holds iteration `it`; x set 1 = iteration it+1 (in flight since the previous half)
+        if (it + 1 < it1) load_a(it + 1);
+        if (it + 2 < it1) load_x(it + 2, 0);
+        TQ(1)
+        mma(0);
+        TQ(2)
+        if (it + 1 < it1) store_stage(1, L1, L1 + AS_SZ);
+        TQ(3)
         __syncthreads();
-        cur ^= 1;
+        TQ(4)
+        if (it + 1 >= it1) break;
+        // odd half: L1 holds iteration it+1; x set 0 = iteration it+2
+        if (it + 2 < it1) load_a(it + 2);
+        if (it + 3 < it1) load_x(it + 3, 1);
+        TQ(1)
+        mma(1);
+        TQ(2)
+        if (it + 2 < it1) store_stage(0, L0, L0 + AS_SZ);
+        TQ(3)
+        __syncthreads();
+        TQ(4)
     }
 
     // ---- epilogue: accumulators -> per-wave LDS tile -> epilogue_tile() (16-B stores, fused demod/noise/bias/act) ------------
@@ -746,6 +780,12 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    TQ(5)
+#if TDGP_C3_ABL & 16
+    if (tid == 0 && (blockIdx.x == 3 || blockIdx.x == 900) && blockIdx.y == 0 && blockIdx.z == 0)
+        printf("conv3 blk %d iters %d: prologue %lld load-issue %lld mma %lld store %lld barrier %lld epilogue %lld\n", (int)blockIdx.x, it1 - it0, tq[0], tq[1], tq[2], tq[3], tq[4], tq[5]);
+#endif
+#undef TQ
 }
 
 // ---- x2 layers: stride-2 transposed 3x3 convolution (conv2d_resample.py:108-125, unflipped weights) --------------------
