@@ -574,3 +574,24 @@ def test_adaptors(tdgp, oracle, idx):
             render_opts=dict(concat_depth=True))
     assert cat.shape == (2, 4, cfg.img_resolution, cfg.img_resolution)
     assert torch.equal(cat[:, :3], out.img) and torch.equal(cat[:, 3:], out.depth_adapted)
+
+
+def test_generator_feature_loop(tdgp):
+    """metrics.compute_feature_stats_for_generator (metric_utils.py:288-320) end to end on the HIP generator: priors -> camera
+    adaptor -> G.forward -> uint8 -> detector -> FeatureStats; deterministic under a fixed seed, max_items respected."""
+    tag, cfg = tdgp.config.configs_adaptor_goldens()[0]
+    G = _gen(tdgp, cfg, 51)
+    det = lambda im: tdgp.distributed.stand_in_features(im, 64)        # noqa: E731
+
+    def run():
+        torch.manual_seed(7)
+        np.random.seed(7)
+        return tdgp.metrics.compute_feature_stats_for_generator(G, det, max_items=10, batch_size=8, batch_gen=4, device=DEV, capture_all=True, capture_mean_cov=True,
+                                                                G_kwargs=dict(noise_mode='const'))
+    a, b = run(), run()
+    assert a.num_items == 10 and a.is_full() and a.get_all().shape == (10, 64)
+    np.testing.assert_array_equal(a.get_all(), b.get_all())
+    mean, cov = a.get_mean_cov()
+    assert np.isfinite(mean).all() and np.isfinite(cov).all()
+    # rank-deficient covariance (10 samples, 64 features): sqrtm is only accurate to ~sqrt(eps) * |cov| there
+    assert abs(tdgp.metrics.frechet_distance(mean, cov, mean, cov)) < 1e-4 * max(1.0, float(np.trace(cov)))
