@@ -10,6 +10,7 @@ The directory name starts with a digit, so import it with ``importlib.import_mod
   generator            Generator / SynthesisNetwork / MappingNetwork with the reference's state-dict names
   adaptors             DepthAdaptor / CameraAdaptor / Conv2dLayer
   metrics              FeatureStats, Frechet distance, camera priors, generator feature loop (host side)
+  inference            generate / generate_trajectory / camera trajectories
   compat               `src.*` module aliases so reference-style call sites resolve to this package
   distributed          batch-sharded multi-GPU generation (one process per GPU, RCCL all-gather of features)
 """
@@ -19,7 +20,15 @@ from .config import GeneratorConfig  # noqa: F401
 
 def __getattr__(name):
     # torch-dependent submodules are imported on first use
-    if name in ('_lib', 'ops', 'renderer', 'generator', 'adaptors', 'metrics', 'compat', 'distributed', 'build'):
+    if name in ('_lib', 'ops', 'renderer', 'generator', 'adaptors', 'metrics', 'inference', 'compat', 'distributed', 'build'):
         import importlib
         return importlib.import_module(f'{__name__}.{name}')
     raise AttributeError(name)
+
+
+def inference_golden_trajectories():
+    """The trajectory configurations behind tests/golden/trajectories.npz (configs/scripts/inference.yaml style entries)."""
+    return dict(point=dict(name='point', num_frames=1, yaw_offset=0.3, pitch_offset=-0.1, fov_offset=2.0),
+                front_circle=dict(name='front_circle', num_frames=8, yaw_diff=0.4, pitch_diff=0.2, fov_diff=1.0),
+                points=dict(name='points', yaw_offsets=[-0.5, 0.0, 0.5], pitch_offset=0.1),
+                line=dict(name='line', num_frames=5, yaw_start=-0.6, yaw_end=0.6, pitch_start=1.2, pitch_end=1.8, fov=None, fov_offset=1.5))

@@ -26,11 +26,46 @@ from . import renderer as _renderer
 
 
 class TensorGroup(dict):
-    """Minimal stand-in for dnnlib.TensorGroup (attribute access to a dict of tensors)."""
-    __getattr__ = dict.__getitem__
+    """Counterpart of dnnlib.TensorGroup (src/dnnlib/util.py:66-170): a dict of tensors aligned on their first axis, with
+    attribute access.  Anything that is not a key is forwarded to every member -- `g[2:5]`, `g.cpu()`, `g.clamp(-1, 1) * 0.5 + 0.5`,
+    `g.repeat_interleave(4, dim=0)`, `g.mean(dim=0, keepdim=True)` -- so the harness code reads like the reference's."""
+
+    def __getattr__(self, name):
+        if name in self:
+            return self[name]
+        if not name.startswith('_') and hasattr(torch.Tensor, name):
+            return lambda *a, **k: TensorGroup(**{key: getattr(v, name)(*a, **k) for key, v in self.items()})
+        raise AttributeError(name)
 
     def __setattr__(self, k, v):
         self[k] = v
+
+    def __getitem__(self, item):
+        if isinstance(item, str):
+            return dict.__getitem__(self, item)
+        return TensorGroup(**{k: v[item] for k, v in self.items()})
+
+    def __len__(self):
+        return len(next(iter(self.values()))) if dict.__len__(self) else 0
+
+    def _zip(self, other, fn):
+        if isinstance(other, TensorGroup):
+            return TensorGroup(**{k: fn(v, other[k]) for k, v in self.items()})
+        return TensorGroup(**{k: fn(v, other) for k, v in self.items()})
+
+    def __add__(self, o): return self._zip(o, lambda a, b: a + b)
+    def __radd__(self, o): return self._zip(o, lambda a, b: b + a)
+    def __sub__(self, o): return self._zip(o, lambda a, b: a - b)
+    def __mul__(self, o): return self._zip(o, lambda a, b: a * b)
+    def __rmul__(self, o): return self._zip(o, lambda a, b: b * a)
+    def __truediv__(self, o): return self._zip(o, lambda a, b: a / b)
+
+    def reshape_each(self, shape_fn):
+        return TensorGroup(**{k: v.reshape(*shape_fn(v)) for k, v in self.items()})
+
+    @staticmethod
+    def cat(groups, dim=0):
+        return TensorGroup(**{k: torch.cat([g[k] for g in groups], dim=dim) for k in groups[0].keys()})
 
 
 def normalize_2nd_moment(x, dim=1, eps=1e-8):

@@ -595,3 +595,29 @@ def test_generator_feature_loop(tdgp):
     assert np.isfinite(mean).all() and np.isfinite(cov).all()
     # rank-deficient covariance (10 samples, 64 features): sqrtm is only accurate to ~sqrt(eps) * |cov| there
     assert abs(tdgp.metrics.frechet_distance(mean, cov, mean, cov)) < 1e-4 * max(1.0, float(np.trace(cov)))
+
+
+def test_generate_trajectory(tdgp):
+    """inference.generate / generate_trajectory (inference_utils.py:88-126): chunked G.synthesis calls with noise_mode='const',
+    [0,1] mapping, depth normalisation, [num_cameras, num_samples, ...] layout."""
+    cfg = tdgp.config.config_tiny()
+    G = _gen(tdgp, cfg, 21)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=2, seed=9)
+    ws = G.mapping(T(inp['z']), T(inp['c']))
+    canon = tdgp.generator.TensorGroup(**{k: T(v) for k, v in inp['camera'].items()})
+    cams = tdgp.inference.generate_camera_trajectory(tdgp.inference_golden_trajectories()['points'], canon)      # 3 cameras per sample
+    R, S = cfg.img_resolution ** 2, cfg.num_ray_steps
+    u1, u2 = torch.rand(6, R, S, device=DEV), torch.rand(6 * R, S, device=DEV)
+    # explicit RNG tensors only make sense for one chunk: generate everything in one G.synthesis call ...
+    frames = tdgp.inference.generate_trajectory(G, ws, cams, batch_size=6, render_opts=dict(return_depth=True), u_coarse=u1, u_fine=u2)
+    assert frames.img.shape == (3, 2, 3, 16, 16) and frames.depth.shape == (3, 2, 1, 16, 16)
+    ref = G.synthesis(ws.repeat_interleave(3, dim=0), camera_params=cams.to(dtype=torch.float32, device=DEV), noise_mode='const',
+                      render_opts=dict(return_depth=True), u_coarse=u1, u_fine=u2)
+    img = (ref.img.clamp(-1, 1).cpu() * 0.5 + 0.5).reshape(2, 3, 3, 16, 16).permute(1, 0, 2, 3, 4)
+    dep = (((ref.depth - 1.0) / 0.5 * 2.0).clamp(-1, 1).cpu() * 0.5 + 0.5).reshape(2, 3, 1, 16, 16).permute(1, 0, 2, 3, 4)
+    assert torch.equal(frames.img, img) and torch.allclose(frames.depth, dep, atol=1e-6)
+    # ... and the chunked form (device RNG) has the same shape and range
+    chunked = tdgp.inference.generate_trajectory(G, ws, cams, batch_size=4)
+    assert chunked.shape == (3, 2, 3, 16, 16) and float(chunked.min()) >= 0.0 and float(chunked.max()) <= 1.0
+    mean_cam = tdgp.inference.approximate_mean_camera_params(G, num_samples=64, device=DEV)
+    assert mean_cam.angles.shape == (1, 3) and mean_cam.fov.shape == (1,)

@@ -56,3 +56,22 @@ def test_sample_camera_params(tdgp, tag):
     cp = tdgp.metrics.sample_camera_params(cam, 6, 'cpu')
     for k in ('angles', 'fov', 'radius', 'look_at'):
         np.testing.assert_array_equal(cp[k].numpy(), g[f'cam_{tag}_{k}'])
+
+
+@pytest.mark.parametrize('name', ['point', 'front_circle', 'points', 'line'])
+def test_camera_trajectories(tdgp, name):
+    """inference.generate_camera_trajectory against the reference's (inference_utils.py:140-186): deterministic, so identical."""
+    g = load_golden('trajectories')
+    canon = tdgp.generator.TensorGroup(**{k: torch.from_numpy(g[f'canon_{k}']) for k in ('angles', 'fov', 'radius', 'look_at')})
+    cp = tdgp.inference.generate_camera_trajectory(tdgp.inference_golden_trajectories()[name], canon)
+    for k in ('angles', 'fov', 'radius', 'look_at'):
+        np.testing.assert_array_equal(np.asarray(cp[k]), g[f'{name}_{k}'])
+
+
+def test_tensor_group(tdgp):
+    TG = tdgp.generator.TensorGroup
+    a = TG(x=torch.arange(6.).reshape(3, 2), y=torch.arange(3.))
+    assert len(a) == 3 and a[1:].x.shape == (2, 2) and a.repeat_interleave(2, dim=0).y.tolist() == [0, 0, 1, 1, 2, 2]
+    b = (a * 2 + 1).clamp(0, 5)
+    assert b.y.tolist() == [1, 3, 5] and TG.cat([a, a]).x.shape == (6, 2) and a.mean(dim=0, keepdim=True).y.shape == (1,)
+    assert not hasattr(a, 'no_such_thing')

@@ -34,7 +34,22 @@ def _import_reference():
     om.DictConfig = DictConfig
     om.OmegaConf = object
     sys.modules.setdefault('omegaconf', om)
-    sys.modules.setdefault('torchvision', types.ModuleType('torchvision'))
+    tv = types.ModuleType('torchvision')
+    tv.__path__ = []                                 # a package, so `import torchvision.transforms.functional` resolves to the stubs below
+    sys.modules.setdefault('torchvision', tv)
+    for sub in ('torchvision.transforms', 'torchvision.transforms.functional', 'torchvision.utils', 'torchvision.io'):
+        m = types.ModuleType(sub)
+        m.__path__ = []
+        sys.modules.setdefault(sub, m)
+    try:
+        import PIL  # noqa: F401
+    except ImportError:                              # inference_utils.py imports PIL for its (unused here) grid-drawing helpers
+        pil = types.ModuleType('PIL')
+        pil.__path__ = []
+        for name in ('Image', 'ImageDraw', 'ImageFont'):
+            setattr(pil, name, types.ModuleType('PIL.' + name))
+            sys.modules.setdefault('PIL.' + name, getattr(pil, name))
+        sys.modules.setdefault('PIL', pil)
     sys.path.insert(0, REF)
 
 
@@ -481,6 +496,19 @@ def gen_metrics():
     save('metrics', **arrays)
 
 
+def gen_trajectories():
+    """generate_camera_trajectory (inference_utils.py:140-186) for every trajectory type (deterministic tensor arithmetic)."""
+    from src.training import inference_utils as iu
+    g = np.random.RandomState(71)
+    canon = TensorGroup(angles=T(g.uniform(-1, 1, (3, 3)).astype(np.float32)), fov=T(g.uniform(10, 40, 3).astype(np.float32)),
+                        radius=T(np.ones(3, np.float32)), look_at=T(g.uniform(0, 1, (3, 3)).astype(np.float32)))
+    arrays = {f'canon_{k}': npy(v) for k, v in canon.items()}
+    for name, tr in tdgp.inference_golden_trajectories().items():
+        cp = iu.generate_camera_trajectory(EasyDict(tr), canon)
+        arrays.update({f'{name}_{k}': np.asarray(npy(v) if isinstance(v, torch.Tensor) else v) for k, v in cp.items()})
+    save('trajectories', **arrays)
+
+
 def main():
     torch.set_num_threads(8)
     if len(sys.argv) > 1:                      # regenerate selected files only: python tools/gen_goldens.py adaptors
@@ -489,6 +517,7 @@ def main():
         return
     gen_adaptors()
     gen_metrics()
+    gen_trajectories()
     gen_bias_act()
     gen_upfirdn2d()
     gen_modconv()
