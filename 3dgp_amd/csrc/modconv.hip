@@ -229,10 +229,16 @@ __device__ __forceinline__ void epilogue_tile(const EpiParams& e, const SideCach
         const int planes = e.Cout / e.out_feat;
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e.bias && okc) bias4 = make_float4(side_bias(e, sc, o, true), side_bias(e, sc, o + 1, true), side_bias(e, sc, o + 2, true), side_bias(e, sc, o + 3, true));
+        // All 16 skip taps of the tile (4 passes x 4 texels, 16 B each) are put in flight BEFORE any of them is consumed, and
+        // without per-pass branches: taken pass by pass, each pass waited out a full L2 round trip and the output stage was
+        // two thirds of the ToRGB kernel (per-phase cycle counts, TDGP_RGB_ABL=16).  Invalid lanes read a clamped address.
         float4 sk[4];
         int addr[4], bq[4];
         float nzq[4];
         bool okp[4];
+        SkipTaps tp[4];
+        float4 ta[4], tb[4], tc[4], td[4];
+        const bool has_skip = e.skip != nullptr;
 #pragma unroll
         for (int pass = 0; pass < 4; pass++) {
             const int px = pass * 8 + pr;
@@ -242,12 +248,19 @@ __device__ __forceinline__ void epilogue_tile(const EpiParams& e, const SideCach
             const int plane = b * planes + pl;
             addr[pass] = ((plane * e.Hout + oy) * e.Wout + ox) * e.out_feat + f;
             nzq[pass] = (e.noise && okp[pass]) ? e.noise[b * e.noise_bstride + (int64_t)oy * e.Wout + ox] : 0.f;
+            if (has_skip) {
+                tp[pass] = skip_taps(h2, w2, oy, ox, e.fir);
+                const float* sp = e.skip + (int64_t)(okc ? plane : b * planes) * h2 * w2 * e.out_feat + (okc ? f : 0);
+                ta[pass] = *(const float4*)(sp + (int64_t)tp[pass].i00 * e.out_feat); tb[pass] = *(const float4*)(sp + (int64_t)tp[pass].i01 * e.out_feat);
+                tc[pass] = *(const float4*)(sp + (int64_t)tp[pass].i10 * e.out_feat); td[pass] = *(const float4*)(sp + (int64_t)tp[pass].i11 * e.out_feat);
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; pass++) {
             sk[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e.skip && okp[pass]) {
-                const SkipTaps t = skip_taps(h2, w2, oy, ox, e.fir);
-                const float* sp = e.skip + (int64_t)plane * h2 * w2 * e.out_feat + f;
-                const float4 a = *(const float4*)(sp + (int64_t)t.i00 * e.out_feat), bb = *(const float4*)(sp + (int64_t)t.i01 * e.out_feat);
-                const float4 c = *(const float4*)(sp + (int64_t)t.i10 * e.out_feat), d = *(const float4*)(sp + (int64_t)t.i11 * e.out_feat);
+            if (has_skip) {
+                const SkipTaps& t = tp[pass];
+                const float4 a = ta[pass], bb = tb[pass], c = tc[pass], d = td[pass];
                 sk[pass].x = fmaf_(t.w11, d.x, fmaf_(t.w10, c.x, fmaf_(t.w01, bb.x, t.w00 * a.x)));
                 sk[pass].y = fmaf_(t.w11, d.y, fmaf_(t.w10, c.y, fmaf_(t.w01, bb.y, t.w00 * a.y)));
                 sk[pass].z = fmaf_(t.w11, d.z, fmaf_(t.w10, c.z, fmaf_(t.w01, bb.z, t.w00 * a.z)));
@@ -1041,6 +1054,9 @@ struct RgbParams {
     uint32_t x_bytes, wp_bytes, st_bytes;       // sizes for the buffer descriptors
 };
 
+#ifndef TDGP_RGB_ABL
+#define TDGP_RGB_ABL 0     // 16: per-phase cycle counts of one wave, printed (timing experiments only)
+#endif
 template <int MT>
 __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
     constexpr int BM = 32 * MT, BN = 128, NCH = 16;                 // 16 packed chunks = 64 channels per iteration
@@ -1051,6 +1067,12 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
     float* side = smem + AS_SZ + XS_SZ;                             // [BM] bias
     const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, l32 = l & 31, half = l >> 5;
     const int64_t px0 = (int64_t)blockIdx.x * BN;
+#if TDGP_RGB_ABL & 16
+    long long tq[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define TR(i) { const long long tn_ = __builtin_readcyclecounter(); tq[i] += tn_ - tprev; tprev = tn_; }
+#else
+#define TR(i)
+#endif
 
     for (int i = tid; i < BM; i += 256) side[i] = (i < p.Cout && p.e.bias) ? p.e.bias[i] : 0.f;
 
@@ -1131,11 +1153,14 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
     const float* Al = As + l32 * 4 + 2 * half;
     const float* Xl = Xs + (wv * 32 + l32) * 4 + 2 * half;
     load_stage(0);
+    TR(0)
     for (int it = 0; it < niter; it++) {
         __syncthreads();                        // the previous iteration's fragments have been read
         store_stage();
         __syncthreads();
+        TR(1)
         if (it + 1 < niter) load_stage(it + 1);
+        TR(2)
         f32x2 fa[2][MT], fb[2];
         auto load_frag = [&](int buf, int ch) {
 #pragma unroll
@@ -1153,6 +1178,7 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
 #pragma unroll
                 for (int m = 0; m < MT; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][m][kk], fb[cb][kk], acc[m], 0, 0, 0);
         }
+        TR(3)
     }
     __syncthreads();
 
@@ -1183,6 +1209,12 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    TR(4)
+#if TDGP_RGB_ABL & 16
+    if (tid == 0 && (blockIdx.x == 5 || blockIdx.x == 9000))
+        printf("torgb blk %d iters %d: prologue+issue %lld wait+store %lld issue-next %lld mma %lld epilogue %lld\n", (int)blockIdx.x, niter, tq[0], tq[1], tq[2], tq[3], tq[4]);
+#endif
+#undef TR
 }
 
 // Split-K reduction: y = epilogue(sum_ks partial[ks]) ; one thread per output element, ks summed in order (deterministic).
