@@ -829,7 +829,7 @@ struct UpParams {
 #endif
 constexpr int UP_CT_W = 68;     // epilogue LDS tile: 32 channels x 64 floats (+4 pad)
 
-template <int MTW, int NTW, int WM, int WN>
+template <int MTW, int NTW, int WM, int WN, bool DEEP>
 __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p) {
     constexpr int NTH = 64 * WM * WN;
     constexpr int BM = 32 * MTW * WM, BN = 32 * NTW * WN;
@@ -887,7 +887,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
     // single set the loads of iteration i+1 had one iteration, and the vmcnt wait in front of the LDS write cost a third of the
     // kernel (ablation without the loads: 125-130 TFLOP/s against 82-88).
     constexpr int NA = (9 * BM + NTH - 1) / NTH;
-    float4 a_reg[2][NA], x_reg[2][NPOS], s_reg[2][NPOS];
+    constexpr int NSET = DEEP ? 2 : 1;         // DEEP: two register sets (needs the VGPRs: the 64x128 tile with its two patch slots per thread spills)
+    float4 a_reg[NSET][NA], x_reg[NSET][NPOS], s_reg[NSET][NPOS];
     uint32_t a_vo[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
@@ -963,10 +964,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
 
     float* const L0 = smem;
     float* const L1 = smem + BUF_SZ;
-    if (it0 < it1) load_stage(it0, 0);
-    if (it0 + 1 < it1) load_stage(it0 + 1, 1);
+    if constexpr (!DEEP) {
+        // single register set: the loads of iteration i+1 fly while iteration i multiplies
+        if (it0 < it1) { load_stage(it0, 0); store_stage(0, L0, L0 + AS_SZ); }
+        __syncthreads();
+        int cur = 0;
+        for (int it = it0; it < it1; it++) {
+            const bool more = it + 1 < it1;
+            if (more) load_stage(it + 1, 0);
+            mma(cur);
+            if (more) store_stage(0, smem + (cur ^ 1) * BUF_SZ, smem + (cur ^ 1) * BUF_SZ + AS_SZ);
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+    load_stage(it0, 0);
+    load_stage(it0 + 1, 1);
     if (it0 < it1) store_stage(0, L0, L0 + AS_SZ);
-    if (it0 + 2 < it1) load_stage(it0 + 2, 0);
+    load_stage(it0 + 2, 0);
     __syncthreads();
 #if TDGP_UP_ABL & 16
     long long tseg[4] = {0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
@@ -974,26 +989,32 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
 #else
 #define TSEG(i)
 #endif
-    for (int it = it0; it < it1; it += 2) {
-        // even half: L0 holds iteration `it`; set 1 = iteration it+1, set 0 = iteration it+2 (both in flight)
+    int it = it0;
+    for (; it + 1 < it1; it += 2) {
+        // even half: L0 holds iteration `it`; set 1 = iteration it+1, set 0 = iteration it+2 (both in flight).
+        // (The loads past the last iteration are issued too -- they fall outside the descriptors or are simply never stored: with
+        //  a fixed number of loads per half-iteration and no exit in the middle of the body, the compiler's s_waitcnt in front of
+        //  the LDS write is vmcnt(<one stage>) instead of the vmcnt(0) it falls back to otherwise, which un-did the second stage.)
         mma(0);
         TSEG(0)
-        if (it + 1 < it1) store_stage(1, L1, L1 + AS_SZ);
+        store_stage(1, L1, L1 + AS_SZ);
         TSEG(1)
-        if (it + 3 < it1) load_stage(it + 3, 1);
+        load_stage(it + 3, 1);
         TSEG(2)
         __syncthreads();
         TSEG(3)
-        if (it + 1 >= it1) break;
         // odd half: L1 holds iteration it+1; set 0 = iteration it+2, set 1 = iteration it+3
         mma(1);
         TSEG(0)
         if (it + 2 < it1) store_stage(0, L0, L0 + AS_SZ);
         TSEG(1)
-        if (it + 4 < it1) load_stage(it + 4, 0);
+        load_stage(it + 4, 0);
         TSEG(2)
         __syncthreads();
         TSEG(3)
+    }
+    if (it < it1) mma(0);               // odd iteration count: the last one sits in L0
+    TSEG(0)
     }
 #if TDGP_UP_ABL & 16
     if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 700) && blockIdx.y == 0 && blockIdx.z == 0)
@@ -1483,18 +1504,18 @@ inline UpPlan up_plan(int B, int Cin, int Cout, int H, int W) {
     return u;
 }
 
-template <int MTW, int NTW, int WM, int WN>
+template <int MTW, int NTW, int WM, int WN, bool DEEP>
 void launch_upconv(const UpParams& u, hipStream_t s) {
     constexpr int BM = 32 * MTW * WM, BN = 32 * NTW * WN, NW = WM * WN;
     constexpr int stage = 2 * (9 * BM * 4 + 2 * (BN + 2) * 4), epi = NW * 32 * UP_CT_W;
     const size_t lds = (size_t)(stage > epi ? stage : epi) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)upconv_mfma_kernel<MTW, NTW, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)upconv_mfma_kernel<MTW, NTW, WM, WN, DEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(cdiv(u.B * u.GS, BN), cdiv(u.Cout, BM), u.ksplit);
-    TDGP_LAUNCH("upconv_mfma_kernel", (upconv_mfma_kernel<MTW, NTW, WM, WN>), grid, dim3(64 * NW), lds, s, u);
+    TDGP_LAUNCH("upconv_mfma_kernel", (upconv_mfma_kernel<MTW, NTW, WM, WN, DEEP>), grid, dim3(64 * NW), lds, s, u);
 }
 
 template <int MT>
@@ -1684,8 +1705,8 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         u.x = x; u.wp = wp; u.styles = styles; u.z = z;
         u.B = B; u.Cin = Cin; u.Cout = Cout; u.CoutP = pi.CoutP; u.H = H; u.W = W; u.G1 = pl.G1; u.GS = pl.GS; u.ksplit = pl.ksplit; u.zslice = pl.zslice;
         u.x_bytes = (uint32_t)((int64_t)B * Cin * H * W * 4); u.wp_bytes = (uint32_t)(pi.wp_floats * 4); u.st_bytes = (uint32_t)((int64_t)B * Cin * 4);
-        if (pl.cfg == 0) launch_upconv<2, 1, 2, 2>(u, s);
-        else launch_upconv<2, 1, 1, 4>(u, s);
+        if (pl.cfg == 0) launch_upconv<2, 1, 2, 2, true>(u, s);
+        else launch_upconv<2, 1, 1, 4, false>(u, s);
         FirParams f;
         f.z = z; f.dcoef = dco; f.noise = noise; f.noise_bstride = noise_bstride; f.bias = bias; f.y = y;
         for (int i = 0; i < 16; i++) f.fir[i] = e.fir[i];
