@@ -735,26 +735,29 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
 
     float* const L0 = smem;
     float* const L1 = smem + BUF_SZ;
-    if (it0 < it1) { load_a(it0); load_x(it0, 0); }
-    if (it0 + 1 < it1) load_x(it0 + 1, 1);
+    // Loads are issued unconditionally (past the last iteration they fall outside the descriptors or are never stored) and
+    // the loop body has no exit in the middle: only then does the compiler wait with vmcnt(<the younger loads>) in front of the
+    // LDS write; with loads under a condition it falls back to vmcnt(0), which silently removes the second stage.
+    load_a(it0); load_x(it0, 0);
+    load_x(it0 + 1, 1);
     if (it0 < it1) store_stage(0, L0, L0 + AS_SZ);
     __syncthreads();
     TQ(0)
-    for (int it = it0; it < it1; it += 2) {
+    int it = it0;
+    for (; it + 1 < it1; it += 2) {
         // even half: L0 holds iteration `it`; x set 1 = iteration it+1 (in flight since the previous half)
-        if (it + 1 < it1) load_a(it + 1);
-        if (it + 2 < it1) load_x(it + 2, 0);
+        load_a(it + 1);
+        load_x(it + 2, 0);
         TQ(1)
         mma(0);
         TQ(2)
-        if (it + 1 < it1) store_stage(1, L1, L1 + AS_SZ);
+        store_stage(1, L1, L1 + AS_SZ);
         TQ(3)
         __syncthreads();
         TQ(4)
-        if (it + 1 >= it1) break;
         // odd half: L1 holds iteration it+1; x set 0 = iteration it+2
-        if (it + 2 < it1) load_a(it + 2);
-        if (it + 3 < it1) load_x(it + 3, 1);
+        load_a(it + 2);
+        load_x(it + 3, 1);
         TQ(1)
         mma(1);
         TQ(2)
@@ -763,6 +766,8 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
         __syncthreads();
         TQ(4)
     }
+    if (it < it1) mma(0);               // odd iteration count: the last one sits in L0
+    TQ(2)
 
     // ---- epilogue: accumulators -> per-wave LDS tile -> epilogue_tile() (16-B stores, fused demod/noise/bias/act) ------------
     float* ct = smem + wv * (32 * CT_LD);
