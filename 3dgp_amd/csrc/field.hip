@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
     const int l = lane_id();
     const int pt = l & 15, q = l >> 4;
     const float sx = (float)(p.W - 1) / 2.f, sy = (float)(p.H - 1) / 2.f;
+    const float b1r[4] = {p.b1[0], p.b1[1], p.b1[2], p.b1[3]};      // layer-2 bias: in registers, not reloaded per tile (a load there drags a vmcnt(0) into the loop)
     f32x4 bias0[MT];                  // layer-1 bias of the hidden units this lane owns (accumulator rows 4*q + r of tile mt)
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) bias0[mt] = (f32x4){b0s[mt * 16 + 4 * q], b0s[mt * 16 + 4 * q + 1], b0s[mt * 16 + 4 * q + 2], b0s[mt * 16 + 4 * q + 3]};
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
             float v = o4[0][c] + o4[1][c];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            o[c] = p.b1[c] + v;
+            o[c] = b1r[c] + v;
         }
         if (p.marcher == 1) {
 #pragma unroll
@@ -320,7 +321,6 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
                 auto address_phase = [&](int k0) {
                     const int ks = min(k0 + gc4, p.S - 1);
                     const float tt = t_grp;
-                    t_grp = tp[min(k0 + 4 + gc4, p.S - 1)];           // next group's depth, in flight during this group
                     const float cx = ox + tt * dxr, cy = oy + tt * dyr, cz = oz + tt * dzr;     // :141 (unfused mul, add)
                     float qc[3];
                     if (p.scale_is_pow2) { qc[0] = cx * p.inv_scale; qc[1] = cy * p.inv_scale; qc[2] = cz * p.inv_scale; }
@@ -352,6 +352,10 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                    // next group's depth: issued LAST -- the compiler waits with vmcnt(0) for this group's value above, and a load placed
+                    // before that wait would be waited for as well (a full memory round trip every fourth sample)
+                    __builtin_amdgcn_sched_barrier(0);
+                    t_grp = tp[min(k0 + 4 + gc4, p.S - 1)];
                 };
                 auto issue_from_table = [&](int j) {                   // sample j of the current group: this lane's point is ray gpt
                     const int rslot = j * 16 + gpt;
