@@ -21,6 +21,7 @@ _PROTOTYPES = {
     'tdgp_profile_enable': (c_int, [c_int]),
     'tdgp_profile_report': (c_int64, [c_char_p, c_int64]),
     'tdgp_bias_act': (c_int, [P, P, P, c_int64, c_int, c_int64, c_int, c_float, c_float, c_float, c_int, P]),
+    'tdgp_bias_act_grad': (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int64, c_int, c_int, c_float, c_float, c_float, c_int, P]),
     'tdgp_upfirdn2d': (c_int, [P, P, P, c_int, c_int, c_int, c_int, POINTER(c_int64), c_int, c_int, POINTER(c_int64),
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'tdgp_modconv_pack_bytes': (c_int64, [c_int, c_int, c_int]),

@@ -23,13 +23,14 @@ _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
 class BiasActPlugin:
-    """Object with the pybind signature of the reference's bias_act plugin (bias_act.cpp:32); forward (grad == 0) only."""
+    """Object with the pybind signature of the reference's bias_act plugin (bias_act.cpp:32): forward (grad 0) and the two
+    derivative forms the reference's autograd wrappers call (grad 1, 2; bias_act.py:172-197)."""
 
     @staticmethod
     def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
-        if grad != 0:
-            raise RuntimeError('bias_act plugin: only the forward pass (grad=0) is implemented on the HIP path')
         _lib.require_cuda(x, 'x')
+        if grad not in (0, 1, 2):
+            raise RuntimeError('bias_act plugin: grad must be 0, 1 or 2')
         if not x.is_contiguous() and not (x.ndim == 4 and x.is_contiguous(memory_format=torch.channels_last)):
             raise RuntimeError('x must be non-overlapping and dense')
         has_b = b is not None and b.numel() > 0
@@ -37,11 +38,22 @@ class BiasActPlugin:
             raise RuntimeError('b must have the same dtype and device as x')
         if has_b and b.numel() != x.shape[dim]:
             raise RuntimeError('b has wrong number of elements')
+        opt = {}
+        for name, t in (('xref', xref), ('yref', yref), ('dy', dy)):        # empty tensor == absent (bias_act.cpp:43-50)
+            if t is not None and t.numel() > 0:
+                if t.shape != x.shape or t.dtype != x.dtype or t.stride() != x.stride():
+                    raise RuntimeError(f'{name} must have the same shape, dtype and layout as x')
+                opt[name] = t
         y = torch.empty_like(x)
         if x.numel():
+            bp, nb, sb = (b.data_ptr(), b.numel(), x.stride(dim)) if has_b else (None, 1, 1)
             with torch.cuda.device(x.device):
-                _lib.call('tdgp_bias_act', x.data_ptr(), b.data_ptr() if has_b else None, y.data_ptr(), x.numel(), b.numel() if has_b else 1,
-                          x.stride(dim) if has_b else 1, int(act), float(alpha), float(gain), float(clamp), _DT[x.dtype], _lib.stream_of(x))
+                if grad == 0:
+                    _lib.call('tdgp_bias_act', x.data_ptr(), bp, y.data_ptr(), x.numel(), nb, sb, int(act), float(alpha), float(gain), float(clamp), _DT[x.dtype],
+                              _lib.stream_of(x))
+                else:
+                    _lib.call('tdgp_bias_act_grad', x.data_ptr(), bp, _lib.ptr(opt.get('xref')), _lib.ptr(opt.get('yref')), _lib.ptr(opt.get('dy')), y.data_ptr(),
+                              x.numel(), nb, sb, int(grad), int(act), float(alpha), float(gain), float(clamp), _DT[x.dtype], _lib.stream_of(x))
         return y
 
 

@@ -56,6 +56,18 @@ int tdgp_bias_act(const void* x, const void* b, void* y, int64_t n, int sizeB, i
                   int act, float alpha, float gain, float clamp, int dtype, tdgp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * bias_act first / second derivative (the training-side forms of the same plugin call).
+ * replaces: src/torch_utils/ops/bias_act.cpp:32 `bias_act(x,b,xref,yref,dy,grad,dim,act,alpha,gain,clamp)` with grad = 1, 2
+ *   grad 1:  y = x * dy * gain * act'(xref + b)       x = incoming gradient        (bias_act.py:172-178)
+ *   grad 2:  y = x * dy * gain * act''(xref + b)      x = second-order gradient    (bias_act.py:190-197)
+ * derivatives are written through yref / gain (xref for swish) exactly as bias_act.cu:60-133; with clamp >= 0 the result is 0
+ * where the forward output yref lay outside (-clamp, clamp).  xref / yref / dy / b may be NULL (read as 0 / 0 / 1 / 0).
+ * --------------------------------------------------------------------------------------------- */
+int tdgp_bias_act_grad(const void* x, const void* b, const void* xref, const void* yref, const void* dy, void* y, int64_t n,
+                       int sizeB, int64_t stepB, int grad, int act, float alpha, float gain, float clamp, int dtype,
+                       tdgp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * upfirdn2d forward on [N,C,H,W] with arbitrary element strides.
  * replaces: src/torch_utils/ops/upfirdn2d.cpp:16
  *   `upfirdn2d(x,f,upx,upy,downx,downy,padx0,padx1,pady0,pady1,flip,gain)`

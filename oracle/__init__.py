@@ -87,6 +87,20 @@ def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None):
     return y
 
 
+def bias_act_grad(x, b, xref, yref, dy, grad, dim=1, act='linear', alpha=None, gain=None, clamp=None):
+    """bias_act plugin call with grad = 1 / 2 (bias_act.cpp:32, bias_act.cu:60-147): x = incoming (second-order) gradient."""
+    x = _f(x)
+    y = np.empty_like(x)
+    alpha = ACT_DEF_ALPHA[act] if alpha is None else alpha
+    gain = ACT_DEF_GAIN[act] if gain is None else gain
+    clamp = -1.0 if clamp is None else clamp
+    opt = [None if t is None else _f(t) for t in (b, xref, yref, dy)]
+    step = int(np.prod(x.shape[dim + 1:])) if opt[0] is not None else 1
+    lib().orc_bias_act_grad(_p(x), _p(opt[0]), _p(opt[1]), _p(opt[2]), _p(opt[3]), _p(y), c_i64(x.size), opt[0].size if opt[0] is not None else 1, c_i64(step),
+                            int(grad), c_int(ACT_IDS[act]), c_float(alpha), c_float(gain), c_float(clamp))
+    return y
+
+
 def setup_filter(f=(1, 3, 3, 1), normalize=True, flip_filter=False, gain=1):
     """upfirdn2d.py:70-114 for the non-separable (<8 taps) case."""
     f = np.asarray(f, dtype=np.float32)

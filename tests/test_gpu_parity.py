@@ -542,7 +542,7 @@ def test_compat_plugins(tdgp, oracle):
     y = tdgp.compat.Upfirdn2dPlugin.upfirdn2d(T(x), T(f), 2, 2, 1, 1, 2, 1, 2, 1, False, 4.0)
     assert_close(N(y), oracle.upsample2d(x, f), 2e-6, 'upsample2d via plugin', 1.0)
     with pytest.raises(RuntimeError):
-        tdgp.compat.BiasActPlugin.bias_act(T(x), T(b), empty, empty, empty, 1, 1, 3, 0.2, 1.0, -1.0)     # grad != 0: not on this path
+        tdgp.compat.BiasActPlugin.bias_act(T(x), T(b), empty, empty, empty, 3, 1, 3, 0.2, 1.0, -1.0)     # grad must be 0, 1 or 2
 
 
 # ------------------------------------------------------------------------------------------------ adaptors
@@ -621,3 +621,27 @@ def test_generate_trajectory(tdgp):
     assert chunked.shape == (3, 2, 3, 16, 16) and float(chunked.min()) >= 0.0 and float(chunked.max()) <= 1.0
     mean_cam = tdgp.inference.approximate_mean_camera_params(G, num_samples=64, device=DEV)
     assert mean_cam.angles.shape == (1, 3) and mean_cam.fov.shape == (1,)
+
+
+@pytest.mark.parametrize('tag', ['', '_clamp'])
+def test_bias_act_grad_plugin(tdgp, tag):
+    """bias_act plugin with grad = 1 / 2 (bias_act.cpp:32; the calls of bias_act.py:172-197) against autograd through the reference's
+    CPU bias_act, for every activation."""
+    from test_oracle_golden import _bias_act_grad_case
+    g = load_golden('bias_act_grad')
+    empty = torch.empty([0], device=DEV)
+    opt = lambda a: empty if a is None else T(a)      # noqa: E731
+    ids = dict(linear=1, relu=2, lrelu=3, tanh=4, sigmoid=5, elu=6, selu=7, softplus=8, swish=9)
+    for act, idx in ids.items():
+        xref, yref, kw = _bias_act_grad_case(g, act, tag)
+        spec = tdgp.ops.bias_act.activation_funcs[act]
+        alpha, gain, clamp = spec.def_alpha, kw.get('gain', spec.def_gain), kw.get('clamp', -1)
+        P = tdgp.compat.BiasActPlugin.bias_act
+        dx = P(T(g['dy']), T(g['b']), opt(xref), opt(yref), empty, 1, 1, idx, alpha, gain, clamp)
+        assert_close(N(dx), g[f'dx_{act}{tag}'], 2e-5, f'dx {act}{tag}', 1.0)
+        ddx = P(T(g['d2']), T(g['b']), opt(xref), opt(yref), T(g['dy']), 2, 1, idx, alpha, gain, clamp)
+        assert_close(N(ddx), g[f'ddx_{act}{tag}'], 5e-5, f'ddx {act}{tag}', 1.0)
+    # 16-bit storage path
+    xh = T(g['dy']).half()
+    dxh = tdgp.compat.BiasActPlugin.bias_act(xh, T(g['b']).half(), empty.half(), T(g['y_lrelu']).half(), empty.half(), 1, 1, 3, 0.2, float(np.sqrt(2)), -1)
+    assert dxh.dtype == torch.float16 and float((dxh.float() - T(g['dx_lrelu'])).abs().max()) < 2e-2

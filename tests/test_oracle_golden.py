@@ -213,3 +213,28 @@ def test_camera_adaptor(oracle, tdgp, idx):
     new = P.camera_adaptor_forward(sd, cfg.to_dict(), cam, g[f'{tag}_z'], g[f'{tag}_c'] if cfg.c_dim > 0 else None)
     for k in ('angles', 'fov', 'radius', 'look_at'):
         assert_close(new[k], g[f'{tag}_new_{k}'], 2e-6, k, 1.0)
+
+
+# ------------------------------------------------------------------------------------------------ bias_act grads
+def _bias_act_grad_case(g, act, tag):
+    """Arguments of the plugin calls BiasActCudaGrad makes (bias_act.py:165-197) for this activation: which of x / y is saved."""
+    ref = dict(linear='', relu='y', lrelu='y', tanh='y', sigmoid='y', elu='y', selu='y', softplus='y', swish='x')[act]
+    kw = dict(clamp=0.8, gain=1.3) if tag else {}
+    xref = g['x'] if ref == 'x' or tag else None          # bias_act.py:152-153: x is saved when 'x' in ref or has_2nd_grad ... (clamp needs y)
+    yref = g[f'y_{act}{tag}'] if ref == 'y' or tag else None
+    if act == 'swish':
+        xref, yref = g['x'], (g[f'y_{act}{tag}'] if tag else None)
+    return xref, yref, kw
+
+
+@pytest.mark.parametrize('tag', ['', '_clamp'])
+def test_bias_act_grad(oracle, tag):
+    g = load_golden('bias_act_grad')
+    for act in ('linear', 'relu', 'lrelu', 'tanh', 'sigmoid', 'elu', 'selu', 'softplus', 'swish'):
+        xref, yref, kw = _bias_act_grad_case(g, act, tag)
+        dx = oracle.bias_act_grad(g['dy'], g['b'], xref, yref, None, 1, act=act, **kw)
+        assert_close(dx, g[f'dx_{act}{tag}'], 2e-5, f'dx {act}{tag}', 1.0)
+        ddy = oracle.bias_act_grad(g['d2'], g['b'], xref, yref, None, 1, act=act, **kw)            # d(dx)/d(dy) . d2: the first-derivative form again
+        assert_close(ddy, g[f'ddy_{act}{tag}'], 2e-5, f'ddy {act}{tag}', 1.0)
+        ddx = oracle.bias_act_grad(g['d2'], g['b'], xref, yref, g['dy'], 2, act=act, **kw)
+        assert_close(ddx, g[f'ddx_{act}{tag}'], 5e-5, f'ddx {act}{tag}', 1.0)

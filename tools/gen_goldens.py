@@ -156,6 +156,30 @@ def gen_bias_act():
     save('bias_act', **arrays)
 
 
+def gen_bias_act_grad():
+    """First / second derivative of the reference's CPU bias_act (autograd through `_bias_act_ref`, bias_act.py:91-120): the values
+    its CUDA plugin returns for grad = 1 / 2 (bias_act.cu:60-147) -- dx = dy * d act / dx, d_x = d2 * dy * d2 act / dx2."""
+    g = np.random.RandomState(81)
+    x = (g.randn(2, 5, 4, 3) * 1.5).astype(np.float32)
+    b = g.randn(5).astype(np.float32)
+    dy = g.randn(*x.shape).astype(np.float32)
+    d2 = g.randn(*x.shape).astype(np.float32)
+    arrays = dict(x=x, b=b, dy=dy, d2=d2)
+    for act in ref_bias_act.activation_funcs:
+        for tag, kw in (('', {}), ('_clamp', dict(clamp=0.8, gain=1.3))):
+            xt = T(x).clone().requires_grad_(True)
+            dyt = T(dy).clone().requires_grad_(True)
+            y = ref_bias_act.bias_act(xt, T(b), act=act, impl='ref', **kw)
+            dx, = torch.autograd.grad(y, xt, dyt, create_graph=True)
+            ddx = torch.autograd.grad(dx, xt, T(d2), allow_unused=True, retain_graph=True)[0] if dx.requires_grad else None
+            ddy = torch.autograd.grad(dx, dyt, T(d2), allow_unused=True)[0] if dx.requires_grad else None
+            arrays[f'y_{act}{tag}'] = npy(y)
+            arrays[f'dx_{act}{tag}'] = npy(dx)
+            arrays[f'ddx_{act}{tag}'] = np.zeros_like(x) if ddx is None else npy(ddx)
+            arrays[f'ddy_{act}{tag}'] = np.zeros_like(x) if ddy is None else npy(ddy)
+    save('bias_act_grad', **arrays)
+
+
 def gen_upfirdn2d():
     g = np.random.RandomState(2)
     arrays = {}
@@ -519,6 +543,7 @@ def main():
     gen_metrics()
     gen_trajectories()
     gen_bias_act()
+    gen_bias_act_grad()
     gen_upfirdn2d()
     gen_modconv()
     gen_field()
