@@ -11,18 +11,20 @@
 // so every sample shares ONE weight matrix (no per-sample weight materialisation: the reference builds a
 // [B,Cout,Cin,3,3] tensor per call) and the modulation rides on the activation staging.
 //
-// Kernel: implicit GEMM, M = Cout, N = output pixels, K = Cin * taps, v_mfma_f32_32x32x2_f32 (exact fp32,
-// no TF32 -- the reference disables TF32 too: training_loop.py:76-77).
-//   * weights pre-packed k-major [Cin/KC][taps][KC][CoutP] -> the A tile is a straight 16-B-vector copy and
-//     A fragments are conflict-free ds_read_b32 (consecutive lanes = consecutive out-channels);
-//   * the block stages ONE halo'd, style-scaled activation patch [(rows+2) x (cols+2)] per input channel in LDS
-//     and reuses it for all taps (9x fewer global reads than an im2col stage); rows are "virtual rows"
-//     (sample-major), so small feature maps (4x4 ... 16x16) fill a 128/256-pixel tile with several samples;
-//   * 4 waves per block, each owning MTW x NTW tiles of 32x32 (64 fp32 accumulators for 2x2);
-//   * up=2 layers run as 4 sub-pixel phases of the stride-2 transposed conv (taps {4,2,2,1}) writing the
-//     (2H+1)x(2W+1) intermediate, followed by one fused FIR(4x4, gain 4) + demod + noise + bias + lrelu kernel;
-//   * ToRGB (1x1, no demod) fuses bias, the x2 FIR upsample of the previous image and the skip add, and can
-//     emit the renderer's channel-last plane layout directly.
+// Kernels: implicit GEMM, M = Cout, N = output pixels, K = Cin * taps, v_mfma_f32_32x32x2_f32 (exact fp32, no TF32 -- the
+// reference disables TF32 too: training_loop.py:76-77).  Weights are pre-packed [Cin/4][tap][Cout][4 channels].
+//   conv3_mfma_kernel<KS>   3x3 / 5x5 stride-1 layers whose width is a multiple of 32 (the hot ones): mask-free, zero rows between
+//                           samples, 8-byte LDS fragment reads with immediate offsets, buffer-load staging;
+//   upconv_mfma_kernel      the x2 layers: stride-2 transposed 3x3 conv over a linearised grid, all four output parities in one
+//                           pass, dense parity-planar intermediate; followed by
+//   fir_act_kernel          FIR(4x4, gain 4) + demod + noise + bias + activation on that intermediate;
+//   torgb_mfma_kernel       1x1, Cout <= 96, channel-last plane output with the fused x2-upsampled skip;
+//   conv_mfma_kernel        generic fallback (any width, k in {1,3,5}, NCHW or channel-last output, per-lane tap masks, "virtual
+//                           rows" so 4x4 ... 16x16 maps fill a tile with several samples): the low-resolution layers and the
+//                           op-level API forms the fast paths do not cover;
+//   demod_kernel, splitk_reduce_kernel, pack_kernel, style_affine_kernel.
+// Every conv kernel parks its accumulator tiles in a per-wave LDS tile and runs the same fused output stage (epilogue_tile):
+// demodulation, noise, bias, activation, gain, clamp, the ToRGB skip, 16-byte stores.
 #include "common.h"
 #include <stdlib.h>
 
@@ -32,13 +34,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KC3 = 4;    // packed channel chunk: weights live as [chunk][tap][Cout][4 channels]
 
-struct Phase {
+struct TapTable {
     int ntaps, halo;    // halo = k/2
     int tap_w[25];      // tap index in the packed weight layout
     int tap_off_y[25];  // dy in [-halo, halo]
     int tap_off_x[25];
     int gridH, gridW;   // output pixels
-    int oy_mul, oy_add, ox_mul, ox_add;
 };
 
 // Everything the output stage needs (shared by the conv kernel's own epilogue and the split-K reduction kernel).
@@ -58,8 +59,8 @@ struct ConvParams {
     EpiParams e;
     int B, Cin, Cout, CoutP, Hin, Win, T;
     int tw_log2;
-    int nphases, ksplit;
-    Phase ph[1];
+    int ksplit;
+    TapTable ph;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float alpha) {
@@ -163,7 +164,7 @@ __device__ __forceinline__ float side_demod(const EpiParams& e, const SideCache&
 // per-lane stores top out near 1.6 TB/s on this chip, which made the output stage 15-25 % of every conv launch:
 //   NCHW / raw split-K partials, `vec`: ct is channel-major; lane = (channel row l>>3 of the pass, pixel quad l&7) stores
 //         float4 = 4 consecutive x of one channel (a 32-pixel subtile is made of whole rows of >= 4 pixels);
-//   NCHW scalar fallback: sub-pixel phases of the x2 layers (stride-2 scatter) and the op-level ToRGB with an NCHW skip;
+//   NCHW scalar fallback: widths that are not a multiple of 4 and the op-level ToRGB with an NCHW skip;
 //   channel-last planes (CL, ToRGB): ct is PIXEL-major; lane = (pixel l>>3 of the pass, channel quad l&7) stores float4 =
 //         4 consecutive features of one texel; the x2-upsampled skip is 4 float4 taps per lane, all 4 passes in flight.
 constexpr int CT_LD = 36;
@@ -286,7 +287,7 @@ __device__ __forceinline__ void epilogue_tile(const EpiParams& e, const SideCach
 
 // -------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution.  Block = 256 threads = WM x WN waves, wave tile = (MTW*32) x (NTW*32).
-// KCS = channels staged per K iteration (a multiple of the packed chunk of 4), MAXT = max taps per phase.
+// KCS = channels staged per K iteration (a multiple of the packed chunk of 4), MAXT = max taps (k*k).
 //
 // K loop: double-buffered LDS, ONE barrier per iteration.
 //   issue global loads of chunk it+1 (packed weights as 16-B vectors, the halo'd activation patch as scalars)
@@ -308,8 +309,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     int* toff_tab = (int*)(smem + 2 * BUF_SZ);                      // [MAXT + 2 (+ pad to 32)]
     float* side = smem + 2 * BUF_SZ + 32;                           // [1 + NSB][BM]: bias, demod coefficients of the tile's samples
 
-    const int phase_id = blockIdx.z % p.nphases, ks = blockIdx.z / p.nphases;
-    const Phase& ph = p.ph[phase_id];
+    const int ks = blockIdx.z;
+    const TapTable& ph = p.ph;
     const int TW = 1 << p.tw_log2, RPS = 32 >> p.tw_log2;
     const int TR = NT * RPS;                        // virtual rows per block tile
     const int R = ph.halo;
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     // so the accumulators never need dynamic register indexing.
     float* ct = smem + wv * (32 * CT_LD);
     const bool ct_pixel_major = (MAXT == 1) && p.ksplit == 1 && p.e.out_layout == 1;       // channel-last epilogue reads float4 of channels
-    const bool vec = ph.ox_mul == 1 && (p.e.Wout & 3) == 0;                               // 4 consecutive lanes = 4 consecutive x of one row
+    const bool vec = (p.e.Wout & 3) == 0;                                                 // 4 consecutive lanes = 4 consecutive x of one row
     const EpiParams& e = p.e;
     SideCache scache;
     scache.lds = side_ok ? side : nullptr; scache.b0 = sb0; scache.bm = BM; scache.m0 = m0;
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
             }
         }
         const int m = tile % MTW;
-        const int poy = pm * ph.oy_mul + ph.oy_add, pox = pn * ph.ox_mul + ph.ox_add;
+        const int poy = pm, pox = pn;
         const int pok = (pk && poy < e.Hout && pox < e.Wout) ? 1 : 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1423,15 +1424,10 @@ inline PackInfo pack_info(int Cout, int Cin, int k) {
     return pi;
 }
 
-// pixel tiles of the largest phase for a block covering NT 32-pixel subtiles
+// pixel tiles of a launch whose blocks cover NT 32-pixel subtiles
 inline int px_tiles(const ConvParams& p, int NT) {
     const int TW = 1 << p.tw_log2, RPS = 32 >> p.tw_log2, TR = NT * RPS;
-    int mx = 0;
-    for (int i = 0; i < p.nphases; i++) {
-        const int t = cdiv(p.ph[i].gridW, TW) * cdiv(p.B * p.ph[i].gridH, TR);
-        mx = t > mx ? t : mx;
-    }
-    return mx;
+    return cdiv(p.ph.gridW, TW) * cdiv(p.B * p.ph.gridH, TR);
 }
 
 // Split-K factor: low-resolution layers have K = Cin*9 = 4608 but only a handful of output tiles, so a plain launch
@@ -1458,11 +1454,11 @@ int launch_conv(ConvParams& p, float* partial, int64_t partial_floats, hipStream
     const int gx = px_tiles(p, NT), gy = cdiv(p.Cout, BM);
     const int niter = cdiv(cdiv(p.Cin, KC3), KCS / KC3);
     const int64_t slice = (int64_t)p.e.B * p.e.Cout * p.e.Hout * p.e.Wout;
-    int ks = pick_ksplit(gx * gy * p.nphases, niter);
+    int ks = pick_ksplit(gx * gy, niter);
     while (ks > 1 && ks * slice > partial_floats) ks--;          // never exceed the caller's workspace
     p.ksplit = ks;
     p.partial = partial;
-    dim3 grid(gx, gy, p.nphases * ks);
+    dim3 grid(gx, gy, ks);
     TDGP_LAUNCH("conv_mfma_kernel", (conv_mfma_kernel<MTW, NTW, WM, WN, KCS, MAXT>), grid, dim3(256), lds, s, p);
     if (ks > 1)
         TDGP_LAUNCH("splitk_reduce_kernel", splitk_reduce_kernel, dim3((int)min((int64_t)2048, cdiv64(slice, 256))), dim3(256), 0, s, partial, ks, p.e);
@@ -1662,15 +1658,14 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         e.dcoef = dco; e.noise = noise; e.noise_bstride = noise_bstride; e.bias = bias; e.skip = skip; e.y = y;
         e.Hout = H; e.Wout = W; e.out_layout = out_layout; e.out_feat = out_feat > 0 ? out_feat : 1;
         e.act = act; e.alpha = alpha; e.gain = gain; e.clamp = clamp;
-        p.nphases = 1;
-        Phase& ph = p.ph[0];
+        TapTable& ph = p.ph;
         ph.ntaps = k * k; ph.halo = k / 2;
         for (int t = 0; t < k * k; t++) {
             ph.tap_w[t] = t;
             ph.tap_off_y[t] = t / k - k / 2;                 // correlation, padding k/2 (conv2d_resample.py:132-134)
             ph.tap_off_x[t] = t % k - k / 2;
         }
-        ph.gridH = H; ph.gridW = W; ph.oy_mul = 1; ph.oy_add = 0; ph.ox_mul = 1; ph.ox_add = 0;
+        ph.gridH = H; ph.gridW = W;
         p.tw_log2 = pick_tw_log2(W);
         if (k >= 3 && (W & 31) == 0) {
             Conv3Params c;
