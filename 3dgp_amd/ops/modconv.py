@@ -119,7 +119,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
                      fused_modconv=True):
     """Signature of the reference's modulated_conv2d (networks_stylegan2.py:31-43).
 
-    Supported forms = the ones the generator forward issues: k in {1,3} with padding == k // 2, down == 1,
+    Supported forms = the ones the generator forward issues (k in {1,3}; 5 for the depth adaptor) with padding == k // 2, down == 1,
     up == 1 (flip_weight=True, correlation) or up == 2 (flip_weight=False, 4x4 resample_filter).  Both values of
     `fused_modconv` give the same result (the two branches of the reference are algebraically identical).
     """

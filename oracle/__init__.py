@@ -177,7 +177,7 @@ def normalize_2nd_moment(x):
 
 def modulated_conv2d(x, weight, styles, noise=None, up=1, demodulate=True, resample_filter=None):
     """Eval/fused modulated conv (networks_stylegan2.py:31-88) for the layer forms on the
-    path: k in {1,3}, padding=k//2, up in {1,2}, flip_weight=(up==1)."""
+    path: odd k (1, 3; 5 for the depth adaptor), padding=k//2, up in {1,2}, flip_weight=(up==1)."""
     x, weight, styles = _f(x), _f(weight), _f(styles)
     B, cin, H, W = x.shape
     cout, cin2, k, k2 = weight.shape
