@@ -675,22 +675,24 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
     }
     const uint32_t a_gstride4 = (uint32_t)(T * p.CoutP) * 16u;
 
+    // (iteration / channel indices are clamped into the tensors: the scalar offset of a buffer load must stay inside the
+    //  descriptor for its range check to be meaningful; the clamped loads of the pipeline's overrun are never stored, a
+    //  duplicated last channel meets zero-padded weights)
     auto load_a = [&](int it) {
-        const uint32_t a_so = (uint32_t)it * a_gstride4;
+        const uint32_t a_so = (uint32_t)min(it, niter - 1) * a_gstride4;
 #pragma unroll
         for (int i = 0; i < NA; i++) a_reg[i] = buf_load4(rw, a_vo[i], a_so);
     };
     auto load_x = [&](int it, int set) {
-        const uint32_t c0 = (uint32_t)it * 4u;
+        const uint32_t c0 = (uint32_t)min(it, niter - 1) * 4u, cl = (uint32_t)(p.Cin - 1);
 #pragma unroll
         for (int k = 0; k < NPOS; k++) {
-            // channels beyond Cin (Cin % 4 != 0 only) read a neighbouring channel or 0; their packed weights are 0
-            x_reg[set][k] = make_float4(buf_load1(rx, pos_xo[k], c0 * chw4), buf_load1(rx, pos_xo[k], (c0 + 1) * chw4), buf_load1(rx, pos_xo[k], (c0 + 2) * chw4),
-                                        buf_load1(rx, pos_xo[k], (c0 + 3) * chw4));
+            x_reg[set][k] = make_float4(buf_load1(rx, pos_xo[k], min(c0, cl) * chw4), buf_load1(rx, pos_xo[k], min(c0 + 1, cl) * chw4),
+                                        buf_load1(rx, pos_xo[k], min(c0 + 2, cl) * chw4), buf_load1(rx, pos_xo[k], min(c0 + 3, cl) * chw4));
             if (p.styles) {
                 if (cin4) s_reg[set][k] = buf_load4(rs, pos_so[k], c0 * 4u);
-                else s_reg[set][k] = make_float4(buf_load1(rs, pos_so[k], c0 * 4u), buf_load1(rs, pos_so[k], c0 * 4u + 4u), buf_load1(rs, pos_so[k], c0 * 4u + 8u),
-                                                 buf_load1(rs, pos_so[k], c0 * 4u + 12u));
+                else s_reg[set][k] = make_float4(buf_load1(rs, pos_so[k], min(c0, cl) * 4u), buf_load1(rs, pos_so[k], min(c0 + 1, cl) * 4u),
+                                                 buf_load1(rs, pos_so[k], min(c0 + 2, cl) * 4u), buf_load1(rs, pos_so[k], min(c0 + 3, cl) * 4u));
             }
         }
     };
@@ -907,20 +909,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
     }
     const uint32_t a_gstride4 = (uint32_t)(9 * p.CoutP) * 16u;
 
+    // (iteration / channel indices are clamped into the tensors: the scalar offset of a buffer load must stay inside the
+    //  descriptor for its range check to be meaningful; the clamped loads of the pipeline's overrun are never stored, a
+    //  duplicated last channel meets zero-padded weights)
     auto load_stage = [&](int it, int set) {
-        const uint32_t a_so = (uint32_t)it * a_gstride4;
+        const int itc = min(it, niter - 1);
+        const uint32_t a_so = (uint32_t)itc * a_gstride4;
 #pragma unroll
         for (int i = 0; i < NA; i++) a_reg[set][i] = buf_load4(rw, a_vo[i], a_so);
-        const uint32_t c0 = (uint32_t)it * 4u;
+        const uint32_t c0 = (uint32_t)itc * 4u, cl = (uint32_t)(p.Cin - 1);
 #pragma unroll
         for (int k = 0; k < NPOS; k++) {
-            // channels beyond Cin (Cin % 4 != 0 only) read a neighbouring channel or 0; their packed weights are 0
-            x_reg[set][k] = make_float4(buf_load1(rx, pos_xo[k], c0 * chw4), buf_load1(rx, pos_xo[k], (c0 + 1) * chw4), buf_load1(rx, pos_xo[k], (c0 + 2) * chw4),
-                                        buf_load1(rx, pos_xo[k], (c0 + 3) * chw4));
+            x_reg[set][k] = make_float4(buf_load1(rx, pos_xo[k], min(c0, cl) * chw4), buf_load1(rx, pos_xo[k], min(c0 + 1, cl) * chw4),
+                                        buf_load1(rx, pos_xo[k], min(c0 + 2, cl) * chw4), buf_load1(rx, pos_xo[k], min(c0 + 3, cl) * chw4));
             if (p.styles) {
                 if (cin4) s_reg[set][k] = buf_load4(rs, pos_so[k], c0 * 4u);
-                else s_reg[set][k] = make_float4(buf_load1(rs, pos_so[k], c0 * 4u), buf_load1(rs, pos_so[k], c0 * 4u + 4u), buf_load1(rs, pos_so[k], c0 * 4u + 8u),
-                                                 buf_load1(rs, pos_so[k], c0 * 4u + 12u));
+                else s_reg[set][k] = make_float4(buf_load1(rs, pos_so[k], min(c0, cl) * 4u), buf_load1(rs, pos_so[k], min(c0 + 1, cl) * 4u),
+                                                 buf_load1(rs, pos_so[k], min(c0 + 2, cl) * 4u), buf_load1(rs, pos_so[k], min(c0 + 3, cl) * 4u));
             }
         }
     };

@@ -156,9 +156,10 @@ def main():
     torch.cuda.synchronize()
     prof = tdgp._lib.profile_report()
     tdgp._lib.profile_enable(False)
-    kernels = {k: dict(ms_per_step=round(v['total_ms'] / args.profile_steps, 4), launches_per_step=v['launches'] // args.profile_steps,
+    nprof = max(args.profile_steps, 1)
+    kernels = {k: dict(ms_per_step=round(v['total_ms'] / nprof, 4), launches_per_step=v['launches'] // nprof,
                        avg_ms=round(v['avg_ms'], 5)) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])}
-    dominant = next(iter(kernels))
+    dominant = next(iter(kernels), None)
     flops = algorithmic_flops(cfg)
     # HBM bytes per launch from the committed PMC passes (tools/profile_bench.sh -> tools/pmc_traffic.py); counters cannot be
     # collected from inside this process, so `traffic` is only filled when that measurement was taken on this very workload.
