@@ -85,3 +85,19 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
     bound = max(pix_tol, 3 * self_noise, 2 * exact_noise)
     assert pix <= bound, f'{what}: max-rel {pix:.3e} > {bound:.3e} (reference self-noise {self_noise:.3e}, reference vs exact {exact_noise:.3e})'
     return rng, pix, self_noise
+
+# ------------------------------------------------------------------------------------------------ upfirdn2d backward
+UPFIRDN_GRAD_CASES = dict(up2=dict(up=(2, 2), down=(1, 1), padding=(2, 1, 2, 1), gain=4.0, flip=False, x_hw=(8, 6)),
+                          fir=dict(up=(1, 1), down=(1, 1), padding=(1, 1, 1, 1), gain=4.0, flip=False, x_hw=(8, 6)),
+                          down2=dict(up=(1, 1), down=(2, 2), padding=(1, 1, 1, 1), gain=1.0, flip=False, x_hw=(8, 6)),
+                          asym=dict(up=(3, 2), down=(2, 1), padding=(2, 1, 0, 3), gain=1.5, flip=True, x_hw=(8, 6)))
+
+
+def upfirdn2d_backward_args(case, f_shape, dy_shape):
+    """The call Upfirdn2dCuda.backward makes (upfirdn2d.py:251-265): up <-> down, flipped filter, padding from the shapes."""
+    (upx, upy), (downx, downy), (px0, px1, py0, py1) = case['up'], case['down'], case['padding']
+    ih, iw = case['x_hw']
+    oh, ow = dy_shape[2:]
+    fh, fw = f_shape
+    pad = [fw - px0 - 1, iw * upx - ow * downx + px0 - upx + 1, fh - py0 - 1, ih * upy - oh * downy + py0 - upy + 1]
+    return dict(up=[downx, downy], down=[upx, upy], padding=pad, flip_filter=not case['flip'], gain=case['gain'])

@@ -645,3 +645,13 @@ def test_bias_act_grad_plugin(tdgp, tag):
     xh = T(g['dy']).half()
     dxh = tdgp.compat.BiasActPlugin.bias_act(xh, T(g['b']).half(), empty.half(), T(g['y_lrelu']).half(), empty.half(), 1, 1, 3, 0.2, float(np.sqrt(2)), -1)
     assert dxh.dtype == torch.float16 and float((dxh.float() - T(g['dx_lrelu'])).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize('name', ['up2', 'fir', 'down2', 'asym'])
+def test_upfirdn2d_backward(tdgp, name):
+    """upfirdn2d's input gradient through the same HIP entry point with swapped factors and the flipped filter (upfirdn2d.py:251-265)."""
+    from conftest import UPFIRDN_GRAD_CASES, upfirdn2d_backward_args
+    g = load_golden('upfirdn2d_grad')
+    dy, f = g[f'{name}_dy'], g[f'{name}_f']
+    dx = tdgp.ops.upfirdn2d.upfirdn2d(T(dy), T(f), **upfirdn2d_backward_args(UPFIRDN_GRAD_CASES[name], f.shape, dy.shape))
+    assert_close(N(dx), g[f'{name}_dx'], 2e-6, f'dx {name}', 1.0)

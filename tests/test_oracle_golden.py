@@ -238,3 +238,13 @@ def test_bias_act_grad(oracle, tag):
         assert_close(ddy, g[f'ddy_{act}{tag}'], 2e-5, f'ddy {act}{tag}', 1.0)
         ddx = oracle.bias_act_grad(g['d2'], g['b'], xref, yref, g['dy'], 2, act=act, **kw)
         assert_close(ddx, g[f'ddx_{act}{tag}'], 5e-5, f'ddx {act}{tag}', 1.0)
+
+
+@pytest.mark.parametrize('name', ['up2', 'fir', 'down2', 'asym'])
+def test_upfirdn2d_backward(oracle, name):
+    """The input gradient of upfirdn2d is another upfirdn2d (upfirdn2d.py:251-265): checked against autograd through the reference."""
+    from conftest import UPFIRDN_GRAD_CASES, upfirdn2d_backward_args
+    g = load_golden('upfirdn2d_grad')
+    dy, f = g[f'{name}_dy'], g[f'{name}_f']
+    dx = oracle.upfirdn2d(dy, f, **upfirdn2d_backward_args(UPFIRDN_GRAD_CASES[name], f.shape, dy.shape))
+    assert_close(dx, g[f'{name}_dx'], 2e-6, f'dx {name}', 1.0)

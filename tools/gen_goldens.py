@@ -211,6 +211,24 @@ def gen_upfirdn2d():
     save('upfirdn2d', **arrays)
 
 
+def gen_upfirdn2d_grad():
+    """Input gradient of upfirdn2d (autograd through `_upfirdn2d_ref`): what Upfirdn2dCuda.backward computes as another upfirdn2d
+    with up <-> down swapped, the flipped filter and the padding of upfirdn2d.py:251-265."""
+    g = np.random.RandomState(91)
+    arrays = {}
+    f = ref_upfirdn2d.setup_filter([1, 3, 3, 1])
+    fa = ref_upfirdn2d.setup_filter([1, 2, 3, 4])
+    cases = dict(up2=dict(f=f, up=2, down=1, padding=[2, 1, 2, 1], gain=4.0), fir=dict(f=f, up=1, down=1, padding=[1, 1, 1, 1], gain=4.0),
+                 down2=dict(f=f, up=1, down=2, padding=[1, 1, 1, 1], gain=1.0), asym=dict(f=fa, up=[3, 2], down=[2, 1], padding=[2, 1, 0, 3], gain=1.5, flip_filter=True))
+    for name, kw in cases.items():
+        x = T(g.randn(2, 3, 8, 6).astype(np.float32)).requires_grad_(True)
+        y = ref_upfirdn2d.upfirdn2d(x, impl='ref', **kw)
+        dy = T(g.randn(*y.shape).astype(np.float32))
+        dx, = torch.autograd.grad(y, x, dy)
+        arrays.update({f'{name}_dy': npy(dy), f'{name}_dx': npy(dx), f'{name}_f': npy(kw['f'])})
+    save('upfirdn2d_grad', **arrays)
+
+
 def gen_modconv():
     g = np.random.RandomState(3)
     arrays = {}
@@ -545,6 +563,7 @@ def main():
     gen_bias_act()
     gen_bias_act_grad()
     gen_upfirdn2d()
+    gen_upfirdn2d_grad()
     gen_modconv()
     gen_field()
     gen_sampling()
