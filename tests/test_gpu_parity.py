@@ -139,17 +139,21 @@ def test_modconv_golden(tdgp, tag):
     (1, 72, 64, 33, 3, 2),       # odd input size, phase grid 34 > one 32-column tile
     (2, 64, 96, 32, 1, 1),       # ToRGB config (96 = 3 x 32 rows)
     (2, 48, 20, 16, 1, 1),
+    (3, 6, 10, 32, 3, 1),        # channel count not a multiple of 4 on the mask-free 3x3 path (scalar style loads, clamped channels)
+    (2, 7, 12, 16, 3, 2),        # ... and on the x2 path; 3 K iterations of a 2-deep pipeline
+    (1, 130, 70, 64, 3, 1),      # Cin % 4 == 2, odd iteration count (33), Cout tail inside a 128-row tile
+    (2, 5, 9, 32, 5, 1),         # 5x5 fast path, ragged channels
 ])
 def test_modconv_oracle(tdgp, oracle, B, cin, cout, H, k, up):
     rs = np.random.RandomState(cin + cout)
     x = rs.randn(B, cin, H, H).astype(np.float32)
     w = rs.randn(cout, cin, k, k).astype(np.float32)
     s = (1 + 0.5 * rs.randn(B, cin)).astype(np.float32)
-    noise = (0.3 * rs.randn(B, 1, H * up, H * up)).astype(np.float32) if k == 3 else None
+    noise = (0.3 * rs.randn(B, 1, H * up, H * up)).astype(np.float32) if k >= 3 else None
     f = oracle.setup_filter([1, 3, 3, 1])
-    ref = oracle.modulated_conv2d(x, w, s, noise=noise, up=up, demodulate=(k == 3), resample_filter=f)
+    ref = oracle.modulated_conv2d(x, w, s, noise=noise, up=up, demodulate=(k >= 3), resample_filter=f)
     y = tdgp.ops.modconv.modulated_conv2d(T(x), T(w), T(s), noise=None if noise is None else T(noise), up=up, padding=k // 2,
-                                          resample_filter=T(f), demodulate=(k == 3), flip_weight=(up == 1))
+                                          resample_filter=T(f), demodulate=(k >= 3), flip_weight=(up == 1))
     assert_close(N(y), ref, 1e-5, 'modconv', 1.0)
 
 
