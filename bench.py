@@ -91,7 +91,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU per step (16: +1 %, 32: +7 % img/s as the low-resolution layers and launch tails amortise)')
     ap.add_argument('--config', default='c3', choices=['c1', 'c2', 'c3', 'c4'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--depth-adaptor', action='store_true', help='also run the DepthAdaptor inside G.forward (SURVEY 8f rank 1; off = the 8a hot path)')
