@@ -29,7 +29,7 @@
 #include "common.h"
 
 // Compile-time ablations for timing experiments (tools/scratch/build_variant.sh): 1 = no tap loads, 2 = no layer-1 MFMAs,
-// 4 = no stores, 8 = no blend.  Always 0 in the shipped library.
+// 4 = no stores, 32 = per-phase cycle counts of one wave (printed).  Always 0 in the shipped library.
 #ifndef TDGP_FIELD_ABL
 #define TDGP_FIELD_ABL 0
 #endif
@@ -375,16 +375,27 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
                             }
                     }
                 };
+#if TDGP_FIELD_ABL & 32
+                long long tf[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define TF(i) { const long long tn_ = __builtin_readcyclecounter(); tf[i] += tn_ - tprev; tprev = tn_; }
+#else
+#define TF(i)
+#endif
                 address_phase(0);
                 issue_from_table(0);
+                TF(1)
                 for (int k = 0; k < p.S; k++) {
                     float g[FQ];
                     blend(g);
+                    TF(0)
                     if (k + 1 < p.S) {
                         if (((k + 1) & 3) == 0) address_phase(k + 1);
+                        TF(1)
                         issue_from_table((k + 1) & 3);
+                        TF(2)
                     }
                     const float4 o = mlp(g);
+                    TF(3)
                     if (q == 0) obuf[pt * 9 + (k & 7)] = o;
                     if ((k & 7) == 7 || k + 1 == p.S) {
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -400,7 +411,13 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                     }
+                    TF(4)
                 }
+#if TDGP_FIELD_ABL & 32
+                if (l == 0 && wvi == 0 && (patch == lb) && (blockIdx.x == 0 || blockIdx.x == 1001))
+                    printf("field blk %d S %d: blend(+tap wait) %lld address %lld issue %lld mlp %lld park/flush %lld\n", (int)blockIdx.x, p.S, tf[0], tf[1], tf[2], tf[3], tf[4]);
+#endif
+#undef TF
             }
             return;
           }

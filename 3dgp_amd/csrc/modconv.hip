@@ -1374,6 +1374,34 @@ __global__ __launch_bounds__(1024) void demod_kernel(const float* __restrict__ s
     }
 }
 
+// All demodulation coefficients of a forward in ONE launch (15 separate launches of this much work are 15 launch latencies):
+// meta[l] = (wsq pointer, styles offset, Cin, Cout, CoutP, output offset), offsets in floats into styles_all / dcoef_all.
+__global__ __launch_bounds__(1024) void demod_batch_kernel(const float* __restrict__ styles_all, const int64_t* __restrict__ meta, float* __restrict__ dcoef_all, int B) {
+    __shared__ float red[16][64];
+    const int64_t* m = meta + (int64_t)blockIdx.z * 6;
+    const float* wsq = (const float*)m[0];
+    const int Cin = (int)m[2], Cout = (int)m[3], CoutP = (int)m[4];
+    const float* styles = styles_all + m[1];
+    float* d = dcoef_all + m[5];
+    const int ol = threadIdx.x & 63, cs = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + ol, b = blockIdx.y;
+    if (blockIdx.x * 64 >= Cout) return;
+    float acc = 0.f;
+    if (o < Cout)
+        for (int c = cs; c < Cin; c += 16) {
+            const float s = styles[b * Cin + c];
+            acc = fmaf_(s * s, wsq[(int64_t)c * CoutP + o], acc);
+        }
+    red[cs][ol] = acc;
+    __syncthreads();
+    if (cs == 0 && o < Cout) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) t += red[k][ol];
+        d[b * Cout + o] = 1.0f / sqrtf(t + 1e-8f);
+    }
+}
+
 // weight [Cout,Cin,k,k] -> packed (zero padded) [nchunks][k*k][CoutP][4] followed by wsq [Cin][CoutP]
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wsq, int Cout, int Cin, int T,
                                                   int KC, int CoutP, int nchunks) {
@@ -1619,7 +1647,7 @@ TDGP_API int64_t tdgp_modconv2d_workspace_bytes(int B, int Cin, int Cout, int H,
     return ws_layout(B, Cin, Cout, H, W, k, up).total;
 }
 
-TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styles, const float* noise, int64_t noise_bstride,
+TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styles, const float* dcoef_in, const float* noise, int64_t noise_bstride,
                             const float* bias, const float* fir4x4, const float* skip, float* y, int B, int Cin, int Cout, int H, int W,
                             int k, int up, int demodulate, int act, float alpha, float gain, float clamp, int out_layout, int out_feat,
                             void* workspace, int64_t workspace_bytes, tdgp_stream_t stream) {
@@ -1645,7 +1673,8 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
     float* dco = (float*)((char*)workspace + wl.dco);
     float* z = (float*)((char*)workspace + wl.z);
     float* partial = (float*)((char*)workspace + wl.partial);
-    if (demodulate) TDGP_LAUNCH("demod_kernel", demod_kernel, dim3(cdiv(Cout, 64), B), dim3(1024), 0, s, styles, wsq, dco, B, Cin, Cout, pi.CoutP);
+    if (demodulate && dcoef_in) dco = const_cast<float*>(dcoef_in);             // precomputed by tdgp_demod_batch
+    else if (demodulate) TDGP_LAUNCH("demod_kernel", demod_kernel, dim3(cdiv(Cout, 64), B), dim3(1024), 0, s, styles, wsq, dco, B, Cin, Cout, pi.CoutP);
     else dco = nullptr;
 
     ConvParams p;
@@ -1721,6 +1750,19 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, FIR_TH) * cdiv(f.OW, FIR_TW);
         TDGP_LAUNCH("fir_act_kernel", fir_act_kernel, dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
     }
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}
+
+TDGP_API int64_t tdgp_modconv_wsq_offset(int Cout, int Cin, int k) {
+    if (Cout < 1 || Cin < 1 || (k != 1 && k != 3 && k != 5)) return -1;
+    return pack_info(Cout, Cin, k).wp_floats * (int64_t)sizeof(float);
+}
+
+TDGP_API int tdgp_demod_batch(const float* styles_all, const int64_t* meta, float* dcoef_all, int B, int num_layers, int max_cout, tdgp_stream_t stream) {
+    TDGP_CHECK(styles_all && meta && dcoef_all, TDGP_EINVAL, "demod_batch: null pointer");
+    TDGP_CHECK(B >= 1 && num_layers >= 1 && max_cout >= 1, TDGP_EINVAL, "demod_batch: bad shape");
+    TDGP_LAUNCH("demod_kernel", demod_batch_kernel, dim3(cdiv(max_cout, 64), B, num_layers), dim3(1024), 0, (hipStream_t)stream, styles_all, meta, dcoef_all, B);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }

@@ -153,6 +153,7 @@ class SynthesisLayer(torch.nn.Module):
             self.register_buffer('noise_const', torch.randn([resolution, resolution]))
             self.noise_strength = torch.nn.Parameter(torch.zeros([]))
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        self._const_noise = None
 
     def _noise(self, batch, noise_mode, device):
         assert noise_mode in ['random', 'const', 'none']
@@ -160,16 +161,20 @@ class SynthesisLayer(torch.nn.Module):
             return None
         if noise_mode == 'random':
             return torch.randn([batch, 1, self.resolution, self.resolution], device=device) * self.noise_strength
-        return self.noise_const * self.noise_strength
+        # noise_const * noise_strength is a function of the weights only: computed once, not once per forward
+        stamp = (self.noise_const.data_ptr(), self.noise_const._version, self.noise_strength.data_ptr(), self.noise_strength._version)
+        if self._const_noise is None or self._const_noise[0] != stamp:
+            self._const_noise = (stamp, (self.noise_const * self.noise_strength).detach())
+        return self._const_noise[1]
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, styles=None):
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, styles=None, dcoef=None):
         if styles is None:
             styles = self.affine(w)
         noise = self._noise(x.shape[0], noise_mode, x.device)
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         fir = _modconv.fir_host_array(self.resample_filter) if self.up == 2 else None
         return _modconv.modconv_forward(x, _modconv._packed(self.weight), styles, noise=noise, bias=self.bias, up=self.up, demodulate=True,
-                                        act=self.activation, gain=self.act_gain * gain, clamp=clamp, fir=fir)
+                                        act=self.activation, gain=self.act_gain * gain, clamp=clamp, fir=fir, dcoef=dcoef)
 
 
 class ToRGBLayer(torch.nn.Module):
@@ -208,17 +213,18 @@ class SynthesisBlock(torch.nn.Module):
         self.num_conv += 1
         self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
 
-    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, styles=None, hwc_feat=0, **layer_kwargs):
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, styles=None, dcoefs=None, hwc_feat=0, **layer_kwargs):
         """-> (x, img).  `styles` (optional) = pre-computed [conv0?, conv1, torgb] style tensors; `hwc_feat` > 0 keeps the
         running image in the channel-last plane layout [B, C/feat, H, W, feat]."""
         assert ws.shape[1] == self.num_conv + self.num_torgb and ws.shape[2] == self.w_dim, f'Wrong shape: ws {tuple(ws.shape)}'
         w_iter = iter(ws.unbind(dim=1))
         s_iter = iter(styles) if styles is not None else iter([None] * 3)
+        d_iter = iter(dcoefs) if dcoefs is not None else iter([None] * 2)
         if self.in_channels == 0:
             x = self.const.to(torch.float32).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
         else:
-            x = self.conv0(x.to(torch.float32), next(w_iter), styles=next(s_iter), **layer_kwargs)
-        x = self.conv1(x, next(w_iter), styles=next(s_iter), **layer_kwargs)
+            x = self.conv0(x.to(torch.float32), next(w_iter), styles=next(s_iter), dcoef=next(d_iter), **layer_kwargs)
+        x = self.conv1(x, next(w_iter), styles=next(s_iter), dcoef=next(d_iter), **layer_kwargs)
         fir = _modconv.fir_host_array(self.resample_filter) if img is not None else None
         img = self.torgb(x, next(w_iter), styles=next(s_iter), skip=img, fir=fir, out_layout=1 if hwc_feat else 0, out_feat=hwc_feat)
         return x, img
@@ -241,6 +247,8 @@ class SynthesisBlocksSequence(torch.nn.Module):
             self.num_ws += block.num_conv + (block.num_torgb if is_last else 0)
             setattr(self, f'b{res}', block)
         self._affine_pack = None
+        self._demod_meta = None
+        self._styles_flat = None
 
     # ---- all style affines of the backbone in one launch (tdgp_style_affine) -------------------------------------
     def _layers(self):
@@ -258,6 +266,7 @@ class SynthesisBlocksSequence(torch.nn.Module):
 
     def invalidate_cache(self):
         self._affine_pack = None
+        self._demod_meta = None
 
     def _pack_affines(self, device):
         key = tuple((l.affine.weight.data_ptr(), l.affine.weight._version, l.affine.bias.data_ptr(), l.affine.bias._version) for l, _, _ in self._layers())
@@ -294,7 +303,27 @@ class SynthesisBlocksSequence(torch.nn.Module):
         with torch.cuda.device(ws.device):
             _lib.call('tdgp_style_affine', ws.data_ptr(), pack['A'].data_ptr(), pack['ab'].data_ptr(), meta.data_ptr(), pack['scale'].data_ptr(),
                       out.data_ptr(), B, ws.shape[1], ws.shape[2], pack['rows'], _lib.stream_of(ws))
+        self._styles_flat = out
         return [out[row0 * B:(row0 + cin) * B].view(B, cin) for row0, cin in pack['blocks']]
+
+    def all_demods(self, B):
+        """Demodulation coefficients of every 3x3 layer, one launch (after all_styles): list of [B, Cout_l] in layer order."""
+        pack = self._affine_pack
+        layers = [(layer, row0) for (layer, _, _), (row0, _) in zip(self._layers(), pack['blocks']) if isinstance(layer, SynthesisLayer)]
+        key = (B, tuple((_modconv._packed(l.weight).buf.data_ptr(), l.weight._version) for l, _ in layers))
+        dm = self._demod_meta
+        if dm is None or dm['key'] != key:
+            rows, off, views = [], 0, []
+            for layer, row0 in layers:
+                pk = _modconv._packed(layer.weight)
+                coutp = (pk.cout + 3) // 4 * 4
+                rows.append([_modconv.wsq_address(pk), row0 * B, pk.cin, pk.cout, coutp, off])
+                views.append((off, pk.cout))
+                off += B * pk.cout
+            dm = self._demod_meta = dict(key=key, meta=torch.tensor(rows, dtype=torch.int64, device=self._styles_flat.device), total=off, views=views,
+                                         max_cout=max(r[3] for r in rows))
+        flat = _modconv.demod_batch(self._styles_flat, dm['meta'], dm['total'], B, dm['max_cout'])
+        return [flat[off:off + B * cout].view(B, cout) for off, cout in dm['views']]
 
     def forward(self, ws, x=None, hwc=False, **block_kwargs):
         """ws [B, num_ws, w_dim] -> planes [B, out_channels, R, R] (NCHW), or HWCPlanes [B,3,R,R,feat] when hwc=True."""
@@ -302,15 +331,17 @@ class SynthesisBlocksSequence(torch.nn.Module):
         _lib.require_cuda(ws, 'ws')
         ws = ws.to(torch.float32)
         styles = self.all_styles(ws)
+        dcoefs = self.all_demods(ws.shape[0])
         feat = self.out_channels // 3 if hwc else 0
         img = None
-        w_idx = s_idx = 0
+        w_idx = s_idx = d_idx = 0
         for res in self.block_resolutions:
             blk = getattr(self, f'b{res}')
             n = blk.num_conv + blk.num_torgb
-            x, img = blk(x, img, ws.narrow(1, w_idx, n), styles=styles[s_idx:s_idx + n], hwc_feat=feat, **block_kwargs)
+            x, img = blk(x, img, ws.narrow(1, w_idx, n), styles=styles[s_idx:s_idx + n], dcoefs=dcoefs[d_idx:d_idx + blk.num_conv], hwc_feat=feat, **block_kwargs)
             w_idx += blk.num_conv
             s_idx += n
+            d_idx += blk.num_conv
         return _renderer.HWCPlanes(img) if hwc else img
 
 

@@ -71,9 +71,10 @@ def _packed(weight):
 
 
 def modconv_forward(x, packed, styles, noise=None, bias=None, up=1, demodulate=True, act='linear', alpha=None, gain=None, clamp=None,
-                    fir=None, skip=None, out_layout=0, out_feat=0):
+                    fir=None, skip=None, out_layout=0, out_feat=0, dcoef=None):
     """One call of tdgp_modconv2d.  x [B,Cin,H,W] fp32 NCHW; returns [B,Cout,H*up,W*up] (out_layout 0) or the
-    channel-last plane tensor [B,Cout/out_feat,H,W,out_feat] (out_layout 1)."""
+    channel-last plane tensor [B,Cout/out_feat,H,W,out_feat] (out_layout 1).  `dcoef`: demodulation coefficients [B,Cout] precomputed by
+    `demod_batch` (else the call computes them)."""
     _lib.require_cuda(x, 'x')
     x = _lib.f32c(x)
     B, cin, H, W = x.shape
@@ -109,7 +110,7 @@ def modconv_forward(x, packed, styles, noise=None, bias=None, up=1, demodulate=T
     ws_bytes = lib.tdgp_modconv2d_workspace_bytes(B, cin, cout, H, W, packed.k, up)
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.call('tdgp_modconv2d', x.data_ptr(), packed.buf.data_ptr(), _lib.ptr(styles), _lib.ptr(noise), nbs, _lib.ptr(bias), fir,
+        _lib.call('tdgp_modconv2d', x.data_ptr(), packed.buf.data_ptr(), _lib.ptr(styles), _lib.ptr(dcoef), _lib.ptr(noise), nbs, _lib.ptr(bias), fir,
                   _lib.ptr(skip), y.data_ptr(), B, cin, cout, H, W, packed.k, up, int(bool(demodulate)), spec.cuda_idx, alpha, gain, clamp,
                   out_layout, out_feat, ws.data_ptr(), ws_bytes, _lib.stream_of(x))
     return y
@@ -139,3 +140,16 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
         raise NotImplementedError('modulated_conv2d: fp32 only (fp32_only=true in configs/model/3dgp.yaml)')
     fir = fir_host_array(resample_filter) if up == 2 else None
     return modconv_forward(x, _packed(weight), styles, noise=noise, bias=None, up=up, demodulate=demodulate, act='linear', gain=1.0, fir=fir)
+
+
+def wsq_address(packed):
+    """Device address of a PackedConv's sum_tap W^2 table (the input of the demodulation)."""
+    return packed.buf.data_ptr() + int(_lib.load().tdgp_modconv_wsq_offset(packed.cout, packed.cin, packed.k))
+
+
+def demod_batch(styles_all, meta, total_floats, B, max_cout):
+    """All demodulation coefficients of a forward in one launch.  meta: int64 [L,6] device tensor (see include/tdgp.h)."""
+    out = torch.empty([total_floats], dtype=torch.float32, device=styles_all.device)
+    with torch.cuda.device(styles_all.device):
+        _lib.call('tdgp_demod_batch', styles_all.data_ptr(), meta.data_ptr(), out.data_ptr(), B, meta.shape[0], max_cout, _lib.stream_of(styles_all))
+    return out

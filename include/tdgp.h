@@ -103,6 +103,8 @@ int tdgp_upfirdn2d(const void* x, const float* f, void* y, int N, int C, int inH
  *       (only with up=1, k=1).
  * out_layout: 0 = NCHW, 1 = plane-major channel-last [B, Cout/feat, H, W, feat] (the renderer's layout;
  *       `feat` = out_feat).
+ * dcoef: NULL (the call computes d itself when demodulate != 0) or the [B,Cout] coefficients precomputed by
+ *       tdgp_demod_batch for this layer.
  * workspace: tdgp_modconv2d_workspace_bytes(...) bytes (0 allowed when it returns 0).
  * k in {1, 3, 5} with padding k/2; up=2 needs k=3.  styles = NULL: plain convolution -- this is how the 5x5
  *       `Conv2dLayer`s of the depth adaptor run (src/training/layers.py:221-236: conv2d_resample + bias_act).
@@ -110,11 +112,19 @@ int tdgp_upfirdn2d(const void* x, const float* f, void* y, int N, int C, int inH
 int64_t tdgp_modconv_pack_bytes(int Cout, int Cin, int k);
 int     tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int Cin, int k, tdgp_stream_t stream);
 int64_t tdgp_modconv2d_workspace_bytes(int B, int Cin, int Cout, int H, int W, int k, int up);
-int     tdgp_modconv2d(const float* x, const void* wpack, const float* styles, const float* noise,
+int     tdgp_modconv2d(const float* x, const void* wpack, const float* styles, const float* dcoef, const float* noise,
                        int64_t noise_bstride, const float* bias, const float* fir4x4, const float* skip,
                        float* y, int B, int Cin, int Cout, int H, int W, int k, int up, int demodulate,
                        int act, float alpha, float gain, float clamp, int out_layout, int out_feat,
                        void* workspace, int64_t workspace_bytes, tdgp_stream_t stream);
+
+/* Demodulation coefficients d[b,o] = rsqrt(sum_c s[b,c]^2 * sum_tap W[o,c,tap]^2 + 1e-8) (networks_stylegan2.py:62) of SEVERAL
+ * layers in one launch.  meta: int64 [num_layers, 6] on the device = (address of the layer's sum_tap W^2 table, i.e. its wpack +
+ * tdgp_modconv_wsq_offset(...) bytes; float offset of its [B,Cin] styles block in styles_all; Cin; Cout; Cout rounded up to 4;
+ * float offset of its [B,Cout] block in dcoef_all).  max_cout = the largest Cout among them. */
+int64_t tdgp_modconv_wsq_offset(int Cout, int Cin, int k);
+int     tdgp_demod_batch(const float* styles_all, const int64_t* meta, float* dcoef_all, int B, int num_layers,
+                         int max_cout, tdgp_stream_t stream);
 
 /* Batched style affines for all layers of the backbone in one launch:
  *   out[obase + b*olen + oidx] = ((ws[b, widx, :] . A[row, :]) * (1/sqrt(w_dim)) + abias[row]) * row_scale[row]

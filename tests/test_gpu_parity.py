@@ -401,6 +401,29 @@ def test_e2e_tiny(tdgp, oracle):
     assert mism_i < 2e-3 and mism_p < 5e-3, (mism_i, mism_p)
 
 
+def test_batched_demod_equals_per_layer(tdgp):
+    """tdgp_demod_batch (all layers' demodulation coefficients in one launch) is the same arithmetic as the per-call path of
+    tdgp_modconv2d: coefficient tables and the backbone output must agree bit for bit."""
+    cfg = tdgp.config.config_mid()
+    G = _gen(tdgp, cfg, 5)
+    dec = G.synthesis.tri_plane_decoder
+    ws = T(np.random.RandomState(2).randn(3, dec.num_ws, cfg.w_dim))
+    styles = dec.all_styles(ws)
+    dcoefs = dec.all_demods(3)
+    layers = [(l, s) for (l, _, _), s in zip(dec._layers(), styles) if isinstance(l, tdgp.generator.SynthesisLayer)]
+    assert len(layers) == len(dcoefs)
+    from importlib import import_module
+    mc = import_module('3dgp_amd.ops.modconv')
+    for (layer, st), d in zip(layers, dcoefs):
+        wsq = N(layer.weight.detach().double().square().sum([2, 3]))                    # [Cout,Cin]
+        want = 1.0 / np.sqrt((N(st).astype(np.float64) ** 2) @ wsq.T + 1e-8)
+        assert_close(N(d), want, 1e-5, 'dcoef', 1.0)
+        x = T(np.random.RandomState(7).randn(3, layer.in_channels, layer.resolution // layer.up, layer.resolution // layer.up))
+        a = layer(x, None, noise_mode='const', styles=st, dcoef=d)
+        b = layer(x, None, noise_mode='const', styles=st)
+        np.testing.assert_array_equal(N(a), N(b))
+
+
 def test_e2e_mid(tdgp, oracle):
     cfg = tdgp.config.config_mid()
     g = load_golden('e2e_mid')
