@@ -1,7 +1,8 @@
 """Inference harness around the generator forward.
 
 Reference: `src/training/inference_utils.py:88-215` -- `generate`, `generate_trajectory`, `generate_camera_trajectory`,
-`approximate_mean_camera_params`, `sample_posterior_camera_params`.  Host-side orchestration only: every frame is one
+`approximate_mean_camera_params`, `sample_posterior_camera_params`; `scripts/inference.py:87-150` -- `sample_z_from_seeds`,
+`sample_c_from_seeds`, `c_idx_to_c`, `sample_ws_from_seeds`.  Host-side orchestration only: every frame is one
 `G.synthesis` call on the HIP path; trajectories are a few hundred floats of tensor arithmetic kept on the CPU like the reference.
 """
 import numpy as np
@@ -91,3 +92,60 @@ def approximate_mean_camera_params(G, num_samples=1024, device='cpu', camera_cfg
     z = torch.randn(num_samples, G.z_dim, device=device)
     c = c_sampler(num_samples).to(device) if c_sampler is not None else torch.zeros(num_samples, G.c_dim, device=device)
     return sample_posterior_camera_params(G, z, c, camera_cfg).mean(dim=0, keepdim=True)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# seeds -> (z, c) -> ws, scripts/inference.py:87-150
+# ----------------------------------------------------------------------------------------------------------------------
+def sample_z_from_seeds(seeds, z_dim):
+    """scripts/inference.py:87-89: one `RandomState(seed).randn(1, z_dim)` row per seed (fp64 draw, cast to fp32)."""
+    rows = [np.random.RandomState(s).randn(1, z_dim) for s in seeds]
+    return torch.from_numpy(np.concatenate(rows, axis=0)).float()
+
+
+def c_idx_to_c(c_idx, c_dim, device='cpu'):
+    """scripts/inference.py:101-106: class indices -> one-hot rows [n, c_dim]."""
+    idx = np.asarray(c_idx)
+    c = np.zeros((len(idx), c_dim))
+    c[np.arange(len(idx)), idx] = 1.0
+    return torch.from_numpy(c).float().to(device)
+
+
+def sample_c_from_seeds(seeds, c_dim, device='cpu'):
+    """scripts/inference.py:93-97: the class of a seed is the first `choice` draw of its own RandomState."""
+    if c_dim == 0:
+        return torch.empty(len(seeds), 0)
+    return c_idx_to_c([np.random.RandomState(s).choice(np.arange(c_dim), size=1).item() for s in seeds], c_dim, device)
+
+
+def sample_ws_from_seeds(G, seeds, truncation_psi=1.0, device='cpu', num_interp_steps=0, classes=None, num_samples_to_avg=256):
+    """scripts/inference.py:110-150 (`cfg.truncation_psi` passed as a number).
+
+    num_interp_steps == 0: ws for every seed (x every class of `classes` when given).  With truncation_psi < 1 on a conditional
+    generator the truncation centre is the PER-CLASS mean of `num_samples_to_avg` mapped samples (torch RNG on `device`), not
+    `w_avg`.  Otherwise seeds are consumed pairwise and ws is `num_interp_steps` linear blends between the two ends."""
+    if num_interp_steps == 0:
+        z = sample_z_from_seeds(seeds, G.z_dim).to(device)
+        c = sample_c_from_seeds(seeds, G.c_dim, device=device) if classes is None else c_idx_to_c(classes, G.c_dim, device)
+        per_class_centre = truncation_psi < 1.0 and G.c_dim > 0
+        if per_class_centre:
+            z_avg = torch.randn(len(c) * num_samples_to_avg, G.z_dim, device=z.device)
+            ws_avg = G.mapping(z_avg, c.repeat_interleave(num_samples_to_avg, dim=0))
+            ws_avg = ws_avg.view(len(c), num_samples_to_avg, G.num_ws, ws_avg.shape[-1]).mean(dim=1)
+            if classes is not None:
+                ws_avg = ws_avg.repeat_interleave(len(seeds), dim=0)
+        if classes is not None:                                            # class-major: every seed under class 0, then class 1, ...
+            z = z.repeat(len(c), 1)
+            c = c.repeat_interleave(len(seeds), dim=0)
+        if per_class_centre:
+            ws = G.mapping(z, c) * truncation_psi + ws_avg * (1 - truncation_psi)
+        else:
+            ws = G.mapping(z, c, truncation_psi=truncation_psi)
+        return ws, z, c
+    assert classes is None
+    z_from, z_to = sample_z_from_seeds(seeds[0::2], G.z_dim).to(device), sample_z_from_seeds(seeds[1::2], G.z_dim).to(device)
+    c_from, c_to = sample_c_from_seeds(seeds[0::2], G.c_dim, device=device), sample_c_from_seeds(seeds[1::2], G.c_dim, device=device)
+    ws_from = G.mapping(z_from, c_from, truncation_psi=truncation_psi)
+    ws_to = G.mapping(z_to, c_to, truncation_psi=truncation_psi)
+    alpha = torch.linspace(0, 1, num_interp_steps, device=device).view(num_interp_steps, 1, 1, 1)
+    return ws_from.unsqueeze(0) * (1 - alpha) + ws_to.unsqueeze(0) * alpha, (z_from, z_to), (c_from, c_to)

@@ -186,23 +186,70 @@ def frechet_distance(mu_gen, sigma_gen, mu_real, sigma_real):
     return float(np.real(m + np.trace(sigma_gen + sigma_real - s * 2)))
 
 
-def compute_feature_stats_for_generator(G, detector, max_items, batch_size=64, batch_gen=4, camera_cfg=None, c_sampler=None, num_gpus=1, rank=0,
-                                        device='cuda', gatherer=None, G_kwargs=None, **stats_kwargs):
-    """metric_utils.py:288-320: generate `batch_size` images per iteration in chunks of `batch_gen`, run the detector, gather the
-    feature block across ranks, accumulate.  `c_sampler(batch) -> c [batch, c_dim]` (the reference draws dataset labels);
-    cameras come from the prior (`camera_cfg`, default camera/base.yaml) and pass through G's camera adaptor when it has one."""
-    assert batch_size % batch_gen == 0
+def iterate_random_conditioning(G, batch_size, device='cpu', camera_cfg=None, dataset=None, frontal_camera=False):
+    """metric_utils.py:60-101: endless (c, camera_params) batches.
+
+    Unconditional generator with a parametric camera prior: c is the empty [batch, 0] tensor and cameras come from the prior.
+    Otherwise every batch draws `batch_size` dataset indices with `np.random.randint` (one call per item, the reference's draw
+    order) and takes labels (`dataset.get_label`) and -- for the 'custom' angle distribution -- camera angles
+    (`dataset.get_camera_angles`) from those items.  `dataset` is any object with `__len__`, `get_label`, `get_camera_angles`
+    (the reference constructs its ImageFolder dataset here; datasets are out of scope).  `frontal_camera` pins the origin
+    angles to (yaw 0, pitch pi/2, roll 0)."""
     camera_cfg = camera_base() if camera_cfg is None else camera_cfg
+    custom = _g(camera_cfg, 'origin.angles')['dist'] == 'custom'
+    if (G.c_dim != 0 or custom) and dataset is None:
+        raise ValueError('a conditional generator / a custom camera distribution draws labels and angles from a dataset')
+    frontal = None
+    if frontal_camera:
+        frontal = torch.stack([torch.zeros(batch_size, device=device), np.pi / 2 + torch.zeros(batch_size, device=device),
+                               torch.zeros(batch_size, device=device)], dim=1)
+    c0 = torch.zeros([batch_size, 0], device=device) if G.c_dim == 0 else None
+    if G.c_dim == 0 and not custom:
+        while True:
+            yield c0, sample_camera_params(camera_cfg, batch_size, device, origin_angles=frontal)
+    while True:
+        idx = [np.random.randint(len(dataset)) for _ in range(batch_size)]
+        c = c0 if G.c_dim == 0 else torch.from_numpy(np.stack([dataset.get_label(i) for i in idx])).to(device)
+        if frontal_camera:
+            angles = frontal
+        elif custom:
+            angles = torch.from_numpy(np.stack([dataset.get_camera_angles(i) for i in idx])).to(device)
+        else:
+            angles = None
+        yield c, sample_camera_params(camera_cfg, len(idx), device, origin_angles=angles)
+
+
+def _generator_batches(G, batch_gen, camera_cfg, c_sampler, dataset, device, frontal_camera=False):
+    """(z, c, camera) batches for the two feature loops below: z first, then the conditioning draw (metric_utils.py:303-307)."""
+    if c_sampler is not None:                 # caller-supplied label sampler instead of a dataset
+        def cond():
+            while True:
+                yield c_sampler(batch_gen).to(device), sample_camera_params(camera_base() if camera_cfg is None else camera_cfg, batch_gen, device)
+        it = cond()
+    else:
+        it = iterate_random_conditioning(G, batch_gen, device, camera_cfg, dataset, frontal_camera)
+    while True:
+        z = torch.randn([batch_gen, G.z_dim], device=device)
+        c, camera_params = next(it)
+        if getattr(G.synthesis, 'camera_adaptor', None) is not None:
+            camera_params = G.synthesis.camera_adaptor(camera_params, z, c)
+        yield z, c, camera_params
+
+
+def compute_feature_stats_for_generator(G, detector, max_items, batch_size=64, batch_gen=4, camera_cfg=None, c_sampler=None, num_gpus=1, rank=0,
+                                        device='cuda', gatherer=None, G_kwargs=None, dataset=None, **stats_kwargs):
+    """metric_utils.py:288-320: generate `batch_size` images per iteration in chunks of `batch_gen`, run the detector, gather the
+    feature block across ranks, accumulate.  Conditioning comes from `iterate_random_conditioning` (labels / custom angles from
+    `dataset`) or, when given, from `c_sampler(batch) -> c [batch, c_dim]`; cameras come from the prior (`camera_cfg`, default
+    camera/base.yaml) and pass through G's camera adaptor when it has one."""
+    assert batch_size % batch_gen == 0
     G_kwargs = {} if G_kwargs is None else G_kwargs
     stats = FeatureStats(max_items=max_items, **stats_kwargs)
+    batches = _generator_batches(G, batch_gen, camera_cfg, c_sampler, dataset, device)
     while not stats.is_full():
         images = []
         for _ in range(batch_size // batch_gen):
-            z = torch.randn([batch_gen, G.z_dim], device=device)
-            c = c_sampler(batch_gen).to(device) if c_sampler is not None else torch.zeros([batch_gen, G.c_dim], device=device)
-            camera_params = sample_camera_params(camera_cfg, batch_gen, device)
-            if getattr(G.synthesis, 'camera_adaptor', None) is not None:
-                camera_params = G.synthesis.camera_adaptor(camera_params, z, c)
+            z, c, camera_params = next(batches)
             img = G(z, c, camera_params, **G_kwargs)
             images.append((img * 127.5 + 128).clamp(0, 255).to(torch.uint8))
         images = torch.cat(images)
@@ -210,3 +257,21 @@ def compute_feature_stats_for_generator(G, detector, max_items, batch_size=64, b
             images = images.repeat([1, 3, 1, 1])
         stats.append_torch(detector(images), num_gpus=num_gpus, rank=rank, gatherer=gatherer)
     return stats
+
+
+def compute_flattened_depth_maps(G, max_items, batch_size=64, batch_gen=4, camera_cfg=None, c_sampler=None, num_gpus=1, rank=0, device='cuda',
+                                 gatherer=None, G_kwargs=None, dataset=None, cut_quantile=0.0):
+    """metric_utils.py:324-349: frontal-camera depth maps of `max_items` generated samples, flattened to [max_items, h*w]
+    (input of the reference's non-flatness score)."""
+    assert batch_size % batch_gen == 0
+    G_kwargs = {} if G_kwargs is None else G_kwargs
+    stats = FeatureStats(max_items=max_items, capture_all=True)
+    batches = _generator_batches(G, batch_gen, camera_cfg, c_sampler, dataset, device, frontal_camera=True)
+    while not stats.is_full():
+        depths = []
+        for _ in range(batch_size // batch_gen):
+            z, c, camera_params = next(batches)
+            out = G(z, c, camera_params, render_opts=dict(return_depth=True, cut_quantile=cut_quantile), **G_kwargs)
+            depths.append(out.depth)
+        stats.append_torch(torch.cat(depths).flatten(start_dim=1), num_gpus=num_gpus, rank=rank, gatherer=gatherer)
+    return torch.from_numpy(stats.get_all())

@@ -75,3 +75,82 @@ def test_tensor_group(tdgp):
     b = (a * 2 + 1).clamp(0, 5)
     assert b.y.tolist() == [1, 3, 5] and TG.cat([a, a]).x.shape == (6, 2) and a.mean(dim=0, keepdim=True).y.shape == (1,)
     assert not hasattr(a, 'no_such_thing')
+
+
+def _cpu_generator(tdgp):
+    cfg = tdgp.config.config_mid()
+    G = tdgp.generator.Generator(cfg)
+    G.load_numpy_state_dict(tdgp.weights.random_state_dict(cfg, seed=11, exercise_all=True))
+    return G.eval()
+
+
+def test_seed_samplers(tdgp):
+    """scripts/inference.py:87-106: z rows and class draws are functions of the seed alone -- bit-identical."""
+    g = load_golden('harness')
+    cfg = tdgp.config.config_mid()
+    seeds = [int(s) for s in g['seeds']]
+    np.testing.assert_array_equal(tdgp.inference.sample_z_from_seeds(seeds, cfg.z_dim).numpy(), g['z'])
+    np.testing.assert_array_equal(tdgp.inference.sample_c_from_seeds(seeds, cfg.c_dim).numpy(), g['c'])
+    assert tdgp.inference.sample_c_from_seeds(seeds, 0).shape == (len(seeds), 0)
+
+
+@pytest.mark.parametrize('tag,kw', [('psi1', dict(truncation_psi=1.0)), ('psi06', dict(truncation_psi=0.6)),
+                                    ('psi06_cls', dict(truncation_psi=0.6, classes=[1, 4])), ('psi1_cls', dict(truncation_psi=1.0, classes=[1, 4])),
+                                    ('interp', dict(truncation_psi=0.8, num_interp_steps=5))])
+def test_sample_ws_from_seeds(tdgp, tag, kw):
+    """scripts/inference.py:110-150: plain / per-class-centre truncation / seeds x classes grid / pairwise interpolation.  The mapping
+    network runs on the CPU here (tiny torch GEMMs, as in the reference); same torch seed -> same truncation-centre samples."""
+    g = load_golden('harness')
+    G = _cpu_generator(tdgp)
+    seeds = [int(s) for s in g['seeds']]
+    torch.manual_seed(81)
+    with torch.no_grad():
+        ws, z, c = tdgp.inference.sample_ws_from_seeds(G, seeds, device='cpu', **kw)
+    assert ws.shape == g[f'ws_{tag}'].shape
+    np.testing.assert_allclose(ws.numpy(), g[f'ws_{tag}'], rtol=0, atol=2e-6)
+    if not isinstance(z, tuple):
+        np.testing.assert_array_equal(z.numpy(), g[f'z_{tag}'])
+        np.testing.assert_array_equal(c.numpy(), g[f'c_{tag}'])
+
+
+class _Dataset:
+    """The same index -> (label, angles) functions as tools/gen_goldens.py:_GoldenDataset."""
+
+    def __init__(self, c_dim, size=11):
+        self.c_dim, self.size = c_dim, size
+
+    def __len__(self):
+        return self.size
+
+    def get_label(self, i):
+        v = np.zeros(self.c_dim, np.float32)
+        v[i % self.c_dim] = 1.0
+        return v
+
+    def get_camera_angles(self, i):
+        return np.array([0.1 * i - 0.5, 1.2 + 0.03 * i, 0.0], np.float32)
+
+
+@pytest.mark.parametrize('tag,c_dim,custom,frontal', [('cond', 5, False, False), ('custom', 5, True, False), ('frontal', 5, False, True),
+                                                      ('uncond', 0, False, False), ('uncond_custom', 0, True, False)])
+def test_iterate_random_conditioning(tdgp, tag, c_dim, custom, frontal):
+    """metric_utils.py:60-101: numpy index draws then the torch/scipy prior draws, in the reference's order -- bit-identical batches."""
+    g = load_golden('harness')
+    cam = tdgp.metrics.camera_base()
+    if custom:
+        cam['origin'] = dict(radius=cam['origin']['radius'], angles=dict(dist='custom'))
+
+    class _G:
+        pass
+    _G.c_dim = c_dim
+    torch.manual_seed(82)
+    np.random.seed(82)
+    it = tdgp.metrics.iterate_random_conditioning(_G, 4, 'cpu', cam, dataset=_Dataset(max(c_dim, 1)), frontal_camera=frontal)
+    for step in range(2):
+        c, cp = next(it)
+        np.testing.assert_array_equal(c.numpy(), g[f'it_{tag}_{step}_c'])
+        for k in ('angles', 'fov', 'radius', 'look_at'):
+            np.testing.assert_array_equal(cp[k].numpy(), g[f'it_{tag}_{step}_{k}'], err_msg=f'{tag} step {step} {k}')
+    if c_dim or custom:
+        with pytest.raises(ValueError):
+            next(tdgp.metrics.iterate_random_conditioning(_G, 4, 'cpu', cam))

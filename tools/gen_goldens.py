@@ -551,6 +551,78 @@ def gen_trajectories():
     save('trajectories', **arrays)
 
 
+class _GoldenDataset:
+    """Stand-in for the reference's ImageFolder dataset in iterate_random_conditioning: labels and camera angles are pure
+    functions of the item index."""
+
+    def __init__(self, c_dim=5, size=11):
+        self.c_dim, self.size = c_dim, size
+
+    def __len__(self):
+        return self.size
+
+    def get_label(self, i):
+        v = np.zeros(self.c_dim, np.float32)
+        v[i % self.c_dim] = 1.0
+        return v
+
+    def get_camera_angles(self, i):
+        return np.array([0.1 * i - 0.5, 1.2 + 0.03 * i, 0.0], np.float32)
+
+
+def gen_harness():
+    """seeds -> ws (scripts/inference.py:87-150) and the conditioning iterator of the metric loops (metric_utils.py:60-101)."""
+    hy = types.ModuleType('hydra')
+    hy.main = lambda **kw: (lambda f: f)
+    sys.modules.setdefault('hydra', hy)
+    sys.modules['torchvision.utils'].make_grid = None
+    ds = types.ModuleType('torchvision.datasets')
+    ds.__path__ = []
+    ds.VisionDataset = object
+    fo = types.ModuleType('torchvision.datasets.folder')
+    fo.pil_loader = None
+    sys.modules.setdefault('torchvision.datasets', ds)
+    sys.modules.setdefault('torchvision.datasets.folder', fo)
+    sys.modules['torchvision'].datasets = ds
+    from scripts import inference as ref_inf
+    from src.metrics import metric_utils as mu
+    arrays = {}
+    cfg = tdgp.config.config_mid()
+    sd = tdgp.weights.random_state_dict(cfg, seed=11, exercise_all=True)
+    G = build_ref_generator(cfg, sd)
+    seeds = [3, 17, 17, 2024, 5, 8]
+    arrays['seeds'] = np.array(seeds)
+    arrays['classes'] = np.array([1, 4])
+    arrays['z'] = npy(ref_inf.sample_z_from_seeds(seeds, G.z_dim))
+    arrays['c'] = npy(ref_inf.sample_c_from_seeds(seeds, G.c_dim))
+    with torch.no_grad():
+        for tag, kw in (('psi1', dict(psi=1.0)), ('psi06', dict(psi=0.6)), ('psi06_cls', dict(psi=0.6, classes=[1, 4])),
+                        ('psi1_cls', dict(psi=1.0, classes=[1, 4])), ('interp', dict(psi=0.8, num_interp_steps=5))):
+            torch.manual_seed(81)
+            ws, z, c = ref_inf.sample_ws_from_seeds(G, seeds, EasyDict(truncation_psi=kw['psi']), 'cpu', num_interp_steps=kw.get('num_interp_steps', 0),
+                                                    classes=kw.get('classes'))
+            arrays[f'ws_{tag}'] = npy(ws)
+            if not isinstance(z, tuple):
+                arrays[f'z_{tag}'], arrays[f'c_{tag}'] = npy(z), npy(c)
+    # the conditioning iterator: conditional generator (labels from the dataset), custom angles, frontal camera, unconditional prior
+    cam = tdgp.metrics.camera_base()
+    to_easy = lambda d: EasyDict({k: to_easy(v) if isinstance(v, dict) else v for k, v in d.items()})      # noqa: E731
+    custom = {**cam, 'origin': dict(radius=cam['origin']['radius'], angles=dict(dist='custom'))}
+    torch.Tensor.pin_memory = lambda self: self      # no GPU in the build container: page-locking is a no-op for the values
+    for tag, c_dim, camcfg, frontal in (('cond', 5, cam, False), ('custom', 5, custom, False), ('frontal', 5, cam, True), ('uncond', 0, cam, False),
+                                        ('uncond_custom', 0, custom, False)):
+        opts = EasyDict(G=EasyDict(c_dim=c_dim, cfg=EasyDict(camera=to_easy(camcfg))), device='cpu',
+                        dataset_kwargs=EasyDict(class_name='__main__._GoldenDataset', c_dim=max(c_dim, 1), size=11))
+        torch.manual_seed(82)
+        np.random.seed(82)
+        it = mu.iterate_random_conditioning(opts, 4, frontal_camera=frontal)
+        for step in range(2):
+            c, cp = next(it)
+            arrays[f'it_{tag}_{step}_c'] = npy(c)
+            arrays.update({f'it_{tag}_{step}_{k}': npy(cp[k]) for k in ('angles', 'fov', 'radius', 'look_at')})
+    save('harness', **arrays)
+
+
 def main():
     torch.set_num_threads(8)
     if len(sys.argv) > 1:                      # regenerate selected files only: python tools/gen_goldens.py adaptors
@@ -560,6 +632,7 @@ def main():
     gen_adaptors()
     gen_metrics()
     gen_trajectories()
+    gen_harness()
     gen_bias_act()
     gen_bias_act_grad()
     gen_upfirdn2d()
