@@ -47,6 +47,15 @@ class Conv2dLayer(torch.nn.Module):
                                         gain=self.act_gain * gain, clamp=act_clamp)
 
 
+def linear_schedule(step, val_start, val_end, period, start_step=0):
+    """training_utils.py:8-18: linear ramp from val_start to val_end over `period` steps, clamped at both ends."""
+    if step >= start_step + period:
+        return val_end
+    if step <= start_step:
+        return val_start
+    return val_start + (val_end - val_start) * (step - start_step) / period
+
+
 class DepthAdaptor(torch.nn.Module):
     """networks_depth_adaptor.py:21-99 (forward, eval)."""
 
@@ -60,6 +69,14 @@ class DepthAdaptor(torch.nn.Module):
         self.head = Conv2dLayer(dims[-1], 1, 1, activation='linear') if len(self.layers) > 0 else None
         self.register_buffer('progress_coef', torch.tensor([0.0]))
         self.near_plane_offset_raw = torch.nn.Parameter(torch.tensor([cfg.near_plane_offset_bias]).float())
+
+    def progressive_update(self, cur_kimg):
+        """:61-62: the selection probability of the raw depth anneals from uniform to selection_start_p over anneal_kimg."""
+        self.progress_coef.data = torch.tensor(linear_schedule(cur_kimg, 0.0, 1.0, self.cfg.anneal_kimg)).to(self.progress_coef.device)
+
+    @property
+    def start_p(self):
+        return (1.0 / (self.cfg.num_hid_layers + 1) * (1 - self.progress_coef) + self.cfg.selection_start_p * self.progress_coef).item()
 
     def get_near_plane_offset(self, w):
         raw = self.near_plane_offset_raw.repeat(len(w))
@@ -77,12 +94,11 @@ class DepthAdaptor(torch.nn.Module):
         layer (:83,:97-99), 'mean' the mean over the input and every head.  The reference adds `0.0 * outs.max()` (a
         DataParallel workaround that only matters for non-finite values); the intermediate heads are therefore only
         evaluated when they are needed ('mean', or `all_outs=True` for the parity tests)."""
-        if self.training:
-            raise NotImplementedError('DepthAdaptor: forward-only (the training-time random head selection is not on this path)')
         x = self.normalize(depth_map.float(), w)
         if self.head is None:
             return x
-        need_all = all_outs or self.cfg.out_strategy == 'mean'
+        pick_random = self.training and self.cfg.out_strategy == 'random'
+        need_all = all_outs or self.cfg.out_strategy == 'mean' or pick_random
         outs = [x]
         for i, layer in enumerate(self.layers):
             x = layer(x)
@@ -90,6 +106,14 @@ class DepthAdaptor(torch.nn.Module):
                 outs.append(self.head(x))
         if all_outs:
             return torch.stack(outs).transpose(0, 1)                                       # [B, num_outs, 1, h, w]
+        if pick_random:
+            # :86-92,96-97: one head per sample, drawn (numpy RNG) with probabilities rising linearly from start_p at the raw depth
+            num_outs = len(outs)
+            idx = np.arange(num_outs)
+            slope = (1 - num_outs * self.start_p) * 2 / (num_outs * (num_outs - 1))
+            random_idx = torch.from_numpy(np.random.choice(idx, size=(len(x),), p=idx * slope + self.start_p))
+            stacked = torch.stack(outs).transpose(0, 1)
+            return stacked[torch.arange(len(x)), random_idx]
         if self.cfg.out_strategy in ('last', 'random'):
             return outs[-1]
         if self.cfg.out_strategy == 'mean':

@@ -18,6 +18,8 @@ class DepthAdaptorConfig:
     out_strategy: str = 'random'
     near_plane_offset_max_fraction: float = 0.25
     near_plane_offset_bias: float = -3.0
+    selection_start_p: float = 0.1      # training-time head selection (networks_depth_adaptor.py:64-66,86-92)
+    anneal_kimg: float = 10000
 
 
 @dataclass
@@ -69,6 +71,11 @@ class GeneratorConfig:
     density_bias: float = 0.0
     img_resolution: int = 256
     max_batch_res: int = 128        # kept for API parity (run_batchwise chunking is a no-op for results)
+    # training-mode forward: patch-wise rendering resolution (configs/training/patch_beta.yaml `resolution`;
+    # None = patch.enabled off -> img_resolution) and the density-noise schedule (configs/model/3dgp.yaml:22-23)
+    patch_resolution: Optional[int] = None
+    nerf_noise_std_init: float = 1.0
+    nerf_noise_kimg_growth: float = 5000
     # enabled in every 3dgp training config (model/base.yaml:32-35); None = module absent, as when
     # `training.use_depth` / `training.learn_camera_dist` are off.  The section-8a hot path (and bench.py's metric) is the
     # generator forward without them.
@@ -131,6 +138,13 @@ def config_mid():
     """Mid-sized golden configuration: exercises MFMA tile edges (channels 64/32, 64^2 planes)."""
     return GeneratorConfig(z_dim=64, w_dim=64, c_dim=10, cbase=2048, cmax=64, tri_plane_res=64, feat_dim=32,
                            mlp_hid=64, num_ray_steps=16, img_resolution=32)
+
+
+def config_train_golden():
+    """The training-mode golden (tools/gen_goldens.py:gen_train_forward): config_mid rendered patch-wise at 16^2."""
+    cfg = config_mid()
+    cfg.patch_resolution = 16
+    return cfg
 
 
 def configs_adaptor_goldens():

@@ -47,6 +47,8 @@ struct FieldParams {
     const float* t;        // [B*R*S]
     const float* w0; const float* b0; const float* w1; const float* b1;
     float* rgbs;           // [B*P,4]
+    const float* snoise;   // [B*P] standard-normal draws or null: sigma += snoise * snoise_std (tri_plane_renderer.py:185-186)
+    float snoise_std;
     int32_t* tap_idx;      // [B*P,3,2] or null
     int64_t total;         // B*P
     int64_t P;
@@ -276,7 +278,11 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
         issue_taps(cx, cy, cz, bplanes, ggp, gvalid);
         blend(g);
         const float4 o = mlp(g);
-        if (q == 0 && valid && (!(TDGP_FIELD_ABL & 4) || o.x == 123.f)) ((float4*)p.rgbs)[gp] = o;
+        if (q == 0 && valid && (!(TDGP_FIELD_ABL & 4) || o.x == 123.f)) {
+            float4 on = o;
+            if (p.snoise) on.w = __fadd_rn(on.w, __fmul_rn(p.snoise[gp], p.snoise_std));
+            ((float4*)p.rgbs)[gp] = on;
+        }
     };
 
     if (p.ray_w > 0) {
@@ -402,8 +408,13 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
                         __builtin_amdgcn_wave_barrier();
                         const int k0 = k & ~7, nk = (k & 7) + 1;
                         const int fr = l >> 2, j = (l & 3) * 2;
-                        const float4 v0 = obuf[fr * 9 + j], v1 = obuf[fr * 9 + j + 1];
+                        float4 v0 = obuf[fr * 9 + j], v1 = obuf[fr * 9 + j + 1];
                         float4* dst = (float4*)p.rgbs + (int64_t)fray * p.S + k0 + j;
+                        if (p.snoise && fok) {
+                            const float* np = p.snoise + (int64_t)fray * p.S + k0 + j;
+                            if (j < nk) v0.w = __fadd_rn(v0.w, __fmul_rn(np[0], p.snoise_std));
+                            if (j + 1 < nk) v1.w = __fadd_rn(v1.w, __fmul_rn(np[1], p.snoise_std));
+                        }
                         if (fok && !(TDGP_FIELD_ABL & 4)) {
                             if (j < nk) dst[0] = v0;
                             if (j + 1 < nk) dst[1] = v1;
@@ -455,8 +466,13 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
                     __builtin_amdgcn_wave_barrier();
                     const int k0 = k & ~7, nk = (k & 7) + 1;
                     const int fr = l >> 2, j = (l & 3) * 2;
-                    const float4 v0 = obuf[fr * 9 + j], v1 = obuf[fr * 9 + j + 1];
+                    float4 v0 = obuf[fr * 9 + j], v1 = obuf[fr * 9 + j + 1];
                     float4* dst = (float4*)p.rgbs + (int64_t)fray * p.S + k0 + j;
+                    if (p.snoise && fok) {
+                        const float* np = p.snoise + (int64_t)fray * p.S + k0 + j;
+                        if (j < nk) v0.w = __fadd_rn(v0.w, __fmul_rn(np[0], p.snoise_std));
+                        if (j + 1 < nk) v1.w = __fadd_rn(v1.w, __fmul_rn(np[1], p.snoise_std));
+                    }
                     if (fok && !(TDGP_FIELD_ABL & 4)) {
                         if (j < nk) dst[0] = v0;
                         if (j + 1 < nk) dst[1] = v1;
@@ -545,17 +561,20 @@ TDGP_API int tdgp_planes_to_hwc(const float* planes_nchw, float* planes_hwc, int
 }
 
 TDGP_API int tdgp_triplane_field(const float* planes_hwc, const float* coords, const float* ray_o, const float* ray_d, const float* t,
-                                 const float* w0, const float* b0, const float* w1, const float* b1, float* rgbs, int32_t* tap_idx, int B,
-                                 int64_t P, int S, int ray_w, int F, int H, int W, int hid, float scale, int marcher, tdgp_stream_t stream) {
+                                 const float* w0, const float* b0, const float* w1, const float* b1, const float* sigma_noise, float density_noise,
+                                 float* rgbs, int32_t* tap_idx, int B, int64_t P, int S, int ray_w, int F, int H, int W, int hid, float scale,
+                                 int marcher, tdgp_stream_t stream) {
     TDGP_CHECK(planes_hwc && w0 && b0 && w1 && b1 && rgbs, TDGP_EINVAL, "triplane_field: null pointer");
     TDGP_CHECK(coords || (ray_o && ray_d && t && S >= 1), TDGP_EINVAL, "triplane_field: need coords, or ray_o/ray_d/t with S >= 1");
     TDGP_CHECK(B >= 0 && P >= 0 && H >= 2 && W >= 2, TDGP_EINVAL, "triplane_field: bad shape");
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "triplane_field: unknown ray marcher %d", marcher);
     TDGP_CHECK(coords || (P % S) == 0, TDGP_EINVAL, "triplane_field: P must be a multiple of S in ray mode");
+    TDGP_CHECK(!(density_noise > 0.f) || sigma_noise, TDGP_EINVAL, "triplane_field: density_noise > 0 needs the sigma_noise draws");
     if (B == 0 || P == 0) return TDGP_OK;
     FieldParams p;
     p.planes = planes_hwc; p.coords = coords; p.ray_o = ray_o; p.ray_d = ray_d; p.t = t;
     p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1; p.rgbs = rgbs; p.tap_idx = tap_idx;
+    p.snoise = density_noise > 0.f ? sigma_noise : nullptr; p.snoise_std = density_noise;
     p.total = (int64_t)B * P; p.P = P; p.S = coords ? 1 : S; p.H = H; p.W = W; p.scale = scale;
     { int ex; p.scale_is_pow2 = (frexpf(scale, &ex) == 0.5f) ? 1 : 0; p.inv_scale = 1.0f / scale; }
     TDGP_CHECK((int64_t)B * P <= INT32_MAX / 4 && (int64_t)3 * H * W * F <= INT32_MAX, TDGP_EINVAL, "triplane_field: tensor too large");

@@ -99,9 +99,10 @@ class FullyConnectedLayer(torch.nn.Module):
 class MappingNetwork(torch.nn.Module):
     """layers.py:66-177 without camera conditioning (`camera_cond` is off in every 3dgp config of the hot path)."""
 
-    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=2, lr_multiplier=0.01):
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=2, lr_multiplier=0.01, w_avg_beta=0.998):
         super().__init__()
         self.z_dim, self.c_dim, self.w_dim, self.num_ws, self.num_layers = z_dim, c_dim, w_dim, num_ws, num_layers
+        self.w_avg_beta = w_avg_beta
         embed_features = w_dim if c_dim > 0 else 0
         if c_dim > 0:
             self.embed = FullyConnectedLayer(c_dim, embed_features)
@@ -113,8 +114,6 @@ class MappingNetwork(torch.nn.Module):
     def forward(self, z, c, camera_angles=None, truncation_psi=1, truncation_cutoff=None, update_emas=False):
         if camera_angles is not None:
             raise NotImplementedError('camera-conditioned mapping (camera_cond) is off in the 3dgp configs')
-        if update_emas:
-            raise NotImplementedError('update_emas is a training-time option')
         x = None
         if self.z_dim > 0:
             assert z.shape[1] == self.z_dim, f'Wrong shape: z {tuple(z.shape)}'
@@ -125,6 +124,8 @@ class MappingNetwork(torch.nn.Module):
             x = torch.cat([x, y], dim=1) if x is not None else y
         for i in range(self.num_layers):
             x = getattr(self, f'fc{i}')(x)
+        if update_emas and self.w_avg_beta is not None:                       # layers.py:156-159: moving average of W
+            self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
         if self.num_ws is not None:
             x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
         if truncation_psi != 1:
@@ -346,7 +347,9 @@ class SynthesisBlocksSequence(torch.nn.Module):
 
 
 class SynthesisNetwork(torch.nn.Module):
-    """networks_epigraf.py:134-261 (eval).  The depth / camera adaptors exist when the configuration carries them."""
+    """networks_epigraf.py:134-261.  The depth / camera adaptors exist when the configuration carries them.  `.train()` switches
+    to the training-mode forward (no autograd -- gradients are SURVEY.md 8f rank 4): rays at `train_resolution` (patch-wise
+    training, `patch_params`), sigma perturbed by `nerf_noise_std` (set by `progressive_update`), random head of the depth adaptor."""
 
     def __init__(self, cfg: GeneratorConfig, img_resolution, img_channels=3):
         super().__init__()
@@ -356,6 +359,8 @@ class SynthesisNetwork(torch.nn.Module):
         self.tri_plane_mlp = _renderer.TriPlaneMLP(cfg.feat_dim, cfg.mlp_hid, out_dim=img_channels, ray_marcher_type=cfg.ray_marcher_type)
         self.num_ws = self.tri_plane_decoder.num_ws
         self.test_resolution = img_resolution
+        self.train_resolution = cfg.patch_resolution if cfg.patch_resolution is not None else img_resolution
+        self.nerf_noise_std = 0.0
         self.renderer = _renderer.ImportanceRenderer(ray_marcher_type=cfg.ray_marcher_type)
         from . import adaptors as _adaptors          # (adaptors imports this module)
         self.depth_adaptor = _adaptors.DepthAdaptor(cfg.depth_adaptor, min_depth=cfg.ray_start, max_depth=cfg.ray_end) if cfg.depth_adaptor is not None else None
@@ -363,11 +368,19 @@ class SynthesisNetwork(torch.nn.Module):
         self._default_render_options = dict(max_batch_res=cfg.max_batch_res, return_depth=False, return_depth_adapted=False, return_weights=False,
                                             concat_depth=False, cut_quantile=0.0, density_bias=cfg.density_bias)
 
+    def progressive_update(self, cur_kimg):
+        """networks_epigraf.py:191-194: density-noise std decays linearly to 0 over nerf_noise_kimg_growth; the depth adaptor anneals."""
+        from .adaptors import linear_schedule
+        self.nerf_noise_std = linear_schedule(cur_kimg, self.cfg.nerf_noise_std_init, 0.0, self.cfg.nerf_noise_kimg_growth)
+        if self.depth_adaptor is not None:
+            self.depth_adaptor.progressive_update(cur_kimg)
+
     def rendering_options(self, render_opts):
-        """networks_epigraf.py:226-231."""
+        """networks_epigraf.py:222,226-231."""
         cfg = self.cfg
         return dict(box_size=cfg.cube_scale * 2, num_proposal_steps=cfg.num_ray_steps, clamp_mode='softplus', use_inf_depth=cfg.use_inf_depth,
-                    ray_start=cfg.ray_start, ray_end=cfg.ray_end, num_fine_steps=cfg.num_ray_steps, density_noise=0.0, last_back=cfg.last_back,
+                    ray_start=cfg.ray_start, ray_end=cfg.ray_end, num_fine_steps=cfg.num_ray_steps,
+                    density_noise=self.nerf_noise_std if self.training else 0.0, last_back=cfg.last_back,
                     white_back=cfg.white_back, max_batch_res=render_opts['max_batch_res'], cut_quantile=render_opts['cut_quantile'],
                     density_bias=render_opts['density_bias'])
 
@@ -378,23 +391,23 @@ class SynthesisNetwork(torch.nn.Module):
         return _renderer.simple_tri_plane_renderer(planes, coords, self.tri_plane_mlp, scale=self.cfg.cube_scale)['sigma']
 
     @torch.no_grad()
-    def forward(self, ws, camera_params, patch_params=None, render_opts={}, u_coarse=None, u_fine=None, update_emas=False, **block_kwargs):
+    def forward(self, ws, camera_params, patch_params=None, render_opts={}, u_coarse=None, u_fine=None, n_coarse=None, n_fine=None,
+                update_emas=False, **block_kwargs):
         """ws [B,num_ws,w_dim]; camera_params {angles [B,3], fov [B], radius [B], look_at [B,3]} -> img [B,3,h,w]
-        (or TensorGroup(img, depth) with render_opts['return_depth'])."""
-        if self.training:
-            raise NotImplementedError('the HIP path implements the eval-mode forward (training is SURVEY.md 8f rank 4)')
+        (or TensorGroup(img, depth) with render_opts['return_depth']).  u_* / n_*: explicit uniform / normal draws of the renderer
+        (stratification, inverse-CDF, density noise) for the parity tests; drawn on the device when absent."""
         render_opts = {**self._default_render_options, **render_opts}
         if (render_opts['return_depth_adapted'] or render_opts['concat_depth']) and self.depth_adaptor is None:
             raise RuntimeError('return_depth_adapted / concat_depth need cfg.depth_adaptor')
         B = ws.shape[0]
         planes = self.tri_plane_decoder(ws[:, :self.tri_plane_decoder.num_ws], hwc=True, **block_kwargs)
-        h = w = self.test_resolution
+        h = w = self.train_resolution if self.training else self.test_resolution
         cam = camera_params
         get = (lambda k: cam[k]) if isinstance(cam, dict) else (lambda k: getattr(cam, k))
         c2w = _renderer.compute_cam2world_matrix(cam)
         ray_o, ray_d = _renderer.sample_rays(c2w, fov=get('fov'), resolution=(h, w), patch_params=patch_params, device=ws.device)
         opts = self.rendering_options(render_opts)
-        opts['u_coarse'], opts['u_fine'] = u_coarse, u_fine
+        opts['u_coarse'], opts['u_fine'], opts['n_coarse'], opts['n_fine'] = u_coarse, u_fine, n_coarse, n_fine
         opts['ray_grid_w'] = w                      # rays are the row-major pixels of an h x w image (sample_rays)
         rgb, depth, _w, _T = self.renderer(planes, self.tri_plane_mlp, ray_o, ray_d, opts)
         img = torch.empty([B, self.img_channels, h, w], dtype=torch.float32, device=ws.device)
@@ -432,6 +445,10 @@ class Generator(torch.nn.Module):
         self.num_ws = self.synthesis.num_ws
         self.mapping = MappingNetwork(z_dim=cfg.z_dim, c_dim=cfg.c_dim, w_dim=cfg.w_dim, num_ws=self.num_ws, num_layers=cfg.map_depth)
         self.eval()
+
+    def progressive_update(self, cur_kimg):
+        """networks_epigraf.py:285-286."""
+        self.synthesis.progressive_update(cur_kimg)
 
     def load_numpy_state_dict(self, sd, strict=True):
         """Load a {reference key: numpy array} state-dict (weights.random_state_dict or an exported checkpoint)."""

@@ -148,7 +148,7 @@ def planes_to_hwc(x):
     return HWCPlanes(out)
 
 
-def _field(planes, mlp_params, scale, coords=None, ray_o=None, ray_d=None, t=None, tap_idx=None, ray_w=0):
+def _field(planes, mlp_params, scale, coords=None, ray_o=None, ray_d=None, t=None, tap_idx=None, ray_w=0, sigma_noise=None, density_noise=0.0):
     w0, b0, w1, b1, marcher = mlp_params
     p = planes.t
     B, _, H, W, F = p.shape
@@ -160,21 +160,27 @@ def _field(planes, mlp_params, scale, coords=None, ray_o=None, ray_d=None, t=Non
     rgbs = torch.empty([B, P, 4], dtype=torch.float32, device=p.device)
     if B * P == 0:
         return rgbs
+    if density_noise > 0.0:
+        sigma_noise = torch.randn([B, P], device=p.device) if sigma_noise is None else _lib.f32c(sigma_noise.to(p.device))
+        if sigma_noise.numel() != B * P:
+            raise RuntimeError(f'sigma noise must have {B}x{P} elements')
     with torch.cuda.device(p.device):
         _lib.call('tdgp_triplane_field', p.data_ptr(), _lib.ptr(coords), _lib.ptr(ray_o), _lib.ptr(ray_d), _lib.ptr(t), w0.data_ptr(),
-                  b0.data_ptr(), w1.data_ptr(), b1.data_ptr(), rgbs.data_ptr(), _lib.ptr(tap_idx), B, P, S, int(ray_w), F, H, W, w0.shape[0],
-                  float(scale), MARCHER_IDS[marcher], _lib.stream_of(p))
+                  b0.data_ptr(), w1.data_ptr(), b1.data_ptr(), _lib.ptr(sigma_noise) if density_noise > 0.0 else None, float(density_noise),
+                  rgbs.data_ptr(), _lib.ptr(tap_idx), B, P, S, int(ray_w), F, H, W, w0.shape[0], float(scale), MARCHER_IDS[marcher],
+                  _lib.stream_of(p))
     return rgbs
 
 
-def simple_tri_plane_renderer(x, coords, mlp, scale=1.0, return_taps=False):
-    """x: [B, 3*feat, H, W] (or HWCPlanes); coords: [B, P, 3] -> {'rgb': [B,P,3], 'sigma': [B,P,1]}."""
+def simple_tri_plane_renderer(x, coords, mlp, scale=1.0, return_taps=False, sigma_noise=None, density_noise=0.0):
+    """x: [B, 3*feat, H, W] (or HWCPlanes); coords: [B, P, 3] -> {'rgb': [B,P,3], 'sigma': [B,P,1]}.  `density_noise` > 0 adds
+    `sigma_noise * density_noise` to sigma inside the kernel (`sigma_noise` [B,P,1] standard-normal draws, drawn here when None)."""
     planes = planes_to_hwc(x)
     _lib.require_cuda(coords, 'coords')
     B = planes.t.shape[0]
     assert coords.ndim == 3 and coords.shape[0] == B and coords.shape[2] == 3, f'Wrong shape: coords {tuple(coords.shape)}'
     taps = torch.empty([B, coords.shape[1], 3, 2], dtype=torch.int32, device=coords.device) if return_taps else None
-    rgbs = _field(planes, _mlp_params(mlp), scale, coords=coords, tap_idx=taps)
+    rgbs = _field(planes, _mlp_params(mlp), scale, coords=coords, tap_idx=taps, sigma_noise=sigma_noise, density_noise=density_noise)
     out = {'rgb': rgbs[..., :3], 'sigma': rgbs[..., 3:4]}
     if return_taps:
         out['taps'] = taps
@@ -273,10 +279,10 @@ class ImportanceRenderer(torch.nn.Module):
         return (d, c, s, perm) if return_perm else (d, c, s)
 
     def run_model(self, planes, decoder, sample_coordinates, rendering_options):
-        """Field evaluation at explicit coordinates (tri_plane_renderer.py:172-187)."""
-        if rendering_options.get('density_noise', 0.0) > 0.0:
-            raise NotImplementedError('density_noise > 0 is a training-time option')
-        return simple_tri_plane_renderer(planes, sample_coordinates, decoder, scale=rendering_options['box_size'] / 2)
+        """Field evaluation at explicit coordinates (tri_plane_renderer.py:172-187); `density_noise` > 0 perturbs sigma with
+        `rendering_options['sigma_noise']` (explicit draws, [B,P,1]) or fresh device-side normal draws."""
+        return simple_tri_plane_renderer(planes, sample_coordinates, decoder, scale=rendering_options['box_size'] / 2,
+                                         sigma_noise=rendering_options.get('sigma_noise'), density_noise=float(rendering_options.get('density_noise', 0.0)))
 
     # -- the whole chain ---------------------------------------------------------------------------------------------
     def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, return_intermediates=False):
@@ -285,8 +291,9 @@ class ImportanceRenderer(torch.nn.Module):
         _lib.require_cuda(ray_origins, 'ray_origins')
         if isinstance(opts.get('ray_start'), str):
             raise NotImplementedError("ray_start='auto' (use_full_box) is never resolved by the reference renderer either (SURVEY.md 8a)")
-        if opts.get('density_noise', 0.0) > 0.0:
-            raise NotImplementedError('density_noise > 0 is a training-time option')
+        dnoise = float(opts.get('density_noise', 0.0))
+        # explicit sigma-noise draws (parity tests): n_coarse [B,R*S,1], n_fine [B,R*N,1] in the reference's point order = DRAW order
+        n_coarse, n_fine = opts.get('n_coarse'), opts.get('n_fine')
         planes = planes_to_hwc(planes)
         mlp = _mlp_params(decoder)
         if mlp[4] != marcher:
@@ -313,7 +320,7 @@ class ImportanceRenderer(torch.nn.Module):
             sdist = torch.empty([B, R, S], dtype=torch.float32, device=dev)
             tdist = torch.empty([B, R, S], dtype=torch.float32, device=dev)
             _lib.call('tdgp_sample_stratified', u_coarse.data_ptr(), sdist.data_ptr(), tdist.data_ptr(), B * R, S, mid, t_near, t_far, stream)
-            rgbs_c = _field(planes, mlp, scale, ray_o=ray_o, ray_d=ray_d, t=tdist, ray_w=ray_w)
+            rgbs_c = _field(planes, mlp, scale, ray_o=ray_o, ray_d=ray_d, t=tdist, ray_w=ray_w, sigma_noise=n_coarse, density_noise=dnoise)
             if N > 0:
                 u_fine = opts.get('u_fine')
                 u_fine = torch.rand([B * R, N], device=dev) if u_fine is None else _lib.f32c(u_fine.to(dev))
@@ -322,10 +329,12 @@ class ImportanceRenderer(torch.nn.Module):
                 tfine = torch.empty([B, R, N], dtype=torch.float32, device=dev)
                 sfine = torch.empty([B, R, N], dtype=torch.float32, device=dev) if return_intermediates else None
                 inds = torch.empty([B * R, N], dtype=torch.int32, device=dev) if return_intermediates else None
-                fperm = torch.empty([B * R, N], dtype=torch.int32, device=dev) if return_intermediates else None
+                fperm = torch.empty([B * R, N], dtype=torch.int32, device=dev) if (return_intermediates or (dnoise > 0.0 and n_fine is not None)) else None
                 _lib.call('tdgp_importance_from_coarse', rgbs_c.data_ptr(), sdist.data_ptr(), u_fine.data_ptr(), tfine.data_ptr(),
                           _lib.ptr(sfine), _lib.ptr(inds), _lib.ptr(fperm), B * R, S, N, mid, flags, dbias, t_near, t_far, stream)
-                rgbs_f = _field(planes, mlp, scale, ray_o=ray_o, ray_d=ray_d, t=tfine, ray_w=ray_w)
+                if dnoise > 0.0 and n_fine is not None:      # the kernel evaluates the fine samples depth-sorted: carry each draw to its slot
+                    n_fine = _lib.f32c(n_fine.to(dev)).reshape(B * R, N).gather(1, fperm.long())
+                rgbs_f = _field(planes, mlp, scale, ray_o=ray_o, ray_d=ray_d, t=tfine, ray_w=ray_w, sigma_noise=n_fine, density_noise=dnoise)
                 rgb = torch.empty([B, R, 3], dtype=torch.float32, device=dev)
                 depth = torch.empty([B, R, 1], dtype=torch.float32, device=dev)
                 wsum = torch.empty([B, R, 1], dtype=torch.float32, device=dev)

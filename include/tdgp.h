@@ -180,11 +180,13 @@ int tdgp_planes_to_hwc(const float* planes_nchw, float* planes_hwc, int B, int F
  * lrelu 0.2 * sqrt(2) applied inside, layers.py:39-58).
  * out: rgbs [B,P,4] = (r,g,b,sigma); marcher=1 applies sigmoid*1.002-0.001 to rgb (networks_epigraf.py:61-62).
  * tap_idx: optional int32 [B,P,3,2] = (floor ix, floor iy) per plane, for integer-row parity tests.
+ * sigma_noise / density_noise: training-time density noise (tri_plane_renderer.py:185-186): sigma += sigma_noise[b,p] * density_noise
+ *          with sigma_noise [B,P] standard-normal draws; density_noise = 0 (sigma_noise may be NULL) turns it off.
  * Requires F % 4 == 0, F <= 64, hid % 16 == 0, hid <= 128. */
 int tdgp_triplane_field(const float* planes_hwc, const float* coords, const float* ray_o, const float* ray_d,
                         const float* t, const float* w0, const float* b0, const float* w1, const float* b1,
-                        float* rgbs, int32_t* tap_idx, int B, int64_t P, int S, int ray_w, int F, int H, int W, int hid,
-                        float scale, int marcher, tdgp_stream_t stream);
+                        const float* sigma_noise, float density_noise, float* rgbs, int32_t* tap_idx, int B, int64_t P,
+                        int S, int ray_w, int F, int H, int W, int hid, float scale, int marcher, tdgp_stream_t stream);
 
 /* Generic marcher on [rays,S,C] colours, [rays,S] densities/depths (any S <= 256, C <= 8).
  * weights: [rays,S] (classical, or mip with inf depth) / [rays,S-1] (mip without); may be NULL.

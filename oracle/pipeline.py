@@ -111,9 +111,15 @@ def synthesis_backbone(sd, cfg, ws, noise_mode='const', return_intermediates=Fal
     return (img, inter) if return_intermediates else img
 
 
-def importance_render(planes, mlp, ray_o, ray_d, opts, u_coarse, u_fine, return_intermediates=False):
+def importance_render(planes, mlp, ray_o, ray_d, opts, u_coarse, u_fine, return_intermediates=False, n_coarse=None, n_fine=None):
     """ImportanceRenderer.forward, tri_plane_renderer.py:126-170.
-    planes [B,3F,H,W]; mlp = (w0,b0,w1,b1); u_coarse [B,R,S]; u_fine [B*R,S]."""
+    planes [B,3F,H,W]; mlp = (w0,b0,w1,b1); u_coarse [B,R,S]; u_fine [B*R,S].  opts['density_noise'] > 0 (training):
+    sigma += n * density_noise after each field evaluation (:185-186), n_coarse [B,R*S,1] / n_fine [B,R*N,1] = the randn draws."""
+    dnoise = np.float32(opts.get('density_noise', 0.0))
+
+    def add_noise(sigma, n):
+        return sigma if not dnoise > 0 else (sigma + np.asarray(n, np.float32).reshape(sigma.shape) * dnoise).astype(np.float32)
+
     mode = opts['ray_marcher_type']
     B, R, _ = ray_o.shape
     S = opts['num_proposal_steps']
@@ -122,7 +128,7 @@ def importance_render(planes, mlp, ray_o, ray_d, opts, u_coarse, u_fine, return_
     tdist = O.s_to_t(sdist, opts['ray_start'], opts['ray_end'])
     out = O.triplane_field(planes, O.ray_points(ray_o, ray_d, tdist), *mlp, scale=scale, mlp_mode=mode)
     col_c = out['rgb'].reshape(B, R, S, 3)
-    den_c = out['sigma'].reshape(B, R, S, 1)
+    den_c = add_noise(out['sigma'], n_coarse).reshape(B, R, S, 1)
 
     def march(c, d, z):
         if mode == 'classical':
@@ -139,7 +145,7 @@ def importance_render(planes, mlp, ray_o, ray_d, opts, u_coarse, u_fine, return_
         tfine = O.s_to_t(sfine[..., 0], opts['ray_start'], opts['ray_end'])
         out = O.triplane_field(planes, O.ray_points(ray_o, ray_d, tfine), *mlp, scale=scale, mlp_mode=mode)
         col_f = out['rgb'].reshape(B, R, N, 3)
-        den_f = out['sigma'].reshape(B, R, N, 1)
+        den_f = add_noise(out['sigma'], n_fine).reshape(B, R, N, 1)
         d_all, c_all, s_all = O.unify_samples(tdist[..., None], col_c, den_c, tfine[..., None], col_f, den_f)
         rgb, depth, wts, fT = march(c_all, s_all, d_all)
         inter.update(weights_coarse=w_c, sdist_fine=sfine, colors_fine=col_f, densities_fine=den_f, all_depths=d_all)
@@ -157,16 +163,20 @@ def render_options(cfg):
                 density_bias=cfg.get('density_bias', 0.0), ray_marcher_type=cfg['ray_marcher_type'])
 
 
-def synthesis_forward(sd, cfg, ws, camera, u_coarse, u_fine, noise_mode='const', return_intermediates=False):
-    """SynthesisNetwork.forward, networks_epigraf.py:210-261 (eval, no adaptors).
-    camera: dict angles [B,3], fov [B], radius [B], look_at [B,3]."""
+def synthesis_forward(sd, cfg, ws, camera, u_coarse, u_fine, noise_mode='const', return_intermediates=False, training=None):
+    """SynthesisNetwork.forward, networks_epigraf.py:210-261 (no adaptors).
+    camera: dict angles [B,3], fov [B], radius [B], look_at [B,3].
+    training = None (eval) or dict(resolution, patch_scales [B,2], patch_offsets [B,2], density_noise, n_coarse, n_fine):
+    the training-mode forward (:220-222) -- rays of a patch at train_resolution, sigma perturbed by the density noise."""
     planes, inter = synthesis_backbone(sd, cfg, ws, noise_mode, return_intermediates=True)
-    h = w = cfg['img_resolution']
+    tr = training or {}
+    h = w = tr.get('resolution', cfg['img_resolution'])
     c2w = O.cam2world(camera['angles'], camera['radius'], camera['look_at'])
-    ray_o, ray_d = O.sample_rays(c2w, camera['fov'], h, w)
+    ray_o, ray_d = O.sample_rays(c2w, camera['fov'], h, w, tr.get('patch_scales'), tr.get('patch_offsets'))
     mlp = tuple(sd[f'synthesis.tri_plane_mlp.model.{i}.{n}'] for i in (0, 1) for n in ('weight', 'bias'))
-    (rgb, depth, wsum, fT), rinter = importance_render(planes, mlp, ray_o, ray_d, render_options(cfg), u_coarse, u_fine,
-                                                       return_intermediates=True)
+    ropts = dict(render_options(cfg), density_noise=tr.get('density_noise', 0.0))
+    (rgb, depth, wsum, fT), rinter = importance_render(planes, mlp, ray_o, ray_d, ropts, u_coarse, u_fine, return_intermediates=True,
+                                                       n_coarse=tr.get('n_coarse'), n_fine=tr.get('n_fine'))
     B = ws.shape[0]
     img = np.ascontiguousarray(rgb.reshape(B, h, w, 3).transpose(0, 3, 1, 2))
     depth = depth.reshape(B, 1, h, w)

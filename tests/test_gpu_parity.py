@@ -682,3 +682,82 @@ def test_upfirdn2d_backward(tdgp, name):
     dy, f = g[f'{name}_dy'], g[f'{name}_f']
     dx = tdgp.ops.upfirdn2d.upfirdn2d(T(dy), T(f), **upfirdn2d_backward_args(UPFIRDN_GRAD_CASES[name], f.shape, dy.shape))
     assert_close(N(dx), g[f'{name}_dx'], 2e-6, f'dx {name}', 1.0)
+
+
+# ------------------------------------------------------------------------------------------------ training-mode forward
+def test_field_density_noise(tdgp, oracle):
+    """sigma += n * density_noise inside the field kernel (tri_plane_renderer.py:185-186), coords mode and ray-walk mode:
+    rgb unchanged bit for bit, sigma = (plain sigma) + fl(n * std) exactly."""
+    rs = np.random.RandomState(13)
+    B, F, H, hid, P = 2, 32, 32, 64, 777
+    planes = T(rs.randn(B, 3 * F, H, H))
+    mlp = _mlp(tdgp, rs.randn(hid, F), 0.3 * rs.randn(hid), rs.randn(4, hid), 0.3 * rs.randn(4), 'classical')
+    coords = T(rs.uniform(-0.55, 0.55, (B, P, 3)))
+    n = T(rs.randn(B, P, 1))
+    plain = tdgp.renderer.simple_tri_plane_renderer(planes, coords, mlp, scale=0.5)
+    noisy = tdgp.renderer.simple_tri_plane_renderer(planes, coords, mlp, scale=0.5, sigma_noise=n, density_noise=0.37)
+    np.testing.assert_array_equal(N(noisy['rgb']), N(plain['rgb']))
+    np.testing.assert_array_equal(N(noisy['sigma']), N(plain['sigma']) + (N(n) * np.float32(0.37)).astype(np.float32))
+    # ray mode (the table-driven walk with parked outputs), S not a multiple of 8
+    R, S = 36, 12
+    cam = dict(angles=T([[0.3, 1.2, 0.0], [-0.6, 1.8, 0.0]]), radius=T([1.0, 1.0]), look_at=T(np.zeros((2, 3))))
+    ro, rd = tdgp.renderer.sample_rays(tdgp.renderer.compute_cam2world_matrix(cam), T([25.0, 40.0]), (6, 6))
+    t = T(np.sort(rs.uniform(0.75, 1.25, (B, R, S)), axis=2))
+    hw = tdgp.renderer.planes_to_hwc(planes)
+    mp = tdgp.renderer._mlp_params(mlp)
+    n2 = T(rs.randn(B, R * S))
+    for ray_w in (0, 6):
+        a = tdgp.renderer._field(hw, mp, 0.5, ray_o=ro, ray_d=rd, t=t, ray_w=ray_w)
+        b = tdgp.renderer._field(hw, mp, 0.5, ray_o=ro, ray_d=rd, t=t, ray_w=ray_w, sigma_noise=n2, density_noise=1.5)
+        np.testing.assert_array_equal(N(b[..., :3]), N(a[..., :3]))
+        np.testing.assert_array_equal(N(b[..., 3]), N(a[..., 3]) + (N(n2) * np.float32(1.5)).astype(np.float32))
+    # device-side draws when none are given: right scale, different every call
+    c = tdgp.renderer._field(hw, mp, 0.5, ray_o=ro, ray_d=rd, t=t, density_noise=2.0)
+    d = N(c[..., 3]) - N(a[..., 3])
+    assert 1.7 < d.std() < 2.3 and abs(d.mean()) < 0.3
+    with pytest.raises(RuntimeError):
+        tdgp.renderer._field(hw, mp, 0.5, ray_o=ro, ray_d=rd, t=t, sigma_noise=n2[:, :5], density_noise=1.0)
+
+
+def test_training_mode_forward(tdgp, oracle):
+    """G.train(): patch rays at train_resolution, density noise from progressive_update, explicit draws -> the reference's
+    training-mode image (tests/golden/train_forward.npz); fused chain with the fine-pass draws carried through the sort."""
+    g = load_golden('train_forward')
+    cfg = tdgp.config.config_train_golden()
+    G = _gen(tdgp, cfg, 91).train()
+    G.progressive_update(3000)
+    ws = G.mapping(T(g['z']), T(g['c']), update_emas=True)
+    assert_close(N(ws), g['ws'], 1e-5, 'ws', 1.0)
+    assert_close(N(G.mapping.w_avg), g['w_avg_after'], 1e-6, 'w_avg', 1.0)
+    kw = dict(camera_params=_cam(g), patch_params=dict(scales=T(g['scales']), offsets=T(g['offsets'])), noise_mode='const',
+              u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']), render_opts=dict(return_depth=True))
+    out = G.synthesis(T(g['ws']), n_coarse=T(g['n_coarse']), n_fine=T(g['n_fine']), **kw)
+    assert out.img.shape == (2, 3, 16, 16)
+    sd = tdgp.weights.random_state_dict(cfg, seed=91, exercise_all=True)
+    cam = {k[4:]: v for k, v in g.items() if k.startswith('cam_')}
+    ex_img, ex_depth = oracle.synthesis_forward(sd, cfg.to_dict(), g['ws'], cam, g['u_coarse'], g['u_fine'], 'const',
+                                                training=dict(resolution=16, patch_scales=g['scales'], patch_offsets=g['offsets'],
+                                                              density_noise=float(g['nerf_noise_std']), n_coarse=g['n_coarse'], n_fine=g['n_fine']))
+    assert_image_parity(N(out.img), g, 'img (training mode)', exact=ex_img)
+    assert_image_parity(N(out.depth), g, 'depth (training mode)', 'depth', exact=ex_depth)
+    # fresh device-side noise: a different image each call, and eval() is back to the full-resolution noise-free forward
+    a, b = G.synthesis(T(g['ws']), **kw).img, G.synthesis(T(g['ws']), **kw).img
+    assert float((a - b).abs().max()) > 1e-4
+    G.eval()
+    kw.pop('patch_params')
+    kw.update(u_coarse=None, u_fine=None)
+    assert G.synthesis(T(g['ws']), **kw).img.shape == (2, 3, cfg.img_resolution, cfg.img_resolution)
+
+
+def test_depth_adaptor_training_selection(tdgp):
+    """DepthAdaptor in .train() with out_strategy 'random' (networks_depth_adaptor.py:86-97): per-sample head drawn with the numpy
+    RNG from the annealed linear distribution -- same seed, same heads as the reference."""
+    g = load_golden('train_forward')
+    tag, cfg = tdgp.config.configs_adaptor_goldens()[0]
+    G = _gen(tdgp, cfg, 51)
+    da = G.synthesis.depth_adaptor.train()
+    da.progressive_update(4000)
+    assert abs(da.start_p - float(g['da_start_p'])) < 1e-7
+    np.random.seed(95)
+    out = da(T(g['da_depth']), T(g['da_w']))
+    assert_close(N(out), g['da_out'], 5e-6, 'randomly selected heads', 1.0)

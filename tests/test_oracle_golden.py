@@ -248,3 +248,45 @@ def test_upfirdn2d_backward(oracle, name):
     dy, f = g[f'{name}_dy'], g[f'{name}_f']
     dx = oracle.upfirdn2d(dy, f, **upfirdn2d_backward_args(UPFIRDN_GRAD_CASES[name], f.shape, dy.shape))
     assert_close(dx, g[f'{name}_dx'], 2e-6, f'dx {name}', 1.0)
+
+
+# ------------------------------------------------------------------------------------------------ training-mode forward
+def _train_kwargs(g):
+    return dict(resolution=16, patch_scales=g['scales'], patch_offsets=g['offsets'], density_noise=float(g['nerf_noise_std']),
+                n_coarse=g['n_coarse'], n_fine=g['n_fine'])
+
+
+def test_training_mode_forward(oracle, tdgp):
+    """SynthesisNetwork.forward in .train() (networks_epigraf.py:220-233): patch rays at train_resolution + density noise from the
+    progressive schedule, against the reference run with the same uniform / normal draws."""
+    g = load_golden('train_forward')
+    cfg = tdgp.config.config_train_golden()
+    sd = tdgp.weights.random_state_dict(cfg, seed=91, exercise_all=True)
+    cam = {k[4:]: v for k, v in g.items() if k.startswith('cam_')}
+    img, depth = oracle.synthesis_forward(sd, cfg.to_dict(), g['ws'], cam, g['u_coarse'], g['u_fine'], 'const', training=_train_kwargs(g))
+    assert img.shape == g['img'].shape == (2, 3, 16, 16)
+    assert_image_parity(img, g, 'img (training mode)')
+    assert_image_parity(depth, g, 'depth (training mode)', 'depth')
+    # the noise matters: the same call without it must be visibly different
+    img0, _ = oracle.synthesis_forward(sd, cfg.to_dict(), g['ws'], cam, g['u_coarse'], g['u_fine'], 'const',
+                                       training=dict(_train_kwargs(g), density_noise=0.0))
+    assert np.abs(img0 - g['img']).max() > 1e-3
+
+
+def test_progressive_schedule_and_w_avg(tdgp):
+    """linear_schedule / progressive_update (training_utils.py:8-18, networks_epigraf.py:191-194) and the W moving average
+    (layers.py:156-159); the mapping network runs on the CPU here."""
+    import torch
+    g = load_golden('train_forward')
+    cfg = tdgp.config.config_train_golden()
+    G = tdgp.generator.Generator(cfg)
+    G.load_numpy_state_dict(tdgp.weights.random_state_dict(cfg, seed=91, exercise_all=True))
+    G.progressive_update(3000)
+    assert G.synthesis.nerf_noise_std == float(g['nerf_noise_std']) == 0.4
+    ls = tdgp.adaptors.linear_schedule
+    assert ls(0, 1.0, 0.0, 5000) == 1.0 and ls(5000, 1.0, 0.0, 5000) == 0.0 and ls(9999, 1.0, 0.0, 5000) == 0.0 and ls(1250, 0.0, 1.0, 5000) == 0.25
+    assert G.synthesis.train_resolution == 16 and G.synthesis.test_resolution == cfg.img_resolution
+    with torch.no_grad():
+        ws = G.mapping(torch.from_numpy(g['z']), torch.from_numpy(g['c']), update_emas=True)
+    assert_close(ws.numpy(), g['ws'], 1e-5, 'ws', 1.0)
+    assert_close(G.mapping.w_avg.numpy(), g['w_avg_after'], 1e-6, 'w_avg', 1.0)

@@ -84,11 +84,17 @@ def save(name, **arrays):
 class PatchedRNG:
     """Feed explicit tensors to the reference's torch.rand_like / torch.rand draws (in call order)."""
 
-    def __init__(self, rand_like=(), rand=()):
-        self.q_like, self.q = list(rand_like), list(rand)
+    def __init__(self, rand_like=(), rand=(), randn_like=()):
+        self.q_like, self.q, self.q_nlike = list(rand_like), list(rand), list(randn_like)
 
     def __enter__(self):
-        self.o_like, self.o = torch.rand_like, torch.rand
+        self.o_like, self.o, self.o_nlike = torch.rand_like, torch.rand, torch.randn_like
+
+        def randn_like(x, *a, **k):
+            v = self.q_nlike.pop(0)
+            assert tuple(v.shape) == tuple(x.shape), (v.shape, x.shape)
+            return v.clone()
+        torch.randn_like = randn_like
 
         def rand_like(x, *a, **k):
             v = self.q_like.pop(0)
@@ -104,8 +110,8 @@ class PatchedRNG:
         return self
 
     def __exit__(self, *exc):
-        torch.rand_like, torch.rand = self.o_like, self.o
-        assert not self.q_like and not self.q, 'unused RNG tensors'
+        torch.rand_like, torch.rand, torch.randn_like = self.o_like, self.o, self.o_nlike
+        assert not self.q_like and not self.q and not self.q_nlike, 'unused RNG tensors'
 
 
 class Capture:
@@ -551,6 +557,68 @@ def gen_trajectories():
     save('trajectories', **arrays)
 
 
+def gen_train_forward():
+    """Training-mode generator forward (networks_epigraf.py:191-194,220-233; no gradients): patch-wise rays at train_resolution,
+    density noise from the progressive schedule, W moving average, the depth adaptor's random head selection."""
+    arrays = {}
+    cfg = tdgp.config.config_train_golden()
+    sd = tdgp.weights.random_state_dict(cfg, seed=91, exercise_all=True)
+    rc = ref_cfg(cfg)
+    rc.patch = EasyDict(enabled=True, resolution=cfg.patch_resolution)
+    rc.nerf_noise_std_init, rc.nerf_noise_kimg_growth = cfg.nerf_noise_std_init, cfg.nerf_noise_kimg_growth
+    G = Generator(rc, img_resolution=cfg.img_resolution, img_channels=3, mapping_kwargs={}, num_fp16_res=0, conv_clamp=None,
+                  fused_modconv_default='inference_only')
+    G.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    G.train()
+    G.progressive_update(3000)
+    arrays['nerf_noise_std'] = np.array(G.synthesis.nerf_noise_std)
+    B, h, S = 2, cfg.patch_resolution, cfg.num_ray_steps
+    R = h * h
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=B, seed=92)
+    g = np.random.RandomState(93)
+    u_coarse, u_fine = g.rand(B, R, S, 1).astype(np.float32), g.rand(B * R, S).astype(np.float32)
+    n_coarse, n_fine = g.randn(B, R * S, 1).astype(np.float32), g.randn(B, R * S, 1).astype(np.float32)
+    scales = g.uniform(0.3, 0.8, (B, 2)).astype(np.float32)
+    offsets = (g.uniform(0, 1, (B, 2)) * (1 - scales)).astype(np.float32)
+    cam = TensorGroup(**{k: T(v) for k, v in inp['camera'].items()})
+    with torch.no_grad():
+        ws = G.mapping(T(inp['z']), T(inp['c']), update_emas=True)
+        arrays['w_avg_after'] = npy(G.mapping.w_avg)
+        with PatchedRNG(rand_like=[T(u_coarse)], rand=[T(u_fine)], randn_like=[T(n_coarse), T(n_fine)]):
+            out = G.synthesis(ws, camera_params=cam, patch_params=dict(scales=T(scales), offsets=T(offsets)), noise_mode='const',
+                              render_opts=dict(return_depth=True))
+        torch.backends.mkldnn.enabled = False          # the reference's own fp32 noise floor (see gen_e2e)
+        torch.set_num_threads(1)
+        with PatchedRNG(rand_like=[T(u_coarse)], rand=[T(u_fine)], randn_like=[T(n_coarse), T(n_fine)]):
+            alt = G.synthesis(ws, camera_params=cam, patch_params=dict(scales=T(scales), offsets=T(offsets)), noise_mode='const',
+                              render_opts=dict(return_depth=True))
+        torch.backends.mkldnn.enabled = True
+        torch.set_num_threads(8)
+    arrays.update(z=inp['z'], c=inp['c'], ws=npy(ws), u_coarse=u_coarse, u_fine=u_fine, n_coarse=n_coarse, n_fine=n_fine, scales=scales, offsets=offsets,
+                  img=npy(out.img), depth=npy(out.depth), img_alt=npy(alt.img), depth_alt=npy(alt.depth),
+                  **{'cam_' + k: v for k, v in inp['camera'].items()})
+    # depth adaptor, training mode: per-sample random head (numpy RNG) after 4000 kimg of annealing
+    from src.training.networks_depth_adaptor import DepthAdaptor
+    tag, acfg = tdgp.config.configs_adaptor_goldens()[0]
+    asd = tdgp.weights.random_state_dict(acfg, seed=51, exercise_all=True)
+    da = acfg.depth_adaptor
+    rda = DepthAdaptor(EasyDict(kernel_size=da.kernel_size, hid_dim=da.hid_dim, num_hid_layers=da.num_hid_layers, out_strategy=da.out_strategy,
+                                near_plane_offset_max_fraction=da.near_plane_offset_max_fraction, near_plane_offset_bias=da.near_plane_offset_bias,
+                                selection_start_p=da.selection_start_p, anneal_kimg=da.anneal_kimg), min_depth=acfg.ray_start, max_depth=acfg.ray_end)
+    pfx = 'synthesis.depth_adaptor.'
+    rda.load_state_dict({k[len(pfx):]: T(v) for k, v in asd.items() if k.startswith(pfx)}, strict=True)
+    rda.train()
+    rda.progressive_update(4000)
+    g = np.random.RandomState(94)
+    depth = g.uniform(acfg.ray_start, acfg.ray_end, (6, 1, acfg.img_resolution, acfg.img_resolution)).astype(np.float32)
+    w = g.randn(6, acfg.w_dim).astype(np.float32)
+    np.random.seed(95)
+    with torch.no_grad():
+        out = rda(T(depth), T(w))
+    arrays.update(da_depth=depth, da_w=w, da_out=npy(out), da_start_p=np.array(rda.start_p))
+    save('train_forward', **arrays)
+
+
 class _GoldenDataset:
     """Stand-in for the reference's ImageFolder dataset in iterate_random_conditioning: labels and camera angles are pure
     functions of the item index."""
@@ -633,6 +701,7 @@ def main():
     gen_metrics()
     gen_trajectories()
     gen_harness()
+    gen_train_forward()
     gen_bias_act()
     gen_bias_act_grad()
     gen_upfirdn2d()
