@@ -1072,6 +1072,89 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
     }
 }
 
+// Output stage of the ToRGB kernel for one 32(pixels) x 32(channels) tile parked PIXEL-major in `ct`: bias + x2-FIR-upsampled skip
+// (upfirdn2d.py:313-348), * gain, clamp, channel-last float4 stores.  lane = (pixel l>>3 of the pass, channel quad l&7).
+// One straight-line block -- 16 tap loads, 4 LDS reads, the math, 4 stores -- with selects instead of branches: with the
+// run-time activation switch of the generic epilogue in here the compiler put a full `s_waitcnt vmcnt(0)` in front of every
+// store, i.e. each of the 12 stores of a 128-pixel tile waited for the acknowledgement of the one before (per-phase counters,
+// TDGP_RGB_ABL=16: output stage 24-36 k cycles per tile against 6 k of MFMA).  ToRGB is linear and has no noise / demodulation.
+// What is left is vector-ALU instruction count: while the SIMD's other wave is in its MFMA phase an instruction of this stage
+// gets in once per 64-cycle MFMA, so the blend runs as v_pk_fma_f32 (two channels per slot, the same fma chain per element),
+// gain / clamp are compiled out when they are 1 / off (PLAIN), and for power-of-two images (POW2: lw = log2 W, lhw = log2 HW)
+// the pixel coordinates come from shifts of the pixel index instead of 16 cross-lane reads.
+typedef float rgb_f32x2 __attribute__((ext_vector_type(2)));
+// G = passes handled together (4: all 16 taps in flight; 2: half the registers, for the multi-tile kernel that keeps the next
+// tile's activations in registers across this stage).
+template <bool SKIP, bool PLAIN, bool POW2, int G>
+__device__ __forceinline__ void rgb_output_tile(const EpiParams& e, const float* __restrict__ bias_lds, const float* ct, int obase, int pb, int poy, int pox,
+                                                int pok, int64_t pix0, int64_t P, int lw, int lhw) {
+    const int l = lane_id(), cg = l & 7, pr = l >> 3;
+    const int o = obase + 4 * cg;
+    const bool okc = o < e.Cout;                                                // Cout and out_feat are multiples of 4 (host check)
+    const int oc = okc ? o : 0;
+    const int pl = oc / e.out_feat, f = oc - pl * e.out_feat;
+    const int planes = e.Cout / e.out_feat;
+    const int h2 = e.Hout / 2, w2 = e.Wout / 2;
+    const float4 bias4 = *(const float4*)(bias_lds + oc);
+    const rgb_f32x2 b01 = {bias4.x, bias4.y}, b23 = {bias4.z, bias4.w};
+    const float lim = e.clamp >= 0.f ? e.clamp : __builtin_inff();
+#pragma unroll
+  for (int g0 = 0; g0 < 4; g0 += G) {
+    float4 ta[G], tb[G], tc[G], td[G];
+    SkipTaps tp[G];
+    int addr[G];
+    bool okp[G];
+#pragma unroll
+    for (int pass = 0; pass < G; pass++) {
+        const int px = (g0 + pass) * 8 + pr;
+        int b, oy, ox;
+        if (POW2) {                                                              // pixel px of this wave's tile: pix0 + 4 * px
+            const int pix = (int)pix0 + 4 * px;                                  // B*H*W < 2^31 - 512 (host check)
+            const bool ok = pix < (int)P;
+            const int pc = ok ? pix : 0;
+            b = pc >> lhw;
+            const int inner = pc & ((1 << lhw) - 1);
+            oy = inner >> lw; ox = inner & ((1 << lw) - 1);
+            okp[pass] = ok && okc;
+        } else {
+            b = __shfl(pb, px, 64); oy = __shfl(poy, px, 64); ox = __shfl(pox, px, 64);
+            okp[pass] = __shfl(pok, px, 64) && okc;
+        }
+        const int plane = b * planes + pl;
+        addr[pass] = ((plane * e.Hout + oy) * e.Wout + ox) * e.out_feat + f;
+        if (SKIP) {
+            tp[pass] = skip_taps(h2, w2, oy, ox, e.fir);
+            const float* sp = e.skip + (int64_t)plane * h2 * w2 * e.out_feat + f;
+            ta[pass] = *(const float4*)(sp + (int64_t)tp[pass].i00 * e.out_feat); tb[pass] = *(const float4*)(sp + (int64_t)tp[pass].i01 * e.out_feat);
+            tc[pass] = *(const float4*)(sp + (int64_t)tp[pass].i10 * e.out_feat); td[pass] = *(const float4*)(sp + (int64_t)tp[pass].i11 * e.out_feat);
+        }
+    }
+    float4 v[G];
+#pragma unroll
+    for (int pass = 0; pass < G; pass++) {
+        const float4 c4 = *(const float4*)&ct[((g0 + pass) * 8 + pr) * CT_LD + 4 * cg];
+        rgb_f32x2 r01 = (rgb_f32x2){c4.x, c4.y} + b01, r23 = (rgb_f32x2){c4.z, c4.w} + b23;
+        if (SKIP) {
+            const SkipTaps& t = tp[pass];
+            const rgb_f32x2 w00 = {t.w00, t.w00}, w01 = {t.w01, t.w01}, w10 = {t.w10, t.w10}, w11 = {t.w11, t.w11};
+            const rgb_f32x2 a01 = {ta[pass].x, ta[pass].y}, a23 = {ta[pass].z, ta[pass].w}, bb01 = {tb[pass].x, tb[pass].y}, bb23 = {tb[pass].z, tb[pass].w};
+            const rgb_f32x2 cc01 = {tc[pass].x, tc[pass].y}, cc23 = {tc[pass].z, tc[pass].w}, d01 = {td[pass].x, td[pass].y}, d23 = {td[pass].z, td[pass].w};
+            r01 = r01 + __builtin_elementwise_fma(w11, d01, __builtin_elementwise_fma(w10, cc01, __builtin_elementwise_fma(w01, bb01, w00 * a01)));
+            r23 = r23 + __builtin_elementwise_fma(w11, d23, __builtin_elementwise_fma(w10, cc23, __builtin_elementwise_fma(w01, bb23, w00 * a23)));
+        }
+        float r[4] = {r01.x, r01.y, r23.x, r23.y};
+        if (!PLAIN) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { r[i] = r[i] * e.gain; r[i] = r[i] < -lim ? -lim : (r[i] > lim ? lim : r[i]); }
+        }
+        v[pass] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+#pragma unroll
+    for (int pass = 0; pass < G; pass++)
+        if (okp[pass]) *(float4*)(e.y + addr[pass]) = v[pass];
+  }
+}
+
 // ---- ToRGB: 1x1 modulated conv without demodulation, Cout <= 96, channel-last plane output with the fused x2 skip ---------
 // (networks_stylegan2.py:252-273).  12 kFLOP against 736 B per pixel at 64 channels: the layer sits on the ridge between the
 // matrix cores and HBM, so the kernel is built to keep both busy -- one block = 128 consecutive pixels (1x1: no halo, tiles
@@ -1084,12 +1167,17 @@ struct RgbParams {
     int B, Cin, Cout, CoutP, HW, W;
     int64_t P;          // B*H*W
     uint32_t x_bytes, wp_bytes, st_bytes;       // sizes for the buffer descriptors
+    int tpb;            // consecutive 128-pixel tiles per block (activations of tile t+1 are in flight while tile t is multiplied and stored)
+    int lw, lhw;        // log2 W, log2 H*W when both are powers of two, else -1
 };
 
 #ifndef TDGP_RGB_ABL
 #define TDGP_RGB_ABL 0     // 16: per-phase cycle counts of one wave, printed (timing experiments only)
 #endif
-template <int MT>
+// RESIDENT: Cin <= 64 -- the whole weight matrix is one LDS stage, loaded once per block, and the block walks `tpb` consecutive
+// tiles with the activations of tile t+1 in flight while tile t is multiplied and stored.
+// FAST: power-of-two image, no clamp, gain 1 (the generator's ToRGB layers) -- the trimmed output stage.
+template <int MT, bool RESIDENT, bool FAST>
 __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
     constexpr int BM = 32 * MT, BN = 128, NCH = 16;                 // 16 packed chunks = 64 channels per iteration
     constexpr int AS_SZ = NCH * BM * 4, XS_SZ = NCH * BN * 4;
@@ -1098,7 +1186,8 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
     float* Xs = smem + AS_SZ;
     float* side = smem + AS_SZ + XS_SZ;                             // [BM] bias
     const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, l32 = l & 31, half = l >> 5;
-    const int64_t px0 = (int64_t)blockIdx.x * BN;
+    const int64_t ntiles = (p.P + BN - 1) / BN;
+    const int64_t t_begin = (int64_t)blockIdx.x * p.tpb, t_end = min(t_begin + p.tpb, ntiles);
 #if TDGP_RGB_ABL & 16
     long long tq[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 #define TR(i) { const long long tn_ = __builtin_readcyclecounter(); tq[i] += tn_ - tprev; tprev = tn_; }
@@ -1111,17 +1200,19 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
     // two 4-channel x 4-pixel micro-tiles per thread and iteration (byte offsets for the buffer loads; kOOB -> 0)
     uint32_t x_vo[2], s_vo[2];
     const int cq = tid >> 5, pq = tid & 31;                        // micro-tile k: channels 4*(cq + 8k) .. +3 of the iteration, pixels 4*pq .. +3
+    auto tile_offsets = [&](int64_t t) {
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int64_t pix = px0 + 4 * pq;
-        x_vo[k] = kOOB; s_vo[k] = kOOB;
-        if (pix < p.P) {
-            const int b = (int)(pix / p.HW), inner = (int)(pix - (int64_t)b * p.HW);
-            const int sb = b * p.Cin + 4 * (cq + 8 * k);
-            s_vo[k] = (uint32_t)sb * 4u;
-            x_vo[k] = (uint32_t)(sb * p.HW + inner) * 4u;
+        for (int k = 0; k < 2; k++) {
+            const int64_t pix = t * BN + 4 * pq;
+            x_vo[k] = kOOB; s_vo[k] = kOOB;
+            if (pix < p.P) {
+                const int b = (int)(pix / p.HW), inner = (int)(pix - (int64_t)b * p.HW);
+                const int sb = b * p.Cin + 4 * (cq + 8 * k);
+                s_vo[k] = (uint32_t)sb * 4u;
+                x_vo[k] = (uint32_t)(sb * p.HW + inner) * 4u;
+            }
         }
-    }
+    };
     const uint32_t hw4 = (uint32_t)p.HW * 4u;
     const bool cin4 = (p.Cin & 3) == 0;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.wp, p.wp_bytes), rs = make_rsrc(p.styles ? p.styles : p.x, p.styles ? p.st_bytes : 0);
@@ -1145,11 +1236,15 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
 
+    const int niter = (p.Cin + 63) >> 6;
+    constexpr bool a_resident = RESIDENT;           // all weights fit one stage: loaded for the block's first tile only
     float4 a_reg[NA], xr[2][4], sr[2];
-    auto load_stage = [&](int it) {
-        const uint32_t a_so = (uint32_t)it * a_gstride4;
+    auto load_stage = [&](int it, bool with_a) {
+        if (with_a) {
+            const uint32_t a_so = (uint32_t)it * a_gstride4;
 #pragma unroll
-        for (int i = 0; i < NA; i++) a_reg[i] = buf_load4(rw, a_vo[i], a_so);
+            for (int i = 0; i < NA; i++) a_reg[i] = buf_load4(rw, a_vo[i], a_so);
+        }
         const uint32_t c0 = (uint32_t)it * 64u;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -1164,10 +1259,12 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
             }
         }
     };
-    auto store_stage = [&]() {
+    auto store_stage = [&](bool with_a) {
+        if (with_a) {
 #pragma unroll
-        for (int i = 0; i < NA; i++)
-            if (tid + i * 256 < NCH * BM) *(float4*)(As + (tid + i * 256) * 4) = a_reg[i];
+            for (int i = 0; i < NA; i++)
+                if (tid + i * 256 < NCH * BM) *(float4*)(As + (tid + i * 256) * 4) = a_reg[i];
+        }
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             // 4x4 register transpose: xr[k][j] = channel j over 4 pixels  ->  per pixel, 4 channels (x style)
@@ -1181,70 +1278,98 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
         }
     };
 
-    const int niter = (p.Cin + 63) >> 6;
     const float* Al = As + l32 * 4 + 2 * half;
     const float* Xl = Xs + (wv * 32 + l32) * 4 + 2 * half;
-    load_stage(0);
-    TR(0)
-    for (int it = 0; it < niter; it++) {
-        __syncthreads();                        // the previous iteration's fragments have been read
-        store_stage();
-        __syncthreads();
-        TR(1)
-        if (it + 1 < niter) load_stage(it + 1);
-        TR(2)
-        f32x2 fa[2][MT], fb[2];
-        auto load_frag = [&](int buf, int ch) {
-#pragma unroll
-            for (int m = 0; m < MT; m++) fa[buf][m] = *(const f32x2*)(Al + (ch * BM + m * 32) * 4);
-            fb[buf] = *(const f32x2*)(Xl + ch * BN * 4);
-        };
-        load_frag(0, 0);
-#pragma unroll
-        for (int ch = 0; ch < NCH; ch++) {
-            const int cb = ch & 1;
-            if (ch + 1 < NCH) load_frag(cb ^ 1, ch + 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kk = 0; kk < 2; kk++)
-#pragma unroll
-                for (int m = 0; m < MT; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][m][kk], fb[cb][kk], acc[m], 0, 0, 0);
-        }
-        TR(3)
-    }
-    __syncthreads();
-
-    // ---- epilogue: bias + FIR-upsampled skip, channel-last float4 stores (epilogue_tile<true>, pixel-major LDS tile) --------
     float* ct = Xs + wv * (32 * CT_LD);
-    const int64_t pix = px0 + 4 * l32 + wv;
-    const int pok = pix < p.P ? 1 : 0;
-    const int64_t pc = pok ? pix : 0;
-    const int pb = (int)(pc / p.HW), inner = (int)(pc - (int64_t)pb * p.HW);
-    const int poy = inner / p.W, pox = inner - poy * p.W;
-    SideCache scache;
-    scache.lds = side; scache.b0 = 0; scache.bm = BM; scache.m0 = 0;
-    const int evar = epi_variant(p.e);
-#pragma unroll 1
-    for (int tile = 0; tile < MT; tile++) {
+    const bool has_skip = p.e.skip != nullptr;
+    if (t_begin >= t_end) return;
+    tile_offsets(t_begin);
+    load_stage(0, true);
+    if (RESIDENT) {                                 // weights: once per block, outside the tile loop (nothing of it stays live in there)
+        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < MT; k++) {
-            if (tile == k) {
-                constexpr int dummy = 0; (void)dummy;
+        for (int i = 0; i < NA; i++)
+            if (tid + i * 256 < NCH * BM) *(float4*)(As + (tid + i * 256) * 4) = a_reg[i];
+    }
+    TR(0)
+    for (int64_t t = t_begin; t < t_end; t++) {
+        for (int it = 0; it < niter; it++) {
+            __syncthreads();                        // the previous stage's fragments (and the previous tile's parked outputs) have been read
+            store_stage(!RESIDENT);
+            __syncthreads();
+            TR(1)
+            // the next stage -- of this tile, or the first one of the next tile -- is in flight during the multiply and the output stage
+            if (it + 1 < niter) load_stage(it + 1, true);
+            TR(2)
+            f32x2 fa[2][MT], fb[2];
+            auto load_frag = [&](int buf, int ch) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) ct[l32 * CT_LD + (r & 3) + 8 * (r >> 2) + 4 * half] = acc[k][r];
+                for (int m = 0; m < MT; m++) fa[buf][m] = *(const f32x2*)(Al + (ch * BM + m * 32) * 4);
+                fb[buf] = *(const f32x2*)(Xl + ch * BN * 4);
+            };
+            load_frag(0, 0);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) {
+                const int cb = ch & 1;
+                if (ch + 1 < NCH) load_frag(cb ^ 1, ch + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                    for (int m = 0; m < MT; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][m][kk], fb[cb][kk], acc[m], 0, 0, 0);
+            }
+            TR(3)
+        }
+        // the next tile's activations are put in flight here, after the multiply (issued before it, the loads land in registers
+        // the fragment reads want and the compiler parks them with a full wait) and ahead of the output stage that hides them
+        // (unconditional -- the block's last tile re-reads itself: a load under a condition makes the compiler wait for it at the join)
+        if (RESIDENT) { tile_offsets(t + 1 < t_end ? t + 1 : t); load_stage(0, false); }
+        __syncthreads();
+
+        // ---- output stage: bias + FIR-upsampled skip, channel-last float4 stores (epilogue_tile<true>, pixel-major LDS tile) ----
+        const int64_t pix = t * BN + 4 * l32 + wv;
+        int pok = 0, pb = 0, poy = 0, pox = 0;
+        constexpr bool LANE_GEOM = !FAST || RESIDENT;   // this lane's pixel, handed to the output stage by cross-lane reads (the
+        if (LANE_GEOM) {                                 // shift form inside the output stage costs the multi-tile kernel ~25 registers)
+            pok = pix < p.P ? 1 : 0;
+            const int64_t pc = pok ? pix : 0;
+            if (FAST) {
+                pb = (int)(pc >> p.lhw);
+                const int inner = (int)pc & ((1 << p.lhw) - 1);
+                poy = inner >> p.lw; pox = inner & ((1 << p.lw) - 1);
+            } else {
+                pb = (int)(pc / p.HW);
+                const int inner = (int)(pc - (int64_t)pb * p.HW);
+                poy = inner / p.W; pox = inner - poy * p.W;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (evar == 1) epilogue_tile<true, 1>(p.e, scache, ct, tile * 32, pb, poy, pox, pok, nullptr, false);
-        else epilogue_tile<true, 0>(p.e, scache, ct, tile * 32, pb, poy, pox, pok, nullptr, false);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        const int64_t pix0 = t * BN + wv;
+#pragma unroll 1
+        for (int tile = 0; tile < MT; tile++) {
+#pragma unroll
+            for (int k = 0; k < MT; k++) {
+                if (tile == k) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; r4++) {
+                        *(float4*)&ct[l32 * CT_LD + 8 * r4 + 4 * half] = make_float4(acc[k][4 * r4], acc[k][4 * r4 + 1], acc[k][4 * r4 + 2], acc[k][4 * r4 + 3]);
+                        acc[k][4 * r4] = 0.f; acc[k][4 * r4 + 1] = 0.f; acc[k][4 * r4 + 2] = 0.f; acc[k][4 * r4 + 3] = 0.f;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            constexpr int G = 4;
+            if (has_skip) rgb_output_tile<true, FAST, !LANE_GEOM, G>(p.e, side, ct, tile * 32, pb, poy, pox, pok, pix0, p.P, p.lw, p.lhw);
+            else rgb_output_tile<false, FAST, !LANE_GEOM, G>(p.e, side, ct, tile * 32, pb, poy, pox, pok, pix0, p.P, p.lw, p.lhw);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        TR(4)
+        if (!RESIDENT) break;                       // one tile per block (tpb = 1): nothing stays live across the output stage
     }
-    TR(4)
 #if TDGP_RGB_ABL & 16
-    if (tid == 0 && (blockIdx.x == 5 || blockIdx.x == 9000))
-        printf("torgb blk %d iters %d: prologue+issue %lld wait+store %lld issue-next %lld mma %lld epilogue %lld\n", (int)blockIdx.x, niter, tq[0], tq[1], tq[2], tq[3], tq[4]);
+    if (tid == 0 && (blockIdx.x == 5 || blockIdx.x == 1000))
+        printf("torgb blk %d tiles %d iters %d: prologue+issue %lld wait+store %lld issue-next %lld mma %lld epilogue %lld\n", (int)blockIdx.x, (int)(t_end - t_begin), niter, tq[0], tq[1], tq[2], tq[3], tq[4]);
 #endif
 #undef TR
 }
@@ -1552,16 +1677,27 @@ void launch_upconv(const UpParams& u, hipStream_t s) {
     TDGP_LAUNCH("upconv_mfma_kernel", (upconv_mfma_kernel<MTW, NTW, WM, WN, DEEP>), grid, dim3(64 * NW), lds, s, u);
 }
 
-template <int MT>
-void launch_torgb(const RgbParams& r, hipStream_t s) {
+template <int MT, bool RESIDENT, bool FAST>
+void launch_torgb_v(const RgbParams& r, hipStream_t s) {
     constexpr int BM = 32 * MT;
     const size_t lds = (size_t)(16 * BM * 4 + 16 * 128 * 4 + BM) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)torgb_mfma_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)torgb_mfma_kernel<MT, RESIDENT, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    TDGP_LAUNCH("torgb_mfma_kernel", (torgb_mfma_kernel<MT>), dim3((unsigned)cdiv64(r.P, 128)), dim3(256), lds, s, r);
+    // RESIDENT: several consecutive tiles per block once there are more tiles than ~4 rounds of the 512 resident blocks
+    RgbParams rr = r;
+    const int64_t ntiles = cdiv64(r.P, 128);
+    rr.tpb = RESIDENT ? (int)max((int64_t)1, min((int64_t)8, ntiles / 2048)) : 1;
+    TDGP_LAUNCH("torgb_mfma_kernel", (torgb_mfma_kernel<MT, RESIDENT, FAST>), dim3((unsigned)cdiv64(ntiles, rr.tpb)), dim3(256), lds, s, rr);
+}
+
+template <int MT>
+void launch_torgb(const RgbParams& r, hipStream_t s) {
+    const bool fast = r.lw >= 0 && r.e.clamp < 0.f && r.e.gain == 1.f;
+    if (r.Cin <= 64) { if (fast) launch_torgb_v<MT, true, true>(r, s); else launch_torgb_v<MT, true, false>(r, s); }
+    else { if (fast) launch_torgb_v<MT, false, true>(r, s); else launch_torgb_v<MT, false, false>(r, s); }
 }
 
 // KS x KS stride-1 fast path (W % 32 == 0)
@@ -1719,10 +1855,15 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         } else if (k == 5) {
             if (Cout > 64) launch_conv<2, 2, 2, 2, 4, 25>(p, partial, wl.partial_floats, s);
             else launch_conv<2, 2, 1, 4, 4, 25>(p, partial, wl.partial_floats, s);
-        } else if (out_layout == 1 && Cout <= 96 && !demodulate && !noise && ((H * W) & 3) == 0) {
+        } else if (out_layout == 1 && Cout <= 96 && !demodulate && !noise && e.act == 1 && ((H * W) & 3) == 0) {
             RgbParams r;
             r.x = x; r.wp = wp; r.styles = styles; r.e = e;
             r.B = B; r.Cin = Cin; r.Cout = Cout; r.CoutP = pi.CoutP; r.HW = H * W; r.W = W; r.P = (int64_t)B * H * W;
+            r.lw = r.lhw = -1;
+            if ((W & (W - 1)) == 0 && (H & (H - 1)) == 0 && (int64_t)B * H * W < ((int64_t)1 << 31) - 512) {
+                r.lw = 0; while ((1 << r.lw) < W) r.lw++;
+                r.lhw = 0; while ((1 << r.lhw) < H * W) r.lhw++;
+            }
             r.x_bytes = (uint32_t)((int64_t)B * Cin * H * W * 4); r.wp_bytes = (uint32_t)(pi.wp_floats * 4); r.st_bytes = (uint32_t)((int64_t)B * Cin * 4);
             if (Cout <= 32) launch_torgb<1>(r, s);
             else if (Cout <= 64) launch_torgb<2>(r, s);

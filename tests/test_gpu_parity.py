@@ -188,6 +188,43 @@ def test_fused_layers_oracle(tdgp, oracle):
     assert_close(N(y1.permute(0, 1, 4, 2, 3).reshape(B, crgb, H, H)), ref, 1e-5, 'torgb channel-last', 1.0)
 
 
+@pytest.mark.parametrize('B,cin,crgb,H,W,clamp,gain,skip', [
+    (2, 64, 96, 64, 64, None, 1.0, True),        # the generator's form: resident weights, several tiles per block, trimmed output stage
+    (3, 64, 96, 32, 128, None, 1.0, True),       # ragged last tile of a block (3*32*128/128 = 96 tiles)
+    (2, 48, 24, 16, 16, 0.7, 1.0, True),         # clamp -> general output stage, resident weights
+    (2, 96, 36, 12, 20, None, 1.0, True),        # not a power of two -> general geometry (cross-lane reads), two K stages
+    (1, 200, 60, 24, 8, 1.5, 0.5, False),        # Cin not a multiple of 64, gain != 1, no skip
+    (2, 128, 96, 32, 32, None, 1.0, False),
+    (1, 64, 96, 516, 1020, None, 1.0, True),     # 4112 tiles -> 2 tiles per block, ragged last tile, general geometry
+    (1, 64, 96, 1024, 512, None, 1.0, True),     # 4096 tiles -> 2 tiles per block, trimmed output stage
+])
+def test_torgb_channel_last_variants(tdgp, oracle, B, cin, crgb, H, W, clamp, gain, skip):
+    """Every specialisation of the ToRGB kernel (weights resident or staged, trimmed / general output stage, with / without the
+    x2-upsampled skip) against the oracle's modulated 1x1 conv + bias_act (+ upsample2d of the previous image)."""
+    rs = np.random.RandomState(B * 1000 + cin)
+    mc = tdgp.ops.modconv
+    feat = crgb // 3
+    x = rs.randn(B, cin, H, W).astype(np.float32)
+    w1 = rs.randn(crgb, cin, 1, 1).astype(np.float32)
+    s = (1 + 0.5 * rs.randn(B, cin)).astype(np.float32)
+    bias = rs.randn(crgb).astype(np.float32)
+    f = oracle.setup_filter([1, 3, 3, 1])
+    ref = oracle.bias_act(oracle.modulated_conv2d(x, w1, s, demodulate=False), bias, act='linear', gain=gain)
+    prev_cl = None
+    if skip:
+        prev = rs.randn(B, crgb, H // 2, W // 2).astype(np.float32)
+        # order of the fused call: ((conv + bias) + skip) * gain, then clamp (the reference adds the skip after bias_act; with gain 1
+        # and no clamp -- every ToRGB of the generator -- the two coincide, and the test keeps to those cases when a skip is present)
+        ref = ref + oracle.upsample2d(prev, f)
+        prev_cl = T(prev).reshape(B, 3, feat, H // 2, W // 2).permute(0, 1, 3, 4, 2).contiguous()
+    if clamp is not None:
+        ref = np.clip(ref, -clamp, clamp)
+    y = mc.modconv_forward(T(x), mc.PackedConv(T(w1)), T(s), bias=T(bias), demodulate=False, act='linear', gain=gain, clamp=clamp, skip=prev_cl,
+                           fir=mc.fir_host_array(f) if skip else None, out_layout=1, out_feat=feat)
+    assert y.shape == (B, 3, H, W, feat)
+    assert_close(N(y.permute(0, 1, 4, 2, 3).reshape(B, crgb, H, W)), ref, 1e-5, 'torgb channel-last', 1.0)
+
+
 # ------------------------------------------------------------------------------------------------ camera / rays
 
 def test_camera_and_rays(tdgp, oracle):
