@@ -1,0 +1,136 @@
+// conv_grad.hip -- weight gradient of a 2-D convolution on the gfx950 matrix cores.
+//
+// Reference: src/torch_utils/ops/conv2d_gradfix.py:141-150 (`Conv2dGradWeight.forward` = aten::convolution_backward with
+// output_mask [0,1,0], non-transposed, groups 1, dilation 1):
+//
+//     dW[o,c,ky,kx] = sum_{b,oy,ox} dy[b,o,oy,ox] * x[b,c, oy*stride + ky - pad, ox*stride + kx - pad]       (zero outside x)
+//
+// Per tap (ky,kx) this is a GEMM  dW_tap[Cout x Cin] = DY[Cout x P] * Xshift_tap[P x Cin]  whose long dimension is the pixel
+// index P = B*OH*OW (up to 2M), while the output is small (<= 2.4 M floats): the launch is split over the K dimension --
+// block (z) owns a slice of (b,oy) rows, writes its partial [Cout,Cin,k,k] and a second kernel sums the slices in slice order
+// (deterministic; fp32 atomics would make the result depend on the block schedule).
+//
+// Block = 256 threads = 2 x 2 waves, each wave one 32(o) x 32(c) MFMA tile (v_mfma_f32_32x32x2_f32, K = 2 pixels per
+// instruction).  Per 32-pixel chunk of an output row the block stages dy[64 o][32 px] and the tap-shifted x[64 c][32 px] in LDS
+// (row pitch 33 floats: the fragment reads of 32 lanes hit 32 banks), the next chunk's global loads are in flight during the
+// 16 MFMAs of the current one.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WGradParams {
+    const float* x;        // [B,Cin,H,W]
+    const float* dy;       // [B,Cout,OH,OW]
+    float* partial;        // [nslice][Cout][Cin][k*k]
+    int B, Cin, Cout, H, W, OH, OW, k, stride, pad;
+    int tiles_c;           // cdiv(Cin, 64)
+    int rows, rows_per_slice;      // rows = B*OH
+};
+
+constexpr int WG_PITCH = 33;
+
+__global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(WGradParams p) {
+    __shared__ float As[64 * WG_PITCH];         // dy tile [o][px]
+    __shared__ float Bs[64 * WG_PITCH];         // x tile  [c][px]
+    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, l32 = l & 31, half = l >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int o0 = (blockIdx.x / p.tiles_c) * 64, c0 = (blockIdx.x % p.tiles_c) * 64;
+    const int tap = blockIdx.y, ky = tap / p.k, kx = tap - ky * p.k;
+    const int row_begin = blockIdx.z * p.rows_per_slice, row_end = min(row_begin + p.rows_per_slice, p.rows);
+    const int chunks_per_row = (p.OW + 31) >> 5;
+    const int nchunks = max(row_end - row_begin, 0) * chunks_per_row;
+
+    // this thread's 8 + 8 staged elements: tile row = (tid >> 5) + 8 * i, pixel = tid & 31
+    const int px = tid & 31, r0 = tid >> 5;
+    float ra[8], rb[8];
+    auto load_chunk = [&](int ch) {
+        const int row = row_begin + ch / chunks_per_row, ox = (ch % chunks_per_row) * 32 + px;
+        const int b = row / p.OH, oy = row - b * p.OH;
+        const int iy = oy * p.stride + ky - p.pad, ix = ox * p.stride + kx - p.pad;
+        const bool oka = ox < p.OW, okb = oka && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int o = o0 + r0 + 8 * i, c = c0 + r0 + 8 * i;
+            ra[i] = (oka && o < p.Cout) ? p.dy[(((int64_t)b * p.Cout + o) * p.OH + oy) * p.OW + ox] : 0.f;
+            rb[i] = (okb && c < p.Cin) ? p.x[(((int64_t)b * p.Cin + c) * p.H + iy) * p.W + ix] : 0.f;
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    if (nchunks > 0) load_chunk(0);
+    const float* al = As + (wm * 32 + l32) * WG_PITCH + half;
+    const float* bl = Bs + (wn * 32 + l32) * WG_PITCH + half;
+    for (int ch = 0; ch < nchunks; ch++) {
+        __syncthreads();                                   // the previous chunk's fragments have been read
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            As[(r0 + 8 * i) * WG_PITCH + px] = ra[i];
+            Bs[(r0 + 8 * i) * WG_PITCH + px] = rb[i];
+        }
+        __syncthreads();
+        if (ch + 1 < nchunks) load_chunk(ch + 1);
+#pragma unroll
+        for (int ks = 0; ks < 16; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(al[2 * ks], bl[2 * ks], acc, 0, 0, 0);
+    }
+
+    // acc[r] = C[m = (r & 3) + 8 * (r >> 2) + 4 * half][n = l32]
+    const int kk = p.k * p.k;
+    float* dst = p.partial + (int64_t)blockIdx.z * p.Cout * p.Cin * kk;
+    const int c = c0 + wn * 32 + l32;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int o = o0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o < p.Cout && c < p.Cin) dst[((int64_t)o * p.Cin + c) * kk + tap] = acc[r];
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int64_t n, int nslice) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < nslice; s++) v += partial[(int64_t)s * n + i];
+        dw[i] = v;
+    }
+}
+
+int wgrad_slices(int B, int Cin, int Cout, int OH, int k) {
+    const int blocks_xy = cdiv(Cout, 64) * cdiv(Cin, 64) * k * k;
+    int ns = cdiv(2048, blocks_xy);                   // ~8 blocks per CU
+    const int rows = B * OH;
+    if (ns > rows) ns = rows;
+    if (ns > 256) ns = 256;
+    return ns < 1 ? 1 : ns;
+}
+
+}  // namespace
+
+TDGP_API int64_t tdgp_conv2d_weight_grad_workspace_bytes(int B, int Cin, int Cout, int OH, int k) {
+    return (int64_t)wgrad_slices(B, Cin, Cout, OH, k) * Cout * Cin * k * k * (int64_t)sizeof(float);
+}
+
+TDGP_API int tdgp_conv2d_weight_grad(const float* x, const float* dy, float* dw, void* workspace, int64_t workspace_bytes, int B, int Cin,
+                                     int Cout, int H, int W, int OH, int OW, int k, int stride, int pad, tdgp_stream_t stream) {
+    TDGP_CHECK(x && dy && dw, TDGP_EINVAL, "conv2d_weight_grad: null pointer");
+    TDGP_CHECK(B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && k >= 1 && stride >= 1 && pad >= 0, TDGP_EINVAL, "conv2d_weight_grad: bad shape");
+    TDGP_CHECK(OH == (H + 2 * pad - k) / stride + 1 && OW == (W + 2 * pad - k) / stride + 1, TDGP_EINVAL,
+               "conv2d_weight_grad: output %dx%d does not match input %dx%d, k=%d, stride=%d, pad=%d", OH, OW, H, W, k, stride, pad);
+    TDGP_CHECK(k <= 7, TDGP_EUNSUPPORTED, "conv2d_weight_grad: kernel size %d > 7", k);
+    const int64_t need = tdgp_conv2d_weight_grad_workspace_bytes(B, Cin, Cout, OH, k);
+    TDGP_CHECK(workspace && workspace_bytes >= need, TDGP_EINVAL, "conv2d_weight_grad: workspace of %lld bytes needed", (long long)need);
+    WGradParams p;
+    p.x = x; p.dy = dy; p.partial = (float*)workspace;
+    p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.k = k; p.stride = stride; p.pad = pad;
+    p.tiles_c = cdiv(Cin, 64);
+    p.rows = B * OH;
+    const int ns = wgrad_slices(B, Cin, Cout, OH, k);
+    p.rows_per_slice = cdiv(p.rows, ns);
+    hipStream_t s = (hipStream_t)stream;
+    TDGP_LAUNCH("conv_wgrad_mfma_kernel", conv_wgrad_mfma_kernel, dim3(cdiv(Cout, 64) * p.tiles_c, k * k, ns), dim3(256), 0, s, p);
+    const int64_t n = (int64_t)Cout * Cin * k * k;
+    TDGP_LAUNCH("wgrad_reduce_kernel", wgrad_reduce_kernel, dim3((int)min((int64_t)1024, cdiv64(n, 256))), dim3(256), 0, s, (const float*)workspace, dw, n, ns);
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}

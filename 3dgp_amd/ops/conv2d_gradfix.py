@@ -1,0 +1,106 @@
+"""conv2d_gradfix: convolution with explicit first-order gradients.
+
+Signature of the reference's `src/torch_utils/ops/conv2d_gradfix.py`: `conv2d(input, weight, bias, stride, padding, dilation,
+groups)`, `conv_transpose2d(...)`, the `no_weight_gradients()` context manager.  The reference routes CUDA tensors through a
+custom autograd function whose backward issues the input gradient as the opposite (transposed) convolution and the weight
+gradient as `aten::convolution_backward` (conv2d_gradfix.py:106-150); everything else falls back to `torch.nn.functional`
+(conv2d_gradfix.py:36-44).
+
+Here the form the generator / adaptor layers use -- stride 1, dilation 1, groups 1, odd square kernel k <= 5, padding k // 2,
+fp32 on the GPU -- runs on the gfx950 kernels:
+    forward        tdgp_modconv2d (unmodulated: the same MFMA implicit-GEMM kernel as the synthesis layers)
+    input grad     tdgp_modconv2d on dy with the flipped, transposed weights (a 'same' stride-1 convolution is its own adjoint form)
+    weight grad    tdgp_conv2d_weight_grad (conv_grad.hip; also stride 2 / any padding through `conv2d_weight_grad`)
+    bias grad      dy.sum([0, 2, 3])
+Other forms take the reference's own fallback, `torch.nn.functional.conv2d / conv_transpose2d` (MIOpen on ROCm, cuDNN there).
+"""
+import contextlib
+
+import torch
+
+from .. import _lib
+from . import modconv as _modconv
+
+weight_gradients_disabled = False           # conv2d_gradfix.py:24
+
+
+@contextlib.contextmanager
+def no_weight_gradients(disable=True):
+    """conv2d_gradfix.py:26-32."""
+    global weight_gradients_disabled
+    old = weight_gradients_disabled
+    if disable:
+        weight_gradients_disabled = True
+    yield
+    weight_gradients_disabled = old
+
+
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else tuple(int(t) for t in v)
+
+
+def _native_form(input, weight, stride, padding, dilation, groups):
+    if not (isinstance(input, torch.Tensor) and input.is_cuda and input.dtype == torch.float32 and weight.dtype == torch.float32):
+        return False
+    kh, kw = int(weight.shape[2]), int(weight.shape[3])
+    return (_pair(stride) == (1, 1) and _pair(dilation) == (1, 1) and groups == 1 and kh == kw and kh in (1, 3, 5)
+            and _pair(padding) == (kh // 2, kh // 2))
+
+
+def conv2d_weight_grad(x, dy, weight_shape, stride=1, padding=0):
+    """dw [Cout,Cin,k,k] of y = conv2d(x, w, stride, padding) given dy (conv2d_gradfix.py:141-150), on the matrix cores."""
+    _lib.require_cuda(x, 'x')
+    x, dy = _lib.f32c(x), _lib.f32c(dy)
+    cout, cin, k, k2 = (int(v) for v in weight_shape)
+    B, _, H, W = x.shape
+    _, _, OH, OW = dy.shape
+    if k != k2 or x.shape[1] != cin or dy.shape[1] != cout or dy.shape[0] != B:
+        raise RuntimeError(f'conv2d_weight_grad: x {tuple(x.shape)}, dy {tuple(dy.shape)} do not fit a weight of shape {tuple(weight_shape)}')
+    dw = torch.empty([cout, cin, k, k], dtype=torch.float32, device=x.device)
+    nbytes = int(_lib.load().tdgp_conv2d_weight_grad_workspace_bytes(B, cin, cout, OH, k))
+    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call('tdgp_conv2d_weight_grad', x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes, B, cin, cout, H, W, OH, OW, k,
+                  int(stride), int(padding), _lib.stream_of(x))
+    return dw
+
+
+def conv2d_input_grad(dy, weight):
+    """dx of a stride-1 'same' convolution: the correlation of dy with the spatially flipped, in/out-transposed weights."""
+    wt = weight.detach().flip([2, 3]).transpose(0, 1).contiguous()
+    return _modconv.modconv_forward(dy, _modconv.PackedConv(wt), None, demodulate=False, act='linear', gain=1.0)
+
+
+class _Conv2dSame(torch.autograd.Function):
+    """conv2d_gradfix.py:106-139 for the native form."""
+
+    @staticmethod
+    def forward(ctx, input, weight, bias):
+        ctx.save_for_backward(input, weight)
+        ctx.has_bias = bias is not None
+        return _modconv.modconv_forward(input, _modconv._packed(weight), None, bias=bias, demodulate=False, act='linear', gain=1.0)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, weight = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        grad_input = grad_weight = grad_bias = None
+        if ctx.needs_input_grad[0]:
+            grad_input = conv2d_input_grad(grad_output, weight)
+        if ctx.needs_input_grad[1] and not weight_gradients_disabled:
+            grad_weight = conv2d_weight_grad(input, grad_output, weight.shape, stride=1, padding=weight.shape[2] // 2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = grad_output.sum([0, 2, 3])
+        return grad_input, grad_weight, grad_bias
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    if _native_form(input, weight, stride, padding, dilation, groups):
+        return _Conv2dSame.apply(input, weight, bias)
+    return torch.nn.functional.conv2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding, dilation=dilation, groups=groups)
+
+
+def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
+    """The reference's fallback form (conv2d_gradfix.py:41-44); the generator's x2 transposed convolution runs fused inside tdgp_modconv2d."""
+    return torch.nn.functional.conv_transpose2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding,
+                                                output_padding=output_padding, groups=groups, dilation=dilation)

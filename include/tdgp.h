@@ -138,6 +138,21 @@ int tdgp_style_affine(const float* ws, const float* A, const float* abias, const
                       tdgp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Convolution weight gradient.
+ * replaces: src/torch_utils/ops/conv2d_gradfix.py:141-150 `Conv2dGradWeight.forward` (aten::convolution_backward, output_mask
+ *           [0,1,0]; non-transposed, groups 1, dilation 1):
+ *   dw[o,c,ky,kx] = sum_{b,oy,ox} dy[b,o,oy,ox] * x[b,c, oy*stride + ky - pad, ox*stride + kx - pad]      (zero outside x)
+ * x [B,Cin,H,W], dy [B,Cout,OH,OW] with OH = (H + 2 pad - k) / stride + 1 (likewise OW), dw [Cout,Cin,k,k], k <= 7.
+ * The pixel sum is split over blocks; the slices are added in slice order (run-to-run deterministic).
+ * workspace: tdgp_conv2d_weight_grad_workspace_bytes(B, Cin, Cout, OH, k) bytes.
+ * (The input gradient of a stride-1 'same' convolution is tdgp_modconv2d on dy with the flipped, transposed weights.)
+ * --------------------------------------------------------------------------------------------- */
+int64_t tdgp_conv2d_weight_grad_workspace_bytes(int B, int Cin, int Cout, int OH, int k);
+int     tdgp_conv2d_weight_grad(const float* x, const float* dy, float* dw, void* workspace, int64_t workspace_bytes, int B,
+                                int Cin, int Cout, int H, int W, int OH, int OW, int k, int stride, int pad,
+                                tdgp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Camera + rays.
  * replaces: src/training/rendering_utils.py:194 `compute_cam2world_matrix(camera_params)`,
  *           src/training/tri_plane_renderer.py:487 `sample_rays(c2w, fov, resolution, patch_params)`

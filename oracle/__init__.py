@@ -195,6 +195,29 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, demodulate=True, resam
     return y
 
 
+def conv2d_weight_grad(x, dy, k, stride=1, padding=0):
+    """dw [Cout,Cin,k,k] of y = conv2d(x, w, stride, padding) given dy (conv2d_gradfix.py:141-150), double accumulation."""
+    x, dy = _f(x), _f(dy)
+    B, cin, H, W = x.shape
+    _, cout, OH, OW = dy.shape
+    assert OH == (H + 2 * padding - k) // stride + 1 and OW == (W + 2 * padding - k) // stride + 1
+    dw = np.empty([cout, cin, k, k], dtype=np.float32)
+    lib().orc_conv2d_weight_grad(_p(x), _p(dy), _p(dw), B, cin, cout, H, W, OH, OW, k, stride, padding)
+    return dw
+
+
+def conv2d_same(x, w):
+    """Stride-1 correlation with padding k // 2 (the unmodulated form of orc_modconv2d)."""
+    x = _f(x)
+    return modulated_conv2d(x, w, np.ones([x.shape[0], x.shape[1]], np.float32), demodulate=False)
+
+
+def conv2d_input_grad(dy, w):
+    """dx of y = conv2d_same(x, w): correlation of dy with the flipped, in/out-transposed weights (conv2d_gradfix.py:126-129)."""
+    wt = np.ascontiguousarray(_f(w)[:, :, ::-1, ::-1].transpose(1, 0, 2, 3))
+    return conv2d_same(dy, wt)
+
+
 def cam2world(angles, radius, look_at):
     angles, radius, look_at = _f(angles), _f(radius), _f(look_at)
     B = angles.shape[0]

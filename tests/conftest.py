@@ -101,3 +101,9 @@ def upfirdn2d_backward_args(case, f_shape, dy_shape):
     fh, fw = f_shape
     pad = [fw - px0 - 1, iw * upx - ow * downx + px0 - upx + 1, fh - py0 - 1, ih * upy - oh * downy + py0 - upy + 1]
     return dict(up=[downx, downy], down=[upx, upy], padding=pad, flip_filter=not case['flip'], gain=case['gain'])
+
+
+# ------------------------------------------------------------------------------------------------ conv2d_gradfix
+CONV_GRAD_CASES = dict(k3=dict(B=2, cin=10, cout=12, H=9, W=14, k=3, stride=1, pad=1), k1=dict(B=3, cin=7, cout=5, H=8, W=8, k=1, stride=1, pad=0),
+                       k5=dict(B=1, cin=4, cout=6, H=12, W=10, k=5, stride=1, pad=2), k3s2=dict(B=2, cin=6, cout=8, H=12, W=16, k=3, stride=2, pad=1),
+                       k3p0=dict(B=2, cin=5, cout=4, H=10, W=9, k=3, stride=1, pad=0))

@@ -798,3 +798,48 @@ def test_depth_adaptor_training_selection(tdgp):
     np.random.seed(95)
     out = da(T(g['da_depth']), T(g['da_w']))
     assert_close(N(out), g['da_out'], 5e-6, 'randomly selected heads', 1.0)
+
+
+# ------------------------------------------------------------------------------------------------ conv2d_gradfix
+@pytest.mark.parametrize('name', ['k3', 'k1', 'k5', 'k3s2', 'k3p0'])
+def test_conv2d_weight_grad_golden(tdgp, name):
+    """tdgp_conv2d_weight_grad (MFMA, split over the pixel dimension) against autograd through the reference's conv2d_gradfix."""
+    from conftest import CONV_GRAD_CASES
+    g, c = load_golden('conv2d_grad'), CONV_GRAD_CASES[name]
+    dw = tdgp.ops.conv2d_gradfix.conv2d_weight_grad(T(g[f'{name}_x']), T(g[f'{name}_dy']), g[f'{name}_w'].shape, c['stride'], c['pad'])
+    assert_close(N(dw), g[f'{name}_dw'], 5e-6, 'dw', 1.0)
+
+
+@pytest.mark.parametrize('name', ['k3', 'k1', 'k5'])
+def test_conv2d_gradfix_autograd(tdgp, name):
+    """ops.conv2d_gradfix.conv2d as an autograd function on the GPU: forward, input / weight / bias gradients vs the reference's."""
+    g = load_golden('conv2d_grad')
+    cg = tdgp.ops.conv2d_gradfix
+    x, w, b = (T(g[f'{name}_{k}']).requires_grad_(True) for k in 'xwb')
+    y = cg.conv2d(x, w, b, padding=w.shape[2] // 2)
+    assert_close(N(y.detach()), g[f'{name}_y'], 5e-6, 'y', 1.0)
+    dx, dw, db = torch.autograd.grad(y, [x, w, b], T(g[f'{name}_dy']))
+    assert_close(N(dx), g[f'{name}_dx'], 5e-6, 'dx', 1.0)
+    assert_close(N(dw), g[f'{name}_dw'], 5e-6, 'dw', 1.0)
+    assert_close(N(db), g[f'{name}_db'], 5e-6, 'db', 1.0)
+    with cg.no_weight_gradients():
+        y = cg.conv2d(x, w, b, padding=w.shape[2] // 2)
+        dx2, = torch.autograd.grad(y, [x], T(g[f'{name}_dy']))
+        assert torch.equal(dx, dx2)
+        y = cg.conv2d(x, w, b, padding=w.shape[2] // 2)
+        assert torch.autograd.grad(y, [w], T(g[f'{name}_dy']), allow_unused=True)[0] is None
+
+
+@pytest.mark.parametrize('B,cin,cout,H,W,k,stride,pad', [(4, 128, 96, 64, 64, 3, 1, 1), (2, 70, 130, 33, 47, 3, 2, 1), (8, 64, 64, 32, 32, 1, 1, 0),
+                                                         (1, 33, 65, 40, 24, 5, 1, 2)])
+def test_conv2d_weight_grad_oracle(tdgp, oracle, B, cin, cout, H, W, k, stride, pad):
+    """Layer-sized weight gradients (several output tiles, ragged channel counts and widths, many pixel slices) vs the
+    double-accumulating oracle, and run-to-run determinism of the sliced sum."""
+    rs = np.random.RandomState(cin + cout)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    x = rs.randn(B, cin, H, W).astype(np.float32)
+    dy = rs.randn(B, cout, OH, OW).astype(np.float32)
+    ref = oracle.conv2d_weight_grad(x, dy, k, stride, pad)
+    dw = tdgp.ops.conv2d_gradfix.conv2d_weight_grad(T(x), T(dy), (cout, cin, k, k), stride, pad)
+    assert_close(N(dw), ref, 2e-5, 'dw', 1.0)
+    assert torch.equal(dw, tdgp.ops.conv2d_gradfix.conv2d_weight_grad(T(x), T(dy), (cout, cin, k, k), stride, pad))

@@ -290,3 +290,38 @@ def test_progressive_schedule_and_w_avg(tdgp):
         ws = G.mapping(torch.from_numpy(g['z']), torch.from_numpy(g['c']), update_emas=True)
     assert_close(ws.numpy(), g['ws'], 1e-5, 'ws', 1.0)
     assert_close(G.mapping.w_avg.numpy(), g['w_avg_after'], 1e-6, 'w_avg', 1.0)
+
+
+# ------------------------------------------------------------------------------------------------ conv2d_gradfix
+@pytest.mark.parametrize('name', ['k3', 'k1', 'k5', 'k3s2', 'k3p0'])
+def test_conv2d_grad_oracle(oracle, name):
+    """Weight gradient (any stride / padding) and, for the 'same' stride-1 forms, forward and input gradient of the oracle against
+    autograd through the reference's conv2d_gradfix.conv2d."""
+    from conftest import CONV_GRAD_CASES
+    g, c = load_golden('conv2d_grad'), CONV_GRAD_CASES[name]
+    dw = oracle.conv2d_weight_grad(g[f'{name}_x'], g[f'{name}_dy'], c['k'], c['stride'], c['pad'])
+    assert_close(dw, g[f'{name}_dw'], 2e-6, 'dw', 1.0)
+    if c['stride'] == 1 and c['pad'] == c['k'] // 2:
+        y = oracle.conv2d_same(g[f'{name}_x'], g[f'{name}_w']) + g[f'{name}_b'][None, :, None, None]
+        assert_close(y, g[f'{name}_y'], 2e-6, 'y', 1.0)
+        assert_close(oracle.conv2d_input_grad(g[f'{name}_dy'], g[f'{name}_w']), g[f'{name}_dx'], 2e-6, 'dx', 1.0)
+
+
+def test_fma_op(tdgp):
+    """ops.fma (fma.py:17-60): value and the un-broadcast gradients, bit for bit (eager tensor arithmetic on both sides)."""
+    import torch
+    g = load_golden('conv2d_grad')
+    a, b, c = (torch.from_numpy(g[f'fma_{k}']).requires_grad_(True) for k in 'abc')
+    out = tdgp.ops.fma.fma(a, b, c)
+    np.testing.assert_array_equal(out.detach().numpy(), g['fma_out'])
+    da, db, dc = torch.autograd.grad(out, [a, b, c], torch.from_numpy(g['fma_dout']))
+    for got, key in ((da, 'fma_da'), (db, 'fma_db'), (dc, 'fma_dc')):
+        np.testing.assert_array_equal(got.numpy(), g[key])
+
+
+def test_conv2d_gradfix_cpu_fallback(tdgp):
+    """CPU tensors take the reference's own fallback (torch conv2d), conv2d_gradfix.py:36-39."""
+    import torch
+    g = load_golden('conv2d_grad')
+    y = tdgp.ops.conv2d_gradfix.conv2d(torch.from_numpy(g['k3_x']), torch.from_numpy(g['k3_w']), torch.from_numpy(g['k3_b']), padding=1)
+    assert_close(y.numpy(), g['k3_y'], 1e-6, 'y', 1.0)

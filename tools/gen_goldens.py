@@ -235,6 +235,39 @@ def gen_upfirdn2d_grad():
     save('upfirdn2d_grad', **arrays)
 
 
+CONV_GRAD_CASES = dict(k3=dict(B=2, cin=10, cout=12, H=9, W=14, k=3, stride=1, pad=1), k1=dict(B=3, cin=7, cout=5, H=8, W=8, k=1, stride=1, pad=0),
+                       k5=dict(B=1, cin=4, cout=6, H=12, W=10, k=5, stride=1, pad=2), k3s2=dict(B=2, cin=6, cout=8, H=12, W=16, k=3, stride=2, pad=1),
+                       k3p0=dict(B=2, cin=5, cout=4, H=10, W=9, k=3, stride=1, pad=0))
+
+
+def gen_conv2d_grad():
+    """conv2d_gradfix.conv2d (conv2d_gradfix.py:34-39; on CPU tensors the reference's own fallback to torch conv2d) under autograd:
+    input / weight / bias gradients for a given dy."""
+    from src.torch_utils.ops import conv2d_gradfix as ref_cg
+    from src.torch_utils.ops import fma as ref_fma
+    arrays = {}
+    for name, c in CONV_GRAD_CASES.items():
+        g = np.random.RandomState(sum(map(ord, name)) + 7)
+        x = T(g.randn(c['B'], c['cin'], c['H'], c['W']).astype(np.float32)).requires_grad_(True)
+        w = T(g.randn(c['cout'], c['cin'], c['k'], c['k']).astype(np.float32)).requires_grad_(True)
+        b = T(g.randn(c['cout']).astype(np.float32)).requires_grad_(True)
+        y = ref_cg.conv2d(x, w, b, stride=c['stride'], padding=c['pad'])
+        dy = T(g.randn(*y.shape).astype(np.float32))
+        dx, dw, db = torch.autograd.grad(y, [x, w, b], dy)
+        arrays.update({f'{name}_x': npy(x), f'{name}_w': npy(w), f'{name}_b': npy(b), f'{name}_y': npy(y), f'{name}_dy': npy(dy), f'{name}_dx': npy(dx),
+                       f'{name}_dw': npy(dw), f'{name}_db': npy(db)})
+    # fma (fma.py): broadcast shapes of the unfused modulated conv, x * dcoefs + noise
+    g = np.random.RandomState(19)
+    a = T(g.randn(2, 6, 5, 5).astype(np.float32)).requires_grad_(True)
+    bb = T(g.randn(2, 6, 1, 1).astype(np.float32)).requires_grad_(True)
+    cc = T(g.randn(1, 1, 5, 5).astype(np.float32)).requires_grad_(True)
+    out = ref_fma.fma(a, bb, cc)
+    dout = T(g.randn(*out.shape).astype(np.float32))
+    da, dbb, dcc = torch.autograd.grad(out, [a, bb, cc], dout)
+    arrays.update(fma_a=npy(a), fma_b=npy(bb), fma_c=npy(cc), fma_out=npy(out), fma_dout=npy(dout), fma_da=npy(da), fma_db=npy(dbb), fma_dc=npy(dcc))
+    save('conv2d_grad', **arrays)
+
+
 def gen_modconv():
     g = np.random.RandomState(3)
     arrays = {}
@@ -706,6 +739,7 @@ def main():
     gen_bias_act_grad()
     gen_upfirdn2d()
     gen_upfirdn2d_grad()
+    gen_conv2d_grad()
     gen_modconv()
     gen_field()
     gen_sampling()
