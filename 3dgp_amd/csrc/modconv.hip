@@ -28,6 +28,19 @@
 #include "common.h"
 #include <stdlib.h>
 
+// A/B switches for timing experiments (tools/scratch/build_variant.sh); the defaults are the shipped code.
+#ifndef TDGP_AB_NO_SCALAR_WV
+#define TDGP_AB_NO_SCALAR_WV 0
+#endif
+#ifndef TDGP_AB_NO_PACKED_EPI
+#define TDGP_AB_NO_PACKED_EPI 0
+#endif
+#if TDGP_AB_NO_SCALAR_WV
+#define TDGP_WAVE_INDEX(tid) ((tid) >> 6)
+#else
+#define TDGP_WAVE_INDEX(tid) __builtin_amdgcn_readfirstlane((tid) >> 6)       // the wave index is uniform: keep it (and all tile arithmetic on it) scalar
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -118,8 +131,35 @@ __device__ __forceinline__ float finish_act(const EpiParams& e, float v) {
         return v;
     }
 }
-// which specialisation a launch can use
-__device__ __forceinline__ int epi_variant(const EpiParams& e) { return (e.clamp < 0.f && (e.act == 1 || e.act == 3)) ? e.act : 0; }
+// which specialisation a launch can use (3 = leaky ReLU written as max(v, alpha * v): needs 0 <= alpha <= 1)
+__device__ __forceinline__ int epi_variant(const EpiParams& e) {
+    if (e.clamp >= 0.f) return 0;
+    if (e.act == 1) return 1;
+    return (e.act == 3 && e.alpha >= 0.f && e.alpha <= 1.f) ? 3 : 0;
+}
+// Four outputs of one channel at once: (v * d + nz) + bb -> activation -> * gain, the arithmetic of finish_act element by element.
+// The specialised forms run as v_pk_{mul,add}_f32 (two elements per vector-ALU slot) and the leaky ReLU as max(v, alpha * v) --
+// the same value for every input, sign of zero included, when 0 <= alpha <= 1 -- : 14 instead of 28 instructions per float4,
+// and in this stage an instruction costs a ~60-cycle slot behind the other waves' MFMAs.
+typedef float epi_f32x2 __attribute__((ext_vector_type(2)));
+template <int ACT>
+__device__ __forceinline__ float4 finish_act4(const EpiParams& e, float4 v, float d, float4 nz, float bb) {
+    if constexpr ((ACT == 1 || ACT == 3) && !TDGP_AB_NO_PACKED_EPI) {
+        const epi_f32x2 d2 = {d, d}, b2 = {bb, bb}, g2 = {e.gain, e.gain};
+        epi_f32x2 lo = ((epi_f32x2){v.x, v.y} * d2 + (epi_f32x2){nz.x, nz.y}) + b2, hi = ((epi_f32x2){v.z, v.w} * d2 + (epi_f32x2){nz.z, nz.w}) + b2;
+        if constexpr (ACT == 3) {
+            const epi_f32x2 a2 = {e.alpha, e.alpha};
+            const epi_f32x2 la = lo * a2, ha = hi * a2;
+            lo = (epi_f32x2){__builtin_fmaxf(lo.x, la.x), __builtin_fmaxf(lo.y, la.y)};
+            hi = (epi_f32x2){__builtin_fmaxf(hi.x, ha.x), __builtin_fmaxf(hi.y, ha.y)};
+        }
+        lo = lo * g2; hi = hi * g2;
+        return make_float4(lo.x, lo.y, hi.x, hi.y);
+    } else {
+        return make_float4(finish_act<ACT>(e, (v.x * d + nz.x) + bb), finish_act<ACT>(e, (v.y * d + nz.y) + bb), finish_act<ACT>(e, (v.z * d + nz.z) + bb),
+                           finish_act<ACT>(e, (v.w * d + nz.w) + bb));
+    }
+}
 
 // demod * acc + noise + bias (+ FIR-upsampled skip) -> activation * gain -> clamp -> store (NCHW or channel-last planes);
 // element-at-a-time form used by the split-K reduction.
@@ -188,11 +228,7 @@ __device__ __forceinline__ void epilogue_tile(const EpiParams& e, const SideCach
                 const int row = pass * 8 + cr, o = obase + row;
                 if (ok4 && o < e.Cout) {
                     float4 v = *(const float4*)&ct[row * CT_LD + 4 * g];
-                    if (!raw) {
-                        const float d = side_demod(e, sc, b4, o, true), bb = side_bias(e, sc, o, true);
-                        v.x = finish_act<ACT>(e, (v.x * d + nz.x) + bb); v.y = finish_act<ACT>(e, (v.y * d + nz.y) + bb);
-                        v.z = finish_act<ACT>(e, (v.z * d + nz.z) + bb); v.w = finish_act<ACT>(e, (v.w * d + nz.w) + bb);
-                    }
+                    if (!raw) v = finish_act4<ACT>(e, v, side_demod(e, sc, b4, o, true), nz, side_bias(e, sc, o, true));
                     *(float4*)(dst + pix + o * cstride) = v;
                 }
             }
@@ -324,7 +360,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     const int vr0 = ty * TR, n0 = tx * TW;
     const int m0 = blockIdx.y * BM;
 
-    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, l = tid & 63, wv = TDGP_WAVE_INDEX(tid);    // wave index: scalar, so is everything derived from it
     const int l32 = l & 31, half = l >> 5;
     const int wm = wv / WN, wn = wv % WN;
 
@@ -607,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
     const int tilesX = p.W >> 5, VR = p.B * H1;
     const int ty = blockIdx.x / tilesX, tx = blockIdx.x % tilesX;
     const int vr0 = ty * NT, n0 = tx * 32, m0 = blockIdx.y * BM, ks = blockIdx.z;
-    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, l32 = l & 31, half = l >> 5;
+    const int tid = threadIdx.x, l = tid & 63, wv = TDGP_WAVE_INDEX(tid), l32 = l & 31, half = l >> 5;     // wave index: scalar
     const int wm = wv / WN, wn = wv % WN;
 
     constexpr int NSB = 4;
@@ -846,7 +882,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int v0 = blockIdx.x * BN, m0 = blockIdx.y * BM, ks = blockIdx.z;
-    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, l32 = l & 31, half = l >> 5;
+    const int tid = threadIdx.x, l = tid & 63, wv = TDGP_WAVE_INDEX(tid), l32 = l & 31, half = l >> 5;     // wave index: scalar
     const int wm = wv / WN, wn = wv % WN;
 
     // ---- activation patch slots of this thread (fixed across the K loop): run 0 = grid points v-(W+1) (dy = -1), run 1 = dy = 0
@@ -1034,8 +1070,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
 #undef TSEG
 
     // ---- epilogue: per (channel tile, point subtile, py): interleave px = 0/1 in a per-wave LDS tile, store 16 B per lane -----
+    // Vector-ALU instructions of this stage queue behind the 64-cycle MFMAs of the SIMD's other waves (~60 cycles each), and with
+    // Cin = 128 the K loop is only 32 iterations: the stage was ~20 % of the 256^2 -> 512^2 layer.  Fast path (whole 32-channel
+    // sub-tile inside Cout, slice < 4 GiB): buffer stores whose per-pass offset is a scalar, LDS reads with immediate offsets, one
+    // integer division per wave -- no per-pass address arithmetic or bounds compares.
     float* ct = smem + wv * (32 * UP_CT_W);
     float* zout = p.z + (int64_t)ks * p.zslice;
+    const bool zbuf = (uint64_t)p.zslice * 4u < 0xFFFF0000ull;
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(zout, zbuf ? (uint32_t)(p.zslice * 4) : 0u);
+    const int q = l & 15, cr = l >> 4;
+    const uint32_t z_vo = (uint32_t)(cr * 4 * p.GS + 4 * q) * 4u;            // channel cr of the pass: 2 parity rows x 2GS floats each
+    const uint32_t z_pass = (uint32_t)(16 * p.GS) * 4u;                      // 4 channels further
+    const int gbase = v0 + wn * NTW * 32;
+    const int b0 = gbase / p.GS, vpb = gbase - b0 * p.GS;
 #pragma unroll 1
     for (int tile = 0; tile < 2 * MTW * NTW; tile++) {
 #pragma unroll
@@ -1053,17 +1100,26 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
         const int py = tile / (MTW * NTW), mm = (tile / NTW) % MTW, nn = tile % NTW;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int g0 = v0 + (wn * NTW + nn) * 32;
-        const int b = g0 / p.GS, vp0 = g0 - b * p.GS;
+        int b = b0, vp0 = vpb + nn * 32;                 // GS is a multiple of 32: the 32 points of a sub-tile share their sample
+        while (vp0 >= p.GS) { vp0 -= p.GS; b++; }
+        const int obase = m0 + (wm * MTW + mm) * 32;
         if (b < p.B && (!(TDGP_UP_ABL & 1) || acc[0][0][0][0] == 123.f)) {
-            const int q = l & 15, cr = l >> 4;
-            const int obase = m0 + (wm * MTW + mm) * 32;
+            if (zbuf && obase + 32 <= p.Cout) {
+                const uint32_t zb = (uint32_t)(((b * p.Cout + obase) * 2 + py) * (2 * p.GS) + 2 * vp0) * 4u;
 #pragma unroll
-            for (int pass = 0; pass < 8; pass++) {
-                const int ch = pass * 4 + cr, o = obase + ch;
-                if (o < p.Cout) {
-                    const float4 v = *(const float4*)&ct[ch * UP_CT_W + 4 * q];
-                    *(float4*)(zout + (((int64_t)b * p.Cout + o) * 2 + py) * (2 * p.GS) + 2 * vp0 + 4 * q) = v;
+                for (int pass = 0; pass < 8; pass++) {
+                    const float4 v = *(const float4*)&ct[(pass * 4 + cr) * UP_CT_W + 4 * q];
+                    const u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+                    __builtin_amdgcn_raw_buffer_store_b128(bits, rz, z_vo, zb + (uint32_t)pass * z_pass, 0);
+                }
+            } else {
+#pragma unroll
+                for (int pass = 0; pass < 8; pass++) {
+                    const int ch = pass * 4 + cr, o = obase + ch;
+                    if (o < p.Cout) {
+                        const float4 v = *(const float4*)&ct[ch * UP_CT_W + 4 * q];
+                        *(float4*)(zout + (((int64_t)b * p.Cout + o) * 2 + py) * (2 * p.GS) + 2 * vp0 + 4 * q) = v;
+                    }
                 }
             }
         }
@@ -1185,7 +1241,7 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
     float* As = smem;
     float* Xs = smem + AS_SZ;
     float* side = smem + AS_SZ + XS_SZ;                             // [BM] bias
-    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, l32 = l & 31, half = l >> 5;
+    const int tid = threadIdx.x, l = tid & 63, wv = TDGP_WAVE_INDEX(tid), l32 = l & 31, half = l >> 5;     // wave index: scalar
     const int64_t ntiles = (p.P + BN - 1) / BN;
     const int64_t t_begin = (int64_t)blockIdx.x * p.tpb, t_end = min(t_begin + p.tpb, ntiles);
 #if TDGP_RGB_ABL & 16
