@@ -35,6 +35,9 @@
 #ifndef TDGP_AB_NO_PACKED_EPI
 #define TDGP_AB_NO_PACKED_EPI 0
 #endif
+#ifndef TDGP_AB_FIR_SERIAL
+#define TDGP_AB_FIR_SERIAL 0
+#endif
 #if TDGP_AB_NO_SCALAR_WV
 #define TDGP_WAVE_INDEX(tid) ((tid) >> 6)
 #else
@@ -1460,8 +1463,11 @@ struct FirParams {
     int act; float alpha, gain, clamp;
 };
 
-constexpr int FIR_TH = 32, FIR_TW = 64;
+// Tile FIR_TH x FIR_TW outputs per block: 32 x 64, or 16 x 128 for wide images (longer contiguous runs per row: 544-B reads,
+// 512-B writes instead of 288 / 256).
+template <int FIR_TH, int FIR_TW>
 __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
+    constexpr int CW = FIR_TW / 4, RPP = 256 / CW;                 // threads per output row, rows per pass
     constexpr int ZP = FIR_TW + 8;                  // window columns ox0-4 .. ox0+67, fetched as aligned 16-B vectors (P2 % 4 == 0)
     __shared__ __attribute__((aligned(16))) float zt[(FIR_TH + 3) * ZP];
     const int tilesX = (p.OW + FIR_TW - 1) / FIR_TW, tilesY = (p.OH + FIR_TH - 1) / FIR_TH;
@@ -1476,6 +1482,27 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
         const float* zp = p.z + ((int64_t)b * p.C + c) * 2 * p.GS2;
         const int nrows = min(FIR_TH, p.OH - oy0) + 3;
         __syncthreads();
+        if (p.ksplit == 1 && !TDGP_AB_FIR_SERIAL) {
+            // no split-K slices to add: all (at most 3) window vectors of a thread are put in flight before the first is written to
+            // LDS.  One load per thread at a time left 8 blocks x 4 KB in flight per CU -- by Little's law ~4 TB/s, which is where
+            // the kernel sat.
+            constexpr int NV = ((FIR_TH + 3) * (ZP / 4) + 255) / 256;
+            float4 wv4[NV];
+#pragma unroll
+            for (int u = 0; u < NV; u++) {
+                const int i = threadIdx.x + u * 256;
+                const int ry = i / (ZP / 4), j = i % (ZP / 4);
+                const int zy = oy0 - 1 + ry, zx = ox0 - 4 + 4 * j;
+                wv4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < nrows * (ZP / 4) && zy >= 0 && zy < p.ZROWS && zx >= 0 && zx < p.P2)
+                    wv4[u] = *(const float4*)(zp + (zy & 1) * p.GS2 + (zy >> 1) * p.P2 + zx);
+            }
+#pragma unroll
+            for (int u = 0; u < NV; u++) {
+                const int i = threadIdx.x + u * 256;
+                if (i < nrows * (ZP / 4)) *(float4*)&zt[(i / (ZP / 4)) * ZP + 4 * (i % (ZP / 4))] = wv4[u];
+            }
+        } else
         for (int i = threadIdx.x; i < nrows * (ZP / 4); i += 256) {
             const int ry = i / (ZP / 4), j = i % (ZP / 4);
             const int zy = oy0 - 1 + ry, zx = ox0 - 4 + 4 * j;
@@ -1494,20 +1521,22 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
             *(float4*)&zt[ry * ZP + 4 * j] = v;
         }
         __syncthreads();
-        const int lx = (threadIdx.x & 15) * 4;
+        const int lx = (threadIdx.x % CW) * 4;
         const float d = p.dcoef ? p.dcoef[b * p.C + c] : 1.f;
         const float bv = p.bias ? p.bias[c] : 0.f;
 #pragma unroll
-        for (int hrow = 0; hrow < FIR_TH / 16; hrow++) {
-            const int ly = (threadIdx.x >> 4) + hrow * 16;
+        for (int hrow = 0; hrow < FIR_TH / RPP; hrow++) {
+            const int ly = threadIdx.x / CW + hrow * RPP;
             const int oy = oy0 + ly;
             if (oy < p.OH && ox0 + lx < p.OW) {
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ky = 0; ky < 4; ky++) {
-                    float win[7];
-#pragma unroll
-                    for (int j = 0; j < 7; j++) win[j] = zt[(ly + ky) * ZP + lx + j + 3];
+                    // window columns lx+3 .. lx+9 out of three aligned 16-B LDS reads (lx .. lx+11): scalar reads at a 4-float lane
+                    // stride hit 8 of the 32 banks (4-way conflict, 7 reads); the vector reads are conflict-free
+                    const float4 wa = *(const float4*)&zt[(ly + ky) * ZP + lx], wb = *(const float4*)&zt[(ly + ky) * ZP + lx + 4],
+                                 wc = *(const float4*)&zt[(ly + ky) * ZP + lx + 8];
+                    const float win[7] = {wa.w, wb.x, wb.y, wb.z, wb.w, wc.x, wc.y};
 #pragma unroll
                     for (int o = 0; o < 4; o++)
 #pragma unroll
@@ -1944,8 +1973,13 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         f.B = B; f.C = Cout; f.ZROWS = 2 * H + 2; f.P2 = 2 * pl.G1; f.GS2 = 2 * pl.GS; f.ksplit = pl.ksplit; f.zslice = pl.zslice;
         f.OH = 2 * H; f.OW = 2 * W;
         f.act = act; f.alpha = alpha; f.gain = gain; f.clamp = clamp;
-        const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, FIR_TH) * cdiv(f.OW, FIR_TW);
-        TDGP_LAUNCH("fir_act_kernel", fir_act_kernel, dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
+        if (f.OW >= 128 && !TDGP_AB_FIR_SERIAL) {
+            const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, 16) * cdiv(f.OW, 128);
+            TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<16, 128>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
+        } else {
+            const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, 32) * cdiv(f.OW, 64);
+            TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<32, 64>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
+        }
     }
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
