@@ -189,6 +189,23 @@ def simple_tri_plane_renderer(x, coords, mlp, scale=1.0, return_taps=False, sigm
 
 # ------------------------------------------------------------------------------------------------ marchers
 
+def ray_march_backward(colors, densities, depths, opts, marcher, d_rgb, d_depth=None, d_weights=None):
+    """Gradients of `_march` w.r.t. colours and raw densities (autograd through tri_plane_renderer.py:299-398), tdgp_ray_march_grad.
+    colors [B,R,S,C], densities / depths [B,R,S,1]; d_rgb [B,R,C], d_depth [B,R,1], d_weights [B,R,M,1] -> (d_colors, d_densities)."""
+    _lib.require_cuda(colors, 'colors')
+    colors, densities, depths, d_rgb = _lib.f32c(colors), _lib.f32c(densities), _lib.f32c(depths), _lib.f32c(d_rgb)
+    d_depth = None if d_depth is None else _lib.f32c(d_depth)
+    d_weights = None if d_weights is None else _lib.f32c(d_weights)
+    B, R, S, C = colors.shape
+    d_colors = torch.empty_like(colors)
+    d_dens = torch.empty_like(densities)
+    with torch.cuda.device(colors.device):
+        _lib.call('tdgp_ray_march_grad', colors.data_ptr(), densities.data_ptr(), depths.data_ptr(), d_rgb.data_ptr(), _lib.ptr(d_depth),
+                  _lib.ptr(d_weights), d_colors.data_ptr(), d_dens.data_ptr(), B * R, S, C, MARCHER_IDS[marcher], _marcher_flags(opts, marcher),
+                  float(opts.get('density_bias', 0.0)), _lib.stream_of(colors))
+    return d_colors, d_dens
+
+
 def _march(colors, densities, depths, opts, marcher):
     _lib.require_cuda(colors, 'colors')
     colors, densities, depths = _lib.f32c(colors), _lib.f32c(densities), _lib.f32c(depths)

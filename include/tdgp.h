@@ -210,6 +210,14 @@ int tdgp_ray_march(const float* colors, const float* densities, const float* dep
                    float* depth, float* weights, float* final_T, int64_t rays, int S, int C, int marcher,
                    int flags, float density_bias, tdgp_stream_t stream);
 
+/* Gradient of tdgp_ray_march: autograd through ClassicalRayMarcher / MipRayMarcher2 (:353-398, :299-349).
+ * d_rgb [rays,C], d_depth [rays] (may be NULL), d_weights [rays,M] (may be NULL; M as in tdgp_ray_march) ->
+ * d_colors [rays,S,C], d_densities [rays,S] (gradient w.r.t. the RAW densities, through softplus / relu).  Depths carry no
+ * gradient.  C in {1,3,4}, S <= 256; marcher / flags / density_bias as in tdgp_ray_march. */
+int tdgp_ray_march_grad(const float* colors, const float* densities, const float* depths, const float* d_rgb,
+                        const float* d_depth, const float* d_weights, float* d_colors, float* d_densities,
+                        int64_t rays, int S, int C, int marcher, int flags, float density_bias, tdgp_stream_t stream);
+
 /* sample_importance: z [rays,S] (s-space), weights [rays,Wn], u [rays,N] -> samples [rays,N].
  * Optional outputs: inds/below/above int32 [rays,N] (searchsorted right=True, clamped), cdf [rays,Wn-1]. */
 int tdgp_sample_importance(const float* z, const float* weights, const float* u, float* samples,

@@ -195,6 +195,22 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, demodulate=True, resam
     return y
 
 
+def ray_march_grad(colors, densities, depths, d_rgb, d_depth=None, d_weights=None, mode='classical', use_inf_depth=True, last_back=False,
+                   white_back=False, clamp_mode='softplus', density_bias=0.0):
+    """(d_colors, d_densities) of march_classical / march_mip (autograd through tri_plane_renderer.py:299-398), double arithmetic.
+    colors [B,R,S,C], densities / depths [B,R,S,1]; d_rgb [B,R,C], d_depth [B,R,1], d_weights [B,R,M,1]."""
+    colors, densities, depths, d_rgb = _f(colors), _f(densities), _f(depths), _f(d_rgb)
+    B, R, S, C = colors.shape
+    assert S <= 512 and C <= 4
+    d_depth = None if d_depth is None else _f(d_depth)
+    d_weights = None if d_weights is None else _f(d_weights)
+    flags = (1 if use_inf_depth else 0) | (2 if last_back else 0) | (4 if white_back else 0) | (8 if clamp_mode == 'relu' else 0)
+    dc, dd = np.empty_like(colors), np.empty_like(densities)
+    lib().orc_ray_march_grad(_p(colors), _p(densities), _p(depths), _p(d_rgb), _p(d_depth), _p(d_weights), _p(dc), _p(dd),
+                             c_i64(B * R), S, C, 1 if mode == 'mip' else 0, flags, c_float(density_bias))
+    return dc, dd
+
+
 def conv2d_weight_grad(x, dy, k, stride=1, padding=0):
     """dw [Cout,Cin,k,k] of y = conv2d(x, w, stride, padding) given dy (conv2d_gradfix.py:141-150), double accumulation."""
     x, dy = _f(x), _f(dy)

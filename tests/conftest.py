@@ -107,3 +107,7 @@ def upfirdn2d_backward_args(case, f_shape, dy_shape):
 CONV_GRAD_CASES = dict(k3=dict(B=2, cin=10, cout=12, H=9, W=14, k=3, stride=1, pad=1), k1=dict(B=3, cin=7, cout=5, H=8, W=8, k=1, stride=1, pad=0),
                        k5=dict(B=1, cin=4, cout=6, H=12, W=10, k=5, stride=1, pad=2), k3s2=dict(B=2, cin=6, cout=8, H=12, W=16, k=3, stride=2, pad=1),
                        k3p0=dict(B=2, cin=5, cout=4, H=10, W=9, k=3, stride=1, pad=0))
+
+MARCH_GRAD_CASES = dict(cl_inf=dict(mode='classical', use_inf_depth=True), cl_noinf_lastback=dict(mode='classical', use_inf_depth=False, last_back=True),
+                        cl_relu=dict(mode='classical', use_inf_depth=True, clamp_mode='relu'), mip_inf=dict(mode='mip', use_inf_depth=True),
+                        mip_noinf_white_bias=dict(mode='mip', use_inf_depth=False, white_back=True, density_bias=-1.0))

@@ -843,3 +843,26 @@ def test_conv2d_weight_grad_oracle(tdgp, oracle, B, cin, cout, H, W, k, stride, 
     dw = tdgp.ops.conv2d_gradfix.conv2d_weight_grad(T(x), T(dy), (cout, cin, k, k), stride, pad)
     assert_close(N(dw), ref, 2e-5, 'dw', 1.0)
     assert torch.equal(dw, tdgp.ops.conv2d_gradfix.conv2d_weight_grad(T(x), T(dy), (cout, cin, k, k), stride, pad))
+
+
+@pytest.mark.parametrize('tag', ['cl_inf', 'cl_noinf_lastback', 'cl_relu', 'mip_inf', 'mip_noinf_white_bias'])
+def test_ray_march_grad(tdgp, oracle, tag):
+    """tdgp_ray_march_grad against autograd through the reference marchers (goldens) and, on a larger random batch with and
+    without the optional incoming gradients, against the double-precision oracle."""
+    from conftest import MARCH_GRAD_CASES
+    g, kw = load_golden('march_grad'), dict(MARCH_GRAD_CASES[tag])
+    mode = kw.pop('mode')
+    dc, dd = tdgp.renderer.ray_march_backward(T(g[f'{tag}_c']), T(g['densities']), T(g['depths']), kw, mode, T(g[f'{tag}_d_rgb']), T(g[f'{tag}_d_depth']),
+                                              T(g[f'{tag}_d_weights']))
+    assert_close(N(dc), g[f'{tag}_dc'], 5e-6, 'd_colors', 1.0)
+    assert_close(N(dd), g[f'{tag}_dd'], 2e-5, 'd_densities', 1.0)
+    rs = np.random.RandomState(31)
+    B, R, S = 2, 700, 128
+    colors = rs.rand(B, R, S, 3).astype(np.float32)
+    dens = (rs.randn(B, R, S, 1) * 2).astype(np.float32)
+    depths = np.sort(0.75 + 0.5 * rs.rand(B, R, S, 1).astype(np.float32), axis=2)
+    d_rgb = rs.randn(B, R, 3).astype(np.float32)
+    rc, rd = oracle.ray_march_grad(colors, dens, depths, d_rgb, mode=mode, **kw)
+    dc, dd = tdgp.renderer.ray_march_backward(T(colors), T(dens), T(depths), kw, mode, T(d_rgb))
+    assert_close(N(dc), rc, 1e-5, 'd_colors (S=128)', 1.0)
+    assert_close(N(dd), rd, 5e-5, 'd_densities (S=128)', 1.0)

@@ -325,3 +325,13 @@ def test_conv2d_gradfix_cpu_fallback(tdgp):
     g = load_golden('conv2d_grad')
     y = tdgp.ops.conv2d_gradfix.conv2d(torch.from_numpy(g['k3_x']), torch.from_numpy(g['k3_w']), torch.from_numpy(g['k3_b']), padding=1)
     assert_close(y.numpy(), g['k3_y'], 1e-6, 'y', 1.0)
+
+
+@pytest.mark.parametrize('tag', ['cl_inf', 'cl_noinf_lastback', 'cl_relu', 'mip_inf', 'mip_noinf_white_bias'])
+def test_ray_march_grad_oracle(oracle, tag):
+    """Gradients of both ray marchers (colours, raw densities) against autograd through the reference, every option."""
+    from conftest import MARCH_GRAD_CASES
+    g, kw = load_golden('march_grad'), MARCH_GRAD_CASES[tag]
+    dc, dd = oracle.ray_march_grad(g[f'{tag}_c'], g['densities'], g['depths'], g[f'{tag}_d_rgb'], g[f'{tag}_d_depth'], g[f'{tag}_d_weights'], **kw)
+    assert_close(dc, g[f'{tag}_dc'], 2e-6, 'd_colors', 1.0)
+    assert_close(dd, g[f'{tag}_dd'], 1e-5, 'd_densities', 1.0)

@@ -400,6 +400,37 @@ def gen_marchers():
     save('marchers', **arrays)
 
 
+MARCH_GRAD_CASES = dict(cl_inf=dict(mode='classical', use_inf_depth=True), cl_noinf_lastback=dict(mode='classical', use_inf_depth=False, last_back=True),
+                        cl_relu=dict(mode='classical', use_inf_depth=True, clamp_mode='relu'), mip_inf=dict(mode='mip', use_inf_depth=True),
+                        mip_noinf_white_bias=dict(mode='mip', use_inf_depth=False, white_back=True, density_bias=-1.0))
+
+
+def gen_march_grad():
+    """Autograd through the reference ray marchers (tri_plane_renderer.py:299-398): gradients w.r.t. colours and raw densities for
+    given d_rgb, d_depth, d_weights."""
+    g = np.random.RandomState(23)
+    B, R, S = 2, 9, 12
+    colors = g.randn(B, R, S, 3).astype(np.float32)
+    dens = (g.randn(B, R, S, 1) * 3).astype(np.float32)
+    dens[0, 0, :, 0] = 25.0            # beyond the softplus threshold
+    dens[0, 1, :, 0] = -30.0           # nearly empty ray
+    dens[0, 2, 3, 0] = 40.0            # an opaque sample in the middle of the ray: q = 1e-10 behind it
+    depths = np.sort(0.75 + 0.5 * g.rand(B, R, S, 1).astype(np.float32), axis=2)
+    arrays = dict(colors=colors, densities=dens, depths=depths)
+    for tag, kw in MARCH_GRAD_CASES.items():
+        mip = kw['mode'] == 'mip'
+        ro = EasyDict(clamp_mode=kw.get('clamp_mode', 'softplus'), cut_quantile=0.0, density_bias=kw.get('density_bias', 0.0), last_back=kw.get('last_back', False),
+                      white_back=kw.get('white_back', False), use_inf_depth=kw['use_inf_depth'])
+        c = T(colors if not mip else (1 / (1 + np.exp(-colors))).astype(np.float32)).requires_grad_(True)
+        d = T(dens).requires_grad_(True)
+        rgb, dep, w, fT = (ref_tpr.MipRayMarcher2() if mip else ref_tpr.ClassicalRayMarcher())(c, d, T(depths), ro)
+        d_rgb, d_dep, d_w = T(g.randn(*rgb.shape).astype(np.float32)), T(g.randn(*dep.shape).astype(np.float32)), T(g.randn(*w.shape).astype(np.float32))
+        dc, dd = torch.autograd.grad([rgb, dep, w], [c, d], [d_rgb, d_dep, d_w])
+        arrays.update({f'{tag}_c': npy(c), f'{tag}_d_rgb': npy(d_rgb), f'{tag}_d_depth': npy(d_dep), f'{tag}_d_weights': npy(d_w), f'{tag}_dc': npy(dc),
+                       f'{tag}_dd': npy(dd)})
+    save('march_grad', **arrays)
+
+
 def gen_camera():
     g = np.random.RandomState(8)
     arrays = {}
@@ -740,6 +771,7 @@ def main():
     gen_upfirdn2d()
     gen_upfirdn2d_grad()
     gen_conv2d_grad()
+    gen_march_grad()
     gen_modconv()
     gen_field()
     gen_sampling()
