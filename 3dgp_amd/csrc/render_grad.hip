@@ -143,3 +143,328 @@ TDGP_API int tdgp_ray_march_grad(const float* colors, const float* densities, co
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }
+
+// =================================================================================================================================
+// Tri-plane field backward: gradients of simple_tri_plane_renderer + TriPlaneMLP (tri_plane_renderer.py:560-588,
+// networks_epigraf.py:46-68) w.r.t. the planes (grid_sample backward: a scatter of 4 taps x 3 planes per point) and the four MLP
+// tensors.  Forward values are recomputed, nothing is saved by the forward pass.
+//
+// One wave = tiles of 32 points; lane = (point l32, half).  Per tile, on v_mfma_f32_32x32x2_f32:
+//     h_pre [hid x 32] = W0s [hid x F] . g [F x 32]                 (g = mean of the three bilinear samples, staged in LDS)
+//     dW0s  [hid x F] += dh_pre [hid x 32] . g^T                     K = the 32 points
+//     dW1s^T[hid x 4] += h [hid x 32] . do^T [32 x 4]                (N padded to 32)
+//     dg    [F x 32]   = W0s^T [F x hid] . dh_pre [hid x 32]
+// with W0s = w0 / sqrt(F), W1s = w1 / sqrt(hid) (layers.py:39-51), h = lrelu(h_pre) sqrt2, o = W1s h + b1, and
+// do = d_out (mip: through sigmoid * 1.002 - 0.001), dh = W1s^T do, dh_pre = dh sqrt2 (h > 0 ? 1 : 0.2) on the vector ALU in the
+// accumulator layout.  dg / 3 goes to the 12 taps of the point with fp32 atomics (like torch's grid_sampler backward, the
+// summation order -- and so the last bits -- of d_planes vary run to run); the weight gradients are accumulated in registers
+// over all tiles of a wave, reduced wave -> block -> grid in a fixed order (deterministic).
+// =================================================================================================================================
+namespace {
+
+typedef float fg_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int FG_PITCH = 33;
+
+struct FieldGradParams {
+    const float* planes;       // [B,3,H,W,F]
+    const float* coords;       // [B,P,3]
+    const float* w0; const float* b0; const float* w1; const float* b1;
+    const float* d_out;        // [B,P,4]
+    float* d_planes;           // [B,3,H,W,F], accumulated into (caller zeroes) or null
+    float* partial;            // [gridDim.x][npart]
+    int64_t total, P;
+    int F, hid, H, W, marcher, npart;
+    float scale, g0, g1;
+};
+
+// NW waves per block: 4 for hid <= 32, 2 for hid <= 64 (LDS: ~21.6 KB per wave there; 2 waves keep three blocks on a CU)
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void triplane_field_grad_kernel(FieldGradParams p) {
+    constexpr int NT = 64 * NW;
+    constexpr int HP = 32 * MT;                               // hid padded to whole MFMA tiles
+    extern __shared__ __attribute__((aligned(16))) float fg_smem[];
+    float* W0s = fg_smem;                                     // [HP][33]   w0 * g0, zero padded
+    float* W1s = W0s + HP * FG_PITCH;                         // [4][HP]    w1 * g1
+    float* B0 = W1s + 4 * HP;                                 // [HP]
+    float* wave_mem = B0 + HP;
+    const int tid = threadIdx.x, l = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = l & 31, half = l >> 5;
+    constexpr int WAVE_FLOATS = 32 * FG_PITCH + 2 * HP * FG_PITCH + 4 * 32;
+    float* gl = wave_mem + wv * WAVE_FLOATS;                  // [32 pts][33]    features
+    float* hl = gl + 32 * FG_PITCH;                           // [HP][33]        h
+    float* dl = hl + HP * FG_PITCH;                           // [HP][33]        dh_pre
+    float* dol = dl + HP * FG_PITCH;                          // [4][32]         do
+
+    for (int i = tid; i < HP * FG_PITCH; i += NT) {
+        const int m = i / FG_PITCH, f = i % FG_PITCH;
+        W0s[i] = (m < p.hid && f < p.F) ? p.w0[m * p.F + f] * p.g0 : 0.f;
+    }
+    for (int i = tid; i < 4 * HP; i += NT) { const int j = i / HP, m = i % HP; W1s[i] = m < p.hid ? p.w1[j * p.hid + m] * p.g1 : 0.f; }
+    for (int i = tid; i < HP; i += NT) B0[i] = i < p.hid ? p.b0[i] : 0.f;
+    __syncthreads();
+
+    fg_f32x16 dW0a[MT], dW1a[MT];
+    float db0a[MT][16], db1a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { dW0a[mt][r] = 0.f; dW1a[mt][r] = 0.f; db0a[mt][r] = 0.f; }
+    const float b1v[4] = {p.b1[0], p.b1[1], p.b1[2], p.b1[3]};
+    const float sx = (float)(p.W - 1) / 2.f, sy = (float)(p.H - 1) / 2.f;
+    const int fh = p.F / 2;                                   // channels of this lane in the gather: [half * fh, half * fh + fh)
+    const float sqrt2 = 1.41421356237309515f;
+
+    const int64_t ntiles = (p.total + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * NW + wv; tile < ntiles; tile += (int64_t)gridDim.x * NW) {
+        const int64_t gp = tile * 32 + l32;
+        const bool valid = gp < p.total;
+        const int64_t gpc = valid ? gp : 0;
+        const int b = (int)(gpc / p.P);
+        // ---- 1. geometry + gather ------------------------------------------------------------------------------------------
+        const float* cp = p.coords + gpc * 3;
+        const float q[3] = {cp[0] / p.scale, cp[1] / p.scale, cp[2] / p.scale};
+        float tw_[3][4];
+        int to_[3][4];
+        float gsum[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) gsum[c] = 0.f;
+        float acc3[3][16];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            const float ix = (q[pl == 2 ? 1 : 0] + 1.0f) * sx, iy = (q[pl == 0 ? 1 : 2] + 1.0f) * sy;
+            const float fx = floorf(ix), fy = floorf(iy);
+            const float twx = ix - fx, te = 1.0f - twx, tn = iy - fy, ts = 1.0f - tn;
+            const float cfx = fminf(fmaxf(fx, -2.f), (float)p.W), cfy = fminf(fmaxf(fy, -2.f), (float)p.H);
+            const int x0 = (int)cfx, y0 = (int)cfy;
+            const float wgt[4] = {ts * te, ts * twx, tn * te, tn * twx};
+            const float* plane = p.planes + ((int64_t)b * 3 + pl) * p.H * p.W * p.F;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int x = x0 + (t & 1), y = y0 + (t >> 1);
+                const bool in = valid && x >= 0 && x < p.W && y >= 0 && y < p.H;
+                tw_[pl][t] = in ? wgt[t] : 0.f;
+                to_[pl][t] = in ? (y * p.W + x) * p.F : 0;
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) acc3[pl][c] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const float* texel = plane + to_[pl][t] + half * fh;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; c4++) {
+                    if (4 * c4 < fh) {
+                        const float4 v = *(const float4*)(texel + 4 * c4);
+                        acc3[pl][4 * c4 + 0] += v.x * tw_[pl][t]; acc3[pl][4 * c4 + 1] += v.y * tw_[pl][t];
+                        acc3[pl][4 * c4 + 2] += v.z * tw_[pl][t]; acc3[pl][4 * c4 + 3] += v.w * tw_[pl][t];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 16; c++) gsum[c] = ((acc3[0][c] + acc3[1][c]) + acc3[2][c]) / 3.0f;
+        // features of the point: [pt][f], zero beyond F
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            if (c < fh) gl[l32 * FG_PITCH + half * fh + c] = gsum[c];
+        }
+        for (int f = p.F + half; f < 32; f += 2) gl[l32 * FG_PITCH + f] = 0.f;
+        const float4 dout4 = valid ? *(const float4*)(p.d_out + gpc * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- 2. h_pre = W0s g + b0 (MFMA), h = lrelu * sqrt2 -> LDS ----------------------------------------------------------
+        fg_f32x16 hacc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) hacc[mt][r] = B0[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+        for (int ks = 0; ks < 16; ks++) {
+            const float bf = gl[l32 * FG_PITCH + 2 * ks + half];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) hacc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(W0s[(mt * 32 + l32) * FG_PITCH + 2 * ks + half], bf, hacc[mt], 0, 0, 0);
+        }
+        float oj[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float hp = hacc[mt][r];
+                const float h = (hp > 0.f ? hp : hp * 0.2f) * sqrt2;
+                hacc[mt][r] = h;
+                hl[m * FG_PITCH + l32] = h;
+#pragma unroll
+                for (int j = 0; j < 4; j++) oj[j] = fmaf_(W1s[j * HP + m], h, oj[j]);
+            }
+        // ---- 3. outputs, incoming gradient ------------------------------------------------------------------------------------
+        float dj[4] = {dout4.x, dout4.y, dout4.z, dout4.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) oj[j] = (oj[j] + __shfl_xor(oj[j], 32, 64)) + b1v[j];
+        if (p.marcher == 1) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) { const float sg = 1.0f / (1.0f + expf(-oj[j])); dj[j] = dj[j] * 1.002f * sg * (1.0f - sg); }
+        }
+        if (half == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { db1a[j] += dj[j]; dol[j * 32 + l32] = dj[j]; }
+        }
+        // ---- 4. dh_pre in the accumulator layout -> LDS ----------------------------------------------------------------------------
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float dh = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; j++) dh = fmaf_(W1s[j * HP + m], dj[j], dh);
+                const float dhp = dh * sqrt2 * (hacc[mt][r] > 0.f ? 1.0f : 0.2f);
+                db0a[mt][r] += dhp;
+                dl[m * FG_PITCH + l32] = dhp;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- 5. weight-gradient GEMMs over the 32 points; dg = W0s^T dh_pre ----------------------------------------------------
+#pragma unroll
+        for (int ks = 0; ks < 16; ks++) {
+            const int k = 2 * ks + half;                                          // point index of this K step
+            const float bg = gl[k * FG_PITCH + l32];                              // B[k = pt][n = f]
+            const float bd = l32 < 4 ? dol[l32 * 32 + k] : 0.f;                   // B[k = pt][n = j]
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                dW0a[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dl[(mt * 32 + l32) * FG_PITCH + k], bg, dW0a[mt], 0, 0, 0);
+                dW1a[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(hl[(mt * 32 + l32) * FG_PITCH + k], bd, dW1a[mt], 0, 0, 0);
+            }
+        }
+        fg_f32x16 dg;
+#pragma unroll
+        for (int r = 0; r < 16; r++) dg[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < HP / 2; ks++) {
+            const int k = 2 * ks + half;                                          // hidden unit of this K step
+            dg = __builtin_amdgcn_mfma_f32_32x32x2f32(W0s[k * FG_PITCH + l32], dl[k * FG_PITCH + l32], dg, 0, 0, 0);   // A[m = f][k], B[k][n = pt]
+        }
+        // ---- 6. scatter: d_plane[tap] += w_tap * dg / 3 ------------------------------------------------------------------------
+        // Transposed through LDS so that ONE atomic instruction adds the 32 channels of one tap (a 128-B line) per half-wave:
+        // issued from the accumulator layout (lane = point) every instruction touched 64 different lines and the kernel ran at
+        // the L2's atomic line rate (82 ms for 8.4 M points).
+        if (p.d_planes) {
+            int* tab_off = (int*)hl;                             // [32 pts][12 taps] float offset into d_planes (h / dh_pre are dead now)
+            float* tab_w = hl + 32 * 12;
+#pragma unroll
+            for (int r = 0; r < 16; r++) gl[l32 * FG_PITCH + (r & 3) + 8 * (r >> 2) + 4 * half] = dg[r];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (((pl * 4 + t) & 1) == half) {
+                        tab_off[l32 * 12 + pl * 4 + t] = (int)((((int64_t)b * 3 + pl) * p.H * p.W) * p.F) + to_[pl][t];
+                        tab_w[l32 * 12 + pl * 4 + t] = tw_[pl][t] / 3.0f;
+                    }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int e2 = 0; e2 < 32 * 12 / 2; e2++) {
+                const int e = 2 * e2 + half;                    // (point, tap) handled by this half-wave; lane = channel
+                const float wt = tab_w[e];
+                if (wt != 0.f && l32 < p.F) unsafeAtomicAdd(p.d_planes + tab_off[e] + l32, wt * gl[(e / 12) * FG_PITCH + l32]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- reduction of the weight gradients: lanes -> wave slot in LDS -> block (fixed order) -> partial[blockIdx] ------------
+    // layout of a slot / of `partial`: dW0 [hid][F] | db0 [hid] | dW1 [4][hid] | db1 [4]
+    __syncthreads();
+    float* slot = wave_mem + wv * WAVE_FLOATS;                 // >= npart floats (host check)
+    for (int i = l; i < p.npart; i += 64) slot[i] = 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int o_db0 = p.hid * p.F, o_dw1 = o_db0 + p.hid, o_db1 = o_dw1 + 4 * p.hid;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < p.hid && l32 < p.F) slot[m * p.F + l32] = dW0a[mt][r];                 // C[m][n = f]
+            if (m < p.hid && l32 < 4) slot[o_dw1 + l32 * p.hid + m] = dW1a[mt][r];          // C[m][n = j]
+            float s = db0a[mt][r];
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
+            if (m < p.hid && l32 == 0) slot[o_db0 + m] = s;
+        }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float s = db1a[j];
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64);
+        if (l == 0) slot[o_db1 + j] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < p.npart; i += NT) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) s += wave_mem[w * WAVE_FLOATS + i];
+        p.partial[(int64_t)blockIdx.x * p.npart + i] = s;
+    }
+}
+
+// d_w0 = g0 * sum dW0s, d_b0, d_w1 = g1 * sum dW1s, d_b1: blocks summed in block order
+__global__ __launch_bounds__(256) void field_grad_reduce_kernel(const float* __restrict__ partial, int nblocks, int npart, int n_w0, int n_b0, int n_w1,
+                                                               float g0, float g1, float* __restrict__ d_w0, float* __restrict__ d_b0,
+                                                               float* __restrict__ d_w1, float* __restrict__ d_b1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npart) return;
+    float s = 0.f;
+    for (int k = 0; k < nblocks; k++) s += partial[(int64_t)k * npart + i];
+    if (i < n_w0) d_w0[i] = s * g0;
+    else if (i < n_w0 + n_b0) d_b0[i - n_w0] = s;
+    else if (i < n_w0 + n_b0 + n_w1) d_w1[i - n_w0 - n_b0] = s * g1;
+    else d_b1[i - n_w0 - n_b0 - n_w1] = s;
+}
+
+int field_grad_blocks(int64_t total) { return (int)min((int64_t)1536, max((int64_t)1, cdiv64(total, 128))); }
+
+}  // namespace
+
+TDGP_API int64_t tdgp_triplane_field_grad_workspace_bytes(int B, int64_t P, int F, int hid) {
+    const int npart = hid * F + hid + 4 * hid + 4;
+    return (int64_t)field_grad_blocks((int64_t)B * P) * npart * (int64_t)sizeof(float);
+}
+
+TDGP_API int tdgp_triplane_field_grad(const float* planes_hwc, const float* coords, const float* w0, const float* b0, const float* w1, const float* b1,
+                                      const float* d_out, float* d_planes_hwc, float* d_w0, float* d_b0, float* d_w1, float* d_b1, void* workspace,
+                                      int64_t workspace_bytes, int B, int64_t P, int F, int H, int W, int hid, float scale, int marcher,
+                                      tdgp_stream_t stream) {
+    TDGP_CHECK(planes_hwc && coords && w0 && b0 && w1 && b1 && d_out && d_w0 && d_b0 && d_w1 && d_b1, TDGP_EINVAL, "triplane_field_grad: null pointer");
+    TDGP_CHECK(B >= 1 && P >= 1 && H >= 2 && W >= 2, TDGP_EINVAL, "triplane_field_grad: bad shape");
+    TDGP_CHECK(F % 8 == 0 && F >= 8 && F <= 32, TDGP_EUNSUPPORTED, "triplane_field_grad: feat_dim=%d (8, 16, 24 or 32)", F);
+    TDGP_CHECK(hid >= 1 && hid <= 64, TDGP_EUNSUPPORTED, "triplane_field_grad: hid_dim=%d > 64", hid);
+    TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "triplane_field_grad: unknown ray marcher %d", marcher);
+    TDGP_CHECK((int64_t)B * 3 * H * W * F <= INT32_MAX, TDGP_EINVAL, "triplane_field_grad: plane tensor too large");
+    const int64_t need = tdgp_triplane_field_grad_workspace_bytes(B, P, F, hid);
+    TDGP_CHECK(workspace && workspace_bytes >= need, TDGP_EINVAL, "triplane_field_grad: workspace of %lld bytes needed", (long long)need);
+    FieldGradParams p;
+    p.planes = planes_hwc; p.coords = coords; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1; p.d_out = d_out; p.d_planes = d_planes_hwc;
+    p.partial = (float*)workspace; p.total = (int64_t)B * P; p.P = P; p.F = F; p.hid = hid; p.H = H; p.W = W; p.marcher = marcher;
+    p.npart = hid * F + hid + 4 * hid + 4;
+    p.scale = scale; p.g0 = (float)(1.0 / sqrt((double)F)); p.g1 = (float)(1.0 / sqrt((double)hid));
+    const int nb = field_grad_blocks(p.total);
+    const int MT = hid <= 32 ? 1 : 2, HP = 32 * MT;
+    const int wave_floats = 32 * FG_PITCH + 2 * HP * FG_PITCH + 4 * 32;
+    TDGP_CHECK(p.npart <= wave_floats, TDGP_EUNSUPPORTED, "triplane_field_grad: reduction slot too small");
+    const int NW = MT == 1 ? 4 : 2;
+    const size_t lds = (size_t)(HP * FG_PITCH + 4 * HP + HP + NW * wave_floats) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (MT == 1) {
+        static bool a1 = false;
+        if (!a1) { (void)hipFuncSetAttribute((const void*)triplane_field_grad_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; }
+        TDGP_LAUNCH("triplane_field_grad_kernel", (triplane_field_grad_kernel<1, 4>), dim3(nb), dim3(256), lds, s, p);
+    } else {
+        static bool a2 = false;
+        if (!a2) { (void)hipFuncSetAttribute((const void*)triplane_field_grad_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a2 = true; }
+        TDGP_LAUNCH("triplane_field_grad_kernel", (triplane_field_grad_kernel<2, 2>), dim3(nb), dim3(128), lds, s, p);
+    }
+    TDGP_LAUNCH("field_grad_reduce_kernel", field_grad_reduce_kernel, dim3(cdiv(p.npart, 256)), dim3(256), 0, s, (const float*)workspace, nb, p.npart, hid * F,
+                hid, 4 * hid, p.g0, p.g1, d_w0, d_b0, d_w1, d_b1);
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}

@@ -187,6 +187,36 @@ def simple_tri_plane_renderer(x, coords, mlp, scale=1.0, return_taps=False, sigm
     return out
 
 
+def simple_tri_plane_renderer_backward(x, coords, mlp, d_rgb, d_sigma, scale=1.0, planes_grad=True):
+    """Gradients of `simple_tri_plane_renderer` (tri_plane_renderer.py:560-588 + TriPlaneMLP) for incoming d_rgb [B,P,3], d_sigma
+    [B,P,1]: returns (d_planes in the field layout [B,3,H,W,F] or None, d_w0, d_b0, d_w1, d_b1).  tdgp_triplane_field_grad: forward
+    values are recomputed; the plane gradient is a scatter with fp32 atomics (as torch's grid_sampler backward)."""
+    planes = planes_to_hwc(x)
+    _lib.require_cuda(coords, 'coords')
+    coords = _lib.f32c(coords)
+    w0, b0, w1, b1, marcher = _mlp_params(mlp)
+    p = planes.t
+    B, _, H, W, F = p.shape
+    P = coords.shape[1]
+    d_out = torch.cat([_lib.f32c(d_rgb), _lib.f32c(d_sigma)], dim=-1).contiguous()
+    d_planes = torch.zeros_like(p) if planes_grad else None
+    hid = w0.shape[0]
+    d_w0, d_b0, d_w1, d_b1 = torch.empty_like(w0), torch.empty_like(b0), torch.empty_like(w1), torch.empty_like(b1)
+    nbytes = int(_lib.load().tdgp_triplane_field_grad_workspace_bytes(B, P, F, hid))
+    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device):
+        _lib.call('tdgp_triplane_field_grad', p.data_ptr(), coords.data_ptr(), w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                  d_out.data_ptr(), _lib.ptr(d_planes), d_w0.data_ptr(), d_b0.data_ptr(), d_w1.data_ptr(), d_b1.data_ptr(), ws.data_ptr(), nbytes,
+                  B, P, F, H, W, hid, float(scale), MARCHER_IDS[marcher], _lib.stream_of(p))
+    return d_planes, d_w0, d_b0, d_w1, d_b1
+
+
+def planes_from_hwc(t):
+    """Field layout [B,3,H,W,F] -> NCHW [B,3F,H,W] (the layout of the reference's plane tensor and of its gradient)."""
+    B, _, H, W, F = t.shape
+    return t.permute(0, 1, 4, 2, 3).reshape(B, 3 * F, H, W).contiguous()
+
+
 # ------------------------------------------------------------------------------------------------ marchers
 
 def ray_march_backward(colors, densities, depths, opts, marcher, d_rgb, d_depth=None, d_weights=None):

@@ -195,6 +195,18 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, demodulate=True, resam
     return y
 
 
+def triplane_field_grad(planes, coords, w0, b0, w1, b1, d_rgb, d_sigma, scale=1.0, mlp_mode='classical'):
+    """(d_planes [B,3F,H,W], d_w0, d_b0, d_w1, d_b1) of triplane_field for incoming d_rgb [B,P,3], d_sigma [B,P,1] (autograd through
+    tri_plane_renderer.py:560-588 + networks_epigraf.py:46-68), double arithmetic."""
+    planes, coords, w0, b0, w1, b1, d_rgb, d_sigma = (_f(a) for a in (planes, coords, w0, b0, w1, b1, d_rgb, d_sigma))
+    B, c3, H, W = planes.shape
+    F, hid, P = c3 // 3, w0.shape[0], coords.shape[1]
+    dp, dw0, db0, dw1, db1 = np.empty_like(planes), np.empty_like(w0), np.empty_like(b0), np.empty_like(w1), np.empty_like(b1)
+    lib().orc_triplane_field_grad(_p(planes), _p(coords), _p(w0), _p(b0), _p(w1), _p(b1), _p(d_rgb), _p(d_sigma), _p(dp), _p(dw0), _p(db0), _p(dw1),
+                                  _p(db1), B, c_i64(P), F, H, W, hid, c_float(scale), 1 if mlp_mode == 'mip' else 0)
+    return dp, dw0, db0, dw1, db1
+
+
 def ray_march_grad(colors, densities, depths, d_rgb, d_depth=None, d_weights=None, mode='classical', use_inf_depth=True, last_back=False,
                    white_back=False, clamp_mode='softplus', density_bias=0.0):
     """(d_colors, d_densities) of march_classical / march_mip (autograd through tri_plane_renderer.py:299-398), double arithmetic.

@@ -866,3 +866,39 @@ def test_ray_march_grad(tdgp, oracle, tag):
     dc, dd = tdgp.renderer.ray_march_backward(T(colors), T(dens), T(depths), kw, mode, T(d_rgb))
     assert_close(N(dc), rc, 1e-5, 'd_colors (S=128)', 1.0)
     assert_close(N(dd), rd, 5e-5, 'd_densities (S=128)', 1.0)
+
+
+@pytest.mark.parametrize('tag', ['small', 'hot'])
+@pytest.mark.parametrize('marcher', ['classical', 'mip'])
+def test_field_grad(tdgp, oracle, tag, marcher):
+    """tdgp_triplane_field_grad (MFMA MLP backward + atomic scatter) against autograd through the reference; the weight gradients
+    are bit-identical run to run, the plane gradient (atomics) to rounding."""
+    g = load_golden('field_grad')
+    k = f'{tag}_{marcher}_'
+    mlp = _mlp(tdgp, g[k + 'w0'], g[k + 'b0'], g[k + 'w1'], g[k + 'b1'], marcher)
+    R = tdgp.renderer
+    res = R.simple_tri_plane_renderer_backward(T(g[f'{tag}_planes']), T(g[f'{tag}_coords']), mlp, T(g[f'{tag}_d_rgb']), T(g[f'{tag}_d_sigma']), scale=0.5)
+    got = dict(d_planes=R.planes_from_hwc(res[0]), d_w0=res[1], d_b0=res[2], d_w1=res[3], d_b1=res[4])
+    for name, t in got.items():
+        assert_close(N(t), g[k + name], 5e-5, name, 1.0)
+    res2 = R.simple_tri_plane_renderer_backward(T(g[f'{tag}_planes']), T(g[f'{tag}_coords']), mlp, T(g[f'{tag}_d_rgb']), T(g[f'{tag}_d_sigma']), scale=0.5)
+    for a, b in zip(res[1:], res2[1:]):
+        assert torch.equal(a, b)
+    assert_close(N(res2[0]), N(res[0]), 1e-5, 'd_planes run to run', 1.0)
+
+
+def test_field_grad_large(tdgp, oracle):
+    """Many tiles per wave, a ragged last tile, several blocks: vs the double-precision oracle."""
+    rs = np.random.RandomState(77)
+    B, F, H, hid, P = 2, 32, 32, 64, 33333
+    planes = rs.randn(B, 3 * F, H, H).astype(np.float32)
+    coords = rs.uniform(-0.6, 0.6, (B, P, 3)).astype(np.float32)
+    w0, b0, w1, b1 = rs.randn(hid, F).astype(np.float32), (0.3 * rs.randn(hid)).astype(np.float32), rs.randn(4, hid).astype(np.float32), (0.3 * rs.randn(4)).astype(np.float32)
+    d_rgb, d_sigma = rs.randn(B, P, 3).astype(np.float32), rs.randn(B, P, 1).astype(np.float32)
+    ref = oracle.triplane_field_grad(planes, coords, w0, b0, w1, b1, d_rgb, d_sigma, scale=0.5, mlp_mode='classical')
+    mlp = _mlp(tdgp, w0, b0, w1, b1, 'classical')
+    R = tdgp.renderer
+    res = R.simple_tri_plane_renderer_backward(T(planes), T(coords), mlp, T(d_rgb), T(d_sigma), scale=0.5)
+    got = (R.planes_from_hwc(res[0]),) + tuple(res[1:])
+    for a, b, name in zip(got, ref, ('d_planes', 'd_w0', 'd_b0', 'd_w1', 'd_b1')):
+        assert_close(N(a), b, 1e-4, name, 1.0)

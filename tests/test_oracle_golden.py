@@ -335,3 +335,15 @@ def test_ray_march_grad_oracle(oracle, tag):
     dc, dd = oracle.ray_march_grad(g[f'{tag}_c'], g['densities'], g['depths'], g[f'{tag}_d_rgb'], g[f'{tag}_d_depth'], g[f'{tag}_d_weights'], **kw)
     assert_close(dc, g[f'{tag}_dc'], 2e-6, 'd_colors', 1.0)
     assert_close(dd, g[f'{tag}_dd'], 1e-5, 'd_densities', 1.0)
+
+
+@pytest.mark.parametrize('tag', ['small', 'hot'])
+@pytest.mark.parametrize('marcher', ['classical', 'mip'])
+def test_field_grad_oracle(oracle, tag, marcher):
+    """grid_sample backward + MLP backward of the tri-plane field against autograd through the reference."""
+    g = load_golden('field_grad')
+    k = f'{tag}_{marcher}_'
+    dp, dw0, db0, dw1, db1 = oracle.triplane_field_grad(g[f'{tag}_planes'], g[f'{tag}_coords'], g[k + 'w0'], g[k + 'b0'], g[k + 'w1'], g[k + 'b1'],
+                                                        g[f'{tag}_d_rgb'], g[f'{tag}_d_sigma'], scale=0.5, mlp_mode=marcher)
+    for got, name in ((dp, 'd_planes'), (dw0, 'd_w0'), (db0, 'd_b0'), (dw1, 'd_w1'), (db1, 'd_b1')):
+        assert_close(got, g[k + name], 2e-5, name, 1.0)

@@ -330,6 +330,34 @@ def gen_field():
     save('field', **arrays)
 
 
+def gen_field_grad():
+    """Autograd through simple_tri_plane_renderer + TriPlaneMLP (grid_sample backward + MLP backward): gradients w.r.t. the planes
+    and the four MLP tensors, both MLP output modes, two (feat, hid) sizes."""
+    arrays = {}
+    for tag, (B, F, R, hid, P) in dict(small=(2, 8, 16, 16, 300), hot=(1, 32, 16, 64, 400)).items():
+        g = np.random.RandomState(44 + F)
+        planes = g.randn(B, 3 * F, R, R).astype(np.float32)
+        coords = (g.rand(B, P, 3).astype(np.float32) * 2 - 1) * 0.62
+        coords[0, :4] = [[0.5, 0.5, 0.5], [-0.5, -0.5, -0.5], [0.0, 0.0, 0.0], [0.5, -0.5, 0.25]]
+        d_rgb, d_sigma = g.randn(B, P, 3).astype(np.float32), g.randn(B, P, 1).astype(np.float32)
+        arrays.update({f'{tag}_planes': planes, f'{tag}_coords': coords, f'{tag}_d_rgb': d_rgb, f'{tag}_d_sigma': d_sigma})
+        for marcher in ('classical', 'mip'):
+            torch.manual_seed(6)
+            mlp = TriPlaneMLP(_mlp_cfg(F, hid, marcher), out_dim=3)
+            with torch.no_grad():
+                mlp.model[0].bias.copy_(T(g.randn(hid).astype(np.float32) * 0.3))
+                mlp.model[1].bias.copy_(T(g.randn(4).astype(np.float32) * 0.3))
+            x = T(planes).requires_grad_(True)
+            out = ref_tpr.simple_tri_plane_renderer(x, T(coords), mlp, scale=0.5)
+            params = [mlp.model[0].weight, mlp.model[0].bias, mlp.model[1].weight, mlp.model[1].bias]
+            grads = torch.autograd.grad([out['rgb'], out['sigma']], [x] + params, [T(d_rgb), T(d_sigma)])
+            for name, t in zip(('w0', 'b0', 'w1', 'b1'), params):
+                arrays[f'{tag}_{marcher}_{name}'] = npy(t)
+            for name, t in zip(('d_planes', 'd_w0', 'd_b0', 'd_w1', 'd_b1'), grads):
+                arrays[f'{tag}_{marcher}_{name}'] = npy(t)
+    save('field_grad', **arrays)
+
+
 def gen_sampling():
     g = np.random.RandomState(6)
     arrays = {}
@@ -772,6 +800,7 @@ def main():
     gen_upfirdn2d_grad()
     gen_conv2d_grad()
     gen_march_grad()
+    gen_field_grad()
     gen_modconv()
     gen_field()
     gen_sampling()
