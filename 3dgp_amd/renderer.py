@@ -331,6 +331,51 @@ class ImportanceRenderer(torch.nn.Module):
         return simple_tri_plane_renderer(planes, sample_coordinates, decoder, scale=rendering_options['box_size'] / 2,
                                          sigma_noise=rendering_options.get('sigma_noise'), density_noise=float(rendering_options.get('density_noise', 0.0)))
 
+    # -- gradient of the whole chain -----------------------------------------------------------------------------------
+    def backward(self, planes, decoder, ray_origins, ray_directions, rendering_options, d_rgb, d_depth=None):
+        """Gradients of `forward` (tri_plane_renderer.py:126-170 under autograd) w.r.t. the planes and the decoder's tensors for
+        incoming d_rgb [B,R,3] / d_depth [B,R,1]: returns dict(planes=[B,3F,H,W], w0, b0, w1, b1).
+
+        The importance samples carry no gradient (`sample_importance` runs under no_grad, :241), so the path is
+        march(unified, sorted) -> gather by the sort permutation -> {coarse, fine} field -> planes / MLP: the forward is replayed
+        stage by stage (same draws: pass `u_coarse / u_fine`, and `n_coarse / n_fine` with density noise), then
+        tdgp_ray_march_grad, an un-sort, and tdgp_triplane_field_grad once per pass (accumulating into the same plane gradient)."""
+        opts = rendering_options
+        marcher = self.ray_marcher_type
+        hw = planes_to_hwc(planes)
+        ray_o, ray_d = _lib.f32c(ray_origins), _lib.f32c(ray_directions)
+        B, R, _ = ray_o.shape
+        S, N = int(opts['num_proposal_steps']), int(opts['num_fine_steps'])
+        scale = opts['box_size'] / 2
+        dnoise = float(opts.get('density_noise', 0.0))
+        s2t = lambda s_: s_ * opts['ray_end'] + (1 - s_) * opts['ray_start']      # noqa: E731
+        sd = self.sample_stratified(ray_o, 0.0, 1.0, S, noise=opts.get('u_coarse'))
+        td = s2t(sd)
+        pts_c = (ray_o.unsqueeze(-2) + td * ray_d.unsqueeze(-2)).reshape(B, -1, 3)
+        out = simple_tri_plane_renderer(hw, pts_c, decoder, scale=scale, sigma_noise=opts.get('n_coarse'), density_noise=dnoise)
+        cc, dc = out['rgb'].reshape(B, R, S, 3), out['sigma'].reshape(B, R, S, 1)
+        if N > 0:
+            _, _, w, _ = self.ray_marcher(cc, dc, sd, opts)
+            sf = self.sample_importance(sd, w, N, u=opts.get('u_fine'))
+            tf = s2t(sf)
+            pts_f = (ray_o.unsqueeze(-2) + tf * ray_d.unsqueeze(-2)).reshape(B, -1, 3)
+            out = simple_tri_plane_renderer(hw, pts_f, decoder, scale=scale, sigma_noise=opts.get('n_fine'), density_noise=dnoise)
+            cf, df = out['rgb'].reshape(B, R, N, 3), out['sigma'].reshape(B, R, N, 1)
+            d_all, c_all, s_all, perm = self.unify_samples(td, cc, dc, tf, cf, df, return_perm=True)
+            g_c, g_s = ray_march_backward(c_all, s_all, d_all, opts, marcher, d_rgb, d_depth)
+            idx = perm.long().unsqueeze(-1)                       # sorted slot k <- concatenated sample perm[k]
+            g_c = torch.zeros_like(g_c).scatter_(2, idx.expand(-1, -1, -1, 3), g_c)
+            g_s = torch.zeros_like(g_s).scatter_(2, idx, g_s)
+            passes = [(pts_c, g_c[:, :, :S], g_s[:, :, :S]), (pts_f, g_c[:, :, S:], g_s[:, :, S:])]
+        else:
+            g_c, g_s = ray_march_backward(cc, dc, sd, opts, marcher, d_rgb, d_depth)
+            passes = [(pts_c, g_c, g_s)]
+        total = None
+        for pts, gc, gs in passes:
+            res = simple_tri_plane_renderer_backward(hw, pts, decoder, gc.reshape(B, -1, 3), gs.reshape(B, -1, 1), scale=scale)
+            total = list(res) if total is None else [a + b for a, b in zip(total, res)]
+        return dict(planes=planes_from_hwc(total[0]), w0=total[1], b0=total[2], w1=total[3], b1=total[4])
+
     # -- the whole chain ---------------------------------------------------------------------------------------------
     def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, return_intermediates=False):
         opts = rendering_options

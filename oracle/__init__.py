@@ -377,6 +377,6 @@ def unify_samples(d1, c1, s1, d2, c2, s2, return_perm=False):
     return (d, c, s, perm) if return_perm else (d, c, s)
 
 
-from .pipeline import (mapping_forward, synthesis_backbone, importance_render, synthesis_forward,  # noqa: E402,F401
+from .pipeline import (mapping_forward, synthesis_backbone, importance_render, importance_render_grad, synthesis_forward,  # noqa: E402,F401
                        generator_forward, block_resolutions, channels_dict, conv2d_layer, depth_adaptor_forward,
                        camera_adaptor_forward)

@@ -155,6 +155,43 @@ def importance_render(planes, mlp, ray_o, ray_d, opts, u_coarse, u_fine, return_
     return (res, inter) if return_intermediates else res
 
 
+def importance_render_grad(planes, mlp, ray_o, ray_d, opts, u_coarse, u_fine, d_rgb, d_depth=None):
+    """Gradients of importance_render w.r.t. planes and the MLP tensors (autograd through tri_plane_renderer.py:126-170; the
+    importance samples are constants, :241): march gradient on the unified samples, un-sort, field gradient of both passes.
+    -> (d_planes, d_w0, d_b0, d_w1, d_b1)"""
+    mode = opts['ray_marcher_type']
+    B, R, _ = ray_o.shape
+    S, N = opts['num_proposal_steps'], opts['num_fine_steps']
+    scale = opts['box_size'] / 2
+    _, inter = importance_render(planes, mlp, ray_o, ray_d, opts, u_coarse, u_fine, return_intermediates=True)
+    sdist = inter['sdist_coarse']
+    tdist = O.s_to_t(sdist, opts['ray_start'], opts['ray_end'])
+    kw = dict(mode=mode, use_inf_depth=opts['use_inf_depth'])
+    if mode == 'classical':
+        kw.update(clamp_mode=opts.get('clamp_mode', 'softplus'), last_back=opts.get('last_back', False))
+    else:
+        kw.update(density_bias=opts.get('density_bias', 0.0), white_back=opts.get('white_back', False))
+    pts_c = O.ray_points(ray_o, ray_d, tdist)
+    if N > 0:
+        tfine = O.s_to_t(inter['sdist_fine'][..., 0], opts['ray_start'], opts['ray_end'])
+        d_all, c_all, s_all, perm = O.unify_samples(tdist[..., None], inter['colors_coarse'], inter['densities_coarse'], tfine[..., None],
+                                                    inter['colors_fine'], inter['densities_fine'], return_perm=True)
+        g_c, g_s = O.ray_march_grad(c_all, s_all, d_all, d_rgb, d_depth, **kw)
+        u_c, u_s = np.zeros_like(g_c), np.zeros_like(g_s)
+        np.put_along_axis(u_c, np.broadcast_to(perm[..., None], g_c.shape), g_c, axis=2)
+        np.put_along_axis(u_s, perm[..., None], g_s, axis=2)
+        passes = [(pts_c, u_c[:, :, :S], u_s[:, :, :S]), (O.ray_points(ray_o, ray_d, tfine), u_c[:, :, S:], u_s[:, :, S:])]
+    else:
+        g_c, g_s = O.ray_march_grad(inter['colors_coarse'], inter['densities_coarse'], sdist[..., None], d_rgb, d_depth, **kw)
+        passes = [(pts_c, g_c, g_s)]
+    total = None
+    for pts, gc, gs in passes:
+        res = O.triplane_field_grad(planes, pts, *mlp, np.ascontiguousarray(gc).reshape(B, -1, 3), np.ascontiguousarray(gs).reshape(B, -1, 1), scale=scale,
+                                    mlp_mode=mode)
+        total = list(res) if total is None else [a + b for a, b in zip(total, res)]
+    return tuple(total)
+
+
 def render_options(cfg):
     """networks_epigraf.py:226-231."""
     return dict(box_size=cfg['cube_scale'] * 2, num_proposal_steps=cfg['num_ray_steps'], num_fine_steps=cfg['num_ray_steps'],

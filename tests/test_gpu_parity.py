@@ -902,3 +902,19 @@ def test_field_grad_large(tdgp, oracle):
     got = (R.planes_from_hwc(res[0]),) + tuple(res[1:])
     for a, b, name in zip(got, ref, ('d_planes', 'd_w0', 'd_b0', 'd_w1', 'd_b1')):
         assert_close(N(a), b, 1e-4, name, 1.0)
+
+
+@pytest.mark.parametrize('marcher', ['classical', 'mip'])
+def test_importance_renderer_backward(tdgp, marcher):
+    """ImportanceRenderer.backward: replayed forward + tdgp_ray_march_grad + un-sort + tdgp_triplane_field_grad for both passes,
+    against autograd through the reference's ImportanceRenderer.forward (same stratification / inverse-CDF draws)."""
+    g = load_golden('render_grad')
+    mlp = _mlp(tdgp, *(g[f'{marcher}_{n}'] for n in ('w0', 'b0', 'w1', 'b1')), marcher)
+    opts = dict(box_size=1.0, num_proposal_steps=8, num_fine_steps=8, clamp_mode='softplus', use_inf_depth=True, ray_start=0.75, ray_end=1.25,
+                white_back=(marcher == 'mip'), density_bias=0.0, u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
+    rend = tdgp.renderer.ImportanceRenderer(marcher)
+    rgb, _, _, _ = rend(T(g['planes']), mlp, T(g['ray_o']), T(g['ray_d']), opts)
+    assert_close(N(rgb), g[f'{marcher}_rgb'], 1e-5, 'rgb', 1.0)
+    res = rend.backward(T(g['planes']), mlp, T(g['ray_o']), T(g['ray_d']), opts, T(g['d_rgb']), T(g['d_depth']))
+    for name in ('planes', 'w0', 'b0', 'w1', 'b1'):
+        assert_close(N(res[name]), g[f'{marcher}_d_{name}'], 1e-4, 'd_' + name, 1.0)

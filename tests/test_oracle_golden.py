@@ -347,3 +347,18 @@ def test_field_grad_oracle(oracle, tag, marcher):
                                                         g[f'{tag}_d_rgb'], g[f'{tag}_d_sigma'], scale=0.5, mlp_mode=marcher)
     for got, name in ((dp, 'd_planes'), (dw0, 'd_w0'), (db0, 'd_b0'), (dw1, 'd_w1'), (db1, 'd_b1')):
         assert_close(got, g[k + name], 2e-5, name, 1.0)
+
+
+@pytest.mark.parametrize('marcher', ['classical', 'mip'])
+def test_importance_render_grad_oracle(oracle, marcher):
+    """Gradient of the whole renderer (coarse pass, constant importance samples, fine pass, sorted merge, marcher) w.r.t. the planes and
+    the MLP tensors against autograd through the reference's ImportanceRenderer.forward."""
+    g = load_golden('render_grad')
+    mlp = tuple(g[f'{marcher}_{n}'] for n in ('w0', 'b0', 'w1', 'b1'))
+    opts = dict(box_size=1.0, num_proposal_steps=8, num_fine_steps=8, clamp_mode='softplus', use_inf_depth=True, ray_start=0.75, ray_end=1.25,
+                white_back=(marcher == 'mip'), density_bias=0.0, ray_marcher_type=marcher)
+    rgb, _, _, _ = oracle.importance_render(g['planes'], mlp, g['ray_o'], g['ray_d'], opts, g['u_coarse'], g['u_fine'])
+    assert_close(rgb, g[f'{marcher}_rgb'], 1e-5, 'rgb', 1.0)
+    res = oracle.importance_render_grad(g['planes'], mlp, g['ray_o'], g['ray_d'], opts, g['u_coarse'], g['u_fine'], g['d_rgb'], g['d_depth'])
+    for got, name in zip(res, ('d_planes', 'd_w0', 'd_b0', 'd_w1', 'd_b1')):
+        assert_close(got, g[f'{marcher}_{name}'], 5e-5, name, 1.0)

@@ -358,6 +358,42 @@ def gen_field_grad():
     save('field_grad', **arrays)
 
 
+def gen_render_grad():
+    """Autograd through ImportanceRenderer.forward (tri_plane_renderer.py:126-170): gradient of sum(rgb * d_rgb) + sum(depth * d_depth)
+    w.r.t. the planes and the decoder tensors, both marchers, with the stratification / inverse-CDF draws fixed."""
+    arrays = {}
+    g = np.random.RandomState(61)
+    B, F, H, hid, hw, S = 2, 8, 16, 16, 6, 8
+    R = hw * hw
+    planes = g.randn(B, 3 * F, H, H).astype(np.float32)
+    cam = TensorGroup(angles=T(np.array([[0.3, 1.2, 0.0], [-0.6, 1.8, 0.0]], np.float32)), radius=T(np.ones(2, np.float32)),
+                      look_at=T(np.zeros((2, 3), np.float32)))
+    ro, rd = ref_tpr.sample_rays(ref_ru.compute_cam2world_matrix(cam), T(np.array([25.0, 40.0], np.float32)), (hw, hw))
+    u1, u2 = g.rand(B, R, S, 1).astype(np.float32), g.rand(B * R, S).astype(np.float32)
+    d_rgb, d_depth = g.randn(B, R, 3).astype(np.float32), g.randn(B, R, 1).astype(np.float32)
+    arrays.update(planes=planes, ray_o=npy(ro), ray_d=npy(rd), u_coarse=u1, u_fine=u2, d_rgb=d_rgb, d_depth=d_depth)
+    for marcher in ('classical', 'mip'):
+        torch.manual_seed(7)
+        mlp = TriPlaneMLP(_mlp_cfg(F, hid, marcher), out_dim=3)
+        with torch.no_grad():
+            mlp.model[0].bias.copy_(T(g.randn(hid).astype(np.float32) * 0.3))
+            mlp.model[1].bias.copy_(T(g.randn(4).astype(np.float32) * 0.3))
+        opts = EasyDict(box_size=1.0, num_proposal_steps=S, num_fine_steps=S, clamp_mode='softplus', use_inf_depth=True, ray_start=0.75, ray_end=1.25,
+                        white_back=(marcher == 'mip'), last_back=False, density_bias=0.0, cut_quantile=0.0, max_batch_res=64, density_noise=0.0)
+        x = T(planes).requires_grad_(True)
+        rend = ref_tpr.ImportanceRenderer(ray_marcher_type=marcher)
+        with PatchedRNG(rand_like=[T(u1)], rand=[T(u2)]):
+            rgb, depth, wsum, fT = rend(x.view(B, 3, F, H, H), mlp, ro, rd, opts)
+        params = [mlp.model[0].weight, mlp.model[0].bias, mlp.model[1].weight, mlp.model[1].bias]
+        grads = torch.autograd.grad([rgb, depth], [x] + params, [T(d_rgb), T(d_depth)])
+        for name, t in zip(('w0', 'b0', 'w1', 'b1'), params):
+            arrays[f'{marcher}_{name}'] = npy(t)
+        for name, t in zip(('d_planes', 'd_w0', 'd_b0', 'd_w1', 'd_b1'), grads):
+            arrays[f'{marcher}_{name}'] = npy(t)
+        arrays[f'{marcher}_rgb'] = npy(rgb)
+    save('render_grad', **arrays)
+
+
 def gen_sampling():
     g = np.random.RandomState(6)
     arrays = {}
@@ -801,6 +837,7 @@ def main():
     gen_conv2d_grad()
     gen_march_grad()
     gen_field_grad()
+    gen_render_grad()
     gen_modconv()
     gen_field()
     gen_sampling()
