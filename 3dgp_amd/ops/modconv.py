@@ -142,6 +142,58 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     return modconv_forward(x, _packed(weight), styles, noise=noise, bias=None, up=up, demodulate=demodulate, act='linear', gain=1.0, fir=fir)
 
 
+class _ModulatedConv2dSame(torch.autograd.Function):
+    """Autograd of the stride-1 modulated convolution (the unfused algebra of networks_stylegan2.py:60-80 under torch autograd):
+        y = conv(x * s, w) * d,     d = rsqrt(sum_{c,k} (w s)^2 + 1e-8)   (demodulate)   or   d = 1
+    forward        tdgp_modconv2d
+    dx             tdgp_modconv2d on dy with the flipped, transposed weights, modulated by d on its input side, times s
+    dw             tdgp_conv2d_weight_grad(x * s, dy * d)  +  the demodulation term  -w (dd d^3)^T s^2
+    ds             sum_{yx} (dx / s-side) x                +  the demodulation term  -s ((dd d^3) W2),   W2 = sum_k w^2
+    with dd[b,o] = sum_{yx} dy y / d.  The [B,C]-sized products are eager tensor ops, the convolutions are the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, styles, demodulate):
+        y = modconv_forward(x, _packed(weight), styles, demodulate=demodulate, act='linear', gain=1.0)
+        ctx.demodulate = demodulate
+        ctx.save_for_backward(x, weight, styles, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import conv2d_gradfix as _cg
+        x, weight, styles, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        k = weight.shape[2]
+        s4 = styles[:, :, None, None]
+        if ctx.demodulate:
+            w2 = weight.detach().square().sum([2, 3])                                    # [O,C]
+            d = (styles.square() @ w2.t() + 1e-8).rsqrt()                                # [B,O]
+        else:
+            d = None
+        wt = weight.detach().flip([2, 3]).transpose(0, 1).contiguous()
+        dxm = modconv_forward(dy, PackedConv(wt), d, demodulate=False, act='linear', gain=1.0)       # conv_T(dy * d, w)
+        dx = dxm * s4 if ctx.needs_input_grad[0] else None
+        ds = (dxm * x).sum([2, 3]) if ctx.needs_input_grad[2] else None
+        dw = None
+        dyd = dy * d[:, :, None, None] if d is not None else dy
+        if ctx.needs_input_grad[1] and not _cg.weight_gradients_disabled:
+            dw = _cg.conv2d_weight_grad(x * s4, dyd, weight.shape, stride=1, padding=k // 2)
+        if d is not None:
+            t = (dy * y).sum([2, 3]) / d * d.pow(3)                                      # dd * d^3, [B,O]
+            if ds is not None:
+                ds = ds - styles * (t @ w2)
+            if dw is not None:
+                dw = dw - weight * (t.t() @ styles.square())[:, :, None, None]
+        return dx, dw, ds, None
+
+
+def modulated_conv2d_autograd(x, weight, styles, demodulate=True):
+    """`modulated_conv2d(x, weight, styles, padding=k // 2, demodulate=...)` (up = down = 1, no noise) with gradients w.r.t. x, weight
+    and styles on the HIP kernels; the noise / bias / activation that follow it in a SynthesisLayer have their own
+    differentiable ops (`fma`, `bias_act`)."""
+    return _ModulatedConv2dSame.apply(x, weight, styles, bool(demodulate))
+
+
 def wsq_address(packed):
     """Device address of a PackedConv's sum_tap W^2 table (the input of the demodulation)."""
     return packed.buf.data_ptr() + int(_lib.load().tdgp_modconv_wsq_offset(packed.cout, packed.cin, packed.k))

@@ -918,3 +918,17 @@ def test_importance_renderer_backward(tdgp, marcher):
     res = rend.backward(T(g['planes']), mlp, T(g['ray_o']), T(g['ray_d']), opts, T(g['d_rgb']), T(g['d_depth']))
     for name in ('planes', 'w0', 'b0', 'w1', 'b1'):
         assert_close(N(res[name]), g[f'{marcher}_d_{name}'], 1e-4, 'd_' + name, 1.0)
+
+
+@pytest.mark.parametrize('tag,demod', [('c3', True), ('rgb', False), ('c3big', True)])
+def test_modulated_conv2d_autograd(tdgp, tag, demod):
+    """ops.modconv.modulated_conv2d_autograd: forward and gradients w.r.t. x, weight, styles (incl. the demodulation terms) against
+    autograd through the reference's unfused modulated_conv2d -- the path train.py takes."""
+    g = load_golden('modconv_grad')
+    x, w, s = (T(g[f'{tag}_{k}']).requires_grad_(True) for k in 'xws')
+    y = tdgp.ops.modconv.modulated_conv2d_autograd(x, w, s, demodulate=demod)
+    assert_close(N(y.detach()), g[f'{tag}_y'], 1e-5, 'y', 1.0)
+    dx, dw, ds = torch.autograd.grad(y, [x, w, s], T(g[f'{tag}_dy']))
+    assert_close(N(dx), g[f'{tag}_dx'], 2e-5, 'dx', 1.0)
+    assert_close(N(dw), g[f'{tag}_dw'], 2e-5, 'dw', 1.0)
+    assert_close(N(ds), g[f'{tag}_ds'], 2e-5, 'ds', 1.0)

@@ -362,3 +362,26 @@ def test_importance_render_grad_oracle(oracle, marcher):
     res = oracle.importance_render_grad(g['planes'], mlp, g['ray_o'], g['ray_d'], opts, g['u_coarse'], g['u_fine'], g['d_rgb'], g['d_depth'])
     for got, name in zip(res, ('d_planes', 'd_w0', 'd_b0', 'd_w1', 'd_b1')):
         assert_close(got, g[f'{marcher}_{name}'], 5e-5, name, 1.0)
+
+
+@pytest.mark.parametrize('tag,demod', [('c3', True), ('rgb', False), ('c3big', True)])
+def test_modconv_grad_oracle(oracle, tag, demod):
+    """The gradient algebra of the stride-1 modulated convolution, composed from the oracle's pieces in float64 numpy (the same
+    decomposition the HIP autograd function uses), against autograd through the reference's unfused modulated_conv2d."""
+    g = load_golden('modconv_grad')
+    x, w, s, y, dy = (g[f'{tag}_{k}'].astype(np.float64) for k in ('x', 'w', 's', 'y', 'dy'))
+    k = w.shape[2]
+    w2 = (w ** 2).sum((2, 3))
+    d = 1.0 / np.sqrt((s ** 2) @ w2.T + 1e-8) if demod else np.ones((x.shape[0], w.shape[0]))
+    dyd = dy * d[:, :, None, None]
+    dxm = oracle.conv2d_input_grad(dyd.astype(np.float32), g[f'{tag}_w']).astype(np.float64)
+    dx = dxm * s[:, :, None, None]
+    ds = (dxm * x).sum((2, 3))
+    dw = oracle.conv2d_weight_grad((x * s[:, :, None, None]).astype(np.float32), dyd.astype(np.float32), k, 1, k // 2).astype(np.float64)
+    if demod:
+        t = (dy * y).sum((2, 3)) / d * d ** 3
+        ds = ds - s * (t @ w2)
+        dw = dw - w * (t.T @ (s ** 2))[:, :, None, None]
+    assert_close(dx, g[f'{tag}_dx'], 1e-5, 'dx', 1.0)
+    assert_close(dw, g[f'{tag}_dw'], 1e-5, 'dw', 1.0)
+    assert_close(ds, g[f'{tag}_ds'], 1e-5, 'ds', 1.0)

@@ -268,6 +268,23 @@ def gen_conv2d_grad():
     save('conv2d_grad', **arrays)
 
 
+def gen_modconv_grad():
+    """Autograd through the reference's unfused modulated_conv2d (networks_stylegan2.py:60-80, the training path): gradients w.r.t.
+    x, weight and styles for the stride-1 forms of the synthesis layers (3x3 demodulated, 1x1 ToRGB)."""
+    arrays = {}
+    for tag, (B, cin, cout, H, W, k, demod) in dict(c3=(2, 12, 10, 9, 12, 3, True), rgb=(3, 16, 6, 8, 8, 1, False), c3big=(2, 40, 36, 16, 16, 3, True)).items():
+        g = np.random.RandomState(70 + cin)
+        x = T(g.randn(B, cin, H, W).astype(np.float32)).requires_grad_(True)
+        w = T(g.randn(cout, cin, k, k).astype(np.float32)).requires_grad_(True)
+        s = T((1 + 0.5 * g.randn(B, cin)).astype(np.float32)).requires_grad_(True)
+        y = ref_sg2.modulated_conv2d(x=x, weight=w, styles=s, padding=k // 2, demodulate=demod, fused_modconv=False)
+        dy = T(g.randn(*y.shape).astype(np.float32))
+        dx, dw, ds = torch.autograd.grad(y, [x, w, s], dy)
+        arrays.update({f'{tag}_x': npy(x), f'{tag}_w': npy(w), f'{tag}_s': npy(s), f'{tag}_y': npy(y), f'{tag}_dy': npy(dy), f'{tag}_dx': npy(dx),
+                       f'{tag}_dw': npy(dw), f'{tag}_ds': npy(ds)})
+    save('modconv_grad', **arrays)
+
+
 def gen_modconv():
     g = np.random.RandomState(3)
     arrays = {}
@@ -838,6 +855,7 @@ def main():
     gen_march_grad()
     gen_field_grad()
     gen_render_grad()
+    gen_modconv_grad()
     gen_modconv()
     gen_field()
     gen_sampling()
