@@ -27,6 +27,7 @@ _PROTOTYPES = {
     'tdgp_modconv_pack_bytes': (c_int64, [c_int, c_int, c_int]),
     'tdgp_modconv_pack': (c_int, [P, P, c_int, c_int, c_int, P]),
     'tdgp_modconv2d_workspace_bytes': (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'tdgp_conv2d': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'tdgp_conv2d_weight_grad_workspace_bytes': (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     'tdgp_conv2d_weight_grad': (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'tdgp_modconv_wsq_offset': (c_int64, [c_int, c_int, c_int]),

@@ -105,7 +105,116 @@ int wgrad_slices(int B, int Cin, int Cout, int OH, int k) {
     return ns < 1 ? 1 : ns;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// General strided convolution (correlation), groups 1, dilation 1:   y[b,o,oy,ox] = bias[o] + sum_{c,ky,kx} w[o,c,ky,kx] x[b,c,oy*st+ky-pad,ox*st+kx-pad]
+// The forms the fused generator kernels do not cover: stride 2 (the input gradient of the x2 transposed convolution, i.e. the
+// adjoint of conv_transpose2d(stride 2) -- conv2d_gradfix.py:126-129 -- and the discriminator's down-sampling convolutions,
+// conv2d_resample.py:104-107) and paddings other than k // 2.  Block = 64 output channels x 64 consecutive pixels of one output
+// row, 2 x 2 waves of 32 x 32 MFMA tiles; K loop over chunks of 8 input channels x all taps, weights as [tap][c][o] and the
+// strided activation patch [c][ky][column] staged in LDS, the next chunk's loads in flight during the MFMAs of the current one.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct ConvFwdParams {
+    const float* x; const float* w; const float* bias; float* y;
+    int B, Cin, Cout, H, W, OH, OW, k, stride, pad;
+    int tiles_x;       // cdiv(OW, 64)
+};
+
+constexpr int CF_KC = 8, CF_APITCH = 65;
+
+template <int K>
+__global__ __launch_bounds__(256) void conv_strided_mfma_kernel(ConvFwdParams p) {
+    constexpr int T = K * K;
+    constexpr int IWP = 64 * 2 + K - 1 + 1;                      // patch columns for stride <= 2 (+1: odd pitch)
+    __shared__ float As[T * CF_KC * CF_APITCH];                  // [tap][c][o]
+    __shared__ float Bs[CF_KC * K * IWP];                        // [c][ky][col]
+    const int tid = threadIdx.x, l = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = l & 31, half = l >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int o0 = blockIdx.y * 64;
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int oy = t % p.OH, b = t / p.OH;
+    const int ox0 = tx * 64;
+    const int iy0 = oy * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
+    const int ncols = 63 * p.stride + K;                         // patch columns in use
+    constexpr int NA = (T * CF_KC * 64 + 255) / 256, NB = (CF_KC * K * IWP + 255) / 256;
+    float ra[NA], rb[NB];
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int e = tid + i * 256;                         // e = (o * KC + c) * T + tap: taps of one (o,c) are contiguous in memory
+            const int tap = e % T, oc = e / T, c = oc % CF_KC, o = oc / CF_KC;
+            ra[i] = (e < T * CF_KC * 64 && o0 + o < p.Cout && c0 + c < p.Cin) ? p.w[((int64_t)(o0 + o) * p.Cin + c0 + c) * T + tap] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int e = tid + i * 256;
+            const int col = e % IWP, r = e / IWP, ky = r % K, c = r / K;
+            const int iy = iy0 + ky, ix = ix0 + col;
+            rb[i] = (e < CF_KC * K * IWP && col < ncols && c0 + c < p.Cin && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                        ? p.x[(((int64_t)b * p.Cin + c0 + c) * p.H + iy) * p.W + ix] : 0.f;
+        }
+    };
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    load_chunk(0);
+    const int colbase = (wn * 32 + l32) * p.stride;
+    for (int c0 = 0; c0 < p.Cin; c0 += CF_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int e = tid + i * 256;
+            if (e < T * CF_KC * 64) { const int tap = e % T, oc = e / T, c = oc % CF_KC, o = oc / CF_KC; As[(tap * CF_KC + c) * CF_APITCH + o] = ra[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int e = tid + i * 256;
+            if (e < CF_KC * K * IWP) Bs[e] = rb[i];
+        }
+        __syncthreads();
+        if (c0 + CF_KC < p.Cin) load_chunk(c0 + CF_KC);
+#pragma unroll
+        for (int ky = 0; ky < K; ky++)
+#pragma unroll
+            for (int kx = 0; kx < K; kx++)
+#pragma unroll
+                for (int ks = 0; ks < CF_KC / 2; ks++) {
+                    const int c = 2 * ks + half;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[((ky * K + kx) * CF_KC + c) * CF_APITCH + wm * 32 + l32],
+                                                               Bs[(c * K + ky) * IWP + colbase + kx], acc, 0, 0, 0);
+                }
+    }
+    const int ox = ox0 + wn * 32 + l32;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int o = o0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (o < p.Cout && ox < p.OW) p.y[(((int64_t)b * p.Cout + o) * p.OH + oy) * p.OW + ox] = acc[r] + (p.bias ? p.bias[o] : 0.f);
+    }
+}
+
 }  // namespace
+
+TDGP_API int tdgp_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int OH, int OW, int k,
+                         int stride, int pad, tdgp_stream_t stream) {
+    TDGP_CHECK(x && w && y, TDGP_EINVAL, "conv2d: null pointer");
+    TDGP_CHECK(B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && pad >= 0, TDGP_EINVAL, "conv2d: bad shape");
+    TDGP_CHECK(stride == 1 || stride == 2, TDGP_EUNSUPPORTED, "conv2d: stride %d (1 or 2)", stride);
+    TDGP_CHECK(k == 1 || k == 3, TDGP_EUNSUPPORTED, "conv2d: kernel size %d (1 or 3)", k);
+    TDGP_CHECK(OH == (H + 2 * pad - k) / stride + 1 && OW == (W + 2 * pad - k) / stride + 1 && OH >= 1 && OW >= 1, TDGP_EINVAL,
+               "conv2d: output %dx%d does not match input %dx%d, k=%d, stride=%d, pad=%d", OH, OW, H, W, k, stride, pad);
+    ConvFwdParams p;
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.k = k; p.stride = stride; p.pad = pad;
+    p.tiles_x = cdiv(OW, 64);
+    const int64_t gx = (int64_t)p.tiles_x * OH * B;
+    TDGP_CHECK(gx <= 2147483647LL, TDGP_EINVAL, "conv2d: too many tiles");
+    const dim3 grid((unsigned)gx, cdiv(Cout, 64)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (k == 1) TDGP_LAUNCH("conv_strided_mfma_kernel", conv_strided_mfma_kernel<1>, grid, block, 0, s, p);
+    else TDGP_LAUNCH("conv_strided_mfma_kernel", conv_strided_mfma_kernel<3>, grid, block, 0, s, p);
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}
 
 TDGP_API int64_t tdgp_conv2d_weight_grad_workspace_bytes(int B, int Cin, int Cout, int OH, int k) {
     return (int64_t)wgrad_slices(B, Cin, Cout, OH, k) * Cout * Cin * k * k * (int64_t)sizeof(float);

@@ -65,6 +65,22 @@ def conv2d_weight_grad(x, dy, weight_shape, stride=1, padding=0):
     return dw
 
 
+def conv2d_strided(x, weight, bias=None, stride=1, padding=0):
+    """Plain convolution (correlation) on tdgp_conv2d: k in {1,3}, stride in {1,2}, any padding -- the forms outside the fused
+    generator kernels (adjoint of the x2 transposed convolution, down-sampling convolutions)."""
+    _lib.require_cuda(x, 'x')
+    x, w = _lib.f32c(x), _lib.f32c(weight.detach())
+    cout, cin, k, _ = (int(v) for v in w.shape)
+    B, _, H, W = x.shape
+    OH, OW = (H + 2 * padding - k) // stride + 1, (W + 2 * padding - k) // stride + 1
+    y = torch.empty([B, cout, OH, OW], dtype=torch.float32, device=x.device)
+    b = None if bias is None else _lib.f32c(bias.detach())
+    with torch.cuda.device(x.device):
+        _lib.call('tdgp_conv2d', x.data_ptr(), w.data_ptr(), _lib.ptr(b), y.data_ptr(), B, cin, cout, H, W, OH, OW, k, int(stride), int(padding),
+                  _lib.stream_of(x))
+    return y
+
+
 def conv2d_input_grad(dy, weight):
     """dx of a stride-1 'same' convolution: the correlation of dy with the spatially flipped, in/out-transposed weights."""
     wt = weight.detach().flip([2, 3]).transpose(0, 1).contiguous()

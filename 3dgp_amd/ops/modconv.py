@@ -187,6 +187,52 @@ class _ModulatedConv2dSame(torch.autograd.Function):
         return dx, dw, ds, None
 
 
+class _ModulatedConv2dUp(torch.autograd.Function):
+    """Autograd of the x2-upsampling modulated convolution of SynthesisLayer (conv2d_resample.py:109-122 under torch autograd):
+        z = conv_transpose2d(x * s, w^T, stride 2)   [2H+1]      y = upfirdn2d(z, f, padding 1, gain 4) * d
+    forward   tdgp_modconv2d (polyphase transposed conv + FIR, fused)
+    dz        tdgp_upfirdn2d on dy * d with the flipped filter and padding 2 (upfirdn2d.py:251-265)
+    dx        tdgp_conv2d(dz, w^T as [Cin,Cout,3,3], stride 2) * s        -- the adjoint of the transposed convolution
+    dw        tdgp_conv2d_weight_grad with the roles swapped (`dy` := x * s, `x` := dz, stride 2), transposed back; + demodulation term
+    ds        sum_{yx} (dx-side) x + demodulation term (as in the stride-1 function)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, styles, fir):
+        y = modconv_forward(x, _packed(weight), styles, up=2, demodulate=True, act='linear', gain=1.0, fir=fir_host_array(fir))
+        ctx.save_for_backward(x, weight, styles, y, fir)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import conv2d_gradfix as _cg
+        from . import upfirdn2d as _u
+        x, weight, styles, y, fir = ctx.saved_tensors
+        dy = dy.contiguous()
+        s4 = styles[:, :, None, None]
+        w2 = weight.detach().square().sum([2, 3])
+        d = (styles.square() @ w2.t() + 1e-8).rsqrt()
+        dz = _u.upfirdn2d(dy * d[:, :, None, None], fir, padding=2, flip_filter=True, gain=4)                # [B,Cout,2H+1,2W+1]
+        wt = weight.detach().transpose(0, 1).contiguous()                                                    # [Cin,Cout,3,3]
+        dxm = _cg.conv2d_strided(dz, wt, stride=2, padding=0)
+        dx = dxm * s4 if ctx.needs_input_grad[0] else None
+        ds = (dxm * x).sum([2, 3]) if ctx.needs_input_grad[2] else None
+        dw = None
+        if ctx.needs_input_grad[1] and not _cg.weight_gradients_disabled:
+            dw = _cg.conv2d_weight_grad(dz, x * s4, wt.shape, stride=2, padding=0).transpose(0, 1)
+        t = (dy * y).sum([2, 3]) / d * d.pow(3)
+        if ds is not None:
+            ds = ds - styles * (t @ w2)
+        if dw is not None:
+            dw = dw - weight * (t.t() @ styles.square())[:, :, None, None]
+        return dx, dw, ds, None
+
+
+def modulated_conv2d_up_autograd(x, weight, styles, resample_filter):
+    """`modulated_conv2d(x, weight, styles, up=2, padding=1, resample_filter=f, flip_weight=False)` (3x3, demodulated, no noise) with
+    gradients w.r.t. x, weight and styles on the HIP kernels."""
+    return _ModulatedConv2dUp.apply(x, weight, styles, resample_filter)
+
+
 def modulated_conv2d_autograd(x, weight, styles, demodulate=True):
     """`modulated_conv2d(x, weight, styles, padding=k // 2, demodulate=...)` (up = down = 1, no noise) with gradients w.r.t. x, weight
     and styles on the HIP kernels; the noise / bias / activation that follow it in a SynthesisLayer have their own

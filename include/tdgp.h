@@ -148,6 +148,13 @@ int tdgp_style_affine(const float* ws, const float* A, const float* abias, const
  * (The input gradient of a stride-1 'same' convolution is tdgp_modconv2d on dy with the flipped, transposed weights.)
  * --------------------------------------------------------------------------------------------- */
 int64_t tdgp_conv2d_weight_grad_workspace_bytes(int B, int Cin, int Cout, int OH, int k);
+/* Plain strided convolution (correlation; groups 1, dilation 1; k in {1,3}, stride in {1,2}, any padding):
+ *   y[b,o,oy,ox] = bias[o] + sum_{c,ky,kx} w[o,c,ky,kx] * x[b,c, oy*stride + ky - pad, ox*stride + kx - pad]
+ * replaces: torch.nn.functional.conv2d as reached from conv2d_gradfix.py:34-39 for the forms the fused kernels do not cover -- the
+ *           adjoint of the x2 transposed convolution (conv2d_gradfix.py:126-129) and the down-sampling convolutions of
+ *           conv2d_resample.py:104-107.  w [Cout,Cin,k,k] as stored by the modules; bias may be NULL. */
+int     tdgp_conv2d(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
+                    int OH, int OW, int k, int stride, int pad, tdgp_stream_t stream);
 int     tdgp_conv2d_weight_grad(const float* x, const float* dy, float* dw, void* workspace, int64_t workspace_bytes, int B,
                                 int Cin, int Cout, int H, int W, int OH, int OW, int k, int stride, int pad,
                                 tdgp_stream_t stream);

@@ -932,3 +932,26 @@ def test_modulated_conv2d_autograd(tdgp, tag, demod):
     assert_close(N(dx), g[f'{tag}_dx'], 2e-5, 'dx', 1.0)
     assert_close(N(dw), g[f'{tag}_dw'], 2e-5, 'dw', 1.0)
     assert_close(N(ds), g[f'{tag}_ds'], 2e-5, 'ds', 1.0)
+
+
+@pytest.mark.parametrize('tag,k,st,pad', [('s2', 3, 2, 0), ('s2p1', 3, 2, 1), ('s1p0', 3, 1, 0), ('k1s2', 1, 2, 0)])
+def test_conv2d_strided(tdgp, tag, k, st, pad):
+    """tdgp_conv2d (strided / unpadded convolutions) against the reference's conv2d_gradfix.conv2d."""
+    g = load_golden('modconv_grad')
+    y = tdgp.ops.conv2d_gradfix.conv2d_strided(T(g[f'conv_{tag}_x']), T(g[f'conv_{tag}_w']), T(g[f'conv_{tag}_b']), stride=st, padding=pad)
+    assert_close(N(y), g[f'conv_{tag}_y'], 1e-5, 'y', 1.0)
+
+
+@pytest.mark.parametrize('tag', ['up', 'upbig'])
+def test_modulated_conv2d_up_autograd(tdgp, oracle, tag):
+    """The x2-upsampling synthesis layer under autograd: transposed conv + FIR forward (fused kernel), FIR-adjoint, stride-2 adjoint
+    convolution, role-swapped weight gradient, demodulation terms -- against autograd through the reference's unfused path."""
+    g = load_golden('modconv_grad')
+    x, w, s = (T(g[f'{tag}_{k}']).requires_grad_(True) for k in 'xws')
+    f = T(oracle.setup_filter([1, 3, 3, 1]))
+    y = tdgp.ops.modconv.modulated_conv2d_up_autograd(x, w, s, f)
+    assert_close(N(y.detach()), g[f'{tag}_y'], 1e-5, 'y', 1.0)
+    dx, dw, ds = torch.autograd.grad(y, [x, w, s], T(g[f'{tag}_dy']))
+    assert_close(N(dx), g[f'{tag}_dx'], 2e-5, 'dx', 1.0)
+    assert_close(N(dw), g[f'{tag}_dw'], 2e-5, 'dw', 1.0)
+    assert_close(N(ds), g[f'{tag}_ds'], 2e-5, 'ds', 1.0)

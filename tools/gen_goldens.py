@@ -272,7 +272,7 @@ def gen_modconv_grad():
     """Autograd through the reference's unfused modulated_conv2d (networks_stylegan2.py:60-80, the training path): gradients w.r.t.
     x, weight and styles for the stride-1 forms of the synthesis layers (3x3 demodulated, 1x1 ToRGB)."""
     arrays = {}
-    for tag, (B, cin, cout, H, W, k, demod) in dict(c3=(2, 12, 10, 9, 12, 3, True), rgb=(3, 16, 6, 8, 8, 1, False), c3big=(2, 40, 36, 16, 16, 3, True)).items():
+    for tag, (B, cin, cout, H, W, k, demod) in dict(c3=(2, 12, 10, 9, 12, 3, True), rgb=(3, 16, 6, 8, 8, 1, False), c3big=(2, 40, 36, 8, 8, 3, True)).items():
         g = np.random.RandomState(70 + cin)
         x = T(g.randn(B, cin, H, W).astype(np.float32)).requires_grad_(True)
         w = T(g.randn(cout, cin, k, k).astype(np.float32)).requires_grad_(True)
@@ -282,6 +282,25 @@ def gen_modconv_grad():
         dx, dw, ds = torch.autograd.grad(y, [x, w, s], dy)
         arrays.update({f'{tag}_x': npy(x), f'{tag}_w': npy(w), f'{tag}_s': npy(s), f'{tag}_y': npy(y), f'{tag}_dy': npy(dy), f'{tag}_dx': npy(dx),
                        f'{tag}_dw': npy(dw), f'{tag}_ds': npy(ds)})
+    # x2-upsampling layer (transposed conv + FIR), SynthesisLayer.forward arguments (networks_stylegan2.py:137-139)
+    f = ref_upfirdn2d.setup_filter([1, 3, 3, 1])
+    for tag, (B, cin, cout, H, W) in dict(up=(2, 12, 10, 6, 9), upbig=(1, 40, 36, 8, 8)).items():
+        g = np.random.RandomState(90 + cin)
+        x = T(g.randn(B, cin, H, W).astype(np.float32)).requires_grad_(True)
+        w = T(g.randn(cout, cin, 3, 3).astype(np.float32)).requires_grad_(True)
+        s = T((1 + 0.5 * g.randn(B, cin)).astype(np.float32)).requires_grad_(True)
+        y = ref_sg2.modulated_conv2d(x=x, weight=w, styles=s, up=2, padding=1, resample_filter=f, flip_weight=False, fused_modconv=False)
+        dy = T(g.randn(*y.shape).astype(np.float32))
+        dx, dw, ds = torch.autograd.grad(y, [x, w, s], dy)
+        arrays.update({f'{tag}_x': npy(x), f'{tag}_w': npy(w), f'{tag}_s': npy(s), f'{tag}_y': npy(y), f'{tag}_dy': npy(dy), f'{tag}_dx': npy(dx),
+                       f'{tag}_dw': npy(dw), f'{tag}_ds': npy(ds)})
+    # plain strided convolutions (forward): the forms of tdgp_conv2d
+    for tag, (B, cin, cout, H, W, k, st, pad) in dict(s2=(2, 10, 7, 13, 17, 3, 2, 0), s2p1=(2, 6, 9, 12, 16, 3, 2, 1), s1p0=(1, 5, 4, 9, 10, 3, 1, 0),
+                                                      k1s2=(2, 8, 6, 8, 8, 1, 2, 0)).items():
+        g = np.random.RandomState(95 + cin)
+        x, w, b = g.randn(B, cin, H, W).astype(np.float32), g.randn(cout, cin, k, k).astype(np.float32), g.randn(cout).astype(np.float32)
+        from src.torch_utils.ops import conv2d_gradfix as ref_cg
+        arrays.update({f'conv_{tag}_x': x, f'conv_{tag}_w': w, f'conv_{tag}_b': b, f'conv_{tag}_y': npy(ref_cg.conv2d(T(x), T(w), T(b), stride=st, padding=pad))})
     save('modconv_grad', **arrays)
 
 
