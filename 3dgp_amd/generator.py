@@ -168,6 +168,21 @@ class SynthesisLayer(torch.nn.Module):
             self._const_noise = (stamp, (self.noise_const * self.noise_strength).detach())
         return self._const_noise[1]
 
+    def forward_autograd(self, x, w, noise_mode='random', gain=1):
+        """The same layer as a chain of differentiable ops (the unfused training path, networks_stylegan2.py:130-146):
+        affine -> modulated conv (stride 1 or x2 transposed + FIR) -> + noise -> bias_act."""
+        styles = self.affine(w)
+        if self.up == 2:
+            y = _modconv.modulated_conv2d_up_autograd(x, self.weight, styles, self.resample_filter)
+        else:
+            y = _modconv.modulated_conv2d_autograd(x, self.weight, styles, demodulate=True)
+        if self.use_noise and noise_mode == 'random':
+            y = y + torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
+        elif self.use_noise and noise_mode == 'const':
+            y = y + self.noise_const * self.noise_strength
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        return _bias_act.bias_act(y, self.bias.to(y.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+
     def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, styles=None, dcoef=None):
         if styles is None:
             styles = self.affine(w)
@@ -188,6 +203,12 @@ class ToRGBLayer(torch.nn.Module):
         self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]))
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+
+    def forward_autograd(self, x, w):
+        """networks_stylegan2.py:168-172 as differentiable ops."""
+        styles = self.affine(w) * self.weight_gain
+        y = _modconv.modulated_conv2d_autograd(x, self.weight, styles, demodulate=False)
+        return _bias_act.bias_act(y, self.bias.to(y.dtype), clamp=self.conv_clamp)
 
     def forward(self, x, w, fused_modconv=True, styles=None, skip=None, fir=None, out_layout=0, out_feat=0):
         if styles is None:
@@ -213,6 +234,20 @@ class SynthesisBlock(torch.nn.Module):
         self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution, use_noise=use_noise, conv_clamp=conv_clamp)
         self.num_conv += 1
         self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
+
+    def forward_autograd(self, x, img, ws, **layer_kwargs):
+        """networks_stylegan2.py:231-273 ('skip' architecture, fp32) as differentiable ops."""
+        w_iter = iter(ws.unbind(dim=1))
+        if self.in_channels == 0:
+            x = self.const.to(torch.float32).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+        else:
+            x = self.conv0.forward_autograd(x, next(w_iter), **layer_kwargs)
+        x = self.conv1.forward_autograd(x, next(w_iter), **layer_kwargs)
+        if img is not None:
+            img = _upfirdn2d.upsample2d(img, self.resample_filter)
+        y = self.torgb.forward_autograd(x, next(w_iter))
+        img = img.add(y) if img is not None else y
+        return x, img
 
     def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, styles=None, dcoefs=None, hwc_feat=0, **layer_kwargs):
         """-> (x, img).  `styles` (optional) = pre-computed [conv0?, conv1, torgb] style tensors; `hwc_feat` > 0 keeps the
@@ -326,6 +361,19 @@ class SynthesisBlocksSequence(torch.nn.Module):
         flat = _modconv.demod_batch(self._styles_flat, dm['meta'], dm['total'], B, dm['max_cout'])
         return [flat[off:off + B * cout].view(B, cout) for off, cout in dm['views']]
 
+    def forward_autograd(self, ws, x=None, **block_kwargs):
+        """ws -> planes [B, out_channels, R, R] through differentiable ops (every parameter and ws receive gradients)."""
+        assert ws.shape[1] == self.num_ws and ws.shape[2] == self.cfg.w_dim, f'Wrong shape: ws {tuple(ws.shape)}'
+        _lib.require_cuda(ws, 'ws')
+        ws = ws.to(torch.float32)
+        img = None
+        w_idx = 0
+        for res in self.block_resolutions:
+            blk = getattr(self, f'b{res}')
+            x, img = blk.forward_autograd(x, img, ws.narrow(1, w_idx, blk.num_conv + blk.num_torgb), **block_kwargs)
+            w_idx += blk.num_conv
+        return img
+
     def forward(self, ws, x=None, hwc=False, **block_kwargs):
         """ws [B, num_ws, w_dim] -> planes [B, out_channels, R, R] (NCHW), or HWCPlanes [B,3,R,R,feat] when hwc=True."""
         assert ws.shape[1] == self.num_ws and ws.shape[2] == self.cfg.w_dim, f'Wrong shape: ws {tuple(ws.shape)}'
@@ -389,6 +437,32 @@ class SynthesisNetwork(torch.nn.Module):
         """networks_epigraf.py:196-208: sigma at explicit coordinates."""
         planes = self.tri_plane_decoder(ws[:, :self.tri_plane_decoder.num_ws], hwc=True, **block_kwargs)
         return _renderer.simple_tri_plane_renderer(planes, coords, self.tri_plane_mlp, scale=self.cfg.cube_scale)['sigma']
+
+    def forward_autograd(self, ws, camera_params, patch_params=None, render_opts={}, u_coarse=None, u_fine=None, n_coarse=None, n_fine=None,
+                         **block_kwargs):
+        """The same forward as a differentiable graph: gradients reach every parameter of the tri-plane
+        backbone, the tri-plane MLP and `ws`.  Backbone = chain of the autograd ops (modulated convolutions, bias_act, upfirdn2d),
+        renderer = one autograd node (`renderer.render_autograd`).  Cameras / rays carry no gradient; the adaptors are not wired in."""
+        if self.depth_adaptor is not None or self.camera_adaptor is not None:
+            raise NotImplementedError('forward_autograd: the depth / camera adaptors are not wired into the differentiable path yet')
+        render_opts = {**self._default_render_options, **render_opts}
+        B = ws.shape[0]
+        planes = self.tri_plane_decoder.forward_autograd(ws[:, :self.tri_plane_decoder.num_ws], **block_kwargs)
+        h = w = self.train_resolution if self.training else self.test_resolution
+        cam = camera_params
+        get = (lambda k: cam[k]) if isinstance(cam, dict) else (lambda k: getattr(cam, k))
+        with torch.no_grad():
+            c2w = _renderer.compute_cam2world_matrix(cam)
+            ray_o, ray_d = _renderer.sample_rays(c2w, fov=get('fov'), resolution=(h, w), patch_params=patch_params, device=ws.device)
+        opts = self.rendering_options(render_opts)
+        opts['u_coarse'], opts['u_fine'], opts['n_coarse'], opts['n_fine'] = u_coarse, u_fine, n_coarse, n_fine
+        opts['ray_grid_w'] = w
+        rgb, depth = _renderer.render_autograd(self.renderer, planes, self.tri_plane_mlp, ray_o, ray_d, opts)
+        img = rgb.reshape(B, h, w, self.img_channels).permute(0, 3, 1, 2).contiguous()
+        depth = depth.reshape(B, 1, h, w)
+        if render_opts['return_depth']:
+            return TensorGroup(img=img, depth=depth)
+        return img
 
     @torch.no_grad()
     def forward(self, ws, camera_params, patch_params=None, render_opts={}, u_coarse=None, u_fine=None, n_coarse=None, n_fine=None,
@@ -455,6 +529,11 @@ class Generator(torch.nn.Module):
         res = self.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()}, strict=strict)
         self.synthesis.tri_plane_decoder.invalidate_cache()
         return res
+
+    def forward_autograd(self, z, c, camera_params, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        """Generator.forward as a differentiable graph: mapping network (eager tensor ops) -> `synthesis.forward_autograd`."""
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.synthesis.forward_autograd(ws, camera_params=camera_params, **synthesis_kwargs)
 
     @torch.no_grad()
     def forward(self, z, c, camera_params, camera_angles_cond=None, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):

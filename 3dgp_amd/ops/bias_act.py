@@ -52,8 +52,69 @@ def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, 
     assert isinstance(x, torch.Tensor)
     assert impl in ['ref', 'cuda']
     if impl == 'cuda' and x.device.type == 'cuda' and _init():
+        if torch.is_grad_enabled() and (x.requires_grad or (b is not None and b.requires_grad)):
+            return _bias_act_autograd(x, b, dim=dim, act=act, alpha=alpha, gain=gain, clamp=clamp)
         return _bias_act_hip(x, b, dim=dim, act=act, alpha=alpha, gain=gain, clamp=clamp)
     return _bias_act_ref(x=x, b=b, dim=dim, act=act, alpha=alpha, gain=gain, clamp=clamp)
+
+
+def _bias_act_autograd(x, b, dim, act, alpha, gain, clamp):
+    """The reference's autograd construction (bias_act.py:126-203) over the HIP kernel: forward = plugin call with grad 0; backward =
+    the same call with grad 1 (and grad 2 behind it), which reads either the input or the output of the forward pass, whichever the
+    activation's derivative is written in (`ref` of the activation table)."""
+    from ..compat import BiasActPlugin as plugin
+    spec, alpha, gain, clamp = _resolve(act, alpha, gain, clamp)
+    null = torch.empty([0], dtype=x.dtype, device=x.device)
+    args = (dim, spec.cuda_idx, alpha, gain, clamp)
+
+    class BiasAct(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, b):
+            ctx.memory_format = torch.channels_last if x.ndim > 2 and x.stride(1) == 1 else torch.contiguous_format
+            x = x.contiguous(memory_format=ctx.memory_format)
+            b = b.contiguous() if b is not None else null
+            y = x
+            if act != 'linear' or gain != 1 or clamp >= 0 or b is not null:
+                y = plugin.bias_act(x, b, null, null, null, 0, *args)
+            ctx.save_for_backward(x if 'x' in spec.ref or spec.has_2nd_grad else null, b if 'x' in spec.ref or spec.has_2nd_grad else null,
+                                  y if 'y' in spec.ref else null)
+            return y
+
+        @staticmethod
+        def backward(ctx, dy):
+            dy = dy.contiguous(memory_format=ctx.memory_format)
+            x, b, y = ctx.saved_tensors
+            dx = db = None
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+                dx = dy
+                if act != 'linear' or gain != 1 or clamp >= 0:
+                    dx = BiasActGrad.apply(dy, x, b, y)
+            if ctx.needs_input_grad[1]:
+                db = dx.sum([i for i in range(dx.ndim) if i != dim])
+            return dx, db
+
+    class BiasActGrad(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, dy, x, b, y):
+            ctx.memory_format = torch.channels_last if dy.ndim > 2 and dy.stride(1) == 1 else torch.contiguous_format
+            dx = plugin.bias_act(dy, b, x, y, null, 1, *args)
+            ctx.save_for_backward(dy if spec.has_2nd_grad else null, x, b, y)
+            return dx
+
+        @staticmethod
+        def backward(ctx, d_dx):
+            d_dx = d_dx.contiguous(memory_format=ctx.memory_format)
+            dy, x, b, y = ctx.saved_tensors
+            d_dy = d_x = d_b = None
+            if ctx.needs_input_grad[0]:
+                d_dy = BiasActGrad.apply(d_dx, x, b, y)
+            if spec.has_2nd_grad and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+                d_x = plugin.bias_act(d_dx, b, x, y, dy, 2, *args)
+            if spec.has_2nd_grad and ctx.needs_input_grad[2]:
+                d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
+            return d_dy, d_x, d_b, None
+
+    return BiasAct.apply(x, b)
 
 
 def _resolve(act, alpha, gain, clamp):

@@ -85,6 +85,8 @@ def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl='cu
     assert isinstance(x, torch.Tensor)
     assert impl in ['ref', 'cuda']
     if impl == 'cuda' and x.device.type == 'cuda' and _init():
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _Upfirdn2dFunction.apply(x, f, up, down, padding, flip_filter, gain)
         return _upfirdn2d_hip(x, f, up=up, down=down, padding=padding, flip_filter=flip_filter, gain=gain)
     return _upfirdn2d_ref(x, f, up=up, down=down, padding=padding, flip_filter=flip_filter, gain=gain)
 
@@ -148,6 +150,34 @@ def _launch(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain
         _lib.call('tdgp_upfirdn2d', x.data_ptr(), f.data_ptr(), y.data_ptr(), n, c, h, w, xs, oh, ow, ys, fh, fw, upx, upy, downx, downy,
                   padx0, padx1, pady0, pady1, int(bool(flip)), float(gain), _DTYPES[x.dtype], _lib.stream_of(x))
     return y
+
+
+class _Upfirdn2dFunction(torch.autograd.Function):
+    """upfirdn2d under autograd (upfirdn2d.py:197-269): the gradient w.r.t. x is upfirdn2d again with up / down swapped, the filter
+    flipped and the padding of :252-257 -- issued through the differentiable entry point, so higher orders work too."""
+
+    @staticmethod
+    def forward(ctx, x, f, up, down, padding, flip_filter, gain):
+        ctx.args = (up, down, padding, flip_filter, gain)
+        ctx.save_for_backward(f)
+        ctx.x_shape = x.shape
+        y = _upfirdn2d_hip(x, f, up=up, down=down, padding=padding, flip_filter=flip_filter, gain=gain)
+        ctx.y_shape = y.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        f, = ctx.saved_tensors
+        up, down, padding, flip_filter, gain = ctx.args
+        upx, upy = _pair(up, 'up')
+        downx, downy = _pair(down, 'down')
+        padx0, padx1, pady0, pady1 = _quad(padding)
+        fw, fh = _filter_wh(f)
+        _, _, ih, iw = ctx.x_shape
+        _, _, oh, ow = ctx.y_shape
+        p = [fw - padx0 - 1, iw * upx - ow * downx + padx0 - upx + 1, fh - pady0 - 1, ih * upy - oh * downy + pady0 - upy + 1]
+        dx = upfirdn2d(dy, f, up=[downx, downy], down=[upx, upy], padding=p, flip_filter=(not flip_filter), gain=gain) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None, None, None
 
 
 def _upfirdn2d_hip(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):

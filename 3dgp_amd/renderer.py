@@ -444,3 +444,46 @@ class ImportanceRenderer(torch.nn.Module):
             return out, dict(sdist_coarse=sdist, tdist_coarse=tdist, rgbs_coarse=rgbs_c, tdist_fine=tfine, sdist_fine=sfine, inds=inds,
                              rgbs_fine=rgbs_f, perm=perm, fine_perm=fperm)
         return out
+
+
+# ------------------------------------------------------------------------------------------------ the renderer under autograd
+class _RenderFunction(torch.autograd.Function):
+    """ImportanceRenderer as one autograd node: forward = the fused chain, backward = `ImportanceRenderer.backward` (replayed forward +
+    tdgp_ray_march_grad + tdgp_triplane_field_grad).  The stochastic draws of the forward (stratification, inverse CDF, density
+    noise) are made here and kept, so the backward differentiates the very image the forward produced."""
+
+    @staticmethod
+    def forward(ctx, planes, w0, b0, w1, b1, renderer, decoder, ray_o, ray_d, opts):
+        opts = dict(opts)
+        B, R, _ = ray_o.shape
+        S, N = int(opts['num_proposal_steps']), int(opts['num_fine_steps'])
+        dev = ray_o.device
+        if opts.get('u_coarse') is None:
+            opts['u_coarse'] = torch.rand([B, R, S, 1], device=dev)
+        if N > 0 and opts.get('u_fine') is None:
+            opts['u_fine'] = torch.rand([B * R, N], device=dev)
+        if float(opts.get('density_noise', 0.0)) > 0.0:
+            if opts.get('n_coarse') is None:
+                opts['n_coarse'] = torch.randn([B, R * S, 1], device=dev)
+            if N > 0 and opts.get('n_fine') is None:
+                opts['n_fine'] = torch.randn([B, R * N, 1], device=dev)
+        rgb, depth, _w, _t = renderer.forward(planes.detach(), decoder, ray_o, ray_d, opts)
+        ctx.save_for_backward(planes)
+        ctx.state = (renderer, decoder, ray_o, ray_d, opts)
+        return rgb, depth
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth):
+        planes, = ctx.saved_tensors
+        renderer, decoder, ray_o, ray_d, opts = ctx.state
+        if d_rgb is None:
+            d_rgb = torch.zeros([ray_o.shape[0], ray_o.shape[1], 3], device=ray_o.device)
+        res = renderer.backward(planes.detach(), decoder, ray_o, ray_d, opts, d_rgb.contiguous(), None if d_depth is None else d_depth.contiguous())
+        return res['planes'], res['w0'], res['b0'], res['w1'], res['b1'], None, None, None, None, None
+
+
+def render_autograd(renderer, planes, decoder, ray_origins, ray_directions, rendering_options):
+    """(rgb [B,R,3], depth [B,R,1]) with gradients flowing to `planes` ([B,3F,H,W]) and the decoder's four tensors."""
+    m = decoder.model
+    return _RenderFunction.apply(planes, m[0].weight, m[0].bias, m[1].weight, m[1].bias, renderer, decoder, ray_origins.detach(), ray_directions.detach(),
+                                 rendering_options)

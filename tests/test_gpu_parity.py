@@ -955,3 +955,32 @@ def test_modulated_conv2d_up_autograd(tdgp, oracle, tag):
     assert_close(N(dx), g[f'{tag}_dx'], 2e-5, 'dx', 1.0)
     assert_close(N(dw), g[f'{tag}_dw'], 2e-5, 'dw', 1.0)
     assert_close(N(ds), g[f'{tag}_ds'], 2e-5, 'ds', 1.0)
+
+
+def test_synthesis_forward_autograd(tdgp):
+    """G.synthesis.forward_autograd: the whole generator forward as a differentiable graph on the HIP kernels.  Gradient of
+    sum(img * d_img) + sum(depth * d_depth) w.r.t. every synthesis parameter (56 tensors: const input, conv / ToRGB weights, biases,
+    noise strengths, style affines, tri-plane MLP) and ws, against autograd through the reference's G.synthesis (tiny config)."""
+    g = load_golden('synthesis_grad')
+    cfg = tdgp.config.config_tiny()
+    G = _gen(tdgp, cfg, 101)
+    for p in G.parameters():
+        p.requires_grad_(True)
+    ws = T(g['ws']).requires_grad_(True)
+    out = G.synthesis.forward_autograd(ws, camera_params=_cam(g), noise_mode='const', u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']),
+                                       render_opts=dict(return_depth=True))
+    assert_image_parity(N(out.img.detach()), g, 'img (autograd path)', pix_tol=2e-4)
+    names = [k[len('grad::'):] for k in g.keys() if k.startswith('grad::')]
+    params = dict(G.named_parameters())
+    grads = torch.autograd.grad([out.img, out.depth], [ws] + [params[n] for n in names], [T(g['d_img']), T(g['d_depth'])], allow_unused=True)
+    assert_close(N(grads[0]), g['d_ws'], 2e-4, 'd_ws', 1.0)
+    worst = 0.0
+    for n, gr in zip(names, grads[1:]):
+        assert gr is not None, n
+        ref = g['grad::' + n]
+        err = float(np.abs(N(gr) - ref).max() / max(np.abs(ref).max(), 1e-12))
+        worst = max(worst, err)
+        assert err <= 3e-4, (n, err)
+    # the same module still serves the fused inference path
+    img = G.synthesis(T(g['ws']), camera_params=_cam(g), noise_mode='const', u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
+    assert_close(N(img), N(out.img.detach()), 2e-5, 'fused vs autograd path', 1.0)

@@ -783,6 +783,36 @@ def gen_train_forward():
     save('train_forward', **arrays)
 
 
+def gen_synthesis_grad():
+    """Autograd through the reference's G.synthesis (eval mode, noise_mode='const', unfused modulated convolutions as in training):
+    gradient of sum(img * d_img) + sum(depth * d_depth) w.r.t. every synthesis parameter and ws, tiny configuration."""
+    cfg = tdgp.config.config_tiny()
+    sd = tdgp.weights.random_state_dict(cfg, seed=101, exercise_all=True)
+    G = Generator(ref_cfg(cfg), img_resolution=cfg.img_resolution, img_channels=3, mapping_kwargs={}, num_fp16_res=0, conv_clamp=None,
+                  fused_modconv_default=False).eval()
+    G.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    B = 2
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=B, seed=102)
+    cam = TensorGroup(**{k: T(v) for k, v in inp['camera'].items()})
+    R, S = cfg.img_resolution ** 2, cfg.num_ray_steps
+    g = np.random.RandomState(103)
+    d_img, d_depth = g.randn(B, 3, cfg.img_resolution, cfg.img_resolution).astype(np.float32), g.randn(B, 1, cfg.img_resolution, cfg.img_resolution).astype(np.float32)
+    with torch.no_grad():
+        ws0 = G.mapping(T(inp['z']), T(inp['c']))
+    ws = ws0.clone().requires_grad_(True)
+    with PatchedRNG(rand_like=[T(inp['u_coarse']).reshape(B, R, S, 1)], rand=[T(inp['u_fine'])]):
+        out = G.synthesis(ws, camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True))
+    names = [n for n, p in G.synthesis.named_parameters()]
+    params = [p for n, p in G.synthesis.named_parameters()]
+    grads = torch.autograd.grad([out.img, out.depth], [ws] + params, [T(d_img), T(d_depth)], allow_unused=True)
+    arrays = dict(z=inp['z'], c=inp['c'], ws=npy(ws0), u_coarse=inp['u_coarse'], u_fine=inp['u_fine'], d_img=d_img, d_depth=d_depth, img=npy(out.img),
+                  depth=npy(out.depth), d_ws=npy(grads[0]), **{'cam_' + k: v for k, v in inp['camera'].items()})
+    for n, gr in zip(names, grads[1:]):
+        if gr is not None:
+            arrays['grad::synthesis.' + n] = npy(gr)
+    save('synthesis_grad', **arrays)
+
+
 class _GoldenDataset:
     """Stand-in for the reference's ImageFolder dataset in iterate_random_conditioning: labels and camera angles are pure
     functions of the item index."""
@@ -865,6 +895,7 @@ def main():
     gen_metrics()
     gen_trajectories()
     gen_harness()
+    gen_synthesis_grad()
     gen_train_forward()
     gen_bias_act()
     gen_bias_act_grad()
