@@ -6,6 +6,11 @@ its own images and the per-batch feature block is exchanged with `world` sequent
 Here the exchange is ONE `all_gather_into_tensor` (RCCL over xGMI on the GPU box: 512 KiB per rank, latency-bound),
 optionally issued on a side stream so it overlaps the next generator step.  There is no other collective on the path:
 the generator forward itself never communicates.
+
+Training side: `allreduce_gradients` is the reference's per-phase gradient exchange
+(`training_loop.py:335-344`): ONE all-reduce over the concatenation of all gradients (about 120 MB for the generator at the
+benchmark configuration: a single large RCCL ring all-reduce, per-link bound on xGMI -- exactly the shape the fabric wants; no
+bucketing), mean over ranks, non-finite values squashed.
 """
 import os
 
@@ -89,3 +94,23 @@ def stand_in_features(img, num_features=2048):
     if f.shape[1] < num_features:
         f = torch.nn.functional.pad(f, (0, num_features - f.shape[1]))
     return f[:, :num_features].contiguous()
+
+
+def allreduce_gradients(params, world=None, group=None):
+    """training_loop.py:335-344: concatenate `param.grad` of every parameter that has one, all-reduce the flat buffer once, divide by
+    the world size, `nan_to_num(nan=0, posinf=1e5, neginf=-1e5)`, and hand every parameter its slice back (views into the flat
+    buffer, as in the reference).  Works on any backend (RCCL on the GPU box, gloo in the CPU tests); world 1 only sanitises.
+    Returns the flat gradient (or None when no parameter has a gradient)."""
+    params = [p for p in params if p.grad is not None]
+    if not params:
+        return None
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    flat = torch.cat([p.grad.flatten() for p in params])
+    if world > 1:
+        dist.all_reduce(flat, group=group)
+        flat /= world
+    torch.nan_to_num(flat, nan=0, posinf=1e5, neginf=-1e5, out=flat)
+    for p, g in zip(params, flat.split([p.numel() for p in params])):
+        p.grad = g.reshape(p.shape)
+    return flat

@@ -47,6 +47,27 @@ def _worker(rank, world, port, q):
     st.append_torch(feats, num_gpus=world, rank=rank, gatherer=g)
     st.append_torch(feats + 100, num_gpus=world, rank=rank)            # gatherer built on demand; only 3 of these 10 rows fit
     ok = ok and st.num_items == 13 and st.is_full() and bool((st.get_all() == torch.cat([ref, ref[:3] + 100]).numpy()).all())
+    # training-side collective (training_loop.py:335-344): one all-reduce over the flat gradient, mean, non-finite values squashed
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    frozen = torch.nn.Parameter(torch.zeros(2))                                   # a parameter without a gradient is skipped
+    x = torch.full([5, 4], float(rank + 1))
+    net(x).sum().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    net[0].bias.grad[0] = float('nan') if rank == 0 else 1.0
+    net[0].bias.grad[1] = float('inf')
+    flat = D.allreduce_gradients(list(net.parameters()) + [frozen])
+    gathered = []
+    for src in range(world):
+        ys = [t.clone() for t in local]
+        for t in ys:
+            dist.broadcast(t, src=src)
+        gathered.append(ys)
+    mean = [sum(gr[i] for gr in gathered) / world for i in range(len(local))]
+    ok = ok and flat is not None and flat.numel() == sum(p.numel() for p in net.parameters()) and frozen.grad is None
+    ok = ok and torch.allclose(net[0].weight.grad, mean[0]) and torch.allclose(net[1].weight.grad, mean[2]) and torch.allclose(net[1].bias.grad, mean[3])
+    ok = ok and float(net[0].bias.grad[0]) == 0.0 and float(net[0].bias.grad[1]) == 1e5 and torch.allclose(net[0].bias.grad[2:], mean[1][2:])
+    ok = ok and net[0].weight.grad.data_ptr() == flat.data_ptr()                  # slices of the flat buffer, as in the reference
     q.put((rank, bool(ok), D.rank_seed(3, rank, world)))
     dist.barrier()
     dist.destroy_process_group()
