@@ -109,7 +109,8 @@ class MappingNetwork(torch.nn.Module):
         feats = [z_dim + embed_features] + [w_dim] * num_layers
         for i in range(num_layers):
             setattr(self, f'fc{i}', FullyConnectedLayer(feats[i], feats[i + 1], activation='lrelu', lr_multiplier=lr_multiplier))
-        self.register_buffer('w_avg', torch.zeros([w_dim]))
+        if num_ws is not None and w_avg_beta is not None:                     # layers.py:119-120
+            self.register_buffer('w_avg', torch.zeros([w_dim]))
 
     def forward(self, z, c, camera_angles=None, truncation_psi=1, truncation_cutoff=None, update_emas=False):
         if camera_angles is not None:

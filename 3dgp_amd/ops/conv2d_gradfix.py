@@ -12,6 +12,8 @@ fp32 on the GPU -- runs on the gfx950 kernels:
     input grad     tdgp_modconv2d on dy with the flipped, transposed weights (a 'same' stride-1 convolution is its own adjoint form)
     weight grad    tdgp_conv2d_weight_grad (conv_grad.hip; also stride 2 / any padding through `conv2d_weight_grad`)
     bias grad      dy.sum([0, 2, 3])
+and the strided form of the discriminator's down-sampling layers (k in {1,3}, stride in {1,2}, padding <= k - 1): forward
+tdgp_conv2d, input gradient = tdgp_conv2d on the zero-stuffed, padded dy with the flipped, transposed weights.
 Other forms take the reference's own fallback, `torch.nn.functional.conv2d / conv_transpose2d` (MIOpen on ROCm, cuDNN there).
 """
 import contextlib
@@ -110,9 +112,59 @@ class _Conv2dSame(torch.autograd.Function):
         return grad_input, grad_weight, grad_bias
 
 
+def _strided_form(input, weight, stride, padding, dilation, groups):
+    """The second native form: k in {1,3}, stride in {1,2}, padding <= k - 1 (the discriminator's down-sampling convolutions)."""
+    if not (isinstance(input, torch.Tensor) and input.is_cuda and input.dtype == torch.float32 and weight.dtype == torch.float32):
+        return False
+    kh, kw = int(weight.shape[2]), int(weight.shape[3])
+    st, pd = _pair(stride), _pair(padding)
+    return (st[0] == st[1] and st[0] in (1, 2) and _pair(dilation) == (1, 1) and groups == 1 and kh == kw and kh in (1, 3) and pd[0] == pd[1]
+            and pd[0] <= kh - 1)
+
+
+def conv2d_strided_input_grad(dy, weight, input_hw, stride, padding):
+    """dx of y = conv2d(x, w, stride, padding) (conv2d_gradfix.py:126-129: the transposed convolution of dy): dy is zero-stuffed by
+    the stride, padded by k - 1 - padding on the left / top (and whatever completes the input size on the right / bottom), and
+    correlated with the flipped, in/out-transposed weights -- one tdgp_conv2d call."""
+    k = int(weight.shape[2])
+    H, W = input_hw
+    B, cout, OH, OW = dy.shape
+    LH, LW = stride * (OH - 1) + 1, stride * (OW - 1) + 1
+    lo = k - 1 - padding
+    d = torch.zeros([B, cout, lo + LH + (H - LH + padding), lo + LW + (W - LW + padding)], dtype=dy.dtype, device=dy.device)
+    d[:, :, lo:lo + LH:stride, lo:lo + LW:stride] = dy
+    wt = weight.detach().flip([2, 3]).transpose(0, 1).contiguous()
+    return conv2d_strided(d, wt, stride=1, padding=0)
+
+
+class _Conv2dStrided(torch.autograd.Function):
+    """conv2d_gradfix.py:106-139 for the strided form."""
+
+    @staticmethod
+    def forward(ctx, input, weight, bias, stride, padding):
+        ctx.save_for_backward(input, weight)
+        ctx.has_bias, ctx.stride, ctx.padding = bias is not None, stride, padding
+        return conv2d_strided(input, weight, bias, stride=stride, padding=padding)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, weight = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        grad_input = grad_weight = grad_bias = None
+        if ctx.needs_input_grad[0]:
+            grad_input = conv2d_strided_input_grad(grad_output, weight, input.shape[2:], ctx.stride, ctx.padding)
+        if ctx.needs_input_grad[1] and not weight_gradients_disabled:
+            grad_weight = conv2d_weight_grad(input, grad_output, weight.shape, stride=ctx.stride, padding=ctx.padding)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = grad_output.sum([0, 2, 3])
+        return grad_input, grad_weight, grad_bias, None, None
+
+
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     if _native_form(input, weight, stride, padding, dilation, groups):
         return _Conv2dSame.apply(input, weight, bias)
+    if _strided_form(input, weight, stride, padding, dilation, groups):
+        return _Conv2dStrided.apply(input, weight, bias, _pair(stride)[0], _pair(padding)[0])
     return torch.nn.functional.conv2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding, dilation=dilation, groups=groups)
 
 

@@ -2,9 +2,9 @@
 
 Signature of the reference's `conv2d_resample(x, w, f, up, down, padding, groups, flip_weight, flip_filter)`
 (src/torch_utils/ops/conv2d_resample.py:46).  On the generator path this algebra is executed inside
-`tdgp_modconv2d`; the stand-alone function is kept for the callers either side of the path (Conv2dLayer in the
-adaptors / discriminator) and composes the native upfirdn2d with PyTorch-ROCm's convolution, which
-is what the reference does with cuDNN (conv2d_gradfix.py:113-115).
+`tdgp_modconv2d`; the stand-alone function is kept for the callers either side of the path (the discriminator's
+Conv2dLayer) and composes the native upfirdn2d with `conv2d_gradfix.conv2d` (HIP kernels for the forms the
+generator / discriminator use; the reference's own `torch.nn.functional` fallback otherwise, conv2d_gradfix.py:36-44).
 """
 import torch
 
@@ -15,7 +15,8 @@ def _conv(x, w, stride=1, padding=0, groups=1, transpose=False, correlate=True):
     # F.conv2d correlates; a true convolution flips the taps first (conv2d_resample.py:29-41)
     if not correlate and (w.shape[2] > 1 or w.shape[3] > 1):
         w = w.flip([2, 3])
-    fn = torch.nn.functional.conv_transpose2d if transpose else torch.nn.functional.conv2d
+    from . import conv2d_gradfix as _cg                   # conv2d_resample.py:29-41 -> conv2d_gradfix: HIP kernels for the native forms
+    fn = _cg.conv_transpose2d if transpose else _cg.conv2d
     return fn(x, w, stride=stride, padding=padding, groups=groups)
 
 

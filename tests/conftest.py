@@ -111,3 +111,35 @@ CONV_GRAD_CASES = dict(k3=dict(B=2, cin=10, cout=12, H=9, W=14, k=3, stride=1, p
 MARCH_GRAD_CASES = dict(cl_inf=dict(mode='classical', use_inf_depth=True), cl_noinf_lastback=dict(mode='classical', use_inf_depth=False, last_back=True),
                         cl_relu=dict(mode='classical', use_inf_depth=True, clamp_mode='relu'), mip_inf=dict(mode='mip', use_inf_depth=True),
                         mip_noinf_white_bias=dict(mode='mip', use_inf_depth=False, white_back=True, density_bias=-1.0))
+
+
+# ------------------------------------------------------------------------------------------------ discriminator
+D_CASES = dict(plain=dict(cfg=dict(c_dim=0, cbase=512, cmax=32), res=32, img_channels=3, B=4),
+               full=dict(cfg=dict(c_dim=5, cbase=512, cmax=32, patch_params_cond=True, hyper_mod=True), res=32, img_channels=4, B=4),
+               extra=dict(cfg=dict(c_dim=3, cbase=256, cmax=16, num_additional_start_blocks=1), res=16, img_channels=3, B=3))
+
+
+def check_discriminator(tdgp, tag, device, tol):
+    """Build the seeded discriminator, run forward + backward on `device`, compare with the reference's logits and gradients."""
+    import torch
+    g, case = load_golden('discriminator'), D_CASES[tag]
+    cfg = tdgp.discriminator.DiscriminatorConfig(**case['cfg'])
+    D = tdgp.discriminator.seeded_discriminator(cfg, case['res'], case['img_channels'], seed=300 + len(tag)).to(device)
+    to = lambda a: torch.from_numpy(a).to(device)                    # noqa: E731
+    img = to(g[f'{tag}_img']).requires_grad_(True)
+    logits, feats = D(img, to(g[f'{tag}_c']), patch_params=dict(scales=to(g[f'{tag}_scales']), offsets=to(g[f'{tag}_offsets'])))
+    assert feats is None and logits.shape == (case['B'],)
+    assert_close(logits.detach().cpu().numpy(), g[f'{tag}_logits'], tol, 'logits', 1.0)
+    params = dict(D.named_parameters())
+    names = [k.split('::', 2)[2] for k in g.keys() if k.startswith(tag + '::grad')]
+    grads = torch.autograd.grad(logits, [img] + [params[n] for n in names], to(g[f'{tag}_d']), allow_unused=True)
+    assert_close(grads[0].cpu().numpy(), g[f'{tag}_d_img'], tol, 'd_img', 1.0)
+    for n, gr in zip(names, grads[1:]):
+        assert gr is not None, n
+        gr = gr.cpu()
+        if f'{tag}::grad::{n}' in g:
+            assert_close(gr.numpy(), g[f'{tag}::grad::{n}'], tol, 'grad ' + n, 1.0)
+        else:
+            assert_close(gr.sum(dim=1).numpy(), g[f'{tag}::gradrows::{n}'], tol, 'grad rows ' + n, 1.0)
+            assert_close(gr.sum(dim=0).numpy(), g[f'{tag}::gradcols::{n}'], tol, 'grad cols ' + n, 1.0)
+    return len(names)

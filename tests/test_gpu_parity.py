@@ -984,3 +984,20 @@ def test_synthesis_forward_autograd(tdgp):
     # the same module still serves the fused inference path
     img = G.synthesis(T(g['ws']), camera_params=_cam(g), noise_mode='const', u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
     assert_close(N(img), N(out.img.detach()), 2e-5, 'fused vs autograd path', 1.0)
+
+
+@pytest.mark.parametrize('tag', ['plain', 'full', 'extra'])
+def test_discriminator_gpu(tdgp, tag):
+    """The discriminator on the HIP ops (stride-1 and stride-2 convolutions forward and backward, upfirdn2d, bias_act): logits,
+    d/d img and every parameter gradient against autograd through the reference."""
+    from conftest import check_discriminator
+    tdgp._lib.profile_enable(True)
+    try:
+        assert check_discriminator(tdgp, tag, DEV, 1e-4) >= 17
+        torch.cuda.synchronize()
+        launched = set(tdgp._lib.profile_report())
+    finally:
+        tdgp._lib.profile_enable(False)
+    # the convolutions really ran on the library's kernels, forward and backward (no silent torch fallback)
+    for k in ('conv_mfma_kernel', 'conv_strided_mfma_kernel', 'conv_wgrad_mfma_kernel', 'bias_act_grad_kernel'):
+        assert k in launched, (k, sorted(launched))

@@ -154,3 +154,12 @@ def test_iterate_random_conditioning(tdgp, tag, c_dim, custom, frontal):
     if c_dim or custom:
         with pytest.raises(ValueError):
             next(tdgp.metrics.iterate_random_conditioning(_G, 4, 'cpu', cam))
+
+
+@pytest.mark.parametrize('tag', ['plain', 'full', 'extra'])
+def test_discriminator_module_cpu(tdgp, tag):
+    """Discriminator module logic (block wiring, conditioning, hyper-modulation, minibatch stddev, Fourier features) on CPU tensors --
+    where every op takes the reference's own torch fallback -- against the reference: logits, d/d img and all parameter gradients.
+    The state dict of the module loads into the reference with strict=True (tools/gen_goldens.py)."""
+    from conftest import check_discriminator
+    assert check_discriminator(tdgp, tag, 'cpu', 2e-5) >= 17

@@ -813,6 +813,53 @@ def gen_synthesis_grad():
     save('synthesis_grad', **arrays)
 
 
+D_CASES = dict(plain=dict(cfg=dict(c_dim=0, cbase=512, cmax=32), res=32, img_channels=3, B=4),
+               full=dict(cfg=dict(c_dim=5, cbase=512, cmax=32, patch_params_cond=True, hyper_mod=True), res=32, img_channels=4, B=4),
+               extra=dict(cfg=dict(c_dim=3, cbase=256, cmax=16, num_additional_start_blocks=1), res=16, img_channels=3, B=3))
+
+
+def gen_discriminator():
+    """Discriminator forward (networks_discriminator.py:259-287, fp32) and the gradient of sum(logits * d) w.r.t. the image and every
+    parameter, for: the plain StyleGAN2 form, the 3dgp form (class + patch conditioning, hyper-modulation, RGB-D input) and a form
+    with an additional non-down-sampling start block.  Weights: our module's own seeded initialisation, loaded strictly into the
+    reference module (key / shape parity)."""
+    from src.training.networks_discriminator import Discriminator as RefD
+    arrays = {}
+    for tag, case in D_CASES.items():
+        cfg = tdgp.discriminator.DiscriminatorConfig(**case['cfg'])
+        mine = tdgp.discriminator.seeded_discriminator(cfg, case['res'], case['img_channels'], seed=300 + len(tag))
+        rcfg = EasyDict(c_dim=cfg.c_dim, cbase=cfg.cbase, cmax=cfg.cmax, fmaps=cfg.fmaps, num_additional_start_blocks=cfg.num_additional_start_blocks,
+                        patch=EasyDict(patch_params_cond=cfg.patch_params_cond), hyper_mod=cfg.hyper_mod, camera_cond=False, camera_cond_drop_p=0.0,
+                        mbstd_group_size=cfg.mbstd_group_size)
+        ref = RefD(rcfg, input_resolution=case['res'], img_channels=case['img_channels'], num_fp16_res=0, conv_clamp=None,
+                   epilogue_kwargs=dict(mbstd_group_size=cfg.mbstd_group_size))
+        ref.load_state_dict(mine.state_dict(), strict=True)
+        g = np.random.RandomState(310 + len(tag))
+        B = case['B']
+        img = T(g.randn(B, case['img_channels'], case['res'], case['res']).astype(np.float32)).requires_grad_(True)
+        c = np.zeros((B, cfg.c_dim), np.float32)
+        if cfg.c_dim:
+            c[np.arange(B), g.randint(0, cfg.c_dim, B)] = 1.0
+        pp = dict(scales=g.uniform(0.3, 1.0, (B, 2)).astype(np.float32), offsets=g.uniform(0.0, 0.5, (B, 2)).astype(np.float32))
+        logits, _ = ref(img, T(c), patch_params={k: T(v) for k, v in pp.items()})
+        d = T(g.randn(B).astype(np.float32))
+        names = [n for n, p in ref.named_parameters()]
+        grads = torch.autograd.grad(logits, [img] + [p for n, p in ref.named_parameters()], d, allow_unused=True)
+        arrays.update({f'{tag}_img': npy(img), f'{tag}_c': c, f'{tag}_scales': pp['scales'], f'{tag}_offsets': pp['offsets'], f'{tag}_logits': npy(logits),
+                       f'{tag}_d': npy(d), f'{tag}_d_img': npy(grads[0])})
+        # weights are NOT stored: the test rebuilds the module from the same seeds.  Gradients of large matrices (the 512-wide
+        # hyper-modulation mapping, the 1001 x 256 embedding) are stored as their row and column sums.
+        for n, gr in zip(names, grads[1:]):
+            if gr is None:
+                continue
+            if gr.numel() > 20000:
+                arrays[f'{tag}::gradrows::{n}'] = npy(gr.sum(dim=1))
+                arrays[f'{tag}::gradcols::{n}'] = npy(gr.sum(dim=0))
+            else:
+                arrays[f'{tag}::grad::{n}'] = npy(gr)
+    save('discriminator', **arrays)
+
+
 class _GoldenDataset:
     """Stand-in for the reference's ImageFolder dataset in iterate_random_conditioning: labels and camera angles are pure
     functions of the item index."""
@@ -896,6 +943,7 @@ def main():
     gen_trajectories()
     gen_harness()
     gen_synthesis_grad()
+    gen_discriminator()
     gen_train_forward()
     gen_bias_act()
     gen_bias_act_grad()
