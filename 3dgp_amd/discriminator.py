@@ -8,7 +8,7 @@ Module and parameter names follow the reference, so its state dict loads with st
 Every convolution goes through `ops.conv2d_resample` -> `ops.upfirdn2d` + `ops.conv2d_gradfix.conv2d` (gfx950 kernels forward and
 backward: stride-1 'same' and the stride-2 down-sampling forms), every activation through `ops.bias_act`; the fully connected
 heads, the minibatch-stddev statistic and the Fourier features are eager tensor ops as in the reference.  Second-order gradients
-(R1) are not provided: the convolution backward passes are not themselves differentiable functions yet.
+(R1) work: the convolution backward passes are differentiable functions over the same kernels (ops/conv2d_gradfix.py).
 """
 from dataclasses import dataclass
 

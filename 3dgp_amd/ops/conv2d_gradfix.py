@@ -83,6 +83,44 @@ def conv2d_strided(x, weight, bias=None, stride=1, padding=0):
     return y
 
 
+class _Conv2dGradWeight(torch.autograd.Function):
+    """conv2d_gradfix.py:141-166: the weight gradient as a function of (grad_output, input) with its own backward, so that
+    second-order terms (R1 regularisation differentiates d logits / d img w.r.t. the weights) flow through the same kernels:
+        d / d grad_output = conv2d(input, gg_weight)            d / d input = the transposed convolution of grad_output with gg_weight"""
+
+    @staticmethod
+    def forward(ctx, grad_output, input, weight_shape, stride, padding):
+        ctx.save_for_backward(grad_output, input)
+        ctx.weight_shape, ctx.stride, ctx.padding = tuple(weight_shape), stride, padding
+        return conv2d_weight_grad(input, grad_output, weight_shape, stride=stride, padding=padding)
+
+    @staticmethod
+    def backward(ctx, gg_weight):
+        grad_output, input = ctx.saved_tensors
+        gg_grad_output = gg_input = None
+        if ctx.needs_input_grad[0]:
+            gg_grad_output = conv2d(input, gg_weight, None, stride=ctx.stride, padding=ctx.padding)
+        if ctx.needs_input_grad[1]:
+            gg_input = _input_grad(grad_output, gg_weight, input.shape[2:], ctx.stride, ctx.padding)
+        return gg_grad_output, gg_input, None, None, None
+
+
+def _input_grad(grad_output, weight, input_hw, stride, padding):
+    """Input gradient of conv2d(x, weight, stride, padding), itself differentiable w.r.t. grad_output and weight: expressed through
+    `conv2d` again (flip / transpose / zero-stuffing are eager tensor ops autograd already knows)."""
+    k = int(weight.shape[2])
+    wt = weight.flip([2, 3]).transpose(0, 1)
+    if stride == 1 and padding == k // 2:
+        return conv2d(grad_output, wt, None, stride=1, padding=padding)
+    H, W = input_hw
+    B, cout, OH, OW = grad_output.shape
+    LH, LW = stride * (OH - 1) + 1, stride * (OW - 1) + 1
+    lo = k - 1 - padding
+    d = grad_output.new_zeros([B, cout, lo + LH + (H - LH + padding), lo + LW + (W - LW + padding)])
+    d[:, :, lo:lo + LH:stride, lo:lo + LW:stride] = grad_output
+    return conv2d(d, wt, None, stride=1, padding=0)
+
+
 def conv2d_input_grad(dy, weight):
     """dx of a stride-1 'same' convolution: the correlation of dy with the spatially flipped, in/out-transposed weights."""
     wt = weight.detach().flip([2, 3]).transpose(0, 1).contiguous()
@@ -96,7 +134,8 @@ class _Conv2dSame(torch.autograd.Function):
     def forward(ctx, input, weight, bias):
         ctx.save_for_backward(input, weight)
         ctx.has_bias = bias is not None
-        return _modconv.modconv_forward(input, _modconv._packed(weight), None, bias=bias, demodulate=False, act='linear', gain=1.0)
+        packed = _modconv._packed(weight) if isinstance(weight, torch.nn.Parameter) else _modconv.PackedConv(weight.contiguous())
+        return _modconv.modconv_forward(input, packed, None, bias=bias, demodulate=False, act='linear', gain=1.0)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -104,9 +143,9 @@ class _Conv2dSame(torch.autograd.Function):
         grad_output = grad_output.contiguous()
         grad_input = grad_weight = grad_bias = None
         if ctx.needs_input_grad[0]:
-            grad_input = conv2d_input_grad(grad_output, weight)
+            grad_input = _input_grad(grad_output, weight, input.shape[2:], 1, weight.shape[2] // 2)
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
-            grad_weight = conv2d_weight_grad(input, grad_output, weight.shape, stride=1, padding=weight.shape[2] // 2)
+            grad_weight = _Conv2dGradWeight.apply(grad_output, input, weight.shape, 1, weight.shape[2] // 2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = grad_output.sum([0, 2, 3])
         return grad_input, grad_weight, grad_bias
@@ -152,9 +191,9 @@ class _Conv2dStrided(torch.autograd.Function):
         grad_output = grad_output.contiguous()
         grad_input = grad_weight = grad_bias = None
         if ctx.needs_input_grad[0]:
-            grad_input = conv2d_strided_input_grad(grad_output, weight, input.shape[2:], ctx.stride, ctx.padding)
+            grad_input = _input_grad(grad_output, weight, input.shape[2:], ctx.stride, ctx.padding)
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
-            grad_weight = conv2d_weight_grad(input, grad_output, weight.shape, stride=ctx.stride, padding=ctx.padding)
+            grad_weight = _Conv2dGradWeight.apply(grad_output, input, weight.shape, ctx.stride, ctx.padding)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = grad_output.sum([0, 2, 3])
         return grad_input, grad_weight, grad_bias, None, None

@@ -143,3 +143,30 @@ def check_discriminator(tdgp, tag, device, tol):
             assert_close(gr.sum(dim=1).numpy(), g[f'{tag}::gradrows::{n}'], tol, 'grad rows ' + n, 1.0)
             assert_close(gr.sum(dim=0).numpy(), g[f'{tag}::gradcols::{n}'], tol, 'grad cols ' + n, 1.0)
     return len(names)
+
+
+def check_discriminator_r1(tdgp, tag, device, tol):
+    """R1 penalty and the (second-order) gradient of sum(penalty * e) w.r.t. every parameter that has one."""
+    import torch
+    g, case = load_golden('discriminator'), D_CASES[tag]
+    cfg = tdgp.discriminator.DiscriminatorConfig(**case['cfg'])
+    D = tdgp.discriminator.seeded_discriminator(cfg, case['res'], case['img_channels'], seed=300 + len(tag)).to(device)
+    to = lambda a: torch.from_numpy(a).to(device)                    # noqa: E731
+    img = to(g[f'{tag}_img']).requires_grad_(True)
+    logits, _ = D(img, to(g[f'{tag}_c']), patch_params=dict(scales=to(g[f'{tag}_scales']), offsets=to(g[f'{tag}_offsets'])))
+    r1_grads, = torch.autograd.grad([logits.sum()], [img], create_graph=True)
+    penalty = r1_grads.square().sum([1, 2, 3])
+    assert_close(penalty.detach().cpu().numpy(), g[f'{tag}_r1_penalty'], tol, 'r1 penalty', 1.0)
+    params = dict(D.named_parameters())
+    names = [k.split('::', 2)[2] for k in g.keys() if k.startswith(tag + '::r1')]
+    names = list(dict.fromkeys(names))
+    grads = torch.autograd.grad((penalty * to(g[f'{tag}_r1_e'])).sum(), [params[n] for n in names], allow_unused=True)
+    for n, gr in zip(names, grads):
+        assert gr is not None, n
+        gr = gr.cpu()
+        if f'{tag}::r1::{n}' in g:
+            assert_close(gr.numpy(), g[f'{tag}::r1::{n}'], tol, 'r1 grad ' + n, 1.0)
+        else:
+            assert_close(gr.sum(dim=1).numpy(), g[f'{tag}::r1rows::{n}'], tol, 'r1 grad rows ' + n, 1.0)
+            assert_close(gr.sum(dim=0).numpy(), g[f'{tag}::r1cols::{n}'], tol, 'r1 grad cols ' + n, 1.0)
+    return len(names)

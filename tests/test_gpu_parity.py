@@ -1001,3 +1001,12 @@ def test_discriminator_gpu(tdgp, tag):
     # the convolutions really ran on the library's kernels, forward and backward (no silent torch fallback)
     for k in ('conv_mfma_kernel', 'conv_strided_mfma_kernel', 'conv_wgrad_mfma_kernel', 'bias_act_grad_kernel'):
         assert k in launched, (k, sorted(launched))
+
+
+@pytest.mark.parametrize('tag', ['plain', 'full'])
+def test_discriminator_r1_gpu(tdgp, tag):
+    """R1 regularisation on the HIP ops: d logits / d img under create_graph=True, its squared norm, and the gradient of that w.r.t. the
+    parameters -- the convolution backward passes are themselves differentiable functions over the same kernels
+    (conv2d_gradfix.py:120-166), bias_act has its second-order kernel, upfirdn2d recurses."""
+    from conftest import check_discriminator_r1
+    assert check_discriminator_r1(tdgp, tag, DEV, 3e-4) >= 10

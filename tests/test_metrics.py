@@ -163,3 +163,10 @@ def test_discriminator_module_cpu(tdgp, tag):
     The state dict of the module loads into the reference with strict=True (tools/gen_goldens.py)."""
     from conftest import check_discriminator
     assert check_discriminator(tdgp, tag, 'cpu', 2e-5) >= 17
+
+
+@pytest.mark.parametrize('tag', ['plain', 'full'])
+def test_discriminator_r1_cpu(tdgp, tag):
+    """R1 penalty of the discriminator module and its second-order parameter gradients (CPU tensors, torch fallbacks) vs the reference."""
+    from conftest import check_discriminator_r1
+    assert check_discriminator_r1(tdgp, tag, 'cpu', 5e-5) >= 10

@@ -847,6 +847,23 @@ def gen_discriminator():
         grads = torch.autograd.grad(logits, [img] + [p for n, p in ref.named_parameters()], d, allow_unused=True)
         arrays.update({f'{tag}_img': npy(img), f'{tag}_c': c, f'{tag}_scales': pp['scales'], f'{tag}_offsets': pp['offsets'], f'{tag}_logits': npy(logits),
                        f'{tag}_d': npy(d), f'{tag}_d_img': npy(grads[0])})
+        # R1 regularisation (loss.py: r1_grads = grad(real_logits.sum(), real_img, create_graph=True); penalty = r1_grads.square().sum([1,2,3])):
+        # the gradient of sum(penalty * e) w.r.t. every parameter is second order in the network
+        img2 = T(npy(img)).requires_grad_(True)
+        logits2, _ = ref(img2, T(c), patch_params={k: T(v) for k, v in pp.items()})
+        r1_grads, = torch.autograd.grad([logits2.sum()], [img2], create_graph=True)
+        penalty = r1_grads.square().sum([1, 2, 3])
+        e = T(g.rand(B).astype(np.float32))
+        r1 = torch.autograd.grad((penalty * e).sum(), [p for n, p in ref.named_parameters()], allow_unused=True)
+        arrays.update({f'{tag}_r1_penalty': npy(penalty), f'{tag}_r1_e': npy(e)})
+        for n, gr in zip(names, r1):
+            if gr is None:
+                continue
+            if gr.numel() > 20000:
+                arrays[f'{tag}::r1rows::{n}'] = npy(gr.sum(dim=1))
+                arrays[f'{tag}::r1cols::{n}'] = npy(gr.sum(dim=0))
+            else:
+                arrays[f'{tag}::r1::{n}'] = npy(gr)
         # weights are NOT stored: the test rebuilds the module from the same seeds.  Gradients of large matrices (the 512-wide
         # hyper-modulation mapping, the 1001 x 256 embedding) are stored as their row and column sums.
         for n, gr in zip(names, grads[1:]):
