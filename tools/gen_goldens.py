@@ -813,8 +813,8 @@ def gen_synthesis_grad():
     save('synthesis_grad', **arrays)
 
 
-D_CASES = dict(plain=dict(cfg=dict(c_dim=0, cbase=512, cmax=32), res=32, img_channels=3, B=4),
-               full=dict(cfg=dict(c_dim=5, cbase=512, cmax=32, patch_params_cond=True, hyper_mod=True), res=32, img_channels=4, B=4),
+D_CASES = dict(plain=dict(cfg=dict(c_dim=0, cbase=256, cmax=16), res=32, img_channels=3, B=4),
+               full=dict(cfg=dict(c_dim=5, cbase=256, cmax=16, patch_params_cond=True, hyper_mod=True), res=32, img_channels=4, B=4),
                extra=dict(cfg=dict(c_dim=3, cbase=256, cmax=16, num_additional_start_blocks=1), res=16, img_channels=3, B=3))
 
 
