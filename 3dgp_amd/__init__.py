@@ -20,7 +20,7 @@ from .config import GeneratorConfig  # noqa: F401
 
 def __getattr__(name):
     # torch-dependent submodules are imported on first use
-    if name in ('_lib', 'ops', 'renderer', 'generator', 'adaptors', 'metrics', 'inference', 'discriminator', 'compat', 'distributed', 'build'):
+    if name in ('_lib', 'ops', 'renderer', 'generator', 'adaptors', 'metrics', 'inference', 'discriminator', 'training', 'compat', 'distributed', 'build'):
         import importlib
         return importlib.import_module(f'{__name__}.{name}')
     raise AttributeError(name)

@@ -43,6 +43,11 @@ class Conv2dLayer(torch.nn.Module):
 
     def forward(self, x, c=None, gain=1):
         act_clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            # differentiable path (training): the same layer as conv2d_gradfix.conv2d + bias_act, both autograd functions on the HIP kernels
+            from .ops import conv2d_gradfix as _cg
+            y = _cg.conv2d(x, self.weight * self.weight_gain, None, padding=self.padding)
+            return _bias_act.bias_act(y, self.bias, act=self.activation, gain=self.act_gain * gain, clamp=act_clamp)
         return _modconv.modconv_forward(x, self._pack(), None, bias=self.bias, up=1, demodulate=False, act=self.activation,
                                         gain=self.act_gain * gain, clamp=act_clamp)
 

@@ -443,10 +443,11 @@ class SynthesisNetwork(torch.nn.Module):
                          **block_kwargs):
         """The same forward as a differentiable graph: gradients reach every parameter of the tri-plane
         backbone, the tri-plane MLP and `ws`.  Backbone = chain of the autograd ops (modulated convolutions, bias_act, upfirdn2d),
-        renderer = one autograd node (`renderer.render_autograd`).  Cameras / rays carry no gradient; the adaptors are not wired in."""
-        if self.depth_adaptor is not None or self.camera_adaptor is not None:
-            raise NotImplementedError('forward_autograd: the depth / camera adaptors are not wired into the differentiable path yet')
+        renderer = one autograd node (`renderer.render_autograd`), depth adaptor = conv2d_gradfix + bias_act.  Cameras / rays carry no
+        gradient (the camera adaptor is applied by the caller, as in loss.py:76-77, and its own parameters get none through the rays)."""
         render_opts = {**self._default_render_options, **render_opts}
+        if (render_opts['return_depth_adapted'] or render_opts['concat_depth']) and self.depth_adaptor is None:
+            raise RuntimeError('return_depth_adapted / concat_depth need cfg.depth_adaptor')
         B = ws.shape[0]
         planes = self.tri_plane_decoder.forward_autograd(ws[:, :self.tri_plane_decoder.num_ws], **block_kwargs)
         h = w = self.train_resolution if self.training else self.test_resolution
@@ -461,8 +462,17 @@ class SynthesisNetwork(torch.nn.Module):
         rgb, depth = _renderer.render_autograd(self.renderer, planes, self.tri_plane_mlp, ray_o, ray_d, opts)
         img = rgb.reshape(B, h, w, self.img_channels).permute(0, 3, 1, 2).contiguous()
         depth = depth.reshape(B, 1, h, w)
-        if render_opts['return_depth']:
-            return TensorGroup(img=img, depth=depth)
+        depth_adapted = None
+        if self.depth_adaptor is not None:                                  # networks_epigraf.py:246-253
+            depth_adapted = self.depth_adaptor(depth, ws[:, 0])
+            img = torch.cat([img, depth_adapted], dim=1) if render_opts['concat_depth'] else img + 0.0 * depth_adapted.max()
+        if render_opts['return_depth'] or render_opts['return_depth_adapted']:
+            out = TensorGroup(img=img)
+            if render_opts['return_depth']:
+                out.depth = depth
+            if render_opts['return_depth_adapted']:
+                out.depth_adapted = depth_adapted
+            return out
         return img
 
     @torch.no_grad()

@@ -28,13 +28,14 @@ def state_dict_spec(cfg: GeneratorConfig):
     root = 'synthesis.tri_plane_decoder'
     img_c = cfg.plane_channels
 
-    def layer(pfx, cin, cout, res, k, noise):
+    def layer(pfx, cin, cout, res, k, noise, synth=True):
         spec[pfx + '.weight'] = (cout, cin, k, k)
         if noise:
             spec[pfx + '.noise_strength'] = ()
         spec[pfx + '.bias'] = (cout,)
-        if noise:
+        if synth:                                          # SynthesisLayer registers the filter with or without noise; ToRGBLayer has none
             spec[pfx + '.resample_filter'] = (4, 4)
+        if noise:
             spec[pfx + '.noise_const'] = (res, res)
         spec[pfx + '.affine.weight'] = (cin, cfg.w_dim)
         spec[pfx + '.affine.bias'] = (cin,)
@@ -48,7 +49,7 @@ def state_dict_spec(cfg: GeneratorConfig):
         else:
             layer(pfx + '.conv0', ch[r // 2], cout, r, 3, cfg.use_noise)
         layer(pfx + '.conv1', cout, cout, r, 3, cfg.use_noise)
-        layer(pfx + '.torgb', cout, img_c, r, 1, False)
+        layer(pfx + '.torgb', cout, img_c, r, 1, False, synth=False)
     spec['synthesis.tri_plane_mlp.model.0.weight'] = (cfg.mlp_hid, cfg.feat_dim)
     spec['synthesis.tri_plane_mlp.model.0.bias'] = (cfg.mlp_hid,)
     spec['synthesis.tri_plane_mlp.model.1.weight'] = (4, cfg.mlp_hid)

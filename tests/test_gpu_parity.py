@@ -1010,3 +1010,66 @@ def test_discriminator_r1_gpu(tdgp, tag):
     (conv2d_gradfix.py:120-166), bias_act has its second-order kernel, upfirdn2d recurses."""
     from conftest import check_discriminator_r1
     assert check_discriminator_r1(tdgp, tag, DEV, 3e-4) >= 10
+
+
+def test_stylegan2_loss_phases(tdgp):
+    """training.StyleGAN2Loss.accumulate_gradients for the phases Gmain, Dmain, Dreg on the HIP ops (differentiable generator, patch-
+    conditioned hyper-modulated discriminator, R1 with second-order gradients): the gradients left in G / D after each phase against
+    the reference's StyleGAN2Loss on the same weights, patch parameters and renderer draws."""
+    g = load_golden('loss')
+    TR = tdgp.training
+    cfg = tdgp.config.config_tiny()
+    cfg.use_noise = False
+    cfg.patch_resolution = 16
+    dcfg = tdgp.discriminator.DiscriminatorConfig(c_dim=0, cbase=256, cmax=16, patch_params_cond=True, hyper_mod=True, mbstd_group_size=2)
+    G = _gen(tdgp, cfg, 201).train()
+    D = tdgp.discriminator.seeded_discriminator(dcfg, 16, 3, seed=202).to(DEV).train()
+    pcfg = TR.PatchConfig(enabled=True, distribution='uniform', resolution=16, min_scale_trg=0.5, max_scale=1.0, anneal_kimg=10, mbstd_group_size=2)
+    loss = TR.StyleGAN2Loss(G, D, DEV, r1_gamma=2.0, patch_cfg=pcfg, synthesis_kwargs=dict(u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine'])))
+    pps = [dict(scales=T(g[f'pp{i}_scales']), offsets=T(g[f'pp{i}_offsets'])) for i in range(3)]
+    queue = []
+    orig = TR.sample_patch_params
+    TR.sample_patch_params = lambda n, pc, device='cpu': queue.pop(0)
+    B = 4
+    c0 = torch.zeros(B, 0, device=DEV)
+
+    def run(phase, pp_list):
+        for m in (G, D):
+            m.zero_grad(set_to_none=True)
+        G.requires_grad_(phase.startswith('G'))
+        D.requires_grad_(phase.startswith('D'))
+        queue[:] = pp_list
+        real = tdgp.generator.TensorGroup(img=T(g['real']), c=c0, depth=torch.zeros(B, 1, 32, 32, device=DEV))
+        gen = tdgp.generator.TensorGroup(z=T(g['z']), c=c0, camera_params=tdgp.generator.TensorGroup(**_cam(g)))
+        loss.accumulate_gradients(phase, real, gen, gain=1, cur_nimg=0)
+        assert not queue
+
+    def check(tag, module, tol):
+        params = dict(module.named_parameters())
+        n_checked = 0
+        for k in g.keys():
+            if not k.startswith(tag + '::'):
+                continue
+            parts = k.split('::')
+            name = parts[-1]
+            gr = params[name].grad
+            assert gr is not None, (tag, name)
+            gr = gr.cpu()
+            got = gr.sum(1) if parts[1] == 'rows' else gr.sum(0) if parts[1] == 'cols' else gr
+            ref = g[k]
+            err = float(np.abs(got.numpy() - ref).max() / max(np.abs(ref).max(), 1e-12))
+            assert err <= tol, (tag, name, err)
+            n_checked += 1
+        return n_checked
+
+    try:
+        run('Gmain', [pps[0]])
+        assert check('Gmain', G, 2e-3) >= 50
+        assert all(p.grad is None for p in D.parameters())
+        run('Dmain', [pps[0], pps[1]])
+        assert check('Dmain', D, 2e-3) >= 30
+        run('Dreg', [pps[2]])
+        assert check('Dreg', D, 2e-3) >= 20
+        assert float(loss.stats['Loss/D/r1_penalty'].min()) > 0
+    finally:
+        TR.sample_patch_params = orig

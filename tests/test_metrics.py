@@ -170,3 +170,29 @@ def test_discriminator_r1_cpu(tdgp, tag):
     """R1 penalty of the discriminator module and its second-order parameter gradients (CPU tensors, torch fallbacks) vs the reference."""
     from conftest import check_discriminator_r1
     assert check_discriminator_r1(tdgp, tag, 'cpu', 5e-5) >= 10
+
+
+def test_training_utils(tdgp):
+    """Patch sampling (numpy + torch RNG in the reference's draw order), patch extraction and the blur of loss.py, bit for bit /
+    to fp32 rounding against the reference (CPU tensors)."""
+    import torch
+    g = load_golden('loss')
+    TR = tdgp.training
+    for dist, extra in (('uniform', {}), ('beta', dict(alpha=1.0, beta=0.4))):
+        pc = TR.PatchConfig(distribution=dist, min_scale=0.3, max_scale=0.9, mbstd_group_size=2, **extra)
+        np.random.seed(7)
+        torch.manual_seed(7)
+        pp = TR.sample_patch_params(8, pc, device='cpu')
+        np.testing.assert_array_equal(pp['scales'].numpy(), g[f'sp_{dist}_scales'])
+        np.testing.assert_array_equal(pp['offsets'].numpy(), g[f'sp_{dist}_offsets'])
+    pp0 = dict(scales=torch.from_numpy(g['pp0_scales']), offsets=torch.from_numpy(g['pp0_offsets']))
+    np.testing.assert_allclose(TR.extract_patches(torch.from_numpy(g['real']), pp0, 16).numpy(), g['patches'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(TR.maybe_blur(torch.from_numpy(g['real']), 1.3).numpy(), g['blurred'], rtol=0, atol=2e-6)
+    # schedule of the patch scale (loss.py:53-62)
+    pc = TR.PatchConfig(distribution='uniform', min_scale_trg=0.25, max_scale=1.0, anneal_kimg=100)
+    loss = TR.StyleGAN2Loss(None, None, 'cpu', patch_cfg=pc)
+    assert pc.min_scale == 1.0
+    loss.progressive_update(50)
+    assert abs(pc.min_scale - 0.625) < 1e-12
+    loss.progressive_update(500)
+    assert pc.min_scale == 0.25

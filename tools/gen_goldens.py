@@ -877,6 +877,102 @@ def gen_discriminator():
     save('discriminator', **arrays)
 
 
+def loss_golden_setup():
+    """Shared description of the loss golden: tiny generator rendered patch-wise at 16^2, patch-conditioned hyper-modulated
+    discriminator, dataset resolution 32."""
+    cfg = tdgp.config.config_tiny()
+    cfg.use_noise = False
+    cfg.patch_resolution = 16
+    dcfg = tdgp.discriminator.DiscriminatorConfig(c_dim=0, cbase=256, cmax=16, patch_params_cond=True, hyper_mod=True, mbstd_group_size=2)
+    return cfg, dcfg
+
+
+def gen_loss():
+    """StyleGAN2Loss.accumulate_gradients (loss.py:117-330) for the phases Gmain, Dmain, Dreg on tiny networks: the gradients left in
+    G / D after each phase, with every random draw (patch parameters, renderer draws) fixed."""
+    ot = types.ModuleType('ot')
+    sys.modules.setdefault('ot', ot)
+    from src.training import loss as ref_loss
+    from src.training.networks_discriminator import Discriminator as RefD
+    cfg, dcfg = loss_golden_setup()
+    B, S, res = 4, cfg.num_ray_steps, cfg.patch_resolution
+    R = res * res
+    sd = tdgp.weights.random_state_dict(cfg, seed=201, exercise_all=True)
+    rc = ref_cfg(cfg)
+    rc.patch = EasyDict(enabled=True, resolution=res)
+    rc.nerf_noise_std_init, rc.nerf_noise_kimg_growth = 0.0, 1
+    G = Generator(rc, img_resolution=cfg.img_resolution, img_channels=3, mapping_kwargs={}, num_fp16_res=0, conv_clamp=None, fused_modconv_default='inference_only')
+    G.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    G.train()
+    mineD = tdgp.discriminator.seeded_discriminator(dcfg, res, 3, seed=202)
+    rd = EasyDict(c_dim=0, cbase=dcfg.cbase, cmax=dcfg.cmax, fmaps=1.0, num_additional_start_blocks=0, patch=EasyDict(patch_params_cond=True), hyper_mod=True,
+                  camera_cond=False, camera_cond_drop_p=0.0, mbstd_group_size=2, logits_clamp_val=1e7)
+    D = RefD(rd, input_resolution=res, img_channels=3, num_fp16_res=0, conv_clamp=None, epilogue_kwargs=dict(mbstd_group_size=2))
+    D.load_state_dict(mineD.state_dict(), strict=True)
+    D.train()
+    full = EasyDict(model=EasyDict(loss_kwargs=EasyDict(blur_init_sigma=0, blur_fade_kimg=0, adv_loss_type='non_saturating', pl_weight=0.0, pl_start_kimg=0,
+                                                       kd=EasyDict(discr=EasyDict(weight=0.0, anneal_kimg=1, loss_type='l2'))),
+                               generator=EasyDict(camera_cond_spoof_p=0.5), discriminator=rd),
+                    training=EasyDict(patch=EasyDict(enabled=True, distribution='uniform', min_scale_trg=0.5, max_scale=1.0, anneal_kimg=10, resolution=res,
+                                                     mbstd_group_size=2, patch_params_cond=True),
+                                      learn_camera_dist=False, use_depth=False, blur_real_depth_sigma=0.0))
+    loss = ref_loss.StyleGAN2Loss(full, 'cpu', G, D, augment_pipe=None, r1_gamma=2.0)
+    g = np.random.RandomState(203)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=B, seed=204)
+    u1, u2 = g.rand(B, R, S, 1).astype(np.float32), g.rand(B * R, S).astype(np.float32)
+    real = g.randn(B, 3, 32, 32).astype(np.float32)
+    sx = g.uniform(0.5, 1.0, (3, B // 2)).astype(np.float32)
+    pps = []
+    for i in range(3):
+        sc = np.repeat(np.stack([sx[i], sx[i]], 1), 2, axis=0)
+        pps.append(dict(scales=sc, offsets=(np.repeat(g.rand(B // 2, 2).astype(np.float32), 2, axis=0) * (1 - sc)).astype(np.float32)))
+    arrays = dict(z=inp['z'], u_coarse=u1, u_fine=u2, real=real, **{'cam_' + k: v for k, v in inp['camera'].items()})
+    for i, pp in enumerate(pps):
+        arrays[f'pp{i}_scales'], arrays[f'pp{i}_offsets'] = pp['scales'], pp['offsets']
+    queue = []
+    ref_loss.sample_patch_params = lambda n, pcfg, device='cpu': {k: T(v) for k, v in queue.pop(0).items()}
+    cam = TensorGroup(**{k: T(v) for k, v in inp['camera'].items()})
+    c0 = torch.zeros(B, 0)
+
+    def run(phase, pp_list, n_render):
+        for m in (G, D):
+            m.zero_grad(set_to_none=True)
+        G.requires_grad_(phase.startswith('G'))
+        D.requires_grad_(phase.startswith('D'))
+        queue[:] = pp_list
+        real_data = TensorGroup(img=T(real), c=c0, depth=torch.zeros(B, 1, 32, 32), camera_angles=cam.angles)
+        gen_data = TensorGroup(z=T(inp['z']), c=c0, camera_params=cam, camera_angles_cond=cam.angles)
+        with PatchedRNG(rand_like=[T(u1)] * n_render, rand=[T(u2)] * n_render):
+            loss.accumulate_gradients(phase=phase, real_data=real_data, gen_data=gen_data, gain=1, cur_nimg=0)
+        assert not queue
+
+    run('Gmain', [pps[0]], 1)
+    for n, p in G.named_parameters():
+        if p.grad is not None:
+            arrays[f'Gmain::{n}'] = npy(p.grad)
+    run('Dmain', [pps[0], pps[1]], 1)
+    run2 = {n: npy(p.grad) for n, p in D.named_parameters() if p.grad is not None}
+    run('Dreg', [pps[2]], 0)
+    run3 = {n: npy(p.grad) for n, p in D.named_parameters() if p.grad is not None}
+    for tag, grads in (('Dmain', run2), ('Dreg', run3)):
+        for n, v in grads.items():
+            if v.size > 20000:
+                arrays[f'{tag}::rows::{n}'], arrays[f'{tag}::cols::{n}'] = v.sum(1), v.sum(0)
+            else:
+                arrays[f'{tag}::{n}'] = v
+    # patch sampling / extraction / blur (training_utils.py:22-143, loss.py:332-338) with seeded RNGs
+    from src.training import training_utils as ref_tu
+    for dist, extra in (('uniform', {}), ('beta', dict(alpha=1.0, beta=0.4))):
+        pc = EasyDict(distribution=dist, min_scale=0.3, max_scale=0.9, mbstd_group_size=2, **extra)
+        np.random.seed(7)
+        torch.manual_seed(7)
+        pp = ref_tu.sample_patch_params(8, pc, device='cpu')
+        arrays[f'sp_{dist}_scales'], arrays[f'sp_{dist}_offsets'] = npy(pp['scales']), npy(pp['offsets'])
+    arrays['patches'] = npy(ref_tu.extract_patches(T(real), {k: T(v) for k, v in pps[0].items()}, resolution=16))
+    arrays['blurred'] = npy(ref_loss.maybe_blur(T(real), 1.3))
+    save('loss', **arrays)
+
+
 class _GoldenDataset:
     """Stand-in for the reference's ImageFolder dataset in iterate_random_conditioning: labels and camera angles are pure
     functions of the item index."""
@@ -961,6 +1057,7 @@ def main():
     gen_harness()
     gen_synthesis_grad()
     gen_discriminator()
+    gen_loss()
     gen_train_forward()
     gen_bias_act()
     gen_bias_act_grad()
