@@ -37,6 +37,20 @@ def no_weight_gradients(disable=True):
     weight_gradients_disabled = old
 
 
+_fallback_seen = set()
+
+
+def _note_fallback(op, input, weight, stride, padding, groups):
+    """A GPU tensor taking the torch.nn.functional path is never silent: one warning per (op, form)."""
+    if isinstance(input, torch.Tensor) and input.is_cuda:
+        key = (op, tuple(weight.shape[2:]), str(stride), str(padding), groups, str(input.dtype))
+        if key not in _fallback_seen:
+            _fallback_seen.add(key)
+            import warnings
+            warnings.warn(f'conv2d_gradfix.{op}: kernel {tuple(weight.shape[2:])}, stride {stride}, padding {padding}, groups {groups}, {input.dtype} has no '
+                          f'native gfx950 form -- running torch.nn.functional (MIOpen), as the reference falls back to cuDNN', RuntimeWarning, stacklevel=3)
+
+
 def _pair(v):
     return (int(v), int(v)) if isinstance(v, int) else tuple(int(t) for t in v)
 
@@ -204,10 +218,12 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
         return _Conv2dSame.apply(input, weight, bias)
     if _strided_form(input, weight, stride, padding, dilation, groups):
         return _Conv2dStrided.apply(input, weight, bias, _pair(stride)[0], _pair(padding)[0])
+    _note_fallback('conv2d', input, weight, stride, padding, groups)
     return torch.nn.functional.conv2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding, dilation=dilation, groups=groups)
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
     """The reference's fallback form (conv2d_gradfix.py:41-44); the generator's x2 transposed convolution runs fused inside tdgp_modconv2d."""
+    _note_fallback('conv_transpose2d', input, weight, stride, padding, groups)
     return torch.nn.functional.conv_transpose2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding,
                                                 output_padding=output_padding, groups=groups, dilation=dilation)
