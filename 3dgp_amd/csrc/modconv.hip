@@ -1014,6 +1014,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
 
     float* const L0 = smem;
     float* const L1 = smem + BUF_SZ;
+#if TDGP_UP_ABL & 16
+    long long tseg[4] = {0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#endif
     if constexpr (!DEEP) {
         // single register set: the loads of iteration i+1 fly while iteration i multiplies
         if (it0 < it1) { load_stage(it0, 0); store_stage(0, L0, L0 + AS_SZ); }
@@ -1034,7 +1037,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
     load_stage(it0 + 2, 0);
     __syncthreads();
 #if TDGP_UP_ABL & 16
-    long long tseg[4] = {0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+    tprev = __builtin_readcyclecounter();
 #define TSEG(i) { const long long tn = __builtin_readcyclecounter(); tseg[i] += tn - tprev; tprev = tn; }
 #else
 #define TSEG(i)
