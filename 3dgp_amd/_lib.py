@@ -30,6 +30,7 @@ _PROTOTYPES = {
     'tdgp_conv2d': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'tdgp_conv2d_weight_grad_workspace_bytes': (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     'tdgp_conv2d_weight_grad': (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'tdgp_conv_transpose2d_x2': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_int64, P]),
     'tdgp_modconv_wsq_offset': (c_int64, [c_int, c_int, c_int]),
     'tdgp_demod_batch': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'tdgp_modconv2d': (c_int, [P, P, P, P, P, c_int64, P, POINTER(c_float), P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

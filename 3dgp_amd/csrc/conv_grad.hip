@@ -27,6 +27,7 @@ struct WGradParams {
     int B, Cin, Cout, H, W, OH, OW, k, stride, pad;
     int tiles_c;           // cdiv(Cin, 64)
     int rows, rows_per_slice;      // rows = B*OH
+    uint32_t x_bytes, dy_bytes;
 };
 
 constexpr int WG_PITCH = 33;
@@ -34,7 +35,7 @@ constexpr int WG_PITCH = 33;
 __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(WGradParams p) {
     __shared__ float As[64 * WG_PITCH];         // dy tile [o][px]
     __shared__ float Bs[64 * WG_PITCH];         // x tile  [c][px]
-    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, l32 = l & 31, half = l >> 5;
+    const int tid = threadIdx.x, l = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = l & 31, half = l >> 5;
     const int wm = wv >> 1, wn = wv & 1;
     const int o0 = (blockIdx.x / p.tiles_c) * 64, c0 = (blockIdx.x % p.tiles_c) * 64;
     const int tap = blockIdx.y, ky = tap / p.k, kx = tap - ky * p.k;
@@ -42,19 +43,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(WGradParams p) {
     const int chunks_per_row = (p.OW + 31) >> 5;
     const int nchunks = max(row_end - row_begin, 0) * chunks_per_row;
 
-    // this thread's 8 + 8 staged elements: tile row = (tid >> 5) + 8 * i, pixel = tid & 31
+    // this thread's 8 + 8 staged elements: tile row = (tid >> 5) + 8 * i, pixel = tid & 31.  Channel part of the byte offset fixed per
+    // thread (rows beyond Cout / Cin -> beyond the descriptor -> 0), position part one vector value per chunk, row/sample part scalar:
+    // the chunk -> (b, oy, ox) arithmetic runs on the scalar unit and each load is one instruction.
     const int px = tid & 31, r0 = tid >> 5;
+    constexpr uint32_t OOB = 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    uint32_t vo[8], vc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int o = o0 + r0 + 8 * i, c = c0 + r0 + 8 * i;
+        vo[i] = o < p.Cout ? (uint32_t)(o * p.OH * p.OW) * 4u : OOB;
+        vc[i] = c < p.Cin ? (uint32_t)(c * p.H * p.W) * 4u : OOB;
+    }
     float ra[8], rb[8];
     auto load_chunk = [&](int ch) {
-        const int row = row_begin + ch / chunks_per_row, ox = (ch % chunks_per_row) * 32 + px;
-        const int b = row / p.OH, oy = row - b * p.OH;
+        const int rr = __builtin_amdgcn_readfirstlane(ch / chunks_per_row);
+        const int row = row_begin + rr, ox = (ch - rr * chunks_per_row) * 32 + px;
+        const int b = row / p.OH, oy = row - b * p.OH;                                   // uniform (scalar unit)
         const int iy = oy * p.stride + ky - p.pad, ix = ox * p.stride + kx - p.pad;
         const bool oka = ox < p.OW, okb = oka && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const uint32_t pa = oka ? (uint32_t)ox * 4u : OOB, pb = okb ? (uint32_t)ix * 4u : OOB;       // OOB + channel offset stays out of range (wraps past 4 GiB are excluded on the host)
+        const uint32_t sa = (uint32_t)((b * p.Cout * p.OH + oy) * p.OW) * 4u, sb = (uint32_t)((b * p.Cin * p.H + (okb ? iy : 0)) * p.W) * 4u;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const int o = o0 + r0 + 8 * i, c = c0 + r0 + 8 * i;
-            ra[i] = (oka && o < p.Cout) ? p.dy[(((int64_t)b * p.Cout + o) * p.OH + oy) * p.OW + ox] : 0.f;
-            rb[i] = (okb && c < p.Cin) ? p.x[(((int64_t)b * p.Cin + c) * p.H + iy) * p.W + ix] : 0.f;
+            const uint32_t oa = (pa == OOB || vo[i] == OOB) ? OOB : vo[i] + pa, ob = (pb == OOB || vc[i] == OOB) ? OOB : vc[i] + pb;
+            ra[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdy, oa, sa, 0));
+            rb[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, ob, sb, 0));
         }
     };
 
@@ -117,6 +133,7 @@ struct ConvFwdParams {
     const float* x; const float* w; const float* bias; float* y;
     int B, Cin, Cout, H, W, OH, OW, k, stride, pad;
     int tiles_x;       // cdiv(OW, 64)
+    uint32_t x_bytes, w_bytes;
 };
 
 constexpr int CF_KC = 8, CF_APITCH = 65;
@@ -138,20 +155,42 @@ __global__ __launch_bounds__(256) void conv_strided_mfma_kernel(ConvFwdParams p)
     const int ncols = 63 * p.stride + K;                         // patch columns in use
     constexpr int NA = (T * CF_KC * 64 + 255) / 256, NB = (CF_KC * K * IWP + 255) / 256;
     float ra[NA], rb[NB];
+    // Loop-invariant per-thread byte offsets (out-of-range elements -> an offset beyond the descriptor: the load returns 0); per chunk
+    // only a SCALAR offset changes.  Computing the addresses inside the K loop cost ~300 vector-ALU instructions per chunk, each
+    // queued behind the other waves' 64-cycle MFMAs: several times the 36 MFMAs of the chunk themselves.
+    constexpr uint32_t OOB = 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    uint32_t va[NA], vb[NB];
+    int ca[NA], cb[NB];                                          // channel of the element inside a chunk (for the ragged last chunk)
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int e = tid + i * 256;                             // e = (o * KC + c) * T + tap: taps of one (o,c) are contiguous in memory
+        const int tap = e % T, oc = e / T, c = oc % CF_KC, o = oc / CF_KC;
+        ca[i] = c;
+        va[i] = (e < T * CF_KC * 64 && o0 + o < p.Cout) ? (uint32_t)(((o0 + o) * p.Cin + c) * T + tap) * 4u : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        const int e = tid + i * 256;
+        const int col = e % IWP, r = e / IWP, ky = r % K, c = r / K;
+        const int iy = iy0 + ky, ix = ix0 + col;
+        cb[i] = c;
+        vb[i] = (e < CF_KC * K * IWP && col < ncols && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? (uint32_t)(((b * p.Cin + c) * p.H + iy) * p.W + ix) * 4u : OOB;
+    }
+    const uint32_t hw4 = (uint32_t)(p.H * p.W) * 4u;
     auto load_chunk = [&](int c0) {
+        const uint32_t sa = (uint32_t)(c0 * T) * 4u, sb = (uint32_t)c0 * hw4;
+        const bool ragged = c0 + CF_KC > p.Cin;                  // uniform: only the last chunk of a Cin that is not a multiple of 8
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const int e = tid + i * 256;                         // e = (o * KC + c) * T + tap: taps of one (o,c) are contiguous in memory
-            const int tap = e % T, oc = e / T, c = oc % CF_KC, o = oc / CF_KC;
-            ra[i] = (e < T * CF_KC * 64 && o0 + o < p.Cout && c0 + c < p.Cin) ? p.w[((int64_t)(o0 + o) * p.Cin + c0 + c) * T + tap] : 0.f;
+            ra[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, va[i], sa, 0));
+            if (ragged && c0 + ca[i] >= p.Cin) ra[i] = 0.f;
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
-            const int e = tid + i * 256;
-            const int col = e % IWP, r = e / IWP, ky = r % K, c = r / K;
-            const int iy = iy0 + ky, ix = ix0 + col;
-            rb[i] = (e < CF_KC * K * IWP && col < ncols && c0 + c < p.Cin && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                        ? p.x[(((int64_t)b * p.Cin + c0 + c) * p.H + iy) * p.W + ix] : 0.f;
+            rb[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vb[i], sb, 0));
+            if (ragged && c0 + cb[i] >= p.Cin) rb[i] = 0.f;
         }
     };
     typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -206,6 +245,9 @@ TDGP_API int tdgp_conv2d(const float* x, const float* w, const float* bias, floa
     ConvFwdParams p;
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.k = k; p.stride = stride; p.pad = pad;
     p.tiles_x = cdiv(OW, 64);
+    TDGP_CHECK((int64_t)B * Cin * H * W < ((int64_t)1 << 30) && (int64_t)Cout * Cin * k * k < ((int64_t)1 << 30), TDGP_EINVAL,
+               "conv2d: tensor too large (addressed through 4 GiB buffer descriptors)");
+    p.x_bytes = (uint32_t)((int64_t)B * Cin * H * W * 4); p.w_bytes = (uint32_t)((int64_t)Cout * Cin * k * k * 4);
     const int64_t gx = (int64_t)p.tiles_x * OH * B;
     TDGP_CHECK(gx <= 2147483647LL, TDGP_EINVAL, "conv2d: too many tiles");
     const dim3 grid((unsigned)gx, cdiv(Cout, 64)), block(256);
@@ -233,6 +275,9 @@ TDGP_API int tdgp_conv2d_weight_grad(const float* x, const float* dy, float* dw,
     p.x = x; p.dy = dy; p.partial = (float*)workspace;
     p.B = B; p.Cin = Cin; p.Cout = Cout; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.k = k; p.stride = stride; p.pad = pad;
     p.tiles_c = cdiv(Cin, 64);
+    TDGP_CHECK((int64_t)B * Cin * H * W < ((int64_t)1 << 30) && (int64_t)B * Cout * OH * OW < ((int64_t)1 << 30), TDGP_EINVAL,
+               "conv2d_weight_grad: tensor too large (addressed through 4 GiB buffer descriptors)");
+    p.x_bytes = (uint32_t)((int64_t)B * Cin * H * W * 4); p.dy_bytes = (uint32_t)((int64_t)B * Cout * OH * OW * 4);
     p.rows = B * OH;
     const int ns = wgrad_slices(B, Cin, Cout, OH, k);
     p.rows_per_slice = cdiv(p.rows, ns);

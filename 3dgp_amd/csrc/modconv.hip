@@ -1564,6 +1564,24 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
     }
 }
 
+// Plain x2 transposed convolution: the parity-planar intermediate Z of upconv_mfma_kernel (split-K slices summed in order) gathered
+// into the NCHW tensor [B,C,2H+1,2W+1] -- conv_transpose2d(stride 2) without the FIR pass, for the input gradient of the stride-2
+// convolutions (conv2d_gradfix.py:126-129).
+__global__ __launch_bounds__(256) void z_gather_kernel(const float* __restrict__ z, float* __restrict__ y, int64_t rows, int OHt, int OWt, int P2, int GS2,
+                                                       int ksplit, int64_t zslice) {
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int i = (int)(r % OHt);
+        const int64_t bc = r / OHt;
+        const float* zp = z + bc * 2 * GS2 + (i & 1) * GS2 + (int64_t)(i >> 1) * P2;
+        float* yp = y + r * OWt;
+        for (int j = threadIdx.x; j < OWt; j += blockDim.x) {
+            float v = zp[j];
+            for (int k = 1; k < ksplit; k++) v += zp[k * zslice + j];
+            yp[j] = v;
+        }
+    }
+}
+
 // d[b,o] = rsqrt(sum_c s[b,c]^2 * wsq[c][o] + 1e-8)      (networks_stylegan2.py:62)
 // block (64 out-channels x 16 channel slices): coalesced wsq rows, 16-way split of the Cin loop, LDS tree at the end.
 __global__ __launch_bounds__(1024) void demod_kernel(const float* __restrict__ styles, const float* __restrict__ wsq, float* __restrict__ d, int B,
@@ -1984,6 +2002,32 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
             TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<32, 64>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
         }
     }
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}
+
+TDGP_API int tdgp_conv_transpose2d_x2(const float* x, const void* wpack, const float* styles, float* y, int B, int Cin, int Cout, int H, int W,
+                                      void* workspace, int64_t workspace_bytes, tdgp_stream_t stream) {
+    TDGP_CHECK(x && wpack && y, TDGP_EINVAL, "conv_transpose2d_x2: null pointer");
+    TDGP_CHECK(B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, TDGP_EINVAL, "conv_transpose2d_x2: bad shape");
+    TDGP_CHECK((int64_t)B * Cin * H * W < ((int64_t)1 << 30) && (int64_t)B * Cout * (H * 2 + 1) * (W * 2 + 1) <= INT32_MAX, TDGP_EINVAL,
+               "conv_transpose2d_x2: tensor too large (activations are addressed through 4 GiB buffer descriptors)");
+    const WsLayout wl = ws_layout(B, Cin, Cout, H, W, 3, 2);
+    TDGP_CHECK(workspace && workspace_bytes >= wl.total, TDGP_EWORKSPACE, "conv_transpose2d_x2: workspace %lld < %lld bytes", (long long)workspace_bytes,
+               (long long)wl.total);
+    hipStream_t s = (hipStream_t)stream;
+    const PackInfo pi = pack_info(Cout, Cin, 3);
+    float* z = (float*)((char*)workspace + wl.z);
+    const UpPlan pl = up_plan(B, Cin, Cout, H, W);
+    UpParams u;
+    u.x = x; u.wp = (const float*)wpack; u.styles = styles; u.z = z;
+    u.B = B; u.Cin = Cin; u.Cout = Cout; u.CoutP = pi.CoutP; u.H = H; u.W = W; u.G1 = pl.G1; u.GS = pl.GS; u.ksplit = pl.ksplit; u.zslice = pl.zslice;
+    u.x_bytes = (uint32_t)((int64_t)B * Cin * H * W * 4); u.wp_bytes = (uint32_t)(pi.wp_floats * 4); u.st_bytes = (uint32_t)((int64_t)B * Cin * 4);
+    if (pl.cfg == 0) launch_upconv<2, 1, 2, 2, true>(u, s);
+    else launch_upconv<2, 1, 1, 4, false>(u, s);
+    const int64_t rows = (int64_t)B * Cout * (2 * H + 1);
+    TDGP_LAUNCH("z_gather_kernel", z_gather_kernel, dim3((unsigned)min((int64_t)65535 * 8, rows)), dim3(256), 0, s, (const float*)z, y, rows, 2 * H + 1, 2 * W + 1,
+                2 * pl.G1, 2 * pl.GS, pl.ksplit, pl.zslice);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }

@@ -119,6 +119,44 @@ class _Conv2dGradWeight(torch.autograd.Function):
         return gg_grad_output, gg_input, None, None, None
 
 
+def conv_transpose2d_x2(x, weight):
+    """y [B,I,2h+1,2w+1] = conv_transpose2d(x [B,O,h,w], weight [O,I,3,3], stride 2): tdgp_conv_transpose2d_x2 (the polyphase MFMA kernel
+    of the up-sampling synthesis layers without its FIR pass)."""
+    _lib.require_cuda(x, 'x')
+    x = _lib.f32c(x)
+    B, O, h, w = x.shape
+    I = int(weight.shape[1])
+    packed = _modconv.PackedConv(weight.detach().transpose(0, 1).contiguous())           # [I,O,3,3]: "Cout" of the transposed op = I
+    y = torch.empty([B, I, 2 * h + 1, 2 * w + 1], dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nbytes = int(lib.tdgp_modconv2d_workspace_bytes(B, O, I, h, w, 3, 2))
+    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call('tdgp_conv_transpose2d_x2', x.data_ptr(), packed.buf.data_ptr(), None, y.data_ptr(), B, O, I, h, w, ws.data_ptr(), nbytes, _lib.stream_of(x))
+    return y
+
+
+class _ConvTranspose2dX2(torch.autograd.Function):
+    """The transposed 3x3 stride-2 convolution as a differentiable function: its adjoint pair is conv2d(., w, stride 2) and the weight
+    gradient with the roles of input and output gradient swapped."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return conv_transpose2d_x2(x, weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = conv2d(g, weight, None, stride=2, padding=0)
+        if ctx.needs_input_grad[1] and not weight_gradients_disabled:
+            gw = _Conv2dGradWeight.apply(x, g, weight.shape, 2, 0)
+        return gx, gw
+
+
 def _input_grad(grad_output, weight, input_hw, stride, padding):
     """Input gradient of conv2d(x, weight, stride, padding), itself differentiable w.r.t. grad_output and weight: expressed through
     `conv2d` again (flip / transpose / zero-stuffing are eager tensor ops autograd already knows)."""
@@ -128,6 +166,8 @@ def _input_grad(grad_output, weight, input_hw, stride, padding):
         return conv2d(grad_output, wt, None, stride=1, padding=padding)
     H, W = input_hw
     B, cout, OH, OW = grad_output.shape
+    if stride == 2 and k == 3 and padding == 0 and H == 2 * OH + 1 and W == 2 * OW + 1 and grad_output.is_cuda:
+        return _ConvTranspose2dX2.apply(grad_output, weight)              # no zero-stuffing: a quarter of the multiplies
     LH, LW = stride * (OH - 1) + 1, stride * (OW - 1) + 1
     lo = k - 1 - padding
     d = grad_output.new_zeros([B, cout, lo + LH + (H - LH + padding), lo + LW + (W - LW + padding)])

@@ -118,6 +118,13 @@ int     tdgp_modconv2d(const float* x, const void* wpack, const float* styles, c
                        int act, float alpha, float gain, float clamp, int out_layout, int out_feat,
                        void* workspace, int64_t workspace_bytes, tdgp_stream_t stream);
 
+/* Plain x2 transposed convolution (the adjoint of a 3x3 stride-2 convolution, conv2d_gradfix.py:126-129):
+ *   y [B,Cout,2H+1,2W+1] = conv_transpose2d(x * styles[:, :, None, None], w.transpose(0,1), stride=2),   w [Cout,Cin,3,3] packed by
+ * tdgp_modconv_pack (the weights of the up-sampling synthesis layers; for the input gradient of y' = conv2d(a, W, stride 2) pass
+ * x = dy' and w = W.transpose(0,1)).  styles may be NULL.  workspace: tdgp_modconv2d_workspace_bytes(B, Cin, Cout, H, W, 3, 2). */
+int     tdgp_conv_transpose2d_x2(const float* x, const void* wpack, const float* styles, float* y, int B, int Cin, int Cout,
+                                 int H, int W, void* workspace, int64_t workspace_bytes, tdgp_stream_t stream);
+
 /* Demodulation coefficients d[b,o] = rsqrt(sum_c s[b,c]^2 * sum_tap W[o,c,tap]^2 + 1e-8) (networks_stylegan2.py:62) of SEVERAL
  * layers in one launch.  meta: int64 [num_layers, 6] on the device = (address of the layer's sum_tap W^2 table, i.e. its wpack +
  * tdgp_modconv_wsq_offset(...) bytes; float offset of its [B,Cin] styles block in styles_all; Cin; Cout; Cout rounded up to 4;

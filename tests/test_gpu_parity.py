@@ -1073,3 +1073,21 @@ def test_stylegan2_loss_phases(tdgp):
         assert float(loss.stats['Loss/D/r1_penalty'].min()) > 0
     finally:
         TR.sample_patch_params = orig
+
+
+def test_conv_transpose2d_x2(tdgp):
+    """tdgp_conv_transpose2d_x2 (polyphase transposed conv without the FIR pass) = the adjoint of the 3x3 stride-2 convolution: against
+    torch's conv_transpose2d, and <conv2d(a, w, s2), g> == <a, convT(g, w)> with the library's own strided convolution."""
+    rs = np.random.RandomState(12)
+    cg = tdgp.ops.conv2d_gradfix
+    for B, O, I, h, w in ((2, 20, 12, 7, 9), (1, 130, 70, 16, 16), (3, 8, 64, 4, 4)):
+        x = T(rs.randn(B, O, h, w))
+        W = T(rs.randn(O, I, 3, 3))
+        y = cg.conv_transpose2d_x2(x, W)
+        ref = torch.nn.functional.conv_transpose2d(x.double(), W.double(), stride=2).float()
+        assert y.shape == ref.shape == (B, I, 2 * h + 1, 2 * w + 1)
+        assert_close(N(y), N(ref), 2e-5, 'conv_transpose2d_x2', 1.0)
+        a = T(rs.randn(B, I, 2 * h + 1, 2 * w + 1))
+        lhs = float((cg.conv2d_strided(a, W, stride=2, padding=0).double() * x.double()).sum())
+        rhs = float((a.double() * y.double()).sum())
+        assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0)

@@ -43,3 +43,7 @@ for name, module, opt in (('Gmain', G, optG), ('Dmain', D, optD), ('Dreg', D, op
     for _ in range(3): phase(name, module, opt)
     torch.cuda.synchronize(); print(f'  {name}: {(time.time() - t0) / 3 * 1e3:.1f} ms')
 print('  losses', {k: float(v.mean()) for k, v in loss.stats.items()})
+for name, module, opt in (('Gmain', G, optG), ('Dmain', D, optD), ('Dreg', D, optD)):
+    t._lib.profile_enable(True); phase(name, module, opt); torch.cuda.synchronize(); r = t._lib.profile_report(); t._lib.profile_enable(False)
+    tot = sum(v['total_ms'] for v in r.values())
+    print(f'  {name}: HIP kernels {tot:.1f} ms:', ', '.join(f"{k.replace('_kernel','')} {v['total_ms']:.1f}" for k, v in sorted(r.items(), key=lambda kv: -kv[1]['total_ms'])[:9]))
