@@ -94,7 +94,7 @@ class EasyDict(dict):
 
 
 def install_src_aliases(override=True):
-    """Register `src.torch_utils.ops.{bias_act,upfirdn2d,conv2d_resample}`, `src.torch_utils.custom_ops` and
+    """Register `src.torch_utils.ops.{bias_act,upfirdn2d,conv2d_resample,conv2d_gradfix,fma}`, `src.torch_utils.custom_ops` and
     `src.dnnlib` (when no real one exists).  Returns the list of module names it (re)bound."""
     bound = []
 
@@ -113,7 +113,9 @@ def install_src_aliases(override=True):
 
     for pkg in ('src', 'src.torch_utils', 'src.torch_utils.ops'):
         ensure_pkg(pkg)
-    for leaf, mod in (('bias_act', _bias_act), ('upfirdn2d', _upfirdn2d), ('conv2d_resample', _conv2d_resample)):
+    from .ops import conv2d_gradfix as _conv2d_gradfix, fma as _fma
+    for leaf, mod in (('bias_act', _bias_act), ('upfirdn2d', _upfirdn2d), ('conv2d_resample', _conv2d_resample), ('conv2d_gradfix', _conv2d_gradfix),
+                      ('fma', _fma)):
         name = f'src.torch_utils.ops.{leaf}'
         if override or name not in sys.modules:
             sys.modules[name] = mod

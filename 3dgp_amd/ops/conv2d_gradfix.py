@@ -23,6 +23,7 @@ import torch
 from .. import _lib
 from . import modconv as _modconv
 
+enabled = True                              # conv2d_gradfix.py:23 (the reference's switch between its custom op and torch; always on here)
 weight_gradients_disabled = False           # conv2d_gradfix.py:24
 
 

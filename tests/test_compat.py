@@ -20,7 +20,8 @@ import importlib, sys
 sys.path.insert(0, %r)
 t = importlib.import_module("3dgp_amd")
 bound = t.compat.install_src_aliases()
-from src.torch_utils.ops import bias_act, upfirdn2d, conv2d_resample
+from src.torch_utils.ops import bias_act, upfirdn2d, conv2d_resample, conv2d_gradfix, fma
+assert conv2d_gradfix is t.ops.conv2d_gradfix and fma is t.ops.fma and conv2d_gradfix.enabled and callable(conv2d_gradfix.no_weight_gradients)
 from src.torch_utils import custom_ops
 from src.dnnlib import EasyDict, TensorGroup
 assert bias_act is t.ops.bias_act and upfirdn2d is t.ops.upfirdn2d and conv2d_resample is t.ops.conv2d_resample
