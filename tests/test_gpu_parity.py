@@ -1091,3 +1091,21 @@ def test_conv_transpose2d_x2(tdgp):
         lhs = float((cg.conv2d_strided(a, W, stride=2, padding=0).double() * x.double()).sum())
         rhs = float((a.double() * y.double()).sum())
         assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0)
+
+
+def test_c4_forward_properties(tdgp):
+    """BASELINE configs[3] (cmax 1024 / cbase 65536: 1024-channel layers, twice the K depth of the benchmark configuration): the
+    forward runs, is finite and bit-reproducible, and the backbone agrees between its two output layouts."""
+    cfg = tdgp.config.config_c4()
+    G = _gen(tdgp, cfg, 3)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=1, seed=4)
+    cam = {k: T(v) for k, v in inp['camera'].items()}
+    kw = dict(noise_mode='const', u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']))
+    a = G(T(inp['z']), T(inp['c']), cam, **kw)
+    b = G(T(inp['z']), T(inp['c']), cam, **kw)
+    assert a.shape == (1, 3, 256, 256) and bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    ws = G.mapping(T(inp['z']), T(inp['c']))
+    dec = G.synthesis.tri_plane_decoder
+    nchw = dec(ws, noise_mode='const')
+    hwc = dec(ws, noise_mode='const', hwc=True).t
+    assert_close(N(hwc.permute(0, 1, 4, 2, 3).reshape(nchw.shape)), N(nchw), 5e-6, 'planes channel-last vs NCHW (c4)', 1.0)
