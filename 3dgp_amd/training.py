@@ -225,3 +225,81 @@ def optimizer_step(module, opt, world=None, grad_clip=None):
     if grad_clip is not None:
         torch.nn.utils.clip_grad_norm_(params, grad_clip)
     opt.step()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# training_loop.py:170-210, 319-372: the pieces of the driver that touch the device
+# ----------------------------------------------------------------------------------------------------------------------
+def broadcast_module(module, src=0):
+    """training_loop.py:173-177: every rank starts from rank 0's parameters and buffers (RCCL broadcast, one tensor at a time)."""
+    import torch.distributed as dist
+    if module is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src)
+
+
+def setup_phases(G, D, G_opt_kwargs, D_opt_kwargs, G_reg_interval=None, D_reg_interval=16, pl_weight=0.0, opt_class=torch.optim.Adam):
+    """training_loop.py:180-205: one optimiser per network; with lazy regularisation (reg_interval > 0) the learning rate and the Adam
+    betas are rescaled by mb_ratio = interval / (interval + 1) and the regulariser gets its own phase every `interval` batches.
+    -> list of dict(name, module, opt, interval)."""
+    phases = []
+    for name, module, opt_kwargs, reg_interval in (('G', G, G_opt_kwargs, G_reg_interval), ('D', D, D_opt_kwargs, D_reg_interval)):
+        if reg_interval in (None, 0):
+            phases.append(dict(name=name + 'all', module=module, opt=opt_class(module.parameters(), **opt_kwargs), interval=1))
+            continue
+        mb_ratio = reg_interval / (reg_interval + 1)
+        kw = dict(opt_kwargs)
+        kw['lr'] = kw['lr'] * mb_ratio
+        kw['betas'] = [beta ** mb_ratio for beta in kw['betas']]
+        opt = opt_class(module.parameters(), **kw)
+        phases.append(dict(name=name + 'main', module=module, opt=opt, interval=1))
+        if name == 'G':
+            assert pl_weight > 0, 'a G regularisation phase needs the path-length regulariser'
+            phases.append(dict(name='Greg_pl', module=module, opt=opt, interval=reg_interval))
+        else:
+            phases.append(dict(name='Dreg', module=module, opt=opt, interval=reg_interval))
+    return phases
+
+
+@torch.no_grad()
+def update_ema(G_ema, G, cur_nimg, batch_size, ema_kimg=10.0, ema_rampup=0.05, ema_start_kimg=0.0):
+    """training_loop.py:357-367: half-life of `ema_kimg` thousand images, ramped up with the number of images seen; buffers copied."""
+    ema_nimg = ema_kimg * 1000
+    if ema_rampup is not None:
+        ema_nimg = min(ema_nimg, cur_nimg * ema_rampup)
+    ema_beta = 0.5 ** (batch_size / max(ema_nimg, 1e-8))
+    if ema_start_kimg > cur_nimg / 1000:
+        ema_beta = 0.0
+    for p_ema, p in zip(G_ema.parameters(), G.parameters()):
+        p_ema.copy_(p.lerp(p_ema, ema_beta))
+    for b_ema, b in zip(G_ema.buffers(), G.buffers()):
+        b_ema.copy_(b)
+    return ema_beta
+
+
+def _split(group, n):
+    """TensorGroup.split(n) of the reference: per-key torch.split, regrouped."""
+    keys = list(group.keys())
+    parts = {k: (group[k].split(n) if isinstance(group[k], TensorGroup) else torch.split(group[k], n)) for k in keys}
+    count = len(next(iter(parts.values())))
+    return [TensorGroup(**{k: parts[k][i] for k in keys}) for i in range(count)]
+
+
+def train_iteration(loss, phases, real_data, all_gen_data, batch_idx, cur_nimg, batch_size, batch_gpu, world=None, grad_clip=None):
+    """training_loop.py:319-347: every phase whose interval divides `batch_idx` zeroes its gradients, accumulates them over the
+    rank's sub-batches of `batch_gpu`, exchanges them (flat all-reduce) and steps.  `all_gen_data` holds `len(phases) * batch_size`
+    latent / camera samples, one `batch_size` slice per phase.  Returns the names of the phases that ran."""
+    ran = []
+    for phase, gen_data in zip(phases, _split(all_gen_data, batch_size)):
+        if batch_idx % phase['interval'] != 0:
+            continue
+        phase['opt'].zero_grad(set_to_none=True)
+        phase['module'].requires_grad_(True)
+        for r, g in zip(_split(real_data, batch_gpu), _split(gen_data, batch_gpu)):
+            loss.accumulate_gradients(phase=phase['name'], real_data=r, gen_data=g, gain=phase['interval'], cur_nimg=cur_nimg)
+        phase['module'].requires_grad_(False)
+        clip = grad_clip if phase['name'] in ('Gmain', 'Gall', 'Greg_pl') else None
+        optimizer_step(phase['module'], phase['opt'], world=world, grad_clip=clip)
+        ran.append(phase['name'])
+    return ran

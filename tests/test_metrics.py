@@ -196,3 +196,54 @@ def test_training_utils(tdgp):
     assert abs(pc.min_scale - 0.625) < 1e-12
     loss.progressive_update(500)
     assert pc.min_scale == 0.25
+
+
+def test_training_driver_pieces(tdgp):
+    """setup_phases (lazy-regularisation rescaling, training_loop.py:180-205), update_ema (:357-367) and train_iteration (:319-347: phase
+    intervals, sub-batch accumulation, one optimiser step per phase) on small CPU modules with a recording loss."""
+    import copy
+    import torch
+    TR = tdgp.training
+    torch.manual_seed(0)
+    G, D = torch.nn.Linear(4, 3), torch.nn.Linear(3, 1)
+    phases = TR.setup_phases(G, D, dict(lr=0.0025, betas=[0.0, 0.99], eps=1e-8), dict(lr=0.002, betas=[0.0, 0.99], eps=1e-8), G_reg_interval=None,
+                             D_reg_interval=16)
+    assert [p['name'] for p in phases] == ['Gall', 'Dmain', 'Dreg'] and [p['interval'] for p in phases] == [1, 1, 16]
+    assert phases[1]['opt'] is phases[2]['opt']
+    g = phases[1]['opt'].param_groups[0]
+    assert abs(g['lr'] - 0.002 * 16 / 17) < 1e-12 and abs(g['betas'][1] - 0.99 ** (16 / 17)) < 1e-12 and g['betas'][0] == 0.0
+    assert phases[0]['opt'].param_groups[0]['lr'] == 0.0025
+    # EMA: beta = 0.5 ** (batch / min(ema_kimg * 1000, cur_nimg * rampup)); buffers copied
+    G_ema = copy.deepcopy(G)
+    with torch.no_grad():
+        for p in G.parameters():
+            p.add_(1.0)
+    before = [p.clone() for p in G_ema.parameters()]
+    beta = TR.update_ema(G_ema, G, cur_nimg=20000, batch_size=64, ema_kimg=10.0, ema_rampup=0.05)
+    assert abs(beta - 0.5 ** (64 / 1000.0)) < 1e-12
+    for pe, p, b in zip(G_ema.parameters(), G.parameters(), before):
+        assert torch.allclose(pe, p + (b - p) * beta, atol=1e-6)
+    assert TR.update_ema(G_ema, G, cur_nimg=500, batch_size=64, ema_start_kimg=1.0) == 0.0
+    assert all(torch.equal(pe, p) for pe, p in zip(G_ema.parameters(), G.parameters()))
+
+    class _Loss:
+        def __init__(self):
+            self.calls = []
+
+        def accumulate_gradients(self, phase, real_data, gen_data, gain, cur_nimg):
+            self.calls.append((phase, tuple(real_data.img.shape), tuple(gen_data.z.shape), gain))
+            module = G if phase.startswith('G') else D
+            assert all(p.requires_grad for p in module.parameters())
+            (sum(p.sum() for p in module.parameters()) * gain).backward()
+
+    TG = tdgp.generator.TensorGroup
+    loss = _Loss()
+    real = TG(img=torch.zeros(8, 3, 4, 4), c=torch.zeros(8, 0))
+    gen = TG(z=torch.arange(24.).view(24, 1), c=torch.zeros(24, 0), camera_params=TG(angles=torch.zeros(24, 3), fov=torch.zeros(24)))
+    w0 = D.weight.detach().clone()
+    assert TR.train_iteration(loss, phases, real, gen, batch_idx=3, cur_nimg=0, batch_size=8, batch_gpu=4, world=1) == ['Gall', 'Dmain']
+    assert [c[0] for c in loss.calls] == ['Gall', 'Gall', 'Dmain', 'Dmain'] and loss.calls[0][1] == (4, 3, 4, 4) and loss.calls[2][2] == (4, 1)
+    assert not torch.equal(D.weight, w0) and not any(p.requires_grad for p in D.parameters())
+    loss.calls.clear()
+    assert TR.train_iteration(loss, phases, real, gen, batch_idx=16, cur_nimg=0, batch_size=8, batch_gpu=8, world=1) == ['Gall', 'Dmain', 'Dreg']
+    assert loss.calls[-1][0] == 'Dreg' and loss.calls[-1][3] == 16
