@@ -31,6 +31,7 @@ _PROTOTYPES = {
     'tdgp_conv2d_weight_grad_workspace_bytes': (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     'tdgp_conv2d_weight_grad': (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'tdgp_conv_transpose2d_x2': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_int64, P]),
+    'tdgp_set_conv_arith': (c_int, [c_int]),
     'tdgp_modconv_wsq_offset': (c_int64, [c_int, c_int, c_int]),
     'tdgp_demod_batch': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'tdgp_modconv2d': (c_int, [P, P, P, P, P, c_int64, P, POINTER(c_float), P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -136,3 +137,14 @@ def profile_report():
         name, n, tot, mn, mx = line.split()
         out[name] = dict(launches=int(n), total_ms=float(tot), avg_ms=float(tot) / max(int(n), 1), min_ms=float(mn), max_ms=float(mx))
     return out
+
+
+def set_conv_arith(mode):
+    """0 (default): fp32 MFMA; 1: split-bf16 (3 x bf16 pieces per operand, 6 piece products, fp32 accumulation) for the 3x3 stride-1
+    convolutions with W % 32 == 0 and >= 256 output tiles.  Process-wide; returns the previous mode."""
+    lib = load()
+    prev = int(lib.tdgp_set_conv_arith(int(mode)))
+    if prev < 0:
+        msg = lib.tdgp_last_error()
+        raise RuntimeError(f'tdgp_set_conv_arith failed ({prev}): {msg.decode() if msg else "?"}')
+    return prev

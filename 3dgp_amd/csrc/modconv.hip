@@ -1134,6 +1134,254 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
     }
 }
 
+// =================================================================================================================================
+// OPT-IN arithmetic (tdgp_set_conv_arith(1); the default path is the fp32 kernel above): 3x3 stride-1 convolution with every fp32
+// operand split into three bf16 pieces (8 + 8 + 8 mantissa bits: hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = top 16 bits
+// of x - hi - mid; all differences exact) and the product formed from the six leading piece products
+//     a*b ~= a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0)            dropped terms <= 3 * 2^-24 |a b|
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-grade results at 16/6 = 2.7x the fp32 MFMA rate.  Not bit-compatible with
+// an fp32 FMA chain (neither is the fp32 MFMA with the CPU), hence opt-in.
+// Block = 64 output channels x 8 virtual rows x 32 columns, 4 waves (1 x 4), wave tile 2 x 2; K chunk = 16 channels.  Weights are
+// pre-split at pack time [chunk16][tap][piece][CoutP][16 bf16]; activations are split while they are staged (style scale first)
+// into [piece][position][16 bf16].  A lane's fragment = 8 consecutive channels (16 B) of its column: channels 8*half .. +7 for
+// both operands, so the hardware's order of the 16 k's inside the instruction does not matter.  LDS: weight stage 54 KB +
+// activation stage 32 KB, single-buffered (one block per CU): the next chunk's loads are in flight during the 216 MFMAs of a chunk.
+// =================================================================================================================================
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+struct Conv3sParams {
+    const float* x; const void* wsp; const float* styles;
+    EpiParams e;
+    int B, Cin, Cout, CoutP, H, W;
+    uint32_t x_bytes, wsp_bytes, st_bytes;
+};
+
+__device__ __forceinline__ void split3(float v, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = __float_as_uint(v) & 0xFFFF0000u;
+    const float r1 = v - __uint_as_float(hi);
+    mid = __float_as_uint(r1) & 0xFFFF0000u;
+    lo = __float_as_uint(r1 - __uint_as_float(mid)) & 0xFFFF0000u;
+}
+
+__global__ __launch_bounds__(256) void conv3s_mfma_kernel(Conv3sParams p) {
+    constexpr int R = 1, T = 9, MTW = 2, NTW = 2, WN = 4, BM = 64, NT = NTW * WN, PR = NT + 2, PC = 34, PSZ = PR * PC;
+    constexpr int AS_BYTES = T * 3 * BM * 32, XS_BYTES = 3 * PSZ * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* As = (char*)smem;
+    char* Xs = As + AS_BYTES;
+    float* side = (float*)(Xs + XS_BYTES);                          // [1 + NSB][BM]
+    const int H1 = p.H + R;
+    const int tilesX = p.W >> 5, VR = p.B * H1;
+    const int ty = blockIdx.x / tilesX, tx = blockIdx.x % tilesX;
+    const int vr0 = ty * NT, n0 = tx * 32, m0 = blockIdx.y * BM;
+    const int tid = threadIdx.x, l = tid & 63, wv = TDGP_WAVE_INDEX(tid), l32 = l & 31, half = l >> 5;
+    const int wn = wv;
+
+    constexpr int NSB = 4;
+    const int sb0 = vr0 / H1, sb1 = min(p.B - 1, (vr0 + NT - 1) / H1);
+    const bool side_ok = (sb1 - sb0 + 1) <= NSB;
+    if (side_ok) {
+        for (int i = tid; i < (2 + sb1 - sb0) * BM; i += 256) {
+            const int slab = i / BM, o = m0 + i % BM;
+            float v = slab == 0 ? 0.f : 1.f;
+            if (o < p.e.Cout) {
+                if (slab == 0) { if (p.e.bias) v = p.e.bias[o]; }
+                else if (p.e.dcoef) v = p.e.dcoef[(sb0 + slab - 1) * p.e.Cout + o];
+            }
+            side[i] = v;
+        }
+    }
+
+    constexpr int NPOS = (PSZ + 255) / 256;
+    uint32_t pos_xo[NPOS], pos_so[NPOS];
+#pragma unroll
+    for (int k = 0; k < NPOS; k++) {
+        const int pos = tid + k * 256;
+        pos_xo[k] = kOOB; pos_so[k] = kOOB;
+        if (pos < PSZ) {
+            const int pr = pos / PC, pc = pos % PC;
+            const int vi = vr0 - R + pr, ix = n0 - R + pc;
+            if (vi >= 0 && ix >= 0 && ix < p.W) {
+                const int b = vi / H1, m = vi - b * H1;
+                if (b < p.B && m < p.H) { pos_xo[k] = (uint32_t)(((b * p.Cin) * p.H + m) * p.W + ix) * 4u; pos_so[k] = (uint32_t)(b * p.Cin) * 4u; }
+            }
+        }
+    }
+    const uint32_t chw4 = (uint32_t)(p.H * p.W) * 4u;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.wsp, p.wsp_bytes), rs = make_rsrc(p.styles ? p.styles : p.x, p.styles ? p.st_bytes : 0);
+
+    f32x16 acc[MTW][NTW];
+#pragma unroll
+    for (int m = 0; m < MTW; m++)
+#pragma unroll
+        for (int n = 0; n < NTW; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+
+    const int niter = (p.Cin + 15) >> 4;
+    constexpr int NA = (T * 3 * BM * 2 + 255) / 256;              // 16-B vectors of the weight stage per thread
+    float4 a_reg[NA];
+    float x_reg[NPOS][16];
+    float4 s_reg[NPOS][4];
+    uint32_t a_vo[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int e = tid + i * 256;
+        a_vo[i] = kOOB;
+        if (e < T * 3 * BM * 2) {
+            const int tp = e / (BM * 2), rem = e % (BM * 2), col = rem >> 1, hf = rem & 1;
+            if (m0 + col < p.CoutP) a_vo[i] = (uint32_t)((tp * p.CoutP + m0 + col) * 2 + hf) * 16u;
+        }
+    }
+    const uint32_t a_gstride = (uint32_t)(T * 3 * p.CoutP) * 32u;
+    auto load_stage = [&](int it) {
+        const int itc = min(it, niter - 1);
+        const uint32_t a_so = (uint32_t)itc * a_gstride;
+#pragma unroll
+        for (int i = 0; i < NA; i++) a_reg[i] = buf_load4(rw, a_vo[i], a_so);
+        const uint32_t c0 = (uint32_t)itc * 16u, cl = (uint32_t)(p.Cin - 1);
+#pragma unroll
+        for (int k = 0; k < NPOS; k++) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) x_reg[k][j] = buf_load1(rx, pos_xo[k], min(c0 + j, cl) * chw4);
+            // (no branches in here: a load under a condition makes the compiler wait for ALL loads at the join -- the host only takes
+            //  this kernel with styles present and Cin % 4 == 0)
+#pragma unroll
+            for (int q = 0; q < 4; q++) s_reg[k][q] = buf_load4(rs, pos_so[k], min(c0 + 4 * q, cl & ~3u) * 4u);
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+            if (tid + i * 256 < T * 3 * BM * 2) *(float4*)(As + (tid + i * 256) * 16) = a_reg[i];
+#pragma unroll
+        for (int k = 0; k < NPOS; k++) {
+            const int pos = tid + k * 256;
+            if (pos < PSZ) {
+                uint32_t pk[3][8];
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) {
+                    float v0 = x_reg[k][j], v1 = x_reg[k][j + 1];
+                    const float4 sq = s_reg[k][j >> 2];
+                    v0 *= (j & 2) ? sq.z : sq.x; v1 *= (j & 2) ? sq.w : sq.y;
+                    uint32_t h0, m0_, l0, h1, m1, l1;
+                    split3(v0, h0, m0_, l0); split3(v1, h1, m1, l1);
+                    pk[0][j >> 1] = (h0 >> 16) | h1; pk[1][j >> 1] = (m0_ >> 16) | m1; pk[2][j >> 1] = (l0 >> 16) | l1;
+                }
+#pragma unroll
+                for (int pc_ = 0; pc_ < 3; pc_++) {
+                    uint4* d = (uint4*)(Xs + (pc_ * PSZ + pos) * 32);
+                    d[0] = make_uint4(pk[pc_][0], pk[pc_][1], pk[pc_][2], pk[pc_][3]);
+                    d[1] = make_uint4(pk[pc_][4], pk[pc_][5], pk[pc_][6], pk[pc_][7]);
+                }
+            }
+        }
+    };
+    auto frag = [&](const char* ptr) { const uint4 v = *(const uint4*)ptr; bf16x8_t r; __builtin_memcpy(&r, &v, 16); return r; };
+    const int a_lane = l32 * 32 + half * 16;                                        // + ((tap*3 + piece)*BM + m*32) * 32
+    const int b_lane = ((wn * NTW + R) * PC + l32 + R) * 32 + half * 16;           // centre tap of subtile 0; + (piece*PSZ + (n + dy)*PC + dx) * 32
+    auto mma = [&]() {
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            const int dy = t / 3 - R, dx = t % 3 - R;
+            bf16x8_t fa[3][MTW], fb[3][NTW];
+#pragma unroll
+            for (int pc_ = 0; pc_ < 3; pc_++) {
+#pragma unroll
+                for (int m = 0; m < MTW; m++) fa[pc_][m] = frag(As + a_lane + ((t * 3 + pc_) * BM + m * 32) * 32);
+#pragma unroll
+                for (int n = 0; n < NTW; n++) fb[pc_][n] = frag(Xs + b_lane + (pc_ * PSZ + (n + dy) * PC + dx) * 32);
+            }
+            // piece products outermost (smallest terms first), the four tiles inside: consecutive MFMAs are independent -- with the
+            // six products of one tile back to back each instruction waited for the result of the one before
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; q++)
+#pragma unroll
+                for (int m = 0; m < MTW; m++)
+#pragma unroll
+                    for (int n = 0; n < NTW; n++) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]][m], fb[PB[q]][n], acc[m][n], 0, 0, 0);
+        }
+    };
+
+#if TDGP_C3_ABL & 32
+    long long ts[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define TS(i) { const long long tn_ = __builtin_readcyclecounter(); ts[i] += tn_ - tprev; tprev = tn_; }
+#else
+#define TS(i)
+#endif
+    load_stage(0);
+    TS(0)
+    for (int it = 0; it < niter; it++) {
+        __syncthreads();                        // the previous chunk's fragments have been read
+        TS(1)
+        store_stage();
+        TS(2)
+        __syncthreads();
+        TS(1)
+        load_stage(it + 1);                     // unconditional (clamped): in flight during this chunk's MFMAs
+        TS(3)
+        mma();
+        TS(4)
+    }
+    __syncthreads();
+#if TDGP_C3_ABL & 32
+    if (tid == 0 && (blockIdx.x == 3 || blockIdx.x == 400) && blockIdx.y == 0)
+        printf("conv3s blk %d iters %d: prologue %lld barrier %lld store(+load wait) %lld load-issue %lld mma %lld\n", (int)blockIdx.x, niter, ts[0], ts[1], ts[2], ts[3], ts[4]);
+#endif
+#undef TS
+
+    float* ct = smem + wv * (32 * CT_LD);
+    const EpiParams& e = p.e;
+    SideCache scache;
+    scache.lds = side_ok ? side : nullptr; scache.b0 = sb0; scache.bm = BM; scache.m0 = m0;
+    const int evar = epi_variant(e);
+#pragma unroll 1
+    for (int tile = 0; tile < MTW * NTW; tile++) {
+#pragma unroll
+        for (int k = 0; k < MTW * NTW; k++) {
+            if (tile == k) {
+                constexpr int dummy = 0; (void)dummy;
+#pragma unroll
+                for (int r = 0; r < 16; r++) ct[((r & 3) + 8 * (r >> 2) + 4 * half) * CT_LD + l32] = acc[k % MTW][k / MTW][r];
+            }
+        }
+        const int m = tile % MTW, n = tile / MTW;
+        const int vi = vr0 + wn * NTW + n;
+        const int pb = vi / H1, poy = vi - pb * H1;
+        const int pok = (vi < VR && poy < p.H) ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (evar == 3) epilogue_tile<false, 3>(e, scache, ct, m0 + m * 32, pb, poy, n0 + l32, pok, nullptr, true);
+        else if (evar == 1) epilogue_tile<false, 1>(e, scache, ct, m0 + m * 32, pb, poy, n0 + l32, pok, nullptr, true);
+        else epilogue_tile<false, 0>(e, scache, ct, m0 + m * 32, pb, poy, n0 + l32, pok, nullptr, true);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// weight [Cout,Cin,3,3] -> split pack [chunk16][tap][piece][CoutP][16 bf16] (zero beyond Cout / Cin)
+__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, uint32_t* __restrict__ wsp, int Cout, int Cin, int CoutP, int niter) {
+    const int64_t total = (int64_t)niter * 9 * 3 * CoutP * 8;                 // u32 words (2 bf16 each)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int jp = (int)(i % 8);                                          // channel pair inside the column's 16 channels
+        int64_t r = i / 8;
+        const int col = (int)(r % CoutP); r /= CoutP;
+        const int piece = (int)(r % 3); r /= 3;
+        const int tap = (int)(r % 9);
+        const int it = (int)(r / 9);
+        uint32_t out = 0;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int c = it * 16 + 2 * jp + q;
+            const float v = (col < Cout && c < Cin) ? w[((int64_t)col * Cin + c) * 9 + tap] : 0.f;
+            uint32_t pc[3];
+            split3(v, pc[0], pc[1], pc[2]);
+            out |= q == 0 ? (pc[piece] >> 16) : pc[piece];
+        }
+        wsp[i] = out;
+    }
+}
+
 // Output stage of the ToRGB kernel for one 32(pixels) x 32(channels) tile parked PIXEL-major in `ct`: bias + x2-FIR-upsampled skip
 // (upfirdn2d.py:313-348), * gain, clamp, channel-last float4 stores.  lane = (pixel l>>3 of the pass, channel quad l&7).
 // One straight-line block -- 16 tap loads, 4 LDS reads, the math, 4 stores -- with selects instead of branches: with the
@@ -1676,7 +1924,7 @@ __global__ __launch_bounds__(256) void style_affine_kernel(const float* __restri
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
-struct PackInfo { int T, KC, CoutP, nchunks; int64_t wp_floats, wsq_floats; };
+struct PackInfo { int T, KC, CoutP, nchunks, niter16; int64_t wp_floats, wsq_floats, wsplit_floats; };
 inline PackInfo pack_info(int Cout, int Cin, int k) {
     PackInfo pi;
     pi.T = k * k;
@@ -1685,6 +1933,8 @@ inline PackInfo pack_info(int Cout, int Cin, int k) {
     pi.nchunks = round_up((Cin + pi.KC - 1) / pi.KC, k == 1 ? 16 : 2);      // zero-padded to whole K iterations (1x1 kernels stage up to 16 chunks)
     pi.wp_floats = (int64_t)pi.nchunks * pi.T * pi.KC * pi.CoutP;
     pi.wsq_floats = (int64_t)Cin * pi.CoutP;
+    pi.niter16 = (Cin + 15) / 16;
+    pi.wsplit_floats = k == 3 ? (int64_t)pi.niter16 * 9 * 3 * pi.CoutP * 8 : 0;      // split-bf16 copy of the 3x3 weights (opt-in arithmetic)
     return pi;
 }
 
@@ -1869,7 +2119,7 @@ WsLayout ws_layout(int B, int Cin, int Cout, int H, int W, int k, int up) {
 TDGP_API int64_t tdgp_modconv_pack_bytes(int Cout, int Cin, int k) {
     if (Cout < 1 || Cin < 1 || (k != 1 && k != 3 && k != 5)) return -1;
     const PackInfo pi = pack_info(Cout, Cin, k);
-    return (pi.wp_floats + pi.wsq_floats) * (int64_t)sizeof(float);
+    return (pi.wp_floats + pi.wsq_floats + pi.wsplit_floats) * (int64_t)sizeof(float);
 }
 
 TDGP_API int tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int Cin, int k, tdgp_stream_t stream) {
@@ -1880,8 +2130,19 @@ TDGP_API int tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int C
     float* wp = (float*)wpack;
     TDGP_LAUNCH("pack_kernel", pack_kernel, dim3((int)min((int64_t)4096, cdiv64(pi.wp_floats, 256))), dim3(256), 0, (hipStream_t)stream, weight, wp,
                        wp + pi.wp_floats, Cout, Cin, pi.T, pi.KC, pi.CoutP, pi.nchunks);
+    if (pi.wsplit_floats > 0)
+        TDGP_LAUNCH("pack_kernel", pack_split_kernel, dim3((int)min((int64_t)4096, cdiv64(pi.wsplit_floats, 256))), dim3(256), 0, (hipStream_t)stream, weight,
+                    (uint32_t*)(wp + pi.wp_floats + pi.wsq_floats), Cout, Cin, pi.CoutP, pi.niter16);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
+}
+
+static int g_conv_arith = 0;
+TDGP_API int tdgp_set_conv_arith(int mode) {
+    TDGP_CHECK(mode == 0 || mode == 1, TDGP_EINVAL, "set_conv_arith: mode %d (0 = fp32 MFMA, 1 = split-bf16 MFMA with fp32 accumulation)", mode);
+    const int old = g_conv_arith;
+    g_conv_arith = mode;
+    return old;
 }
 
 
@@ -1948,7 +2209,17 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
             c.x = x; c.wp = wp; c.styles = styles; c.partial = nullptr; c.e = e;
             c.B = B; c.Cin = Cin; c.Cout = Cout; c.CoutP = pi.CoutP; c.H = H; c.W = W; c.ksplit = 1;
             c.x_bytes = (uint32_t)((int64_t)B * Cin * H * W * 4); c.wp_bytes = (uint32_t)(pi.wp_floats * 4); c.st_bytes = (uint32_t)((int64_t)B * Cin * 4);
-            if (k == 3) {
+            const int s_blocks = (W >> 5) * cdiv(B * (H + 1), 8) * cdiv(Cout, 64);
+            if (k == 3 && g_conv_arith == 1 && s_blocks >= 256 && styles && (Cin & 3) == 0) {
+                Conv3sParams q;
+                q.x = x; q.wsp = wp + pi.wp_floats + pi.wsq_floats; q.styles = styles; q.e = e;
+                q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W;
+                q.x_bytes = c.x_bytes; q.wsp_bytes = (uint32_t)(pi.wsplit_floats * 4); q.st_bytes = c.st_bytes;
+                const size_t lds = (size_t)(9 * 3 * 64 * 32 + 3 * 10 * 34 * 32 + 5 * 64 * 4);
+                static bool attr_set = false;
+                if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+                TDGP_LAUNCH("conv_mfma_kernel", conv3s_mfma_kernel, dim3((W >> 5) * cdiv(B * (H + 1), 8), cdiv(Cout, 64)), dim3(256), lds, s, q);
+            } else if (k == 3) {
                 if (Cout > 64) launch_conv3<3, 2, 2, 2, 2>(c, partial, wl.partial_floats, s);
                 else launch_conv3<3, 2, 2, 1, 4>(c, partial, wl.partial_floats, s);
             } else {

@@ -96,6 +96,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--depth-adaptor', action='store_true', help='also run the DepthAdaptor inside G.forward (SURVEY 8f rank 1; off = the 8a hot path)')
     ap.add_argument('--profile-steps', type=int, default=2)
+    ap.add_argument('--arith', default='f32', choices=['f32', 'split'],
+                    help="arithmetic of the large 3x3 convolutions: f32 = fp32 MFMA (default, the reported metric); split = opt-in 3 x bf16 split operands, "
+                         "6 piece products, fp32 accumulation (fp32-grade results; reported with dtype 'bf16x3->f32' and never mixed with the default line)")
     args = ap.parse_args()
 
     tdgp = importlib.import_module('3dgp_amd')
@@ -106,6 +109,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     tdgp._lib.load()                       # the HIP library must be there: no fallback
+    if args.arith == 'split':
+        tdgp._lib.set_conv_arith(1)
 
     cfg = getattr(tdgp.config, f'config_{args.config}')()
     if args.depth_adaptor:
@@ -185,7 +190,7 @@ def main():
             'metric': 'generator-forward img/s @256^2, 64 steps' if args.config in ('c3', 'c4') else f'generator-forward img/s ({args.config})',
             'value': round(total_imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32' if args.arith == 'f32' else 'bf16x3->f32 (3x3 layers), f32 elsewhere', 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[2]: ImageNet 256x256, {cfg.num_ray_steps}(+{cfg.num_ray_steps}) ray steps, cmax {cfg.cmax}, '
                                    f'c_dim {cfg.c_dim}, tri-plane {cfg.tri_plane_res}^2 x {cfg.plane_channels}, full HIP path' if args.config == 'c3'
                        else args.config, 'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'img_resolution': cfg.img_resolution,

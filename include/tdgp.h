@@ -125,6 +125,11 @@ int     tdgp_modconv2d(const float* x, const void* wpack, const float* styles, c
 int     tdgp_conv_transpose2d_x2(const float* x, const void* wpack, const float* styles, float* y, int B, int Cin, int Cout,
                                  int H, int W, void* workspace, int64_t workspace_bytes, tdgp_stream_t stream);
 
+/* Arithmetic of the 3x3 stride-1 convolutions (W % 32 == 0, >= 256 output tiles): 0 (default) = fp32 MFMA; 1 = every fp32 operand
+ * split into three bf16 pieces, six piece products per multiply on the bf16 MFMA with fp32 accumulation (fp32-grade results, not
+ * bit-identical to mode 0).  Process-wide; returns the previous mode (negative on error). */
+int     tdgp_set_conv_arith(int mode);
+
 /* Demodulation coefficients d[b,o] = rsqrt(sum_c s[b,c]^2 * sum_tap W[o,c,tap]^2 + 1e-8) (networks_stylegan2.py:62) of SEVERAL
  * layers in one launch.  meta: int64 [num_layers, 6] on the device = (address of the layer's sum_tap W^2 table, i.e. its wpack +
  * tdgp_modconv_wsq_offset(...) bytes; float offset of its [B,Cin] styles block in styles_all; Cin; Cout; Cout rounded up to 4;

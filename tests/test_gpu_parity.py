@@ -533,6 +533,25 @@ def test_full_size_backbone_vs_oracle(tdgp, oracle, full_c3):
     assert_close(got, ref, 1e-5, 'tri-planes 512^2', 1.0)
 
 
+def test_full_size_backbone_split_arith(tdgp, oracle, full_c3):
+    """The opt-in split-bf16 arithmetic on the whole backbone at its real shapes (it takes the 64^2 ... 512^2 stride-1 layers): the
+    tri-planes agree with the fp32-MFMA run to fp32 rounding and, on one sample, with the CPU oracle within the same tolerance as the
+    default path."""
+    G, ws = full_c3['G'], full_c3['ws']
+    prev = tdgp._lib.set_conv_arith(1)
+    try:
+        planes = G.synthesis.tri_plane_decoder(ws, noise_mode='const', hwc=True)
+    finally:
+        tdgp._lib.set_conv_arith(prev)
+    a, b = N(planes.t), N(full_c3['planes'].t)
+    assert not np.array_equal(a, b)
+    assert_close(a, b, 5e-6, 'split vs fp32 tri-planes', 1.0)
+    cfg, sd = full_c3['cfg'], full_c3['sd']
+    oracle.set_threads(min(64, __import__('os').cpu_count() or 1))
+    ref = oracle.synthesis_backbone(sd, cfg.to_dict(), N(ws)[:1], 'const')
+    assert_close(a[:1].transpose(0, 1, 4, 2, 3).reshape(1, 96, 512, 512), ref, 1e-5, 'split tri-planes vs oracle', 1.0)
+
+
 def test_full_size_renderer_strip_vs_oracle(tdgp, oracle, full_c3):
     """256^2 x (64 + 64) samples: the HIP renderer on the real 100 MB tri-planes; a strip of 3 x 256 rays is re-rendered by the
     oracle from the same planes and must agree (rays are independent, so a strip is a full-fidelity check)."""
@@ -1109,3 +1128,35 @@ def test_c4_forward_properties(tdgp):
     nchw = dec(ws, noise_mode='const')
     hwc = dec(ws, noise_mode='const', hwc=True).t
     assert_close(N(hwc.permute(0, 1, 4, 2, 3).reshape(nchw.shape)), N(nchw), 5e-6, 'planes channel-last vs NCHW (c4)', 1.0)
+
+
+@pytest.mark.parametrize('B,cin,cout,H', [(8, 64, 64, 128), (8, 128, 96, 64), (4, 40, 130, 128)])
+def test_conv_split_arith(tdgp, oracle, B, cin, cout, H):
+    """Opt-in arithmetic (tdgp_set_conv_arith(1)): fp32 operands split into three bf16 pieces, six piece products per multiply on the
+    bf16 MFMA, fp32 accumulation.  Same layer through both modes against the double-accumulating oracle: the split path must be as
+    close to the exact result as the fp32 MFMA path (it keeps all 24 mantissa bits; dropped terms <= 3 * 2^-24 per product)."""
+    rs = np.random.RandomState(cin + cout)
+    mc = tdgp.ops.modconv
+    x = rs.randn(B, cin, H, H).astype(np.float32)
+    w = rs.randn(cout, cin, 3, 3).astype(np.float32)
+    s = (1 + 0.5 * rs.randn(B, cin)).astype(np.float32)
+    bias = rs.randn(cout).astype(np.float32)
+    noise = (0.3 * rs.randn(H, H)).astype(np.float32)
+    ref = oracle.bias_act(oracle.modulated_conv2d(x, w, s, noise=noise), bias, act='lrelu')
+    pk = mc.PackedConv(T(w))
+    kw = dict(noise=T(noise), bias=T(bias), demodulate=True, act='lrelu')
+    y32 = mc.modconv_forward(T(x), pk, T(s), **kw)
+    prev = tdgp._lib.set_conv_arith(1)
+    try:
+        tdgp._lib.profile_enable(True)
+        ysp = mc.modconv_forward(T(x), pk, T(s), **kw)
+        torch.cuda.synchronize()
+        tdgp._lib.profile_report()
+        tdgp._lib.profile_enable(False)
+    finally:
+        tdgp._lib.set_conv_arith(prev)
+    scale = np.abs(ref).max()
+    e32, esp = np.abs(N(y32) - ref).max() / scale, np.abs(N(ysp) - ref).max() / scale
+    assert e32 < 2e-6 and esp < 4e-6, (e32, esp)
+    assert not torch.equal(y32, ysp) or cin < 16            # the two modes are different arithmetic (this also proves the split kernel ran)
+    assert tdgp._lib.set_conv_arith(0) == 0

@@ -2,6 +2,7 @@ import sys, os, importlib, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 t = importlib.import_module('3dgp_amd'); mc = t.ops.modconv
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+if os.environ.get('TDGP_ARITH') == 'split': t._lib.set_conv_arith(1)
 f = np.outer([1,3,3,1],[1,3,3,1]).astype(np.float32)/64
 def run(cin,cout,H,k,up,reps=5):
     x = torch.randn(B,cin,H,H,device='cuda'); w = torch.randn(cout,cin,k,k,device='cuda'); s = torch.rand(B,cin,device='cuda')+0.5
