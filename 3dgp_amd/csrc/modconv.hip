@@ -1136,8 +1136,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
 
 // =================================================================================================================================
 // OPT-IN arithmetic (tdgp_set_conv_arith(1); the default path is the fp32 kernel above): 3x3 stride-1 convolution with every fp32
-// operand split into three bf16 pieces (8 + 8 + 8 mantissa bits: hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = top 16 bits
-// of x - hi - mid; all differences exact) and the product formed from the six leading piece products
+// operand split into three bf16 pieces (8 + 8 + 8 mantissa bits: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), round to
+// nearest; all differences exact) and the product formed from the six leading piece products
 //     a*b ~= a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0)            dropped terms <= 3 * 2^-24 |a b|
 // on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-grade results at 16/6 = 2.7x the fp32 MFMA rate.  Not bit-compatible with
 // an fp32 FMA chain (neither is the fp32 MFMA with the CPU), hence opt-in.
@@ -1155,11 +1155,18 @@ struct Conv3sParams {
     uint32_t x_bytes, wsp_bytes, st_bytes;
 };
 
-__device__ __forceinline__ void split3(float v, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-    hi = __float_as_uint(v) & 0xFFFF0000u;
-    const float r1 = v - __uint_as_float(hi);
-    mid = __float_as_uint(r1) & 0xFFFF0000u;
-    lo = __float_as_uint(r1 - __uint_as_float(mid)) & 0xFFFF0000u;
+// Two values at a time: v_cvt_pk_bf16_f32 (round to nearest even, already packed as a channel pair), the residual by an exact
+// v_pk_add_f32 -- 9 vector-ALU instructions per pair.  x = hi + mid + lo + r with |r| <= 2^-25 |x|.
+typedef float split_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 split_b2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(float v0, float v1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    split_f2 v = {v0, v1};
+    const split_b2 h = __builtin_convertvector(v, split_b2);
+    v = v - __builtin_convertvector(h, split_f2);
+    const split_b2 m = __builtin_convertvector(v, split_b2);
+    v = v - __builtin_convertvector(m, split_f2);
+    const split_b2 l = __builtin_convertvector(v, split_b2);
+    __builtin_memcpy(&hi, &h, 4); __builtin_memcpy(&mid, &m, 4); __builtin_memcpy(&lo, &l, 4);
 }
 
 __global__ __launch_bounds__(256) void conv3s_mfma_kernel(Conv3sParams p) {
@@ -1233,20 +1240,21 @@ __global__ __launch_bounds__(256) void conv3s_mfma_kernel(Conv3sParams p) {
         }
     }
     const uint32_t a_gstride = (uint32_t)(T * 3 * p.CoutP) * 32u;
-    auto load_stage = [&](int it) {
+    // The NLOAD = 14 + 32 + 8 loads of a stage, as a list: part `part` of `nparts` issues its share (2.3 k cycles per chunk: ~40 cycles
+    // of address-path time per wave-wide load).  (No branches: a load under a condition makes the compiler wait for ALL
+    // loads at the join -- the host only takes this kernel with styles present and Cin % 4 == 0.)
+    constexpr int NLOAD = NA + NPOS * 16 + NPOS * 4;
+    auto load_part = [&](int it, int part, int nparts) {
         const int itc = min(it, niter - 1);
         const uint32_t a_so = (uint32_t)itc * a_gstride;
-#pragma unroll
-        for (int i = 0; i < NA; i++) a_reg[i] = buf_load4(rw, a_vo[i], a_so);
         const uint32_t c0 = (uint32_t)itc * 16u, cl = (uint32_t)(p.Cin - 1);
+        const int per = (NLOAD + nparts - 1) / nparts;
 #pragma unroll
-        for (int k = 0; k < NPOS; k++) {
-#pragma unroll
-            for (int j = 0; j < 16; j++) x_reg[k][j] = buf_load1(rx, pos_xo[k], min(c0 + j, cl) * chw4);
-            // (no branches in here: a load under a condition makes the compiler wait for ALL loads at the join -- the host only takes
-            //  this kernel with styles present and Cin % 4 == 0)
-#pragma unroll
-            for (int q = 0; q < 4; q++) s_reg[k][q] = buf_load4(rs, pos_so[k], min(c0 + 4 * q, cl & ~3u) * 4u);
+        for (int idx = 0; idx < NLOAD; idx++) {
+            if (idx < part * per || idx >= (part + 1) * per) continue;
+            if (idx < NA) a_reg[idx] = buf_load4(rw, a_vo[idx], a_so);
+            else if (idx < NA + NPOS * 16) { const int k = (idx - NA) / 16, j = (idx - NA) % 16; x_reg[k][j] = buf_load1(rx, pos_xo[k], min(c0 + j, cl) * chw4); }
+            else { const int k = (idx - NA - NPOS * 16) / 4, q = (idx - NA - NPOS * 16) % 4; s_reg[k][q] = buf_load4(rs, pos_so[k], min(c0 + 4 * q, cl & ~3u) * 4u); }
         }
     };
     auto store_stage = [&]() {
@@ -1263,9 +1271,7 @@ __global__ __launch_bounds__(256) void conv3s_mfma_kernel(Conv3sParams p) {
                     float v0 = x_reg[k][j], v1 = x_reg[k][j + 1];
                     const float4 sq = s_reg[k][j >> 2];
                     v0 *= (j & 2) ? sq.z : sq.x; v1 *= (j & 2) ? sq.w : sq.y;
-                    uint32_t h0, m0_, l0, h1, m1, l1;
-                    split3(v0, h0, m0_, l0); split3(v1, h1, m1, l1);
-                    pk[0][j >> 1] = (h0 >> 16) | h1; pk[1][j >> 1] = (m0_ >> 16) | m1; pk[2][j >> 1] = (l0 >> 16) | l1;
+                    split3_pair(v0, v1, pk[0][j >> 1], pk[1][j >> 1], pk[2][j >> 1]);
                 }
 #pragma unroll
                 for (int pc_ = 0; pc_ < 3; pc_++) {
@@ -1279,7 +1285,7 @@ __global__ __launch_bounds__(256) void conv3s_mfma_kernel(Conv3sParams p) {
     auto frag = [&](const char* ptr) { const uint4 v = *(const uint4*)ptr; bf16x8_t r; __builtin_memcpy(&r, &v, 16); return r; };
     const int a_lane = l32 * 32 + half * 16;                                        // + ((tap*3 + piece)*BM + m*32) * 32
     const int b_lane = ((wn * NTW + R) * PC + l32 + R) * 32 + half * 16;           // centre tap of subtile 0; + (piece*PSZ + (n + dy)*PC + dx) * 32
-    auto mma = [&]() {
+    auto mma = [&](int it_next) {
 #pragma unroll
         for (int t = 0; t < T; t++) {
             const int dy = t / 3 - R, dx = t % 3 - R;
@@ -1309,7 +1315,7 @@ __global__ __launch_bounds__(256) void conv3s_mfma_kernel(Conv3sParams p) {
 #else
 #define TS(i)
 #endif
-    load_stage(0);
+    load_part(0, 0, 1);
     TS(0)
     for (int it = 0; it < niter; it++) {
         __syncthreads();                        // the previous chunk's fragments have been read
@@ -1318,9 +1324,9 @@ __global__ __launch_bounds__(256) void conv3s_mfma_kernel(Conv3sParams p) {
         TS(2)
         __syncthreads();
         TS(1)
-        load_stage(it + 1);                     // unconditional (clamped): in flight during this chunk's MFMAs
-        TS(3)
-        mma();
+        load_part(it + 1, 0, 1);                // unconditional (clamped): in flight during this chunk's MFMAs.  (Spreading these 54
+        TS(3)                                   //  loads over the nine taps does not help: with one wave per SIMD the ~40 cycles of
+        mma(it + 1);                            //  address-path time per load stall the MFMA stream wherever they are issued.)
         TS(4)
     }
     __syncthreads();
@@ -1369,16 +1375,15 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
         const int piece = (int)(r % 3); r /= 3;
         const int tap = (int)(r % 9);
         const int it = (int)(r / 9);
-        uint32_t out = 0;
+        float v[2];
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const int c = it * 16 + 2 * jp + q;
-            const float v = (col < Cout && c < Cin) ? w[((int64_t)col * Cin + c) * 9 + tap] : 0.f;
-            uint32_t pc[3];
-            split3(v, pc[0], pc[1], pc[2]);
-            out |= q == 0 ? (pc[piece] >> 16) : pc[piece];
+            v[q] = (col < Cout && c < Cin) ? w[((int64_t)col * Cin + c) * 9 + tap] : 0.f;
         }
-        wsp[i] = out;
+        uint32_t pc[3];
+        split3_pair(v[0], v[1], pc[0], pc[1], pc[2]);
+        wsp[i] = pc[piece];
     }
 }
 
