@@ -808,7 +808,10 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
         __syncthreads();
         TQ(4)
     }
-    if (it < it1) mma(0);               // odd iteration count: the last one sits in L0
+    if (it < it1) {                     // odd iteration count: the last one sits in L0 -- and the epilogue's per-wave tiles overlay the
+        mma(0);                         // stage buffers: every wave must be done reading them (without this barrier a fast wave's
+        __syncthreads();                // epilogue corrupted a slow wave's last fragments: rare, wave-tile-sized errors)
+    }
     TQ(2)
 
     // ---- epilogue: accumulators -> per-wave LDS tile -> epilogue_tile() (16-B stores, fused demod/noise/bias/act) ------------
@@ -1066,7 +1069,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void upconv_mfma_kernel(UpParams p
         __syncthreads();
         TSEG(3)
     }
-    if (it < it1) mma(0);               // odd iteration count: the last one sits in L0
+    if (it < it1) {                     // odd iteration count: the last one sits in L0 -- and the epilogue's per-wave tiles overlay the
+        mma(0);                         // stage buffers: every wave must be done reading them (without this barrier a fast wave's
+        __syncthreads();                // epilogue corrupted a slow wave's last fragments: rare, wave-tile-sized errors)
+    }
     TSEG(0)
     }
 #if TDGP_UP_ABL & 16
@@ -1169,13 +1175,14 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, uint32_t& hi, ui
     __builtin_memcpy(&hi, &h, 4); __builtin_memcpy(&mid, &m, 4); __builtin_memcpy(&lo, &l, 4);
 }
 
-__global__ __launch_bounds__(256) void conv3s_mfma_kernel(Conv3sParams p) {
-    constexpr int R = 1, T = 9, MTW = 2, NTW = 2, WN = 4, BM = 64, NT = NTW * WN, PR = NT + 2, PC = 34, PSZ = PR * PC;
-    constexpr int AS_BYTES = T * 3 * BM * 32, XS_BYTES = 3 * PSZ * 32;
+__global__ __launch_bounds__(256, 2) void conv3s_mfma_kernel(Conv3sParams p) {
+    constexpr int R = 1, MTW = 2, NTW = 2, WN = 4, BM = 64, NT = NTW * WN, PR = NT + 2, PC = 34, PSZ = PR * PC;
+    constexpr int AROW_BYTES = 3 * 3 * BM * 32, XS_BYTES = 3 * PSZ * 32;      // one tap row of weights: [dx][piece][64 columns][32 B]
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* As = (char*)smem;
-    char* Xs = As + AS_BYTES;
+    char* As = (char*)smem;                                           // two tap-row buffers
+    char* Xs = As + 2 * AROW_BYTES;
     float* side = (float*)(Xs + XS_BYTES);                          // [1 + NSB][BM]
+    float* sty = side + (1 + 4) * BM;                               // [2][Cin]: the styles of the two samples a block can touch
     const int H1 = p.H + R;
     const int tilesX = p.W >> 5, VR = p.B * H1;
     const int ty = blockIdx.x / tilesX, tx = blockIdx.x % tilesX;
@@ -1198,23 +1205,35 @@ __global__ __launch_bounds__(256) void conv3s_mfma_kernel(Conv3sParams p) {
         }
     }
 
-    constexpr int NPOS = (PSZ + 255) / 256;
-    uint32_t pos_xo[NPOS], pos_so[NPOS];
+    // Staging work items = (position of the 10 x 34 patch, channel half): 680 items over 256 threads, half-major, so a wave-wide load
+    // reads consecutive positions of one channel plane (few cache lines: the loads are bound by lines per clock in the CU's vector
+    // memory path) and the splitting work is even across the waves (whole positions left wave 0 with twice the work of waves 2, 3).
+    // The styles of the (at most two) samples a block touches sit in LDS.
+    constexpr int NITEM = PSZ * 2, NSLOT = (NITEM + 255) / 256;
+    const int b_lo = max(vr0 - R, 0) / H1;
+    for (int i = tid; i < 2 * p.Cin; i += 256) {
+        const int sb = i >= p.Cin ? 1 : 0;
+        sty[i] = p.styles[min(b_lo + sb, p.B - 1) * p.Cin + (i - sb * p.Cin)];
+    }
+    uint32_t it_xo[NSLOT], it_st[NSLOT], it_ld[NSLOT];
 #pragma unroll
-    for (int k = 0; k < NPOS; k++) {
-        const int pos = tid + k * 256;
-        pos_xo[k] = kOOB; pos_so[k] = kOOB;
-        if (pos < PSZ) {
+    for (int k = 0; k < NSLOT; k++) {
+        const int e = tid + k * 256, hf = e >= PSZ ? 1 : 0, pos = e - hf * PSZ;
+        it_xo[k] = kOOB; it_st[k] = (uint32_t)(8 * hf); it_ld[k] = (uint32_t)(pos * 32 + hf * 16);
+        if (e < NITEM) {
             const int pr = pos / PC, pc = pos % PC;
             const int vi = vr0 - R + pr, ix = n0 - R + pc;
             if (vi >= 0 && ix >= 0 && ix < p.W) {
                 const int b = vi / H1, m = vi - b * H1;
-                if (b < p.B && m < p.H) { pos_xo[k] = (uint32_t)(((b * p.Cin) * p.H + m) * p.W + ix) * 4u; pos_so[k] = (uint32_t)(b * p.Cin) * 4u; }
+                if (b < p.B && m < p.H) {
+                    it_xo[k] = (uint32_t)(((b * p.Cin + 8 * hf) * p.H + m) * p.W + ix) * 4u;
+                    it_st[k] = (uint32_t)((b - b_lo) * p.Cin + 8 * hf);
+                }
             }
         }
     }
     const uint32_t chw4 = (uint32_t)(p.H * p.W) * 4u;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.wsp, p.wsp_bytes), rs = make_rsrc(p.styles ? p.styles : p.x, p.styles ? p.st_bytes : 0);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.wsp, p.wsp_bytes);
 
     f32x16 acc[MTW][NTW];
 #pragma unroll
@@ -1224,76 +1243,73 @@ __global__ __launch_bounds__(256) void conv3s_mfma_kernel(Conv3sParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
 
-    const int niter = (p.Cin + 15) >> 4;
-    constexpr int NA = (T * 3 * BM * 2 + 255) / 256;              // 16-B vectors of the weight stage per thread
+    const int niter = p.Cin >> 4;                                   // the host only takes this kernel with Cin % 16 == 0
+    constexpr int NAV = 3 * 3 * BM * 2;                             // 16-B vectors of one tap row of weights
+    constexpr int NA = (NAV + 255) / 256;
     float4 a_reg[NA];
-    float x_reg[NPOS][16];
-    float4 s_reg[NPOS][4];
+    float x_reg[NSLOT][8];
     uint32_t a_vo[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
         const int e = tid + i * 256;
         a_vo[i] = kOOB;
-        if (e < T * 3 * BM * 2) {
+        if (e < NAV) {
             const int tp = e / (BM * 2), rem = e % (BM * 2), col = rem >> 1, hf = rem & 1;
             if (m0 + col < p.CoutP) a_vo[i] = (uint32_t)((tp * p.CoutP + m0 + col) * 2 + hf) * 16u;
         }
     }
-    const uint32_t a_gstride = (uint32_t)(T * 3 * p.CoutP) * 32u;
-    // The NLOAD = 14 + 32 + 8 loads of a stage, as a list: part `part` of `nparts` issues its share (2.3 k cycles per chunk: ~40 cycles
-    // of address-path time per wave-wide load).  (No branches: a load under a condition makes the compiler wait for ALL
-    // loads at the join -- the host only takes this kernel with styles present and Cin % 4 == 0.)
-    constexpr int NLOAD = NA + NPOS * 16 + NPOS * 4;
-    auto load_part = [&](int it, int part, int nparts) {
-        const int itc = min(it, niter - 1);
-        const uint32_t a_so = (uint32_t)itc * a_gstride;
-        const uint32_t c0 = (uint32_t)itc * 16u, cl = (uint32_t)(p.Cin - 1);
-        const int per = (NLOAD + nparts - 1) / nparts;
+    const uint32_t a_gstride = (uint32_t)(9 * p.CoutP) * 32u;      // one tap row = 3 taps x 3 pieces x CoutP columns x 32 B
+    const int nstage = 3 * niter;
+    // No branches around loads (a load under a condition makes the compiler wait for ALL loads at the join): stages past the end
+    // re-read the last one.
+    auto load_a = [&](int g) {
+        const uint32_t a_so = (uint32_t)min(g, nstage - 1) * a_gstride;
 #pragma unroll
-        for (int idx = 0; idx < NLOAD; idx++) {
-            if (idx < part * per || idx >= (part + 1) * per) continue;
-            if (idx < NA) a_reg[idx] = buf_load4(rw, a_vo[idx], a_so);
-            else if (idx < NA + NPOS * 16) { const int k = (idx - NA) / 16, j = (idx - NA) % 16; x_reg[k][j] = buf_load1(rx, pos_xo[k], min(c0 + j, cl) * chw4); }
-            else { const int k = (idx - NA - NPOS * 16) / 4, q = (idx - NA - NPOS * 16) % 4; s_reg[k][q] = buf_load4(rs, pos_so[k], min(c0 + 4 * q, cl & ~3u) * 4u); }
-        }
+        for (int i = 0; i < NA; i++) a_reg[i] = buf_load4(rw, a_vo[i], a_so);
     };
-    auto store_stage = [&]() {
+    auto store_a = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NA; i++)
-            if (tid + i * 256 < T * 3 * BM * 2) *(float4*)(As + (tid + i * 256) * 16) = a_reg[i];
+            if (tid + i * 256 < NAV) *(float4*)(As + buf * AROW_BYTES + (tid + i * 256) * 16) = a_reg[i];
+    };
+    auto load_x = [&](int it) {
+        const uint32_t c0 = (uint32_t)min(it, niter - 1) * 16u;
 #pragma unroll
-        for (int k = 0; k < NPOS; k++) {
-            const int pos = tid + k * 256;
-            if (pos < PSZ) {
-                uint32_t pk[3][8];
+        for (int k = 0; k < NSLOT; k++)
 #pragma unroll
-                for (int j = 0; j < 16; j += 2) {
-                    float v0 = x_reg[k][j], v1 = x_reg[k][j + 1];
-                    const float4 sq = s_reg[k][j >> 2];
-                    v0 *= (j & 2) ? sq.z : sq.x; v1 *= (j & 2) ? sq.w : sq.y;
-                    split3_pair(v0, v1, pk[0][j >> 1], pk[1][j >> 1], pk[2][j >> 1]);
-                }
+            for (int j = 0; j < 8; j++) x_reg[k][j] = buf_load1(rx, it_xo[k], (c0 + j) * chw4);
+    };
+    auto store_x = [&](int it) {
+        const uint32_t c0 = (uint32_t)it * 16u;
+        float4 sq[NSLOT][2];
 #pragma unroll
-                for (int pc_ = 0; pc_ < 3; pc_++) {
-                    uint4* d = (uint4*)(Xs + (pc_ * PSZ + pos) * 32);
-                    d[0] = make_uint4(pk[pc_][0], pk[pc_][1], pk[pc_][2], pk[pc_][3]);
-                    d[1] = make_uint4(pk[pc_][4], pk[pc_][5], pk[pc_][6], pk[pc_][7]);
-                }
+        for (int k = 0; k < NSLOT; k++) { sq[k][0] = *(const float4*)&sty[it_st[k] + c0]; sq[k][1] = *(const float4*)&sty[it_st[k] + c0 + 4]; }
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) {
+            uint32_t pk[3][4];
+            split3_pair(x_reg[k][0] * sq[k][0].x, x_reg[k][1] * sq[k][0].y, pk[0][0], pk[1][0], pk[2][0]);
+            split3_pair(x_reg[k][2] * sq[k][0].z, x_reg[k][3] * sq[k][0].w, pk[0][1], pk[1][1], pk[2][1]);
+            split3_pair(x_reg[k][4] * sq[k][1].x, x_reg[k][5] * sq[k][1].y, pk[0][2], pk[1][2], pk[2][2]);
+            split3_pair(x_reg[k][6] * sq[k][1].z, x_reg[k][7] * sq[k][1].w, pk[0][3], pk[1][3], pk[2][3]);
+            if (tid + k * 256 < NITEM) {
+#pragma unroll
+                for (int pc_ = 0; pc_ < 3; pc_++) *(uint4*)(Xs + pc_ * (PSZ * 32) + it_ld[k]) = make_uint4(pk[pc_][0], pk[pc_][1], pk[pc_][2], pk[pc_][3]);
             }
         }
     };
     auto frag = [&](const char* ptr) { const uint4 v = *(const uint4*)ptr; bf16x8_t r; __builtin_memcpy(&r, &v, 16); return r; };
-    const int a_lane = l32 * 32 + half * 16;                                        // + ((tap*3 + piece)*BM + m*32) * 32
+    const int a_lane = l32 * 32 + half * 16;                                        // + ((dx*3 + piece)*BM + m*32) * 32
     const int b_lane = ((wn * NTW + R) * PC + l32 + R) * 32 + half * 16;           // centre tap of subtile 0; + (piece*PSZ + (n + dy)*PC + dx) * 32
-    auto mma = [&](int it_next) {
+    auto mma_row = [&](int row, int buf) {
+        const int dy = row - R;
 #pragma unroll
-        for (int t = 0; t < T; t++) {
-            const int dy = t / 3 - R, dx = t % 3 - R;
+        for (int tx_ = 0; tx_ < 3; tx_++) {
+            const int dx = tx_ - R;
             bf16x8_t fa[3][MTW], fb[3][NTW];
 #pragma unroll
             for (int pc_ = 0; pc_ < 3; pc_++) {
 #pragma unroll
-                for (int m = 0; m < MTW; m++) fa[pc_][m] = frag(As + a_lane + ((t * 3 + pc_) * BM + m * 32) * 32);
+                for (int m = 0; m < MTW; m++) fa[pc_][m] = frag(As + buf * AROW_BYTES + a_lane + ((tx_ * 3 + pc_) * BM + m * 32) * 32);
 #pragma unroll
                 for (int n = 0; n < NTW; n++) fb[pc_][n] = frag(Xs + b_lane + (pc_ * PSZ + (n + dy) * PC + dx) * 32);
             }
@@ -1315,26 +1331,45 @@ __global__ __launch_bounds__(256) void conv3s_mfma_kernel(Conv3sParams p) {
 #else
 #define TS(i)
 #endif
-    load_part(0, 0, 1);
+    // Two blocks per CU (LDS 75 KB each): one block's staging and barriers run under the other's MFMAs.  Per chunk of 16 channels:
+    // the activation stage once, the weights one tap row at a time through two buffers.
+    load_x(0);
+    load_a(0);
     TS(0)
     for (int it = 0; it < niter; it++) {
+        const int g = 3 * it;
         __syncthreads();                        // the previous chunk's fragments have been read
         TS(1)
-        store_stage();
+        store_x(it);
+        store_a(0);
         TS(2)
+        load_a(g + 1);
+        TS(3)
         __syncthreads();
         TS(1)
-        load_part(it + 1, 0, 1);                // unconditional (clamped): in flight during this chunk's MFMAs.  (Spreading these 54
-        TS(3)                                   //  loads over the nine taps does not help: with one wave per SIMD the ~40 cycles of
-        mma(it + 1);                            //  address-path time per load stall the MFMA stream wherever they are issued.)
+        load_x(it + 1);                         // in flight during this chunk's MFMAs
+        TS(3)
+        mma_row(0, 0);
+        TS(4)
+        store_a(1);
+        TS(2)
+        load_a(g + 2);
+        TS(3)
+        __syncthreads();
+        TS(1)
+        mma_row(1, 1);
+        TS(4)
+        store_a(0);                             // buffer 0 was last read before the barrier above
+        TS(2)
+        load_a(g + 3);
+        TS(3)
+        __syncthreads();
+        TS(1)
+        mma_row(2, 0);
         TS(4)
     }
     __syncthreads();
-#if TDGP_C3_ABL & 32
-    if (tid == 0 && (blockIdx.x == 3 || blockIdx.x == 400) && blockIdx.y == 0)
-        printf("conv3s blk %d iters %d: prologue %lld barrier %lld store(+load wait) %lld load-issue %lld mma %lld\n", (int)blockIdx.x, niter, ts[0], ts[1], ts[2], ts[3], ts[4]);
-#endif
-#undef TS
+    TS(0)
 
     float* ct = smem + wv * (32 * CT_LD);
     const EpiParams& e = p.e;
@@ -1363,6 +1398,12 @@ __global__ __launch_bounds__(256) void conv3s_mfma_kernel(Conv3sParams p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+#if TDGP_C3_ABL & 32
+    TS(1)
+    if (tid == 0 && (blockIdx.x == 3 || blockIdx.x == 400) && blockIdx.y == 0)
+        printf("conv3s blk %d iters %d: prologue %lld barrier+epilogue %lld store(+load wait) %lld load-issue %lld mma %lld\n", (int)blockIdx.x, niter, ts[0], ts[1], ts[2], ts[3], ts[4]);
+#endif
+#undef TS
 }
 
 // weight [Cout,Cin,3,3] -> split pack [chunk16][tap][piece][CoutP][16 bf16] (zero beyond Cout / Cin)
@@ -2215,14 +2256,14 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
             c.B = B; c.Cin = Cin; c.Cout = Cout; c.CoutP = pi.CoutP; c.H = H; c.W = W; c.ksplit = 1;
             c.x_bytes = (uint32_t)((int64_t)B * Cin * H * W * 4); c.wp_bytes = (uint32_t)(pi.wp_floats * 4); c.st_bytes = (uint32_t)((int64_t)B * Cin * 4);
             const int s_blocks = (W >> 5) * cdiv(B * (H + 1), 8) * cdiv(Cout, 64);
-            if (k == 3 && g_conv_arith == 1 && s_blocks >= 256 && styles && (Cin & 3) == 0) {
+            if (k == 3 && g_conv_arith == 1 && s_blocks >= 256 && styles && (Cin & 15) == 0 && Cin <= 2048 && H >= 16) {
                 Conv3sParams q;
                 q.x = x; q.wsp = wp + pi.wp_floats + pi.wsq_floats; q.styles = styles; q.e = e;
                 q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W;
                 q.x_bytes = c.x_bytes; q.wsp_bytes = (uint32_t)(pi.wsplit_floats * 4); q.st_bytes = c.st_bytes;
-                const size_t lds = (size_t)(9 * 3 * 64 * 32 + 3 * 10 * 34 * 32 + 5 * 64 * 4);
+                const size_t lds = (size_t)(2 * 3 * 3 * 64 * 32 + 3 * 10 * 34 * 32 + 5 * 64 * 4 + 2 * Cin * 4);
                 static bool attr_set = false;
-                if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+                if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds - 2 * Cin * 4 + 2 * 2048 * 4)); attr_set = true; }
                 TDGP_LAUNCH("conv_mfma_kernel", conv3s_mfma_kernel, dim3((W >> 5) * cdiv(B * (H + 1), 8), cdiv(Cout, 64)), dim3(256), lds, s, q);
             } else if (k == 3) {
                 if (Cout > 64) launch_conv3<3, 2, 2, 2, 2>(c, partial, wl.partial_floats, s);

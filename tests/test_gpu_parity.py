@@ -1128,9 +1128,35 @@ def test_c4_forward_properties(tdgp):
     nchw = dec(ws, noise_mode='const')
     hwc = dec(ws, noise_mode='const', hwc=True).t
     assert_close(N(hwc.permute(0, 1, 4, 2, 3).reshape(nchw.shape)), N(nchw), 5e-6, 'planes channel-last vs NCHW (c4)', 1.0)
+    # Regression: with an odd number of K iterations per split-K slice (here the 512 -> 256 x2 layer: 128 iterations in 3 slices) the
+    # last multiply was not fenced from the epilogue's LDS tiles, and roughly one run in ten came out with a wave tile of garbage.
+    for _ in range(40):
+        assert torch.equal(dec(ws, noise_mode='const'), nchw)
 
 
-@pytest.mark.parametrize('B,cin,cout,H', [(8, 64, 64, 128), (8, 128, 96, 64), (4, 40, 130, 128)])
+@pytest.mark.parametrize('cin,cout,H,up', [(36, 96, 32, 2), (20, 160, 64, 2), (44, 64, 32, 1), (12, 130, 64, 1)])
+def test_conv_odd_iteration_count_is_deterministic(tdgp, oracle, cin, cout, H, up):
+    """Odd K-iteration counts (Cin / 4 odd) leave the last multiply outside the double-buffered loop: it must still be fenced from
+    the epilogue, which overlays the stage buffers -- correct against the oracle and bit-identical over repeated launches."""
+    rs = np.random.RandomState(cin * 7 + cout)
+    mc = tdgp.ops.modconv
+    B = 2
+    x = rs.randn(B, cin, H, H).astype(np.float32)
+    w = rs.randn(cout, cin, 3, 3).astype(np.float32)
+    s = (1 + 0.5 * rs.randn(B, cin)).astype(np.float32)
+    bias = rs.randn(cout).astype(np.float32)
+    f = oracle.setup_filter([1, 3, 3, 1])
+    ref = oracle.bias_act(oracle.modulated_conv2d(x, w, s, up=up, resample_filter=f if up == 2 else None), bias, act='lrelu')
+    pk = mc.PackedConv(T(w))
+    kw = dict(bias=T(bias), demodulate=True, act='lrelu', up=up, fir=mc.fir_host_array(f) if up == 2 else None)
+    xs, ss = T(x), T(s)
+    y0 = mc.modconv_forward(xs, pk, ss, **kw)
+    assert_close(N(y0), ref, 1e-5, f'modconv up{up} odd iteration count', 1.0)
+    for _ in range(60):
+        assert torch.equal(mc.modconv_forward(xs, pk, ss, **kw), y0)
+
+
+@pytest.mark.parametrize('B,cin,cout,H', [(8, 64, 64, 128), (8, 128, 96, 64), (4, 48, 130, 128)])
 def test_conv_split_arith(tdgp, oracle, B, cin, cout, H):
     """Opt-in arithmetic (tdgp_set_conv_arith(1)): fp32 operands split into three bf16 pieces, six piece products per multiply on the
     bf16 MFMA, fp32 accumulation.  Same layer through both modes against the double-accumulating oracle: the split path must be as
