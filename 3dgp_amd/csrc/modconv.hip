@@ -1406,6 +1406,215 @@ __global__ __launch_bounds__(256, 2) void conv3s_mfma_kernel(Conv3sParams p) {
 #undef TS
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same arithmetic for the x2 layers: upconv_mfma_kernel's linearised-grid transposed convolution (same Z layout, so the FIR /
+// output stage is shared) on the bf16 MFMA.  Block = 64 output channels x 128 consecutive grid points, 4 waves (1 x 4), a wave
+// owns 32 points x 64 channels x the four output parities (8 accumulator tiles); K chunk = 16 channels, the two activation runs
+// (dy = -1, dy = 0; 129 positions each) staged once per chunk, the weights one tap row (= one ky) at a time through two buffers:
+// 62 KB of LDS, two blocks per CU.  No split-K (these launches have >= 256 blocks).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct Up3sParams {
+    const float* x; const void* wsp; const float* styles; float* z;
+    int B, Cin, Cout, CoutP, H, W, G1, GS;
+    int64_t zslice;
+    uint32_t x_bytes, wsp_bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void upconv3s_mfma_kernel(Up3sParams p) {
+    constexpr int MTW = 2, BM = 64, BN = 128, XP = BN + 2;
+    constexpr int AROW_BYTES = 3 * 3 * BM * 32, XPIECE = 2 * XP * 32, XS_BYTES = 3 * XPIECE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* As = (char*)smem;                                           // two tap-row buffers (the epilogue's tiles overlay them)
+    char* Xs = As + 2 * AROW_BYTES;                                   // [piece][run][position][16 bf16]
+    float* sty = (float*)(Xs + XS_BYTES);                             // [2][Cin]: the styles of the two samples a block can touch
+    const int v0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int tid = threadIdx.x, l = tid & 63, wv = TDGP_WAVE_INDEX(tid), l32 = l & 31, half = l >> 5;
+    const int wn = wv;
+
+    const int b_lo = max(v0 - 1 - p.G1, 0) / p.GS;
+    for (int i = tid; i < 2 * p.Cin; i += 256) {
+        const int sb = i >= p.Cin ? 1 : 0;
+        sty[i] = p.styles[min(b_lo + sb, p.B - 1) * p.Cin + (i - sb * p.Cin)];
+    }
+    // staging items = (channel half, run, position): 2 x 2 x 129, half-major (a wave-wide load = consecutive positions of one plane)
+    constexpr int NRUN = BN + 1, NITEM = 2 * 2 * NRUN, NSLOT = (NITEM + 255) / 256;
+    uint32_t it_xo[NSLOT], it_st[NSLOT], it_ld[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) {
+        const int e = tid + k * 256;
+        const int hf = e / (2 * NRUN), rem = e - hf * (2 * NRUN), seg = rem / NRUN, idx = rem - seg * NRUN;
+        it_xo[k] = kOOB; it_st[k] = (uint32_t)(8 * (hf & 1)); it_ld[k] = (uint32_t)((seg * XP + idx) * 32 + (hf & 1) * 16);
+        if (e < NITEM) {
+            const int g = v0 + idx - 1 - (seg == 0 ? p.G1 : 0);
+            if (g >= 0) {
+                const int b = g / p.GS, vp = g - b * p.GS;
+                const int m = vp / p.G1, n = vp - m * p.G1;
+                if (b < p.B && m < p.H && n < p.W) {
+                    it_xo[k] = (uint32_t)(((b * p.Cin + 8 * hf) * p.H + m) * p.W + n) * 4u;
+                    it_st[k] = (uint32_t)((b - b_lo) * p.Cin + 8 * hf);
+                }
+            }
+        }
+    }
+    const uint32_t chw4 = (uint32_t)(p.H * p.W) * 4u;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.wsp, p.wsp_bytes);
+
+    f32x16 acc[4][MTW];                                               // [py*2+px][channel tile]
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int m = 0; m < MTW; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[q][m][r] = 0.f;
+
+    const int niter = p.Cin >> 4;                                   // the host only takes this kernel with Cin % 16 == 0
+    // Weights: one tap row (18 KB, a verbatim copy of the packed rows) per stage, fetched by LDS-direct buffer loads (no staging
+    // registers -- with 128 accumulator registers there are none to spare -- and no ds_write): vector e = tid + 256 i lands at
+    // byte 16 e of the buffer, i.e. each wave-wide load writes 1 KB at a wave-uniform LDS base.
+    constexpr int NAV = 3 * 3 * BM * 2, NA = (NAV + 255) / 256;
+    float x_reg[NSLOT][8];
+    uint32_t a_vo[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int e = tid + i * 256;
+        const int tp = e / (BM * 2), rem = e % (BM * 2), col = rem >> 1, hf = rem & 1;
+        a_vo[i] = (uint32_t)((tp * p.CoutP + min(m0 + col, p.CoutP - 1)) * 2 + hf) * 16u;
+    }
+    const uint32_t a_gstride = (uint32_t)(9 * p.CoutP) * 32u;
+    const int nstage = 3 * niter;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto load_a = [&](int g, int buf) {
+        const uint32_t a_so = (uint32_t)min(g, nstage - 1) * a_gstride;
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            if (i * 256 + wv * 64 < NAV)        // wave-uniform (NAV is a multiple of 64)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(As + buf * AROW_BYTES + (i * 256 + wv * 64) * 16), 16, a_vo[i], a_so, 0, 0);
+        }
+    };
+    auto wait_loads = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };        // vmcnt(0): the LDS-direct loads have landed
+    auto load_x = [&](int it) {
+        const uint32_t c0 = (uint32_t)min(it, niter - 1) * 16u;
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) x_reg[k][j] = buf_load1(rx, it_xo[k], (c0 + j) * chw4);
+    };
+    auto store_x = [&](int it) {
+        const uint32_t c0 = (uint32_t)it * 16u;
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) {
+            const float4 s0 = *(const float4*)&sty[it_st[k] + c0], s1 = *(const float4*)&sty[it_st[k] + c0 + 4];
+            uint32_t pk[3][4];
+            split3_pair(x_reg[k][0] * s0.x, x_reg[k][1] * s0.y, pk[0][0], pk[1][0], pk[2][0]);
+            split3_pair(x_reg[k][2] * s0.z, x_reg[k][3] * s0.w, pk[0][1], pk[1][1], pk[2][1]);
+            split3_pair(x_reg[k][4] * s1.x, x_reg[k][5] * s1.y, pk[0][2], pk[1][2], pk[2][2]);
+            split3_pair(x_reg[k][6] * s1.z, x_reg[k][7] * s1.w, pk[0][3], pk[1][3], pk[2][3]);
+            if (tid + k * 256 < NITEM) {
+#pragma unroll
+                for (int pc_ = 0; pc_ < 3; pc_++) *(uint4*)(Xs + pc_ * XPIECE + it_ld[k]) = make_uint4(pk[pc_][0], pk[pc_][1], pk[pc_][2], pk[pc_][3]);
+            }
+        }
+    };
+    auto frag = [&](const char* ptr) { const uint4 v = *(const uint4*)ptr; bf16x8_t r; __builtin_memcpy(&r, &v, 16); return r; };
+    const int a_lane = l32 * 32 + half * 16;                        // + ((e*3 + piece)*BM + m*32) * 32
+    const int b_lane = (wn * 32 + l32) * 32 + half * 16;            // + piece*XPIECE + (run*XP + dxi) * 32
+    auto mma_row = [&](int a, int buf) {                            // tap row a = ky: Z[2m+py, 2n+px] += w[a,e] x[m - (a==2), n - (e==2)]
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            __builtin_amdgcn_sched_barrier(0);                       // one tap's fragments live at a time (128 accumulator registers: no room to hoist the next tap's reads)
+            const int q = (a & 1) * 2 + (e & 1);
+            const int run = a == 2 ? 0 : 1, dxi = e == 2 ? 0 : 1;
+            bf16x8_t fa[3][MTW], fb[3];
+#pragma unroll
+            for (int pc_ = 0; pc_ < 3; pc_++) {
+#pragma unroll
+                for (int m = 0; m < MTW; m++) fa[pc_][m] = frag(As + buf * AROW_BYTES + a_lane + ((e * 3 + pc_) * BM + m * 32) * 32);
+                fb[pc_] = frag(Xs + b_lane + pc_ * XPIECE + (run * XP + dxi) * 32);
+            }
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int pp = 0; pp < 6; pp++)
+#pragma unroll
+                for (int m = 0; m < MTW; m++) acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pp]][m], fb[PB[pp]], acc[q][m], 0, 0, 0);
+        }
+    };
+
+    // Tap row g (global index 3 * chunk + ky) lives in buffer g & 1.  One barrier per tap row: behind it every wave has finished the
+    // previous row, so the other buffer is free for the LDS-direct loads of the next row, which land under this row's MFMAs.
+    load_a(0, 0);
+    for (int it = 0; it < niter; it++) {
+        const int g = 3 * it, b0 = g & 1;
+        wait_loads();                           // tap row g has landed (and the activation registers)
+        __syncthreads();                        // ... for every wave; the previous chunk's fragments have been read
+        load_x(it);                             // (not prefetched across the chunk: 24 loop-carried registers next to the 128 accumulators made
+        store_x(it);                            //  the compiler spill accumulator tiles; the co-resident block's MFMAs cover this latency instead)
+        load_a(g + 1, b0 ^ 1);
+        __syncthreads();
+        mma_row(0, b0);
+        wait_loads();
+        __syncthreads();
+        load_a(g + 2, b0);
+        mma_row(1, b0 ^ 1);
+        wait_loads();
+        __syncthreads();
+        load_a(g + 3, b0 ^ 1);
+        mma_row(2, b0);
+    }
+    wait_loads();
+    __syncthreads();                                                // every wave is done with the stage buffers the tiles below overlay
+
+    // ---- epilogue (as in upconv_mfma_kernel): interleave px = 0/1 through a per-wave LDS tile, 16-B buffer stores into Z ----
+    float* ct = smem + wv * (32 * UP_CT_W);
+    const bool zbuf = (uint64_t)p.zslice * 4u < 0xFFFF0000ull;
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(p.z, zbuf ? (uint32_t)(p.zslice * 4) : 0u);
+    const int q4 = l & 15, cr = l >> 4;
+    const uint32_t z_vo = (uint32_t)(cr * 4 * p.GS + 4 * q4) * 4u;
+    const uint32_t z_pass = (uint32_t)(16 * p.GS) * 4u;
+    const int gbase = v0 + wn * 32;
+    const int b = gbase / p.GS, vp0 = gbase - b * p.GS;                // GS is a multiple of 32: the 32 points of a wave share their sample
+#pragma unroll 1
+    for (int tile = 0; tile < 2 * MTW; tile++) {
+#pragma unroll
+        for (int k = 0; k < 2 * MTW; k++) {
+            if (tile == k) {
+                constexpr int dummy = 0; (void)dummy;
+                const int py = k / MTW, mm = k % MTW;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    *(float2*)&ct[row * UP_CT_W + 2 * l32] = make_float2(acc[py * 2][mm][r], acc[py * 2 + 1][mm][r]);
+                }
+            }
+        }
+        const int py = tile / MTW, mm = tile % MTW;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int obase = m0 + mm * 32;
+        if (b < p.B) {
+            if (zbuf && obase + 32 <= p.Cout) {
+                const uint32_t zb = (uint32_t)(((b * p.Cout + obase) * 2 + py) * (2 * p.GS) + 2 * vp0) * 4u;
+#pragma unroll
+                for (int pass = 0; pass < 8; pass++) {
+                    const float4 v = *(const float4*)&ct[(pass * 4 + cr) * UP_CT_W + 4 * q4];
+                    const u32x4 bits = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+                    __builtin_amdgcn_raw_buffer_store_b128(bits, rz, z_vo, zb + (uint32_t)pass * z_pass, 0);
+                }
+            } else {
+#pragma unroll
+                for (int pass = 0; pass < 8; pass++) {
+                    const int ch = pass * 4 + cr, o = obase + ch;
+                    if (o < p.Cout) {
+                        const float4 v = *(const float4*)&ct[ch * UP_CT_W + 4 * q4];
+                        *(float4*)(p.z + (((int64_t)b * p.Cout + o) * 2 + py) * (2 * p.GS) + 2 * vp0 + 4 * q4) = v;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // weight [Cout,Cin,3,3] -> split pack [chunk16][tap][piece][CoutP][16 bf16] (zero beyond Cout / Cin)
 __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, uint32_t* __restrict__ wsp, int Cout, int Cin, int CoutP, int niter) {
     const int64_t total = (int64_t)niter * 9 * 3 * CoutP * 8;                 // u32 words (2 bf16 each)
@@ -2303,12 +2512,24 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         u.x = x; u.wp = wp; u.styles = styles; u.z = z;
         u.B = B; u.Cin = Cin; u.Cout = Cout; u.CoutP = pi.CoutP; u.H = H; u.W = W; u.G1 = pl.G1; u.GS = pl.GS; u.ksplit = pl.ksplit; u.zslice = pl.zslice;
         u.x_bytes = (uint32_t)((int64_t)B * Cin * H * W * 4); u.wp_bytes = (uint32_t)(pi.wp_floats * 4); u.st_bytes = (uint32_t)((int64_t)B * Cin * 4);
-        if (pl.cfg == 0) launch_upconv<2, 1, 2, 2, true>(u, s);
+        // opt-in split-bf16 arithmetic (tdgp_set_conv_arith(1)): same Z, one slice
+        const int s_blocks = cdiv(B * pl.GS, 128) * cdiv(Cout, 64);
+        const bool split = g_conv_arith == 1 && s_blocks >= 256 && styles && (Cin & 15) == 0 && Cin <= 2048 && pl.GS >= 2 * (128 + pl.G1 + 2);
+        if (split) {
+            Up3sParams q;
+            q.x = x; q.wsp = wp + pi.wp_floats + pi.wsq_floats; q.styles = styles; q.z = z;
+            q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W; q.G1 = pl.G1; q.GS = pl.GS; q.zslice = pl.zslice;
+            q.x_bytes = u.x_bytes; q.wsp_bytes = (uint32_t)(pi.wsplit_floats * 4);
+            const size_t lds = (size_t)(2 * 3 * 3 * 64 * 32 + 3 * 2 * 130 * 32 + 2 * Cin * 4);
+            static bool attr_set = false;
+            if (!attr_set) { (void)hipFuncSetAttribute((const void*)upconv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds - 2 * Cin * 4 + 2 * 2048 * 4)); attr_set = true; }
+            TDGP_LAUNCH("upconv_mfma_kernel", upconv3s_mfma_kernel, dim3(cdiv(B * pl.GS, 128), cdiv(Cout, 64)), dim3(256), lds, s, q);
+        } else if (pl.cfg == 0) launch_upconv<2, 1, 2, 2, true>(u, s);
         else launch_upconv<2, 1, 1, 4, false>(u, s);
         FirParams f;
         f.z = z; f.dcoef = dco; f.noise = noise; f.noise_bstride = noise_bstride; f.bias = bias; f.y = y;
         for (int i = 0; i < 16; i++) f.fir[i] = e.fir[i];
-        f.B = B; f.C = Cout; f.ZROWS = 2 * H + 2; f.P2 = 2 * pl.G1; f.GS2 = 2 * pl.GS; f.ksplit = pl.ksplit; f.zslice = pl.zslice;
+        f.B = B; f.C = Cout; f.ZROWS = 2 * H + 2; f.P2 = 2 * pl.G1; f.GS2 = 2 * pl.GS; f.ksplit = split ? 1 : pl.ksplit; f.zslice = pl.zslice;
         f.OH = 2 * H; f.OW = 2 * W;
         f.act = act; f.alpha = alpha; f.gain = gain; f.clamp = clamp;
         if (f.OW >= 128 && !TDGP_AB_FIR_SERIAL) {

@@ -1134,6 +1134,36 @@ def test_c4_forward_properties(tdgp):
         assert torch.equal(dec(ws, noise_mode='const'), nchw)
 
 
+@pytest.mark.parametrize('B,cin,cout,H', [(8, 64, 64, 64), (4, 128, 96, 96), (3, 48, 130, 128)])
+def test_upconv_split_arith(tdgp, oracle, B, cin, cout, H):
+    """The x2 (transposed conv + FIR) layers under tdgp_set_conv_arith(1): bf16 x 3 split operands on the bf16 MFMA, same Z layout and
+    FIR / output stage as the fp32 kernel.  Against the double-accumulating oracle, next to the fp32-MFMA result of the same layer."""
+    rs = np.random.RandomState(cin + 3 * cout)
+    mc = tdgp.ops.modconv
+    x = rs.randn(B, cin, H, H).astype(np.float32)
+    w = rs.randn(cout, cin, 3, 3).astype(np.float32)
+    s = (1 + 0.5 * rs.randn(B, cin)).astype(np.float32)
+    bias = rs.randn(cout).astype(np.float32)
+    noise = (0.3 * rs.randn(2 * H, 2 * H)).astype(np.float32)
+    f = oracle.setup_filter([1, 3, 3, 1])
+    ref = oracle.bias_act(oracle.modulated_conv2d(x, w, s, noise=noise, up=2, resample_filter=f), bias, act='lrelu')
+    pk = mc.PackedConv(T(w))
+    kw = dict(noise=T(noise), bias=T(bias), demodulate=True, act='lrelu', up=2, fir=mc.fir_host_array(f))
+    y32 = mc.modconv_forward(T(x), pk, T(s), **kw)
+    prev = tdgp._lib.set_conv_arith(1)
+    try:
+        ysp = mc.modconv_forward(T(x), pk, T(s), **kw)
+        for _ in range(5):
+            assert torch.equal(mc.modconv_forward(T(x), pk, T(s), **kw), ysp)
+    finally:
+        tdgp._lib.set_conv_arith(prev)
+    scale = np.abs(ref).max()
+    e32, esp = np.abs(N(y32) - ref).max() / scale, np.abs(N(ysp) - ref).max() / scale
+    assert e32 < 2e-6 and esp < 4e-6, (e32, esp)
+    assert not torch.equal(y32, ysp)                        # different arithmetic: the split kernel ran
+    assert tdgp._lib.set_conv_arith(0) == 0
+
+
 @pytest.mark.parametrize('cin,cout,H,up', [(36, 96, 32, 2), (20, 160, 64, 2), (44, 64, 32, 1), (12, 130, 64, 1)])
 def test_conv_odd_iteration_count_is_deterministic(tdgp, oracle, cin, cout, H, up):
     """Odd K-iteration counts (Cin / 4 odd) leave the last multiply outside the double-buffered loop: it must still be fenced from
