@@ -1244,34 +1244,31 @@ __global__ __launch_bounds__(256, 2) void conv3s_mfma_kernel(Conv3sParams p) {
             for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
 
     const int niter = p.Cin >> 4;                                   // the host only takes this kernel with Cin % 16 == 0
+    // Weights: one tap row (18 KB, a verbatim copy of the packed rows) per stage, fetched by LDS-direct buffer loads -- no staging
+    // registers, no ds_write: vector e = tid + 256 i lands at byte 16 e of the buffer, i.e. each wave-wide load writes 1 KB at a
+    // wave-uniform LDS base.  Tap row g (global index 3 * chunk + ky) lives in buffer g & 1.
     constexpr int NAV = 3 * 3 * BM * 2;                             // 16-B vectors of one tap row of weights
     constexpr int NA = (NAV + 255) / 256;
-    float4 a_reg[NA];
     float x_reg[NSLOT][8];
     uint32_t a_vo[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
         const int e = tid + i * 256;
-        a_vo[i] = kOOB;
-        if (e < NAV) {
-            const int tp = e / (BM * 2), rem = e % (BM * 2), col = rem >> 1, hf = rem & 1;
-            if (m0 + col < p.CoutP) a_vo[i] = (uint32_t)((tp * p.CoutP + m0 + col) * 2 + hf) * 16u;
-        }
+        const int tp = e / (BM * 2), rem = e % (BM * 2), col = rem >> 1, hf = rem & 1;
+        a_vo[i] = (uint32_t)((tp * p.CoutP + min(m0 + col, p.CoutP - 1)) * 2 + hf) * 16u;      // (columns past CoutP: a duplicate, never stored)
     }
     const uint32_t a_gstride = (uint32_t)(9 * p.CoutP) * 32u;      // one tap row = 3 taps x 3 pieces x CoutP columns x 32 B
     const int nstage = 3 * niter;
-    // No branches around loads (a load under a condition makes the compiler wait for ALL loads at the join): stages past the end
-    // re-read the last one.
-    auto load_a = [&](int g) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto load_a = [&](int g, int buf) {                             // stages past the end re-read the last one
         const uint32_t a_so = (uint32_t)min(g, nstage - 1) * a_gstride;
 #pragma unroll
-        for (int i = 0; i < NA; i++) a_reg[i] = buf_load4(rw, a_vo[i], a_so);
+        for (int i = 0; i < NA; i++) {
+            if (i * 256 + wv * 64 < NAV)                            // wave-uniform (NAV is a multiple of 64)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(As + buf * AROW_BYTES + (i * 256 + wv * 64) * 16), 16, a_vo[i], a_so, 0, 0);
+        }
     };
-    auto store_a = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NA; i++)
-            if (tid + i * 256 < NAV) *(float4*)(As + buf * AROW_BYTES + (tid + i * 256) * 16) = a_reg[i];
-    };
+    auto wait_loads = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };        // vmcnt(0): the LDS-direct loads have landed
     auto load_x = [&](int it) {
         const uint32_t c0 = (uint32_t)min(it, niter - 1) * 16u;
 #pragma unroll
@@ -1332,42 +1329,41 @@ __global__ __launch_bounds__(256, 2) void conv3s_mfma_kernel(Conv3sParams p) {
 #define TS(i)
 #endif
     // Two blocks per CU (LDS 75 KB each): one block's staging and barriers run under the other's MFMAs.  Per chunk of 16 channels:
-    // the activation stage once, the weights one tap row at a time through two buffers.
+    // the activation stage once, the weights one tap row at a time; one barrier per tap row, behind which the other weight buffer is
+    // free for the next row's loads, which land under this row's MFMAs.
     load_x(0);
-    load_a(0);
+    load_a(0, 0);
     TS(0)
     for (int it = 0; it < niter; it++) {
-        const int g = 3 * it;
-        __syncthreads();                        // the previous chunk's fragments have been read
+        const int g = 3 * it, b0 = g & 1;
+        wait_loads();                           // tap row g has landed (and the activation registers)
+        __syncthreads();                        // ... for every wave; the previous chunk's fragments have been read
         TS(1)
         store_x(it);
-        store_a(0);
         TS(2)
-        load_a(g + 1);
-        TS(3)
-        __syncthreads();
-        TS(1)
+        load_a(g + 1, b0 ^ 1);
         load_x(it + 1);                         // in flight during this chunk's MFMAs
         TS(3)
-        mma_row(0, 0);
-        TS(4)
-        store_a(1);
-        TS(2)
-        load_a(g + 2);
-        TS(3)
         __syncthreads();
         TS(1)
-        mma_row(1, 1);
+        mma_row(0, b0);
         TS(4)
-        store_a(0);                             // buffer 0 was last read before the barrier above
-        TS(2)
-        load_a(g + 3);
-        TS(3)
+        wait_loads();
         __syncthreads();
         TS(1)
-        mma_row(2, 0);
+        load_a(g + 2, b0);
+        TS(3)
+        mma_row(1, b0 ^ 1);
+        TS(4)
+        wait_loads();
+        __syncthreads();
+        TS(1)
+        load_a(g + 3, b0 ^ 1);
+        TS(3)
+        mma_row(2, b0);
         TS(4)
     }
+    wait_loads();
     __syncthreads();
     TS(0)
 
