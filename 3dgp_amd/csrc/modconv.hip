@@ -1422,16 +1422,13 @@ __global__ __launch_bounds__(256, 2) void upconv3s_mfma_kernel(Up3sParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = (char*)smem;                                           // two tap-row buffers (the epilogue's tiles overlay them)
     char* Xs = As + 2 * AROW_BYTES;                                   // [piece][run][position][16 bf16]
-    float* sty = (float*)(Xs + XS_BYTES);                             // [2][Cin]: the styles of the two samples a block can touch
+    float* Xraw = (float*)(Xs + XS_BYTES);                            // the next chunk's fp32 activations as they arrive: [slot][channel][thread]
+    float* styc = Xraw + (2 * 8 * 256 + 8 * 64);                      // [chunk parity][2 samples][16 channels] (+ 32 floats of slack per buffer)
     const int v0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     const int tid = threadIdx.x, l = tid & 63, wv = TDGP_WAVE_INDEX(tid), l32 = l & 31, half = l >> 5;
     const int wn = wv;
 
     const int b_lo = max(v0 - 1 - p.G1, 0) / p.GS;
-    for (int i = tid; i < 2 * p.Cin; i += 256) {
-        const int sb = i >= p.Cin ? 1 : 0;
-        sty[i] = p.styles[min(b_lo + sb, p.B - 1) * p.Cin + (i - sb * p.Cin)];
-    }
     // staging items = (channel half, run, position): 2 x 2 x 129, half-major (a wave-wide load = consecutive positions of one plane)
     constexpr int NRUN = BN + 1, NITEM = 2 * 2 * NRUN, NSLOT = (NITEM + 255) / 256;
     uint32_t it_xo[NSLOT], it_st[NSLOT], it_ld[NSLOT];
@@ -1447,13 +1444,14 @@ __global__ __launch_bounds__(256, 2) void upconv3s_mfma_kernel(Up3sParams p) {
                 const int m = vp / p.G1, n = vp - m * p.G1;
                 if (b < p.B && m < p.H && n < p.W) {
                     it_xo[k] = (uint32_t)(((b * p.Cin + 8 * hf) * p.H + m) * p.W + n) * 4u;
-                    it_st[k] = (uint32_t)((b - b_lo) * p.Cin + 8 * hf);
+                    it_st[k] = (uint32_t)((b - b_lo) * 16 + 8 * hf);
                 }
             }
         }
     }
     const uint32_t chw4 = (uint32_t)(p.H * p.W) * 4u;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.wsp, p.wsp_bytes);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.wsp, p.wsp_bytes), rs = make_rsrc(p.styles, (uint32_t)(p.B * p.Cin) * 4u);
+    const uint32_t s_vo = (uint32_t)(min(b_lo + ((l >> 4) & 1), p.B - 1) * p.Cin + (l & 15)) * 4u;       // styles of the chunk: lane = (sample, channel)
 
     f32x16 acc[4][MTW];                                               // [py*2+px][channel tile]
 #pragma unroll
@@ -1468,7 +1466,6 @@ __global__ __launch_bounds__(256, 2) void upconv3s_mfma_kernel(Up3sParams p) {
     // registers -- with 128 accumulator registers there are none to spare -- and no ds_write): vector e = tid + 256 i lands at
     // byte 16 e of the buffer, i.e. each wave-wide load writes 1 KB at a wave-uniform LDS base.
     constexpr int NAV = 3 * 3 * BM * 2, NA = (NAV + 255) / 256;
-    float x_reg[NSLOT][8];
     uint32_t a_vo[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
@@ -1488,26 +1485,41 @@ __global__ __launch_bounds__(256, 2) void upconv3s_mfma_kernel(Up3sParams p) {
         }
     };
     auto wait_loads = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };        // vmcnt(0): the LDS-direct loads have landed
+    // The activations never sit in registers across the MFMAs (24 loop-carried registers next to the 128 accumulators made the compiler
+    // spill accumulator tiles): LDS-direct loads drop the next chunk's fp32 values into Xraw, the split reads them back from there.
+    // Out-of-range positions carry an out-of-bounds offset and arrive as zeros.
     auto load_x = [&](int it) {
         const uint32_t c0 = (uint32_t)min(it, niter - 1) * 16u;
 #pragma unroll
-        for (int k = 0; k < NSLOT; k++)
+        for (int k = 0; k < NSLOT; k++) {
+            if (k * 256 + wv * 64 < NITEM) {                        // wave-uniform: slot 2 has items in wave 0 only
+                float* dst = Xraw + (k < 2 ? (k * 8) * 256 + wv * 64 : 2 * 8 * 256);
 #pragma unroll
-            for (int j = 0; j < 8; j++) x_reg[k][j] = buf_load1(rx, it_xo[k], (c0 + j) * chw4);
+                for (int j = 0; j < 8; j++)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(dst + j * (k < 2 ? 256 : 64)), 4, it_xo[k], (c0 + j) * chw4, 0, 0);
+            }
+        }
+        if (wv == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(styc + (it & 1) * 64), 4, s_vo, c0 * 4u, 0, 0);
     };
     auto store_x = [&](int it) {
-        const uint32_t c0 = (uint32_t)it * 16u;
+        const float* sc = styc + (it & 1) * 64;
 #pragma unroll
         for (int k = 0; k < NSLOT; k++) {
-            const float4 s0 = *(const float4*)&sty[it_st[k] + c0], s1 = *(const float4*)&sty[it_st[k] + c0 + 4];
-            uint32_t pk[3][4];
-            split3_pair(x_reg[k][0] * s0.x, x_reg[k][1] * s0.y, pk[0][0], pk[1][0], pk[2][0]);
-            split3_pair(x_reg[k][2] * s0.z, x_reg[k][3] * s0.w, pk[0][1], pk[1][1], pk[2][1]);
-            split3_pair(x_reg[k][4] * s1.x, x_reg[k][5] * s1.y, pk[0][2], pk[1][2], pk[2][2]);
-            split3_pair(x_reg[k][6] * s1.z, x_reg[k][7] * s1.w, pk[0][3], pk[1][3], pk[2][3]);
-            if (tid + k * 256 < NITEM) {
+            if (k * 256 + wv * 64 < NITEM) {
+                const float* src = Xraw + (k < 2 ? (k * 8) * 256 + tid : 2 * 8 * 256 + l);
+                float xv[8];
 #pragma unroll
-                for (int pc_ = 0; pc_ < 3; pc_++) *(uint4*)(Xs + pc_ * XPIECE + it_ld[k]) = make_uint4(pk[pc_][0], pk[pc_][1], pk[pc_][2], pk[pc_][3]);
+                for (int j = 0; j < 8; j++) xv[j] = src[j * (k < 2 ? 256 : 64)];
+                const float4 s0 = *(const float4*)&sc[it_st[k]], s1 = *(const float4*)&sc[it_st[k] + 4];
+                uint32_t pk[3][4];
+                split3_pair(xv[0] * s0.x, xv[1] * s0.y, pk[0][0], pk[1][0], pk[2][0]);
+                split3_pair(xv[2] * s0.z, xv[3] * s0.w, pk[0][1], pk[1][1], pk[2][1]);
+                split3_pair(xv[4] * s1.x, xv[5] * s1.y, pk[0][2], pk[1][2], pk[2][2]);
+                split3_pair(xv[6] * s1.z, xv[7] * s1.w, pk[0][3], pk[1][3], pk[2][3]);
+                if (tid + k * 256 < NITEM) {
+#pragma unroll
+                    for (int pc_ = 0; pc_ < 3; pc_++) *(uint4*)(Xs + pc_ * XPIECE + it_ld[k]) = make_uint4(pk[pc_][0], pk[pc_][1], pk[pc_][2], pk[pc_][3]);
+                }
             }
         }
     };
@@ -1538,20 +1550,21 @@ __global__ __launch_bounds__(256, 2) void upconv3s_mfma_kernel(Up3sParams p) {
     // Tap row g (global index 3 * chunk + ky) lives in buffer g & 1.  One barrier per tap row: behind it every wave has finished the
     // previous row, so the other buffer is free for the LDS-direct loads of the next row, which land under this row's MFMAs.
     load_a(0, 0);
+    load_x(0);
     for (int it = 0; it < niter; it++) {
         const int g = 3 * it, b0 = g & 1;
-        wait_loads();                           // tap row g has landed (and the activation registers)
+        wait_loads();                           // tap row g, the chunk's activations and styles have landed
         __syncthreads();                        // ... for every wave; the previous chunk's fragments have been read
-        load_x(it);                             // (not prefetched across the chunk: 24 loop-carried registers next to the 128 accumulators made
-        store_x(it);                            //  the compiler spill accumulator tiles; the co-resident block's MFMAs cover this latency instead)
+        store_x(it);
         load_a(g + 1, b0 ^ 1);
-        __syncthreads();
+        __syncthreads();                        // the split activations are in place, Xraw is free again
         mma_row(0, b0);
         wait_loads();
         __syncthreads();
         load_a(g + 2, b0);
+        load_x(it + 1);                         // younger than the weight loads: the wait below leaves them in flight
         mma_row(1, b0 ^ 1);
-        wait_loads();
+        if (wv == 0) __builtin_amdgcn_s_waitcnt(0x4F79); else __builtin_amdgcn_s_waitcnt(0x4F70);       // vmcnt(25 | 16): tap row g+2 has landed
         __syncthreads();
         load_a(g + 3, b0 ^ 1);
         mma_row(2, b0);
@@ -2516,9 +2529,9 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
             q.x = x; q.wsp = wp + pi.wp_floats + pi.wsq_floats; q.styles = styles; q.z = z;
             q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W; q.G1 = pl.G1; q.GS = pl.GS; q.zslice = pl.zslice;
             q.x_bytes = u.x_bytes; q.wsp_bytes = (uint32_t)(pi.wsplit_floats * 4);
-            const size_t lds = (size_t)(2 * 3 * 3 * 64 * 32 + 3 * 2 * 130 * 32 + 2 * Cin * 4);
+            const size_t lds = (size_t)(2 * 3 * 3 * 64 * 32 + 3 * 2 * 130 * 32 + (2 * 8 * 256 + 8 * 64) * 4 + 2 * 64 * 4);
             static bool attr_set = false;
-            if (!attr_set) { (void)hipFuncSetAttribute((const void*)upconv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds - 2 * Cin * 4 + 2 * 2048 * 4)); attr_set = true; }
+            if (!attr_set) { (void)hipFuncSetAttribute((const void*)upconv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
             TDGP_LAUNCH("upconv_mfma_kernel", upconv3s_mfma_kernel, dim3(cdiv(B * pl.GS, 128), cdiv(Cout, 64)), dim3(256), lds, s, q);
         } else if (pl.cfg == 0) launch_upconv<2, 1, 2, 2, true>(u, s);
         else launch_upconv<2, 1, 1, 4, false>(u, s);

@@ -190,7 +190,7 @@ def main():
             'metric': 'generator-forward img/s @256^2, 64 steps' if args.config in ('c3', 'c4') else f'generator-forward img/s ({args.config})',
             'value': round(total_imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.arith == 'f32' else 'bf16x3->f32 (3x3 layers), f32 elsewhere', 'data': 'synthetic',
+            'dtype': 'f32' if args.arith == 'f32' else 'bf16x3->f32 (3x3 and x2 layers), f32 elsewhere', 'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[2]: ImageNet 256x256, {cfg.num_ray_steps}(+{cfg.num_ray_steps}) ray steps, cmax {cfg.cmax}, '
                                    f'c_dim {cfg.c_dim}, tri-plane {cfg.tri_plane_res}^2 x {cfg.plane_channels}, full HIP path' if args.config == 'c3'
                        else args.config, 'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'img_resolution': cfg.img_resolution,
