@@ -25,6 +25,7 @@
 //   demod_kernel, splitk_reduce_kernel, pack_kernel, style_affine_kernel.
 // Every conv kernel parks its accumulator tiles in a per-wave LDS tile and runs the same fused output stage (epilogue_tile):
 // demodulation, noise, bias, activation, gain, clamp, the ToRGB skip, 16-byte stores.
+#include <type_traits>
 #include "common.h"
 #include <stdlib.h>
 
@@ -1161,6 +1162,28 @@ struct Conv3sParams {
     uint32_t x_bytes, wsp_bytes, st_bytes;
 };
 
+// Compile-time loop (the LDS fragment reads below take their offsets as instruction immediates).
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+// LDS fragment read the compiler's waitcnt pass cannot see.  Why: with an LDS-direct buffer load in flight hipcc puts s_waitcnt vmcnt(0)
+// in front of every ds_read of the same LDS object (may alias the load's destination) and in front of every __syncthreads() (the
+// workgroup release fence) -- i.e. a tap row's weight loads could never fly under the previous row's MFMAs.  These reads, the
+// lgkmcnt waits that make their results usable and the barriers are therefore spelled out; vmcnt is waited for explicitly where a
+// buffer is about to be read.
+template <int OFF> __device__ __forceinline__ bf16x8_t lds_frag(uint32_t addr) {
+    bf16x8_t r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// LDS addresses are carried as integers (byte offsets in the LDS aperture): a generic -> LDS pointer cast of a computed pointer drags a
+// null check along (and tripped a backend assertion in one build); the array itself is a known object, its cast folds to a constant.
+#define TDGP_LDS_BASE(arr) ((uint32_t)(uintptr_t)(lds_ptr_t)(arr))
+__device__ __forceinline__ lds_ptr_t lds_ptr(uint32_t addr) { return (lds_ptr_t)(uintptr_t)addr; }
+// this wave's LDS writes have completed, then the block barrier -- no fence (a fence would wait for the LDS-direct loads in flight)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Two values at a time: v_cvt_pk_bf16_f32 (round to nearest even, already packed as a channel pair), the residual by an exact
 // v_pk_add_f32 -- 9 vector-ALU instructions per pair.  x = hi + mid + lo + r with |r| <= 2^-25 |x|.
 typedef float split_f2 __attribute__((ext_vector_type(2)));
@@ -1180,6 +1203,7 @@ __global__ __launch_bounds__(256, 2) void conv3s_mfma_kernel(Conv3sParams p) {
     constexpr int AROW_BYTES = 3 * 3 * BM * 32, XS_BYTES = 3 * PSZ * 32;      // one tap row of weights: [dx][piece][64 columns][32 B]
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = (char*)smem;                                           // two tap-row buffers
+    const uint32_t lds0 = TDGP_LDS_BASE(smem);
     char* Xs = As + 2 * AROW_BYTES;
     float* side = (float*)(Xs + XS_BYTES);                          // [1 + NSB][BM]
     float* sty = side + (1 + 4) * BM;                               // [2][Cin]: the styles of the two samples a block can touch
@@ -1259,13 +1283,12 @@ __global__ __launch_bounds__(256, 2) void conv3s_mfma_kernel(Conv3sParams p) {
     }
     const uint32_t a_gstride = (uint32_t)(9 * p.CoutP) * 32u;      // one tap row = 3 taps x 3 pieces x CoutP columns x 32 B
     const int nstage = 3 * niter;
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
     auto load_a = [&](int g, int buf) {                             // stages past the end re-read the last one
         const uint32_t a_so = (uint32_t)min(g, nstage - 1) * a_gstride;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            if (i * 256 + wv * 64 < NAV)                            // wave-uniform (NAV is a multiple of 64)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(As + buf * AROW_BYTES + (i * 256 + wv * 64) * 16), 16, a_vo[i], a_so, 0, 0);
+            if (i * 256 + 192 < NAV || i * 256 + wv * 64 < NAV)                            // wave-uniform (NAV is a multiple of 64)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, lds_ptr(lds0 + (uint32_t)(buf * AROW_BYTES + (i * 256 + wv * 64) * 16)), 16, a_vo[i], a_so, 0, 0);
         }
     };
     auto wait_loads = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };        // vmcnt(0): the LDS-direct loads have landed
@@ -1421,6 +1444,7 @@ __global__ __launch_bounds__(256, 2) void upconv3s_mfma_kernel(Up3sParams p) {
     constexpr int AROW_BYTES = 3 * 3 * BM * 32, XPIECE = 2 * XP * 32, XS_BYTES = 3 * XPIECE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* As = (char*)smem;                                           // two tap-row buffers (the epilogue's tiles overlay them)
+    const uint32_t lds0 = TDGP_LDS_BASE(smem), xraw0 = lds0 + (uint32_t)(2 * AROW_BYTES + XS_BYTES);
     char* Xs = As + 2 * AROW_BYTES;                                   // [piece][run][position][16 bf16]
     float* Xraw = (float*)(Xs + XS_BYTES);                            // the next chunk's fp32 activations as they arrive: [slot][channel][thread]
     float* styc = Xraw + (2 * 8 * 256 + 8 * 64);                      // [chunk parity][2 samples][16 channels] (+ 32 floats of slack per buffer)
@@ -1475,13 +1499,12 @@ __global__ __launch_bounds__(256, 2) void upconv3s_mfma_kernel(Up3sParams p) {
     }
     const uint32_t a_gstride = (uint32_t)(9 * p.CoutP) * 32u;
     const int nstage = 3 * niter;
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
     auto load_a = [&](int g, int buf) {
         const uint32_t a_so = (uint32_t)min(g, nstage - 1) * a_gstride;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            if (i * 256 + wv * 64 < NAV)        // wave-uniform (NAV is a multiple of 64)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(As + buf * AROW_BYTES + (i * 256 + wv * 64) * 16), 16, a_vo[i], a_so, 0, 0);
+            if (i * 256 + 192 < NAV || i * 256 + wv * 64 < NAV)        // wave-uniform (NAV is a multiple of 64)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, lds_ptr(lds0 + (uint32_t)(buf * AROW_BYTES + (i * 256 + wv * 64) * 16)), 16, a_vo[i], a_so, 0, 0);
         }
     };
     auto wait_loads = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };        // vmcnt(0): the LDS-direct loads have landed
@@ -1492,20 +1515,20 @@ __global__ __launch_bounds__(256, 2) void upconv3s_mfma_kernel(Up3sParams p) {
         const uint32_t c0 = (uint32_t)min(it, niter - 1) * 16u;
 #pragma unroll
         for (int k = 0; k < NSLOT; k++) {
-            if (k * 256 + wv * 64 < NITEM) {                        // wave-uniform: slot 2 has items in wave 0 only
-                float* dst = Xraw + (k < 2 ? (k * 8) * 256 + wv * 64 : 2 * 8 * 256);
+            if (k * 256 + 192 < NITEM || k * 256 + wv * 64 < NITEM) {                        // wave-uniform: slot 2 has items in wave 0 only
+                const uint32_t dst = xraw0 + (uint32_t)(k < 2 ? (k * 8) * 256 + wv * 64 : 2 * 8 * 256) * 4u;
 #pragma unroll
                 for (int j = 0; j < 8; j++)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(dst + j * (k < 2 ? 256 : 64)), 4, it_xo[k], (c0 + j) * chw4, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, lds_ptr(dst + (uint32_t)(j * (k < 2 ? 256 : 64)) * 4u), 4, it_xo[k], (c0 + j) * chw4, 0, 0);
             }
         }
-        if (wv == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(styc + (it & 1) * 64), 4, s_vo, c0 * 4u, 0, 0);
+        if (wv == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds_ptr(xraw0 + (uint32_t)(2 * 8 * 256 + 8 * 64 + (it & 1) * 64) * 4u), 4, s_vo, c0 * 4u, 0, 0);
     };
     auto store_x = [&](int it) {
         const float* sc = styc + (it & 1) * 64;
 #pragma unroll
         for (int k = 0; k < NSLOT; k++) {
-            if (k * 256 + wv * 64 < NITEM) {
+            if (k * 256 + 192 < NITEM || k * 256 + wv * 64 < NITEM) {
                 const float* src = Xraw + (k < 2 ? (k * 8) * 256 + tid : 2 * 8 * 256 + l);
                 float xv[8];
 #pragma unroll
@@ -1523,51 +1546,84 @@ __global__ __launch_bounds__(256, 2) void upconv3s_mfma_kernel(Up3sParams p) {
             }
         }
     };
-    auto frag = [&](const char* ptr) { const uint4 v = *(const uint4*)ptr; bf16x8_t r; __builtin_memcpy(&r, &v, 16); return r; };
-    const int a_lane = l32 * 32 + half * 16;                        // + ((e*3 + piece)*BM + m*32) * 32
-    const int b_lane = (wn * 32 + l32) * 32 + half * 16;            // + piece*XPIECE + (run*XP + dxi) * 32
-    auto mma_row = [&](int a, int buf) {                            // tap row a = ky: Z[2m+py, 2n+px] += w[a,e] x[m - (a==2), n - (e==2)]
-#pragma unroll
-        for (int e = 0; e < 3; e++) {
-            __builtin_amdgcn_sched_barrier(0);                       // one tap's fragments live at a time (128 accumulator registers: no room to hoist the next tap's reads)
-            const int q = (a & 1) * 2 + (e & 1);
-            const int run = a == 2 ? 0 : 1, dxi = e == 2 ? 0 : 1;
-            bf16x8_t fa[3][MTW], fb[3];
-#pragma unroll
-            for (int pc_ = 0; pc_ < 3; pc_++) {
-#pragma unroll
-                for (int m = 0; m < MTW; m++) fa[pc_][m] = frag(As + buf * AROW_BYTES + a_lane + ((e * 3 + pc_) * BM + m * 32) * 32);
-                fb[pc_] = frag(Xs + b_lane + pc_ * XPIECE + (run * XP + dxi) * 32);
+    const uint32_t a_addr0 = lds0 + (uint32_t)(l32 * 32 + half * 16);               // + buf*AROW_BYTES; immediates: ((e*3 + piece)*BM + m*32) * 32
+    const uint32_t x_addr = lds0 + (uint32_t)(2 * AROW_BYTES) + (uint32_t)((wn * 32 + l32) * 32 + half * 16);    // immediates: piece*XPIECE + (run*XP + dxi) * 32
+    // tap row a = ky: Z[2m+py, 2n+px] += w[a,e] x[m - (a==2), n - (e==2)].  The next tap's nine fragments are requested before this
+    // tap's twelve MFMAs are issued (lgkmcnt(9): this tap's have arrived, the next tap's may still be on their way).
+    auto mma_row = [&](auto A_, int buf) {
+        constexpr int a = decltype(A_)::value;
+        const uint32_t a_addr = a_addr0 + (uint32_t)(buf * AROW_BYTES);
+        bf16x8_t fr[2][9];                                           // [tap parity][fa(piece, m) = 2*piece + m | fb(piece) = 6 + piece]
+        auto request = [&](auto E_, auto S_) {
+            constexpr int e = decltype(E_)::value, st = decltype(S_)::value;
+            constexpr int run = a == 2 ? 0 : 1, dxi = e == 2 ? 0 : 1;
+            static_for<0, 3>([&](auto P_) {
+                constexpr int pc = decltype(P_)::value;
+                fr[st][2 * pc] = lds_frag<((e * 3 + pc) * BM) * 32>(a_addr);
+                fr[st][2 * pc + 1] = lds_frag<((e * 3 + pc) * BM + 32) * 32>(a_addr);
+                fr[st][6 + pc] = lds_frag<pc * XPIECE + (run * XP + dxi) * 32>(x_addr);
+            });
+        };
+        request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        static_for<0, 3>([&](auto E_) {
+            constexpr int e = decltype(E_)::value, st = e & 1;
+            constexpr int q = (a & 1) * 2 + (e & 1);
+            if constexpr (e < 2) {
+                request(std::integral_constant<int, e + 1>{}, std::integral_constant<int, st ^ 1>{});
+                asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(fr[st][0]), "+v"(fr[st][1]), "+v"(fr[st][2]), "+v"(fr[st][3]), "+v"(fr[st][4]), "+v"(fr[st][5]),
+                             "+v"(fr[st][6]), "+v"(fr[st][7]), "+v"(fr[st][8]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[st][0]), "+v"(fr[st][1]), "+v"(fr[st][2]), "+v"(fr[st][3]), "+v"(fr[st][4]), "+v"(fr[st][5]),
+                             "+v"(fr[st][6]), "+v"(fr[st][7]), "+v"(fr[st][8]));
             }
             constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
             for (int pp = 0; pp < 6; pp++)
 #pragma unroll
-                for (int m = 0; m < MTW; m++) acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pp]][m], fb[PB[pp]], acc[q][m], 0, 0, 0);
-        }
+                for (int m = 0; m < MTW; m++) acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[st][2 * PA[pp] + m], fr[st][6 + PB[pp]], acc[q][m], 0, 0, 0);
+        });
     };
+    constexpr std::integral_constant<int, 0> R0{}; constexpr std::integral_constant<int, 1> R1{}; constexpr std::integral_constant<int, 2> R2{};
 
     // Tap row g (global index 3 * chunk + ky) lives in buffer g & 1.  One barrier per tap row: behind it every wave has finished the
     // previous row, so the other buffer is free for the LDS-direct loads of the next row, which land under this row's MFMAs.
+#if TDGP_C3_ABL & 32
+    long long ts[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define TS(i) { const long long tn_ = __builtin_readcyclecounter(); ts[i] += tn_ - tprev; tprev = tn_; }
+#else
+#define TS(i)
+#endif
     load_a(0, 0);
     load_x(0);
+    TS(0)
     for (int it = 0; it < niter; it++) {
         const int g = 3 * it, b0 = g & 1;
         wait_loads();                           // tap row g, the chunk's activations and styles have landed
-        __syncthreads();                        // ... for every wave; the previous chunk's fragments have been read
+        lds_barrier();                          // ... for every wave; the previous chunk's fragments have been read
+        TS(1)
         store_x(it);
-        load_a(g + 1, b0 ^ 1);
-        __syncthreads();                        // the split activations are in place, Xraw is free again
-        mma_row(0, b0);
+        TS(2)
+        load_a(g + 1, b0 ^ 1);                  // lands under tap row g's MFMAs
+        TS(3)
+        lds_barrier();                          // the split activations are in place, Xraw is free again
+        TS(1)
+        mma_row(R0, b0);
+        TS(4)
         wait_loads();
-        __syncthreads();
+        lds_barrier();
+        TS(1)
         load_a(g + 2, b0);
         load_x(it + 1);                         // younger than the weight loads: the wait below leaves them in flight
-        mma_row(1, b0 ^ 1);
+        TS(3)
+        mma_row(R1, b0 ^ 1);
+        TS(4)
         if (wv == 0) __builtin_amdgcn_s_waitcnt(0x4F79); else __builtin_amdgcn_s_waitcnt(0x4F70);       // vmcnt(25 | 16): tap row g+2 has landed
-        __syncthreads();
+        lds_barrier();
+        TS(1)
         load_a(g + 3, b0 ^ 1);
-        mma_row(2, b0);
+        TS(3)
+        mma_row(R2, b0);
+        TS(4)
     }
     wait_loads();
     __syncthreads();                                                // every wave is done with the stage buffers the tiles below overlay
@@ -1622,6 +1678,12 @@ __global__ __launch_bounds__(256, 2) void upconv3s_mfma_kernel(Up3sParams p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+#if TDGP_C3_ABL & 32
+    TS(5)
+    if (tid == 0 && (blockIdx.x == 3 || blockIdx.x == 400) && blockIdx.y == 0)
+        printf("upconv3s blk %d iters %d: prologue %lld wait+barrier %lld store %lld load-issue %lld mma %lld epilogue %lld\n", (int)blockIdx.x, niter, ts[0], ts[1], ts[2], ts[3], ts[4], ts[5]);
+#endif
+#undef TS
 }
 
 // weight [Cout,Cin,3,3] -> split pack [chunk16][tap][piece][CoutP][16 bf16] (zero beyond Cout / Cin)
