@@ -125,9 +125,12 @@ int     tdgp_modconv2d(const float* x, const void* wpack, const float* styles, c
 int     tdgp_conv_transpose2d_x2(const float* x, const void* wpack, const float* styles, float* y, int B, int Cin, int Cout,
                                  int H, int W, void* workspace, int64_t workspace_bytes, tdgp_stream_t stream);
 
-/* Arithmetic of the 3x3 stride-1 convolutions (W % 32 == 0, >= 256 output tiles): 0 (default) = fp32 MFMA; 1 = every fp32 operand
- * split into three bf16 pieces, six piece products per multiply on the bf16 MFMA with fp32 accumulation (fp32-grade results, not
- * bit-identical to mode 0).  Process-wide; returns the previous mode (negative on error). */
+/* Arithmetic of the large 3x3 convolutions of tdgp_modconv2d -- stride 1 (W % 32 == 0) and the x2 transposed form, launches of
+ * >= 256 tiles with styles present and Cin % 16 == 0: 0 (default) = fp32 MFMA; 1 = every fp32 operand split into three bf16
+ * pieces, six piece products per multiply on the bf16 MFMA with fp32 accumulation (fp32-grade results, <= 4e-6 of the exact
+ * layer output, not bit-identical to mode 0; layers outside those conditions keep the fp32 kernels).  Process-wide; returns the
+ * previous mode (negative on error).  No counterpart in the reference: its convolutions are cuDNN fp32 with TF32 disabled
+ * (training_loop.py:76-77). */
 int     tdgp_set_conv_arith(int mode);
 
 /* Demodulation coefficients d[b,o] = rsqrt(sum_c s[b,c]^2 * sum_tap W[o,c,tap]^2 + 1e-8) (networks_stylegan2.py:62) of SEVERAL
