@@ -247,3 +247,23 @@ def test_training_driver_pieces(tdgp):
     loss.calls.clear()
     assert TR.train_iteration(loss, phases, real, gen, batch_idx=16, cur_nimg=0, batch_size=8, batch_gpu=8, world=1) == ['Gall', 'Dmain', 'Dreg']
     assert loss.calls[-1][0] == 'Dreg' and loss.calls[-1][3] == 16
+
+
+def test_bench_flop_model_matches_survey(tdgp):
+    """bench.py's algorithmic FLOP per image (what `roofline.achieved` is computed from) against SURVEY.md 8(d): conv1 83.7 G,
+    conv0 (x2 layers) 35.4 G, ToRGB 6.2 G, renderer 45.1 G for BASELINE configs[2]; 488.9 G backbone for configs[3]."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    f3 = bench.algorithmic_flops(tdgp.config.config_c3())
+    g = {k: v[0] / 1e9 for k, v in f3.items()}
+    assert abs(g['conv_mfma_kernel'] - 83.7) < 0.1 and f3['conv_mfma_kernel'][1] == 8
+    assert abs(g['upconv_mfma_kernel'] - 35.4) < 0.1 and f3['upconv_mfma_kernel'][1] == 7
+    assert abs(g['torgb_mfma_kernel'] - 6.2) < 0.05 and f3['torgb_mfma_kernel'][1] == 8
+    assert abs(g['triplane_field_kernel'] - 45.1) < 0.1 and f3['triplane_field_kernel'][1] == 2
+    assert abs(sum(g.values()) - 170.4) < 0.3                  # 171.7 G in the SURVEY includes the 1.3 G of the FIR passes (no matrix work)
+    f4 = bench.algorithmic_flops(tdgp.config.config_c4())
+    back4 = sum(f4[k][0] for k in ('conv_mfma_kernel', 'upconv_mfma_kernel', 'torgb_mfma_kernel')) / 1e9
+    assert abs(back4 - 488.9) < 0.5
+    assert bench.PEAK_FP32_MFMA_TFLOPS == 157.3
