@@ -8,7 +8,7 @@
 // Mapping: ONE 64-lane wavefront per ray (4 rays per 256-thread block), samples across lanes, per-wave LDS
 // scratch, no block-level synchronisation.  Scans (transmittance cumprod, cdf cumsum) are fp64 wave scans
 // rounded to fp32 per prefix, which reproduces torch's sequential-fp64 CPU accumulation;
-// reductions are fp64 wave sums rounded once.  exp/log1p are evaluated in fp64: these kernels are HBM/latency
+// reductions are fp64 wave sums rounded once, except sample_pdf's normaliser, which follows torch's fp32 order bit for bit.  exp/log1p are evaluated in fp64: these kernels are HBM/latency
 // bound (2S*20 B per ray), the fp64 transcendental costs nothing measurable and keeps the importance-sampling
 // integer decisions (searchsorted index, sort permutation) identical to the CPU oracle.
 #include "common.h"
@@ -106,6 +106,46 @@ __device__ void march_mip_lds(const float* z, const float* sig, float* w, int S,
 }
 
 // ------------------------------------------------------------------------------------------------
+// torch.sum(x, -1) of the reference's CPU path over x[i] = w1[i] + eps, i < n, IN TORCH'S OWN ORDER: the value is
+// sample_pdf's normaliser (tri_plane_renderer.py:272) and its last bit decides which cdf knot a draw falls behind,
+// i.e. the searchsorted indices.  ATen's sum kernel (cpu/SumKernel.cpp, AVX2 dispatch: 8 fp32 lanes) cuts the row
+// into nv = n/8 vectors, adds them into 4 interleaved vector accumulators (acc[k] += V[4i+k]), the nv%4 left-over
+// vectors into accumulator 0, then acc0 += acc1, acc2, acc3, and finally a scalar takes the n%8 tail elements in
+// order followed by the 8 lanes of acc0 in order (no cascade level is reached below 512 elements; n <= 254 here).
+// Rows shorter than 8 run the same scheme on scalars.  Lane (a = (l>>3)&3, col = l&7) plays lane col of accumulator a;
+// every lane returns the result.
+// ------------------------------------------------------------------------------------------------
+__device__ float torch_order_sum_lds(const float* w1, int n, float eps) {
+    const int l = lane_id();
+    if (n >= 8) {
+        const int nv = n >> 3, nilp = nv >> 2;
+        const int col = l & 7, a = (l >> 3) & 3;
+        float acc = 0.f;
+        for (int i = 0; i < nilp; i++) acc = __fadd_rn(acc, __fadd_rn(w1[(4 * i + a) * 8 + col], eps));
+        for (int j = 4 * nilp; j < nv; j++) {
+            const float v = __fadd_rn(w1[j * 8 + col], eps);
+            if (a == 0) acc = __fadd_rn(acc, v);
+        }
+        float p = __shfl(acc, col, 64);
+        p = __fadd_rn(p, __shfl(acc, col + 8, 64));
+        p = __fadd_rn(p, __shfl(acc, col + 16, 64));
+        p = __fadd_rn(p, __shfl(acc, col + 24, 64));
+        float fin = 0.f;
+        for (int k = nv * 8; k < n; k++) fin = __fadd_rn(fin, __fadd_rn(w1[k], eps));
+#pragma unroll
+        for (int c = 0; c < 8; c++) fin = __fadd_rn(fin, __shfl(p, c, 64));
+        return fin;
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nilp = n >> 2;                       // 0 or 1
+    if (nilp)
+        for (int k = 0; k < 4; k++) acc[k] = __fadd_rn(acc[k], __fadd_rn(w1[k], eps));
+    for (int r = 4 * nilp; r < n; r++) acc[0] = __fadd_rn(acc[0], __fadd_rn(w1[r], eps));
+    for (int k = 1; k < 4; k++) acc[0] = __fadd_rn(acc[0], acc[k]);
+    return acc[0];
+}
+
+// ------------------------------------------------------------------------------------------------
 // sample_importance + sample_pdf on LDS-resident z[S] (s-space) and weights w[Wn].
 // tri_plane_renderer.py:237-295.  Clobbers sc.w / sc.cdf / sc.bins.
 // Lane j produces sample j (strided by 64).  `emit(j, sample, ind, below, above)` consumes the results.
@@ -141,10 +181,8 @@ __device__ void importance_lds(SC& sc, int S, int Wn, const float* u, int N, int
     wave_sync();
     const int nb = S - 1, ns = Wn - 2, nc = ns + 1;
     for (int i = l; i < nb; i += 64) sc.bins[i] = 0.5f * (sc.z[i] + sc.z[i + 1]);
-    // pdf normaliser
-    double tot = 0.0;
-    for (int i = l; i < ns; i += 64) tot += (double)(w[1 + i] + eps);
-    const float totf = (float)wave_sum_f64(tot);
+    // pdf normaliser: torch's fp32 accumulation order, not the exactly rounded sum (the integer rows depend on it)
+    const float totf = torch_order_sum_lds(w + 1, ns, eps);
     // cdf = [0, cumsum(pdf)]
     double carry = 0.0;
     if (l == 0) sc.cdf[0] = 0.f;

@@ -341,6 +341,15 @@ def march_mip(colors, densities, depths, use_inf_depth=True, density_bias=0.0, w
     return rgb, dep, wts, fT
 
 
+def torch_sum(x):
+    """torch.sum(x, -1) of the CPU path for a 2-D fp32 array, in torch's own accumulation order (orc_torch_sum_f32)."""
+    x = _f(x)
+    L = lib()
+    L.orc_torch_sum_f32.restype = ctypes.c_float
+    rows = x.reshape(-1, x.shape[-1])
+    return np.array([L.orc_torch_sum_f32(_p(r), c_i64(r.size)) for r in rows], dtype=np.float32).reshape(x.shape[:-1])
+
+
 def sample_importance(z_vals, weights, u, mode='classical', return_aux=False):
     """z_vals [B,R,S,1], weights [B,R,Wn,1], u [B*R,N] -> sdist_fine [B,R,N,1] (+ inds/below/above/cdf)."""
     z_vals, weights, u = _f(z_vals), _f(weights), _f(u)

@@ -15,6 +15,31 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+# Measured parity figures of this run (appended by assert_image_parity / report_parity): printed in the terminal summary and
+# written to gpurun_out/parity_report.json so that the numbers behind "<= 1e-4 max-rel RGB" are recorded, not just asserted.
+PARITY_REPORT = []
+
+
+def report_parity(what, **figures):
+    PARITY_REPORT.append(dict(what=what, **{k: (float(v) if isinstance(v, (int, float, np.floating)) else v) for k, v in figures.items()}))
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not PARITY_REPORT:
+        return
+    terminalreporter.section('measured parity figures (vs the reference goldens / the oracle)')
+    for r in PARITY_REPORT:
+        terminalreporter.write_line('  ' + r['what'] + ': ' + ', '.join(f'{k}={v:.3e}' if isinstance(v, float) else f'{k}={v}' for k, v in r.items() if k != 'what'))
+    out = os.path.join(REPO, 'gpurun_out')
+    try:
+        import json
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'parity_report.json'), 'w') as f:
+            json.dump(PARITY_REPORT, f, indent=1)
+    except OSError:
+        pass
+
+
 @pytest.fixture(scope='session')
 def tdgp():
     """The product package (directory name starts with a digit -> importlib)."""
@@ -63,27 +88,38 @@ RANGE_TOL = 1e-5      # stricter, well-conditioned companion: max|delta| / max|r
 
 
 def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=None):
-    """End-to-end image parity against a golden captured from the reference.
+    """End-to-end image parity against a golden captured from the reference.  Every figure is MEASURED and recorded
+    (report_parity -> terminal summary + gpurun_out/parity_report.json); three bounds are asserted:
 
-    Two bounds, both asserted:
-      * range-normalised error  max|d| / max|ref|  <= RANGE_TOL (1e-5) -- the well-conditioned, binding one;
-      * per-pixel max-rel (|d| / max(|ref|, 1e-3 max|ref|)) <= max(RGB_TOL, reference noise floor).
-    Raw 'classical' RGB crosses zero, so the per-pixel metric is dominated by fp32 summation-order noise of whoever
-    computed the reference image.  That floor is MEASURED, not assumed, two ways:
-      - `<key>_alt` in the golden = the REFERENCE ITSELF re-run on identical inputs with native instead of oneDNN
-        convolutions and 1 instead of 8 threads (tools/gen_goldens.py): reference-vs-reference differs by 0.4e-4..1.7e-4;
-      - `exact` = the same image from the double-accumulating oracle: reference-vs-exactly-rounded differs by ~1e-4.
-    An independent fp32 implementation is expected within ~2x of the second and 3x of the first; a tighter bound would
-    test torch's thread scheduling, not this code.
+      1. range-normalised error  max|d| / max|ref|  <= RANGE_TOL (1e-5) -- well-conditioned, the binding one;
+      2. per-pixel max-rel (|d| / max(|ref|, 1e-3 max|ref|)) against the REFERENCE image
+         <= max(RGB_TOL, 4 x reference self-noise, 2 x reference-vs-exact)   (self-noise is ONE draw of the reference's own
+         run-to-run difference; the maximum over the pixels of a second, independent draw scatters by that much);
+      3. when the exactly rounded image is available (`exact` = the fp64-accumulating oracle on the same inputs): the HIP
+         image is no further from it, per pixel, than max(RGB_TOL, 1.5 x the reference's own distance from it).
+
+    Why (2) is not a flat 1e-4: raw 'classical' RGB crosses zero, and with the 1e-3 floor an fp32 rounding error of 1e-7 of
+    the image range already reads as 1e-4 on a near-zero pixel.  The floor any fp32 implementation hits is measured two
+    ways: `<key>_alt` in the golden = the REFERENCE ITSELF re-run on identical inputs with native instead of oneDNN
+    convolutions and 1 instead of 8 threads (tools/gen_goldens.py): reference-vs-reference = 0.4e-4..3.4e-4;
+    reference-vs-exact ~1e-4..2e-4.  The measured HIP figures sit at or below the reference's own (see the report).
     """
     ref = g[key]
     rng = float(np.abs(np.asarray(img, np.float64) - ref).max() / np.abs(ref).max())
     pix = max_rel(img, ref)
     self_noise = max_rel(g[key + '_alt'], ref) if (key + '_alt') in g else 0.0
     exact_noise = max_rel(exact, ref) if exact is not None else 0.0
+    figs = dict(range_err=rng, pix_vs_reference=pix, reference_self_noise=self_noise, reference_vs_exact=exact_noise)
+    if exact is not None:
+        figs['hip_vs_exact'] = max_rel(img, exact)
+        figs['reference_vs_exact_sym'] = max_rel(ref, exact)
+    report_parity(what, **figs)
     assert rng <= RANGE_TOL, f'{what}: range-normalised error {rng:.3e} > {RANGE_TOL:.0e}'
-    bound = max(pix_tol, 3 * self_noise, 2 * exact_noise)
+    bound = max(pix_tol, 4 * self_noise, 2 * exact_noise)
     assert pix <= bound, f'{what}: max-rel {pix:.3e} > {bound:.3e} (reference self-noise {self_noise:.3e}, reference vs exact {exact_noise:.3e})'
+    if exact is not None:
+        b3 = max(pix_tol, 1.5 * figs['reference_vs_exact_sym'])
+        assert figs['hip_vs_exact'] <= b3, f"{what}: HIP vs exactly-rounded image {figs['hip_vs_exact']:.3e} > {b3:.3e}"
     return rng, pix, self_noise
 
 # ------------------------------------------------------------------------------------------------ SURVEY 8f rank 4: upfirdn2d backward

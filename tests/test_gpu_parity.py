@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_close, assert_image_parity, load_golden
+from conftest import assert_close, assert_image_parity, load_golden, report_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -294,11 +294,35 @@ def test_stratified_importance(tdgp, oracle, marcher):
     np.testing.assert_array_equal(N(sd), g[f'{marcher}_sdist'])                  # bit-exact vs the reference
     sf, aux = R.sample_importance(T(g[f'{marcher}_sdist']), T(g[f'{marcher}_weights']), u.shape[2], u=T(g[f'{marcher}_u_fine']), return_aux=True)
     osf, oaux = oracle.sample_importance(g[f'{marcher}_sdist'], g[f'{marcher}_weights'], g[f'{marcher}_u_fine'], marcher, return_aux=True)
-    for k in ('inds', 'below', 'above'):                                         # INT rows: bit-exact vs the oracle
+    for k in ('inds', 'below', 'above'):                                         # INT rows: bit-exact vs the REFERENCE and the oracle
+        np.testing.assert_array_equal(aux[k].cpu().numpy().astype(np.int64), g[f'{marcher}_{k}'])
         np.testing.assert_array_equal(aux[k].cpu().numpy().astype(np.int64), oaux[k])
     np.testing.assert_array_equal(N(aux['cdf']), oaux['cdf'])
     np.testing.assert_array_equal(N(sf), osf)
-    assert_close(N(sf), g[f'{marcher}_sdist_fine'], 2e-5, 'sdist_fine vs reference')
+    np.testing.assert_array_equal(N(sf), g[f'{marcher}_sdist_fine'])             # the fine samples themselves: bit-exact vs the reference
+
+
+@pytest.mark.parametrize('marcher', ['classical', 'mip'])
+@pytest.mark.parametrize('S', [32, 48, 64, 96])
+def test_importance_hot_sizes(tdgp, marcher, S):
+    """sample_importance at the ray-step counts of BASELINE configs[0..4] against vectors captured from the reference: 0 integer
+    mismatches, fine samples bit-identical (the pdf normaliser follows torch's CPU sum order in the kernel)."""
+    g = load_golden('sampling_hot')
+    tag = f'{marcher}{S}'
+    R = tdgp.renderer.ImportanceRenderer(marcher)
+    sf, aux = R.sample_importance(T(g[f'{tag}_sdist']), T(g[f'{tag}_weights']), S, u=T(g[f'{tag}_u_fine']), return_aux=True)
+    np.testing.assert_array_equal(aux['inds'].cpu().numpy().astype(np.int64), g[f'{tag}_inds'].astype(np.int64))
+    np.testing.assert_array_equal(N(sf), g[f'{tag}_sdist_fine'])
+
+
+def test_importance_stage_of_e2e(tdgp):
+    """The importance-sampling stage with the arguments the reference's forward passed it (captured at tri_plane_renderer.py:153)."""
+    g = load_golden('e2e_tiny')
+    R = tdgp.renderer.ImportanceRenderer('classical')
+    S = g['imp_sdist'].shape[2]
+    sf, aux = R.sample_importance(T(g['imp_sdist']), T(g['imp_weights']), S, u=T(g['u_fine']), return_aux=True)
+    np.testing.assert_array_equal(aux['inds'].cpu().numpy().astype(np.int64), g['inds'])
+    np.testing.assert_array_equal(N(sf), g['imp_sdist_fine'])
 
 
 def test_unify(tdgp):
@@ -415,10 +439,10 @@ def test_e2e_tiny(tdgp, oracle):
     assert_close(N(hwc.permute(0, 1, 4, 2, 3).reshape(planes.shape)), N(planes), 2e-6, 'planes channel-last vs NCHW', 1.0)
     out = G.synthesis(ws, camera_params=_cam(g), noise_mode='const', render_opts=dict(return_depth=True), u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
     ex_img, ex_depth = _exact(oracle, tdgp, cfg, 21, g)
-    assert_image_parity(N(out.img), g, 'img', exact=ex_img)
-    assert_image_parity(N(out.depth), g, 'depth', 'depth', exact=ex_depth)
+    assert_image_parity(N(out.img), g, 'e2e_tiny img', exact=ex_img)
+    assert_image_parity(N(out.depth), g, 'e2e_tiny depth', 'depth', exact=ex_depth)
     img2 = G(T(g['z']), T(g['c']), _cam(g), noise_mode='const', u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
-    assert_image_parity(N(img2), g, 'img via Generator.forward', exact=ex_img)
+    assert_image_parity(N(img2), g, 'e2e_tiny img via Generator.forward', exact=ex_img)
     img3 = G.synthesis(ws, camera_params=_cam(g), noise_mode='none', u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
     assert_close(N(img3), g['img_noise_none'], 1e-5, 'img noise none', 1.0)
     # renderer integer rows on the golden planes: inds and sort permutation vs the oracle, exact
@@ -432,10 +456,15 @@ def test_e2e_tiny(tdgp, oracle):
     (rgb, dep, _, _), inter = G.synthesis.renderer(T(g['planes']), G.synthesis.tri_plane_mlp, T(g['ray_o']), T(g['ray_d']), opts, return_intermediates=True)
     np.testing.assert_array_equal(N(inter['sdist_coarse']), ointer['sdist_coarse'])
     assert_close(N(rgb), orgb, 1e-5, 'renderer rgb vs oracle', 1.0)
-    # the chain is not bit-identical (fp32 MFMA vs fp64-accumulated MLP), so integer rows may flip only where u sits on a cdf knot
-    mism_i = (inter['inds'].cpu().numpy().reshape(-1) != g['inds'].reshape(-1)).mean()
-    mism_p = (inter['perm'].cpu().numpy().reshape(-1) != g['perm'].reshape(-1)).mean()
-    assert mism_i < 2e-3 and mism_p < 5e-3, (mism_i, mism_p)
+    # Stage by stage the integer rows are bit-exact vs the reference (test_importance_stage_of_e2e, test_importance_hot_sizes,
+    # test_unify: reference inputs in, reference integers out).  Through the whole CHAIN they cannot be promised: the densities
+    # feeding the cdf come from an fp32 MLP whose summation order differs from MKL's sgemm (and torch's expf is Sleef's 1-ulp
+    # routine), so a draw that sits within an ulp of a cdf knot may land on the other side.  Counted and recorded, bounded loosely.
+    ni = int((inter['inds'].cpu().numpy().reshape(-1) != g['inds'].reshape(-1)).sum())
+    npm = int((inter['perm'].cpu().numpy().reshape(-1) != g['perm'].reshape(-1)).sum())
+    report_parity('e2e_tiny integer rows through the whole chain', inds_mismatches=ni, inds_total=int(g['inds'].size), perm_mismatches=npm,
+                  perm_total=int(g['perm'].size))
+    assert ni <= 2e-3 * g['inds'].size and npm <= 5e-3 * g['perm'].size, (ni, npm)
 
 
 def test_batched_demod_equals_per_layer(tdgp):
@@ -468,8 +497,8 @@ def test_e2e_mid(tdgp, oracle):
     out = G.synthesis(T(g['ws']), camera_params=_cam(g), noise_mode='const', render_opts=dict(return_depth=True), u_coarse=T(g['u_coarse']),
                       u_fine=T(g['u_fine']))
     ex_img, ex_depth = _exact(oracle, tdgp, cfg, 31, g)
-    assert_image_parity(N(out.img), g, 'img', exact=ex_img)
-    assert_image_parity(N(out.depth), g, 'depth', 'depth', exact=ex_depth)
+    assert_image_parity(N(out.img), g, 'e2e_mid img', exact=ex_img)
+    assert_image_parity(N(out.depth), g, 'e2e_mid depth', 'depth', exact=ex_depth)
 
 
 def test_e2e_tiny_mip(tdgp, oracle):
@@ -481,8 +510,8 @@ def test_e2e_tiny_mip(tdgp, oracle):
     out = G.synthesis(T(g['ws']), camera_params=_cam(g), noise_mode='const', render_opts=dict(return_depth=True), u_coarse=T(g['u_coarse']),
                       u_fine=T(g['u_fine']))
     ex_img, ex_depth = _exact(oracle, tdgp, cfg, 41, g)
-    assert_image_parity(N(out.img), g, 'img', exact=ex_img)
-    assert_image_parity(N(out.depth), g, 'depth', 'depth', exact=ex_depth)
+    assert_image_parity(N(out.img), g, 'e2e_tiny_mip img', exact=ex_img)
+    assert_image_parity(N(out.depth), g, 'e2e_tiny_mip depth', 'depth', exact=ex_depth)
 
 
 def test_e2e_vs_oracle_bigger(tdgp, oracle):
@@ -501,8 +530,8 @@ def test_e2e_vs_oracle_bigger(tdgp, oracle):
     # Two fp32 evaluations (MFMA fp32 chains vs fp64-accumulated oracle) of a signed image: the range-normalised bound
     # (1e-5) is the binding one; the per-pixel metric has no reference self-noise to calibrate against here, so it is
     # bounded at 1e-3 (= abs error <= 1e-6 of the image range on near-zero pixels).
-    assert_image_parity(N(out.img), dict(img=oimg), 'img vs oracle', pix_tol=1e-3)
-    assert_image_parity(N(out.depth), dict(depth=odepth), 'depth vs oracle', 'depth', pix_tol=1e-3)
+    assert_image_parity(N(out.img), dict(img=oimg), 'e2e_bigger img vs oracle', pix_tol=1e-3)
+    assert_image_parity(N(out.depth), dict(depth=odepth), 'e2e_bigger depth vs oracle', 'depth', pix_tol=1e-3)
 
 
 # ------------------------------------------------------------------------------------------------ full size (BASELINE configs[2])
@@ -576,6 +605,79 @@ def test_full_size_renderer_strip_vs_oracle(tdgp, oracle, full_c3):
     scale = np.abs(orgb).max()
     assert np.abs(got - orgb).max() / scale < 1e-5, np.abs(got - orgb).max() / scale
     assert np.abs(depth.reshape(2, R)[:, sel] - odepth[..., 0]).max() < 1e-5
+
+
+def _config_vs_oracle(tdgp, oracle, cfg, rows, seed, tag):
+    """One BASELINE configuration at its REAL size, HIP against the CPU oracle: the whole backbone for one sample (every layer shape,
+    tile configuration and split-K factor of that configuration) and a strip of image rows through the whole renderer from the same
+    planes (rays are independent: a strip is a full-fidelity check of ray generation, both field passes, importance sampling, merge
+    and compositing at this configuration's ray-step count)."""
+    sd = tdgp.weights.random_state_dict(cfg, seed=seed, exercise_all=True)
+    G = tdgp.generator.Generator(cfg)
+    G.load_numpy_state_dict(sd)
+    G = G.to(DEV)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=2, seed=seed + 1)
+    ws = G.mapping(T(inp['z']), T(inp['c']))
+    ows = oracle.mapping_forward(sd, cfg.to_dict(), inp['z'], inp['c'])
+    assert_close(N(ws), ows, 1e-5, tag + ' ws', 1.0)
+    planes = G.synthesis.tri_plane_decoder(ws, noise_mode='const', hwc=True)
+    res, F3 = cfg.tri_plane_res, 3 * cfg.feat_dim
+    oracle.set_threads(min(64, __import__('os').cpu_count() or 1))
+    ref = oracle.synthesis_backbone(sd, cfg.to_dict(), N(ws)[:1], 'const')
+    planes_nchw = N(planes.t.permute(0, 1, 4, 2, 3).reshape(2, F3, res, res))
+    assert_close(planes_nchw[:1], ref, 1e-5, tag + f' tri-planes {res}^2', 1.0)
+    report_parity(tag + ' backbone vs oracle (one sample, real size)', range_err=float(np.abs(planes_nchw[:1] - ref).max() / np.abs(ref).max()))
+    cam = {k: T(v) for k, v in inp['camera'].items()}
+    out = G.synthesis(ws, camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True), u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']))
+    img, depth = N(out.img), N(out.depth)
+    h = cfg.img_resolution
+    assert img.shape == (2, 3, h, h) and np.isfinite(img).all()
+    from oracle.pipeline import render_options
+    mlp = tuple(sd[f'synthesis.tri_plane_mlp.model.{i}.{n}'] for i in (0, 1) for n in ('weight', 'bias'))
+    c2w = oracle.cam2world(inp['camera']['angles'], inp['camera']['radius'], inp['camera']['look_at'])
+    ro, rd = oracle.sample_rays(c2w, inp['camera']['fov'], h, h)
+    R, S = h * h, cfg.num_ray_steps
+    sel = np.concatenate([np.arange(r * h, (r + 1) * h) for r in rows])
+    u1 = inp['u_coarse'].reshape(2, R, S)[:, sel]
+    u2 = inp['u_fine'].reshape(2, R, S)[:, sel].reshape(-1, S)
+    orgb, odepth, _, _ = oracle.importance_render(planes_nchw, mlp, ro[:, sel], rd[:, sel], render_options(cfg.to_dict()), u1, u2)
+    got = img.reshape(2, 3, R)[:, :, sel].transpose(0, 2, 1)
+    e_rgb = float(np.abs(got - orgb).max() / np.abs(orgb).max())
+    e_dep = float(np.abs(depth.reshape(2, R)[:, sel] - odepth[..., 0]).max())
+    report_parity(tag + f' renderer strip vs oracle ({len(rows)} rows x {h} rays x {S}+{S} samples)', rgb_range_err=e_rgb, depth_abs_err=e_dep,
+                  rgb_pix_max_rel=__import__('conftest').max_rel(got, orgb))
+    assert e_rgb < 1e-5 and e_dep < 1e-5, (e_rgb, e_dep)
+
+
+def test_config_c1_vs_oracle(tdgp, oracle):
+    """BASELINE configs[0]: SDFood-like 64^2, 32(+32) ray steps, single class (c_dim 0), cmax 512."""
+    _config_vs_oracle(tdgp, oracle, tdgp.config.config_c1(), rows=[0, 17, 40, 63], seed=101, tag='C1 64^2/32')
+
+
+def test_config_c2_vs_oracle(tdgp, oracle):
+    """BASELINE configs[1]: Dogs 128^2, 48(+48) ray steps (a pdf row of 46 elements, ray tiles of 3 x 16 samples)."""
+    _config_vs_oracle(tdgp, oracle, tdgp.config.config_c2(), rows=[0, 77, 127], seed=103, tag='C2 128^2/48')
+
+
+def test_config_c4_backbone_vs_oracle(tdgp, oracle):
+    """BASELINE configs[3] (cmax 1024 / cbase 65536): the whole backbone of one sample against the oracle -- 1024-channel layers,
+    odd split-K slice counts (where the round-1 LDS race lived), 488.9 GFLOP; ~40 s of host time."""
+    cfg = tdgp.config.config_c4()
+    sd = tdgp.weights.random_state_dict(cfg, seed=107, exercise_all=True)
+    G = tdgp.generator.Generator(cfg)
+    G.load_numpy_state_dict(sd)
+    G = G.to(DEV)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=1, seed=108)
+    ws = G.mapping(T(inp['z']), T(inp['c']))
+    planes = G.synthesis.tri_plane_decoder(ws, noise_mode='const', hwc=True)
+    oracle.set_threads(min(64, __import__('os').cpu_count() or 1))
+    ref = oracle.synthesis_backbone(sd, cfg.to_dict(), N(ws), 'const')
+    got = N(planes.t.permute(0, 1, 4, 2, 3).reshape(1, 96, 512, 512))
+    report_parity('C4 cmax-1024 backbone vs oracle (one sample)', range_err=float(np.abs(got - ref).max() / np.abs(ref).max()))
+    assert_close(got, ref, 1e-5, 'C4 tri-planes 512^2', 1.0)
+    for _ in range(5):                                       # and it is deterministic (the race showed as ~1 bad run in 10)
+        again = G.synthesis.tri_plane_decoder(ws, noise_mode='const', hwc=True)
+        assert torch.equal(again.t, planes.t)
 
 
 def test_full_size_properties(tdgp, full_c3):

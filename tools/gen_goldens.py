@@ -471,6 +471,36 @@ def gen_sampling():
     save('sampling', **arrays)
 
 
+def gen_sampling_hot():
+    """sample_importance at the ray-step counts of BASELINE configs[0..4] (S = 32, 48, 64, 96): the pdf rows have S-2 = 30, 46,
+    62, 94 elements, i.e. 3 / 5 / 7 / 11 whole 8-lane vectors plus a 6-element tail in torch's CPU sum kernel -- every branch of
+    its accumulation order (4-way interleave, left-over vectors, scalar tail).  Weights are realistic compositing weights
+    (alpha * transmittance of random densities, many near zero) so cdf knots cluster the way they do in a render."""
+    g = np.random.RandomState(66)
+    arrays = {}
+    for marcher in ('classical', 'mip'):
+        rend = ref_tpr.ImportanceRenderer(marcher)
+        for S in (32, 48, 64, 96):
+            B, R = 1, 64
+            u = g.rand(B, R, S, 1).astype(np.float32)
+            with PatchedRNG(rand_like=[T(u)]):
+                sd = rend.sample_stratified(torch.zeros(B, R, 3), 0.0, 1.0, S)
+            sig = np.maximum(g.randn(B, R, S, 1) * 4.0 - 1.0, 0).astype(np.float32) * (g.rand(B, R, S, 1) > 0.5)
+            alpha = 1.0 - np.exp(-sig * (1.0 / S) * 20.0)
+            Tr = np.cumprod(np.concatenate([np.ones_like(alpha[:, :, :1]), 1.0 - alpha[:, :, :-1] + 1e-10], 2), 2)
+            wts = (alpha * Tr).astype(np.float32)
+            Wn = S if marcher == 'classical' else S - 1            # MipRayMarcher2 without inf depth returns S-1 weights
+            wts = wts[:, :, :Wn]
+            u2 = g.rand(B * R, S).astype(np.float32)
+            with PatchedRNG(rand=[T(u2)]), Capture() as cap:
+                sf = rend.sample_importance(sd, T(wts), S)
+            tag = f'{marcher}{S}'
+            arrays[f'{tag}_sdist'], arrays[f'{tag}_weights'], arrays[f'{tag}_u_fine'] = npy(sd), wts, u2
+            arrays[f'{tag}_sdist_fine'] = npy(sf)
+            arrays[f'{tag}_inds'] = npy(cap.inds[0]).astype(np.int16)
+    save('sampling_hot', **arrays)
+
+
 def gen_marchers():
     g = np.random.RandomState(7)
     arrays = {}
@@ -605,9 +635,21 @@ def gen_e2e(tag, cfg, batch, seed, keep_intermediates):
     arrays['seed'] = np.array([seed, batch], dtype=np.int64)
     with torch.no_grad():
         ws = G.mapping(T(inp['z']), T(inp['c']))
+        stage = {}
+        rend = G.synthesis.renderer
+        o_si = rend.sample_importance
+
+        def si(z_vals, weights, n):                      # the importance-sampling stage as the reference calls it (:153)
+            r = o_si(z_vals, weights, n)
+            stage.update(imp_sdist=npy(z_vals), imp_weights=npy(weights), imp_sdist_fine=npy(r))
+            return r
+        rend.sample_importance = si
         with PatchedRNG(rand_like=[T(inp['u_coarse']).reshape(batch, R, S, 1)], rand=[T(inp['u_fine'])]), Capture() as cap:
             out = G.synthesis(ws, camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True))
+        rend.sample_importance = o_si
         arrays.update(ws=npy(ws), img=npy(out.img), depth=npy(out.depth))
+        if keep_intermediates:
+            arrays.update(stage)
         # The reference's own fp32 reproducibility: same inputs, native (non-oneDNN) convolutions, 1 thread.
         # |img - img_alt| is the noise floor any fp32 re-implementation is compared against (parity).
         torch.backends.mkldnn.enabled = False
@@ -1071,6 +1113,7 @@ def main():
     gen_modconv()
     gen_field()
     gen_sampling()
+    gen_sampling_hot()
     gen_marchers()
     gen_camera()
     gen_mapping()
