@@ -43,14 +43,14 @@ _PROTOTYPES = {
     'tdgp_planes_to_hwc': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     'tdgp_triplane_field': (c_int, [P, P, P, P, P, P, P, P, P, P, c_float, P, P, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                     c_int, P]),
-    'tdgp_ray_march': (c_int, [P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, P]),
+    'tdgp_ray_march': (c_int, [P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, P]),
     'tdgp_triplane_field_grad_workspace_bytes': (c_int64, [c_int, c_int64, c_int, c_int]),
     'tdgp_triplane_field_grad': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'tdgp_ray_march_grad': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, P]),
     'tdgp_sample_importance': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, P]),
     'tdgp_unify_samples': (c_int, [P, P, P, c_int, P, P, P, c_int, P, P, P, P, c_int64, c_int, P]),
-    'tdgp_importance_from_coarse': (c_int, [P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, c_float, P]),
-    'tdgp_merge_composite': (c_int, [P, P, c_int, P, P, c_int, P, P, P, P, P, P, c_int64, c_int, c_int, c_float, P]),
+    'tdgp_importance_from_coarse': (c_int, [P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P]),
+    'tdgp_merge_composite': (c_int, [P, P, c_int, P, P, c_int, P, P, P, P, P, P, c_int64, c_int, c_int, c_float, c_float, P]),
     'tdgp_rays_to_image': (c_int, [P, P, c_int, c_int, P]),
 }
 EXPORTS = tuple(_PROTOTYPES)

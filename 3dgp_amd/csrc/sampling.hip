@@ -48,7 +48,7 @@ __device__ __forceinline__ float s2t(float s, float t_near, float t_far) { retur
 // tri_plane_renderer.py:355-387.
 // flags: bit0 use_inf_depth, bit1 last_back, bit3 relu clamp
 // ------------------------------------------------------------------------------------------------
-__device__ void march_classical_lds(const float* z, const float* sig, float* w, int S, int flags, float& final_T, float& wagg) {
+__device__ void march_classical_lds(const float* z, const float* sig, float* w, int S, int flags, float cut_thr, float& final_T, float& wagg) {
     const int l = lane_id();
     double carry = 1.0, wsum = 0.0;
     for (int base = 0; base < S; base += 64) {
@@ -57,6 +57,7 @@ __device__ void march_classical_lds(const float* z, const float* sig, float* w, 
         if (i < S) {
             float delta = (i < S - 1) ? (z[i + 1] - z[i]) : ((flags & 1) ? 1e10f : 1e-3f);
             float sp = (flags & 8) ? (sig[i] > 0.f ? sig[i] : 0.f) : softplus20(sig[i]);
+            if (sp < cut_thr) sp = 0.f;                        // cut_quantile (:366-368); cut_thr = 0 never cuts (sp >= 0)
             alpha = 1.0f - (float)exp((double)(-delta * sp));
             fac = (1.0f - alpha) + 1e-10f;
         }
@@ -76,7 +77,7 @@ __device__ void march_classical_lds(const float* z, const float* sig, float* w, 
 
 // mip marcher weights on LDS-resident data: M = S (inf depth) or S-1 mid-point samples.
 // tri_plane_renderer.py:305-334.
-__device__ void march_mip_lds(const float* z, const float* sig, float* w, int S, int flags, float density_bias, float& final_T,
+__device__ void march_mip_lds(const float* z, const float* sig, float* w, int S, int flags, float density_bias, float cut_thr, float& final_T,
                               float& wagg) {
     const int l = lane_id();
     const int M = (flags & 1) ? S : S - 1;
@@ -89,6 +90,7 @@ __device__ void march_mip_lds(const float* z, const float* sig, float* w, int S,
             if (i < S - 1) { delta = z[i + 1] - z[i]; smid = (sig[i] + sig[i + 1]) / 2.f; }
             else { delta = 1e10f; smid = sig[S - 1]; }
             float sp = softplus20(smid + density_bias);
+            if (sp < cut_thr) sp = 0.f;                        // cut_quantile (:324-326)
             float dd = sp * delta;
             alpha = 1.0f - (float)exp((double)(-dd));
             fac = (1.0f - alpha) + 1e-10f;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void stratified_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void ray_march_kernel(const float* __restrict__ colors, const float* __restrict__ dens,
                                                        const float* __restrict__ depths, float* __restrict__ rgb, float* __restrict__ depth_o,
                                                        float* __restrict__ weights, float* __restrict__ final_T, int64_t rays, int S, int C,
-                                                       int marcher, int flags, float density_bias) {
+                                                       int marcher, int flags, float density_bias, float cut_thr) {
     __shared__ WaveScratch scratch[RAYS_PER_BLOCK];
     const int wv = threadIdx.x >> 6, l = lane_id();
     const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
@@ -250,8 +252,8 @@ __global__ __launch_bounds__(256) void ray_march_kernel(const float* __restrict_
     wave_sync();
     float fT, wagg;
     const int M = (marcher == 0) ? S : ((flags & 1) ? S : S - 1);
-    if (marcher == 0) march_classical_lds(sc.z, sc.sig, sc.w, S, flags, fT, wagg);
-    else march_mip_lds(sc.z, sc.sig, sc.w, S, flags, density_bias, fT, wagg);
+    if (marcher == 0) march_classical_lds(sc.z, sc.sig, sc.w, S, flags, cut_thr, fT, wagg);
+    else march_mip_lds(sc.z, sc.sig, sc.w, S, flags, density_bias, cut_thr, fT, wagg);
     if (weights) for (int i = l; i < M; i += 64) weights[r * M + i] = sc.w[i];
     // composite: sum_i w_i * c_i  (products rounded to fp32, accumulated in fp64)
     for (int c = 0; c <= C; c++) {          // c == C: depth
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256) void importance_from_coarse_kernel(const float
                                                                     const float* __restrict__ u_fine, float* __restrict__ tfine,
                                                                     float* __restrict__ sfine, int32_t* __restrict__ inds,
                                                                     int32_t* __restrict__ fine_perm, int64_t rays, int S, int N,
-                                                                    int marcher, int flags, float density_bias, float t_near, float t_far) {
+                                                                    int marcher, int flags, float density_bias, float cut_thr, float t_near, float t_far) {
     __shared__ WaveScratchT<MS> scratch[RAYS_PER_BLOCK];
     const int wv = threadIdx.x >> 6, l = lane_id();
     const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
@@ -368,8 +370,8 @@ __global__ __launch_bounds__(256) void importance_from_coarse_kernel(const float
     TPH(0)
     float fT, wagg;
     int Wn = S;
-    if (marcher == 0) march_classical_lds(sc.z, sc.sig, sc.w, S, flags, fT, wagg);
-    else { march_mip_lds(sc.z, sc.sig, sc.w, S, flags, density_bias, fT, wagg); Wn = (flags & 1) ? S : S - 1; }
+    if (marcher == 0) march_classical_lds(sc.z, sc.sig, sc.w, S, flags, cut_thr, fT, wagg);
+    else { march_mip_lds(sc.z, sc.sig, sc.w, S, flags, density_bias, cut_thr, fT, wagg); Wn = (flags & 1) ? S : S - 1; }
     TPH(1)
     float* tkey = sc.col[0];
     importance_lds(sc, S, Wn, u_fine + r * N, N, marcher, [&](int j, float smp, int ind, int, int) {
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void merge_composite_kernel(const float* __res
                                                              const float* __restrict__ rgbs2, const float* __restrict__ t2, int S2,
                                                              float* __restrict__ rgb, float* __restrict__ depth_o, float* __restrict__ wsum_o,
                                                              float* __restrict__ final_T, int32_t* __restrict__ perm, const int32_t* __restrict__ perm2, int64_t rays,
-                                                             int marcher, int flags, float density_bias) {
+                                                             int marcher, int flags, float density_bias, float cut_thr) {
     __shared__ WaveScratchT<MS> scratch[RAYS_PER_BLOCK];
     const int wv = threadIdx.x >> 6, l = lane_id();
     const int64_t r = (int64_t)blockIdx.x * RAYS_PER_BLOCK + wv;
@@ -495,8 +497,8 @@ __global__ __launch_bounds__(256) void merge_composite_kernel(const float* __res
     TPH(2)
     float fT, wagg;
     const int Mm = (marcher == 0) ? M : ((flags & 1) ? M : M - 1);
-    if (marcher == 0) march_classical_lds(sc.z, sc.sig, sc.w, M, flags, fT, wagg);
-    else march_mip_lds(sc.z, sc.sig, sc.w, M, flags, density_bias, fT, wagg);
+    if (marcher == 0) march_classical_lds(sc.z, sc.sig, sc.w, M, flags, cut_thr, fT, wagg);
+    else march_mip_lds(sc.z, sc.sig, sc.w, M, flags, density_bias, cut_thr, fT, wagg);
     TPH(3)
     double acc[4] = {0.0, 0.0, 0.0, 0.0}, wacc = 0.0;
     for (int i = l; i < Mm; i += 64) {
@@ -550,14 +552,14 @@ TDGP_API int tdgp_sample_stratified(const float* u, float* sdist, float* tdist, 
 }
 
 TDGP_API int tdgp_ray_march(const float* colors, const float* densities, const float* depths, float* rgb, float* depth, float* weights,
-                            float* final_T, int64_t rays, int S, int C, int marcher, int flags, float density_bias, tdgp_stream_t stream) {
+                            float* final_T, int64_t rays, int S, int C, int marcher, int flags, float density_bias, float cut_threshold, tdgp_stream_t stream) {
     TDGP_CHECK(colors && densities && depths && rgb && depth && final_T, TDGP_EINVAL, "ray_march: null pointer");
     TDGP_CHECK(S >= 2 && S <= MAXS, TDGP_EUNSUPPORTED, "ray_march: S=%d outside [2,%d]", S, MAXS);
     TDGP_CHECK(C >= 1 && C <= 8, TDGP_EUNSUPPORTED, "ray_march: C=%d outside [1,8]", C);
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "ray_march: unknown ray marcher %d", marcher);
     if (rays == 0) return TDGP_OK;
     TDGP_LAUNCH("ray_march_kernel", ray_march_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, colors, densities, depths, rgb, depth, weights,
-                       final_T, rays, S, C, marcher, flags, density_bias);
+                       final_T, rays, S, C, marcher, flags, density_bias, cut_threshold);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }
@@ -586,34 +588,34 @@ TDGP_API int tdgp_unify_samples(const float* d1, const float* c1, const float* s
 
 TDGP_API int tdgp_importance_from_coarse(const float* rgbs_coarse, const float* sdist, const float* u_fine, float* tdist_fine,
                                          float* sdist_fine, int32_t* inds, int32_t* fine_perm, int64_t rays, int S, int N, int marcher, int flags,
-                                         float density_bias, float t_near, float t_far, tdgp_stream_t stream) {
+                                         float density_bias, float cut_threshold, float t_near, float t_far, tdgp_stream_t stream) {
     TDGP_CHECK(rgbs_coarse && sdist && u_fine && tdist_fine, TDGP_EINVAL, "importance_from_coarse: null pointer");
     TDGP_CHECK(S >= 4 && S <= MAXS && N >= 1, TDGP_EUNSUPPORTED, "importance_from_coarse: bad S=%d N=%d", S, N);
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "importance_from_coarse: unknown ray marcher %d", marcher);
     if (rays == 0) return TDGP_OK;
     if (S <= 128 && N <= 128)
         TDGP_LAUNCH("importance_from_coarse_kernel", importance_from_coarse_kernel<128>, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, sdist,
-                           u_fine, tdist_fine, sdist_fine, inds, fine_perm, rays, S, N, marcher, flags, density_bias, t_near, t_far);
+                           u_fine, tdist_fine, sdist_fine, inds, fine_perm, rays, S, N, marcher, flags, density_bias, cut_threshold, t_near, t_far);
     else
         TDGP_LAUNCH("importance_from_coarse_kernel", importance_from_coarse_kernel<MAXS>, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, sdist,
-                           u_fine, tdist_fine, sdist_fine, inds, fine_perm, rays, S, N, marcher, flags, density_bias, t_near, t_far);
+                           u_fine, tdist_fine, sdist_fine, inds, fine_perm, rays, S, N, marcher, flags, density_bias, cut_threshold, t_near, t_far);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }
 
 TDGP_API int tdgp_merge_composite(const float* rgbs_coarse, const float* t_coarse, int S1, const float* rgbs_fine, const float* t_fine, int S2,
                                   float* rgb, float* depth, float* wsum, float* final_T, int32_t* perm, const int32_t* fine_perm, int64_t rays,
-                                  int marcher, int flags, float density_bias, tdgp_stream_t stream) {
+                                  int marcher, int flags, float density_bias, float cut_threshold, tdgp_stream_t stream) {
     TDGP_CHECK(rgbs_coarse && t_coarse && rgbs_fine && t_fine && rgb && depth, TDGP_EINVAL, "merge_composite: null pointer");
     TDGP_CHECK(S1 >= 1 && S2 >= 1 && S1 + S2 <= MAXS, TDGP_EUNSUPPORTED, "merge_composite: S1+S2=%d > %d", S1 + S2, MAXS);
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "merge_composite: unknown ray marcher %d", marcher);
     if (rays == 0) return TDGP_OK;
     if (S1 + S2 <= 128)
         TDGP_LAUNCH("merge_composite_kernel", merge_composite_kernel<128>, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, t_coarse, S1,
-                           rgbs_fine, t_fine, S2, rgb, depth, wsum, final_T, perm, fine_perm, rays, marcher, flags, density_bias);
+                           rgbs_fine, t_fine, S2, rgb, depth, wsum, final_T, perm, fine_perm, rays, marcher, flags, density_bias, cut_threshold);
     else
         TDGP_LAUNCH("merge_composite_kernel", merge_composite_kernel<MAXS>, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, t_coarse, S1,
-                           rgbs_fine, t_fine, S2, rgb, depth, wsum, final_T, perm, fine_perm, rays, marcher, flags, density_bias);
+                           rgbs_fine, t_fine, S2, rgb, depth, wsum, final_T, perm, fine_perm, rays, marcher, flags, density_bias, cut_threshold);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }

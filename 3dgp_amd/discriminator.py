@@ -255,8 +255,8 @@ class Discriminator(torch.nn.Module):
 
     def forward(self, img, c, patch_params=None, camera_angles=None, update_emas=False, predict_feat=False, **block_kwargs):
         B = img.shape[0]
-        if camera_angles is not None:
-            raise NotImplementedError('camera-conditioned discriminator (camera_cond) is off in every 3dgp config')
+        # networks_discriminator.py:256-281: `camera_angles` is only forwarded to the head mapping's camera encoder (camera_cond, off
+        # in every 3dgp config and not built here); the reference's callers always pass it, so it is accepted and ignored.
         patch_embs = None
         if self.scalar_enc is not None:
             cond = torch.cat([patch_params['scales'][:, [0]], patch_params['offsets']], dim=1)

@@ -113,8 +113,9 @@ class MappingNetwork(torch.nn.Module):
             self.register_buffer('w_avg', torch.zeros([w_dim]))
 
     def forward(self, z, c, camera_angles=None, truncation_psi=1, truncation_cutoff=None, update_emas=False):
-        if camera_angles is not None:
-            raise NotImplementedError('camera-conditioned mapping (camera_cond) is off in the 3dgp configs')
+        # layers.py:126-137: `camera_angles` only feeds `camera_scalar_enc`, which exists when camera_cond is on.  No 3dgp config
+        # turns it on and this module is never built with it, so -- exactly like the reference with camera_cond off -- the argument
+        # is accepted and ignored (metric_utils.py:310,344 and loss.py:70 always pass it).
         x = None
         if self.z_dim > 0:
             assert z.shape[1] == self.z_dim, f'Wrong shape: z {tuple(z.shape)}'

@@ -40,13 +40,43 @@ def _marcher_flags(opts, marcher):
         flags |= 8
     elif mode != 'softplus':
         raise NotImplementedError(f'Uknown clamp mode: {mode}')
-    if opts.get('cut_quantile', 0.0) > 0.0:
-        raise NotImplementedError('cut_quantile > 0 (NFS metric only) is outside the accelerated path')
+    q = opts.get('cut_quantile', 0.0)
+    assert q <= 1.0, f'Wrong cut_quantile argument: {q}'
     if opts.get('sp_beta', 1.0) != 1.0:
         raise NotImplementedError('softplus beta != 1 is not on the generator path')
     if opts.get('white_back_end_idx', 0) > 0 or opts.get('fill_mode') is not None:
         raise NotImplementedError('white_back_end_idx / fill_mode debugging options are not on the generator path')
     return flags
+
+
+def _quantile(x, q):
+    """torch.quantile(x, q) over all elements (linear interpolation between order statistics), also past torch.quantile's
+    16M-element input limit (a 256^2 x 128-sample batch of 2 already exceeds it)."""
+    x = x.reshape(-1).float()
+    n = x.numel()
+    if n <= (1 << 24):
+        return torch.quantile(x, float(q))
+    xs = torch.sort(x).values
+    pos = float(q) * (n - 1)
+    lo = int(pos)
+    return torch.lerp(xs[lo], xs[min(lo + 1, n - 1)], pos - lo)
+
+
+def _cut_threshold(sigma, opts, marcher, flags):
+    """The `cut_quantile` option of both marchers (tri_plane_renderer.py:324-326, 366-368; used by the non-flatness score with
+    0.5): activated densities below the GLOBAL quantile -- over every ray and sample of the call -- are zeroed before alpha.
+    sigma [rays, S] raw densities in march order -> the threshold the kernels apply (0.0 = off: activated densities are >= 0)."""
+    q = float(opts.get('cut_quantile', 0.0))
+    if q <= 0.0:
+        return 0.0
+    if marcher == 'classical':
+        dens = torch.relu(sigma) if (flags & 8) else torch.nn.functional.softplus(sigma)
+    else:
+        mid = (sigma[:, :-1] + sigma[:, 1:]) / 2
+        if flags & 1:
+            mid = torch.cat([mid, sigma[:, -1:]], dim=1)
+        dens = torch.nn.functional.softplus(mid + float(opts.get('density_bias', 0.0)))
+    return float(_quantile(dens, q))
 
 
 # ------------------------------------------------------------------------------------------------ camera + rays
@@ -249,7 +279,7 @@ def _march(colors, densities, depths, opts, marcher):
     with torch.cuda.device(colors.device):
         _lib.call('tdgp_ray_march', colors.data_ptr(), densities.data_ptr(), depths.data_ptr(), rgb.data_ptr(), depth.data_ptr(),
                   weights.data_ptr(), final_T.data_ptr(), B * R, S, C, MARCHER_IDS[marcher], flags, float(opts.get('density_bias', 0.0)),
-                  _lib.stream_of(colors))
+                  _cut_threshold(densities.reshape(B * R, S), opts, marcher, flags), _lib.stream_of(colors))
     return rgb, depth, weights, final_T
 
 
@@ -342,6 +372,8 @@ class ImportanceRenderer(torch.nn.Module):
         tdgp_ray_march_grad, an un-sort, and tdgp_triplane_field_grad once per pass (accumulating into the same plane gradient)."""
         opts = rendering_options
         marcher = self.ray_marcher_type
+        if float(opts.get('cut_quantile', 0.0)) > 0.0:
+            raise NotImplementedError('cut_quantile is an inference-only option (non-flatness score); it has no gradient path here')
         hw = planes_to_hwc(planes)
         ray_o, ray_d = _lib.f32c(ray_origins), _lib.f32c(ray_directions)
         B, R, _ = ray_o.shape
@@ -422,8 +454,10 @@ class ImportanceRenderer(torch.nn.Module):
                 sfine = torch.empty([B, R, N], dtype=torch.float32, device=dev) if return_intermediates else None
                 inds = torch.empty([B * R, N], dtype=torch.int32, device=dev) if return_intermediates else None
                 fperm = torch.empty([B * R, N], dtype=torch.int32, device=dev) if (return_intermediates or (dnoise > 0.0 and n_fine is not None)) else None
+                cut = float(opts.get('cut_quantile', 0.0)) > 0.0
+                thr_c = _cut_threshold(rgbs_c[..., 3].reshape(B * R, S), opts, marcher, flags) if cut else 0.0
                 _lib.call('tdgp_importance_from_coarse', rgbs_c.data_ptr(), sdist.data_ptr(), u_fine.data_ptr(), tfine.data_ptr(),
-                          _lib.ptr(sfine), _lib.ptr(inds), _lib.ptr(fperm), B * R, S, N, mid, flags, dbias, t_near, t_far, stream)
+                          _lib.ptr(sfine), _lib.ptr(inds), _lib.ptr(fperm), B * R, S, N, mid, flags, dbias, thr_c, t_near, t_far, stream)
                 if dnoise > 0.0 and n_fine is not None:      # the kernel evaluates the fine samples depth-sorted: carry each draw to its slot
                     n_fine = _lib.f32c(n_fine.to(dev)).reshape(B * R, N).gather(1, fperm.long())
                 rgbs_f = _field(planes, mlp, scale, ray_o=ray_o, ray_d=ray_d, t=tfine, ray_w=ray_w, sigma_noise=n_fine, density_noise=dnoise)
@@ -431,9 +465,19 @@ class ImportanceRenderer(torch.nn.Module):
                 depth = torch.empty([B, R, 1], dtype=torch.float32, device=dev)
                 wsum = torch.empty([B, R, 1], dtype=torch.float32, device=dev)
                 final_T = torch.empty([B, R], dtype=torch.float32, device=dev)
-                perm = torch.empty([B, R, S + N], dtype=torch.int32, device=dev) if return_intermediates else None
+                perm = torch.empty([B, R, S + N], dtype=torch.int32, device=dev) if (return_intermediates or (cut and marcher == 'mip')) else None
+                thr_f = 0.0
+                if cut:
+                    sig_all = torch.cat([rgbs_c[..., 3].reshape(B * R, S), rgbs_f[..., 3].reshape(B * R, N)], dim=1)
+                    if marcher == 'mip':
+                        # mid-point densities depend on the merged order: one merge pass for the permutation (the fine list is stored
+                        # depth-sorted, so the permutation is taken without fine_perm), then the thresholded pass
+                        _lib.call('tdgp_merge_composite', rgbs_c.data_ptr(), tdist.data_ptr(), S, rgbs_f.data_ptr(), tfine.data_ptr(), N, rgb.data_ptr(),
+                                  depth.data_ptr(), wsum.data_ptr(), final_T.data_ptr(), perm.data_ptr(), None, B * R, mid, flags, dbias, 0.0, stream)
+                        sig_all = sig_all.gather(1, perm.reshape(B * R, S + N).long())
+                    thr_f = _cut_threshold(sig_all, opts, marcher, flags)
                 _lib.call('tdgp_merge_composite', rgbs_c.data_ptr(), tdist.data_ptr(), S, rgbs_f.data_ptr(), tfine.data_ptr(), N, rgb.data_ptr(),
-                          depth.data_ptr(), wsum.data_ptr(), final_T.data_ptr(), _lib.ptr(perm), _lib.ptr(fperm), B * R, mid, flags, dbias, stream)
+                          depth.data_ptr(), wsum.data_ptr(), final_T.data_ptr(), _lib.ptr(perm), _lib.ptr(fperm), B * R, mid, flags, dbias, thr_f, stream)
             else:
                 rgbs4 = rgbs_c.reshape(B, R, S, 4)
                 rgb, depth, w, final_T = _march(rgbs4[..., :3], rgbs4[..., 3:4], sdist.reshape(B, R, S, 1), opts, marcher)

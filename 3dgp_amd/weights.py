@@ -172,6 +172,15 @@ def config_from_json(d):
     """The dict written by tools/export_reference_checkpoint.py (or GeneratorConfig.to_dict()) -> GeneratorConfig."""
     from .config import CameraAdaptorConfig, CameraRanges, DepthAdaptorConfig
     d = dict(d)
+    chk = d.pop('checked_options', None)          # written by the exporter: options that change the forward and are not implemented here
+    if chk:
+        bad = [k for k in ('use_full_box', 'ray_start_is_auto', 'has_view_cond', 'camera_cond') if chk.get(k)]
+        if chk.get('mlp_n_layers', 2) != 2:
+            bad.append('mlp_n_layers')
+        if not chk.get('fp32_only', True) and chk.get('num_fp16_res', 0) > 0:
+            bad.append('num_fp16_res')
+        if bad:
+            raise NotImplementedError(f'exported generator uses options this package does not implement: {bad}')
     da, ca = d.pop('depth_adaptor', None), d.pop('camera_adaptor', None)
     cfg = GeneratorConfig(**d)
     if da is not None:

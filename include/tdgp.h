@@ -239,10 +239,12 @@ int     tdgp_triplane_field_grad(const float* planes_hwc, const float* coords, c
 
 /* Generic marcher on [rays,S,C] colours, [rays,S] densities/depths (any S <= 256, C <= 8).
  * weights: [rays,S] (classical, or mip with inf depth) / [rays,S-1] (mip without); may be NULL.
- * flags: bit0 use_inf_depth, bit1 last_back (classical), bit2 white_back (mip), bit3 clamp_mode relu. */
+ * flags: bit0 use_inf_depth, bit1 last_back (classical), bit2 white_back (mip), bit3 clamp_mode relu.
+ * cut_threshold: the `cut_quantile` option (tri_plane_renderer.py:324-326, 366-368): activated densities below it are set to 0
+ * before alpha; the caller computes it (the reference takes torch.quantile over the whole activated-density tensor); 0 = off. */
 int tdgp_ray_march(const float* colors, const float* densities, const float* depths, float* rgb,
                    float* depth, float* weights, float* final_T, int64_t rays, int S, int C, int marcher,
-                   int flags, float density_bias, tdgp_stream_t stream);
+                   int flags, float density_bias, float cut_threshold, tdgp_stream_t stream);
 
 /* Gradient of tdgp_ray_march: autograd through ClassicalRayMarcher / MipRayMarcher2 (:353-398, :299-349).
  * d_rgb [rays,C], d_depth [rays] (may be NULL), d_weights [rays,M] (may be NULL; M as in tdgp_ray_march) ->
@@ -268,11 +270,12 @@ int tdgp_unify_samples(const float* d1, const float* c1, const float* s1, int S1
  * rgbs_coarse [rays,S,4], sdist [rays,S], u_fine [rays,N] -> tdist_fine [rays,N] WRITTEN IN ASCENDING DEPTH ORDER (stable):
  * the reference keeps draw order and sorts coarse+fine together afterwards, so the final composite is unchanged, but the
  * second field pass becomes spatially coherent and the merge below is a merge of two sorted lists.
- * Optional: sdist_fine [rays,N] and inds int32 [rays,N] in DRAW order; fine_perm int32 [rays,N]: draw index of sorted slot. */
+ * Optional: sdist_fine [rays,N] and inds int32 [rays,N] in DRAW order; fine_perm int32 [rays,N]: draw index of sorted slot.
+ * cut_threshold as in tdgp_ray_march (here and in tdgp_merge_composite). */
 int tdgp_importance_from_coarse(const float* rgbs_coarse, const float* sdist, const float* u_fine,
                                 float* tdist_fine, float* sdist_fine, int32_t* inds, int32_t* fine_perm,
                                 int64_t rays, int S, int N, int marcher, int flags, float density_bias,
-                                float t_near, float t_far, tdgp_stream_t stream);
+                                float cut_threshold, float t_near, float t_far, tdgp_stream_t stream);
 
 /* Fused chain, step 2: merge coarse+fine by depth (stable, coarse before fine on ties), march in t-space.
  * rgbs_* [rays,S*,4], t_* [rays,S*] (any order; ascending lists take a fast path) -> rgb [rays,3], depth [rays],
@@ -282,7 +285,7 @@ int tdgp_merge_composite(const float* rgbs_coarse, const float* t_coarse, int S1
                          const float* rgbs_fine, const float* t_fine, int S2,
                          float* rgb, float* depth, float* wsum, float* final_T, int32_t* perm,
                          const int32_t* fine_perm, int64_t rays, int marcher, int flags, float density_bias,
-                         tdgp_stream_t stream);
+                         float cut_threshold, tdgp_stream_t stream);
 
 /* [B, h*w, 3] ray colours -> [B,3,h,w] image (networks_epigraf.py:242). */
 int tdgp_rays_to_image(const float* rgb, float* img, int B, int hw, tdgp_stream_t stream);

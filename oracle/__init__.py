@@ -315,21 +315,46 @@ def triplane_field(planes, coords, w0, b0, w1, b1, scale, mlp_mode='classical', 
     return out
 
 
-def march_classical(colors, densities, depths, use_inf_depth=True, clamp_mode='softplus', last_back=False):
+def _softplus32(x):
+    """F.softplus (threshold 20) as the C marchers evaluate it: log1p(exp(x)) in double, rounded to fp32."""
+    x = np.asarray(x, np.float32)
+    return np.where(x > 20.0, x, np.log1p(np.exp(np.minimum(x, 20.0).astype(np.float64))).astype(np.float32)).astype(np.float32)
+
+
+def cut_threshold(densities, cut_quantile, mode='classical', use_inf_depth=True, clamp_mode='softplus', density_bias=0.0):
+    """The threshold of the marchers' `cut_quantile` option (tri_plane_renderer.py:324-326, 366-368): torch.quantile (linear
+    interpolation) over ALL activated densities of the call; densities [B,R,S,1] raw, in march order.  0.0 = off."""
+    if not cut_quantile > 0.0:
+        return 0.0
+    assert cut_quantile <= 1.0
+    d = np.asarray(densities, np.float32)[..., 0]
+    if mode == 'classical':
+        act = np.maximum(d, 0) if clamp_mode == 'relu' else _softplus32(d)
+    else:
+        mid = ((d[..., :-1] + d[..., 1:]) / np.float32(2)).astype(np.float32)
+        if use_inf_depth:
+            mid = np.concatenate([mid, d[..., -1:]], axis=-1)
+        act = _softplus32((mid + np.float32(density_bias)).astype(np.float32))
+    return float(np.quantile(act.reshape(-1).astype(np.float32), np.float32(cut_quantile)))
+
+
+def march_classical(colors, densities, depths, use_inf_depth=True, clamp_mode='softplus', last_back=False, cut_quantile=0.0):
     """[B,R,S,C],[B,R,S,1],[B,R,S,1] -> rgb [B,R,C], depth [B,R,1], weights [B,R,S,1], final_T [B,R]."""
     colors, densities, depths = _f(colors), _f(densities), _f(depths)
+    thr = cut_threshold(densities, cut_quantile, 'classical', use_inf_depth, clamp_mode)
     B, R, S, C = colors.shape
     rgb = np.empty([B, R, C], dtype=np.float32)
     dep = np.empty([B, R, 1], dtype=np.float32)
     wts = np.empty([B, R, S, 1], dtype=np.float32)
     fT = np.empty([B, R], dtype=np.float32)
     lib().orc_march_classical(_p(colors), _p(densities), _p(depths), _p(rgb), _p(dep), _p(wts), _p(fT),
-                              c_i64(B * R), S, C, int(bool(use_inf_depth)), int(clamp_mode == 'relu'), int(bool(last_back)))
+                              c_i64(B * R), S, C, int(bool(use_inf_depth)), int(clamp_mode == 'relu'), int(bool(last_back)), c_float(thr))
     return rgb, dep, wts, fT
 
 
-def march_mip(colors, densities, depths, use_inf_depth=True, density_bias=0.0, white_back=False):
+def march_mip(colors, densities, depths, use_inf_depth=True, density_bias=0.0, white_back=False, cut_quantile=0.0):
     colors, densities, depths = _f(colors), _f(densities), _f(depths)
+    thr = cut_threshold(densities, cut_quantile, 'mip', use_inf_depth, 'softplus', density_bias)
     B, R, S, C = colors.shape
     M = S if use_inf_depth else S - 1
     rgb = np.empty([B, R, C], dtype=np.float32)
@@ -337,7 +362,7 @@ def march_mip(colors, densities, depths, use_inf_depth=True, density_bias=0.0, w
     wts = np.empty([B, R, M, 1], dtype=np.float32)
     fT = np.empty([B, R], dtype=np.float32)
     lib().orc_march_mip(_p(colors), _p(densities), _p(depths), _p(rgb), _p(dep), _p(wts), _p(fT),
-                        c_i64(B * R), S, C, int(bool(use_inf_depth)), c_float(density_bias), int(bool(white_back)))
+                        c_i64(B * R), S, C, int(bool(use_inf_depth)), c_float(density_bias), int(bool(white_back)), c_float(thr))
     return rgb, dep, wts, fT
 
 

@@ -133,9 +133,9 @@ def importance_render(planes, mlp, ray_o, ray_d, opts, u_coarse, u_fine, return_
     def march(c, d, z):
         if mode == 'classical':
             return O.march_classical(c, d, z, use_inf_depth=opts['use_inf_depth'], clamp_mode=opts.get('clamp_mode', 'softplus'),
-                                     last_back=opts.get('last_back', False))
+                                     last_back=opts.get('last_back', False), cut_quantile=opts.get('cut_quantile', 0.0))
         return O.march_mip(c, d, z, use_inf_depth=opts['use_inf_depth'], density_bias=opts.get('density_bias', 0.0),
-                           white_back=opts.get('white_back', False))
+                           white_back=opts.get('white_back', False), cut_quantile=opts.get('cut_quantile', 0.0))
 
     inter = dict(sdist_coarse=sdist, colors_coarse=col_c, densities_coarse=den_c)
     N = opts['num_fine_steps']
@@ -197,7 +197,7 @@ def render_options(cfg):
     return dict(box_size=cfg['cube_scale'] * 2, num_proposal_steps=cfg['num_ray_steps'], num_fine_steps=cfg['num_ray_steps'],
                 clamp_mode='softplus', use_inf_depth=cfg['use_inf_depth'], ray_start=cfg['ray_start'], ray_end=cfg['ray_end'],
                 last_back=cfg.get('last_back', False), white_back=cfg.get('white_back', False),
-                density_bias=cfg.get('density_bias', 0.0), ray_marcher_type=cfg['ray_marcher_type'])
+                density_bias=cfg.get('density_bias', 0.0), ray_marcher_type=cfg['ray_marcher_type'], cut_quantile=cfg.get('cut_quantile', 0.0))
 
 
 def synthesis_forward(sd, cfg, ws, camera, u_coarse, u_fine, noise_mode='const', return_intermediates=False, training=None):

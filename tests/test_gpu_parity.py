@@ -336,7 +336,8 @@ def test_unify(tdgp):
 
 
 @pytest.mark.parametrize('tag,kw', [('cl_inf', dict(use_inf_depth=True)), ('cl_noinf', dict(use_inf_depth=False)),
-                                    ('cl_lastback', dict(use_inf_depth=True, last_back=True)), ('cl_relu', dict(use_inf_depth=True, clamp_mode='relu'))])
+                                    ('cl_lastback', dict(use_inf_depth=True, last_back=True)), ('cl_relu', dict(use_inf_depth=True, clamp_mode='relu')),
+                                    ('cl_cut', dict(use_inf_depth=True, cut_quantile=0.5))])
 def test_march_classical(tdgp, oracle, tag, kw):
     g = load_golden('marchers')
     rgb, dep, w, fT = tdgp.renderer.ClassicalRayMarcher()(T(g['colors']), T(g['densities']), T(g['depths']), dict(kw))
@@ -351,7 +352,8 @@ def test_march_classical(tdgp, oracle, tag, kw):
 
 
 @pytest.mark.parametrize('tag,kw', [('mip_inf', dict(use_inf_depth=True)), ('mip_noinf_white', dict(use_inf_depth=False, white_back=True)),
-                                    ('mip_bias', dict(use_inf_depth=True, density_bias=-1.0))])
+                                    ('mip_bias', dict(use_inf_depth=True, density_bias=-1.0)),
+                                    ('mip_cut', dict(use_inf_depth=True, cut_quantile=0.3))])
 def test_march_mip(tdgp, tag, kw):
     g = load_golden('marchers')
     rgb, dep, w, fT = tdgp.renderer.MipRayMarcher2()(T(g['colors01']), T(g['densities']), T(g['depths']), dict(kw))
@@ -465,6 +467,29 @@ def test_e2e_tiny(tdgp, oracle):
     report_parity('e2e_tiny integer rows through the whole chain', inds_mismatches=ni, inds_total=int(g['inds'].size), perm_mismatches=npm,
                   perm_total=int(g['perm'].size))
     assert ni <= 2e-3 * g['inds'].size and npm <= 5e-3 * g['perm'].size, (ni, npm)
+
+
+def test_e2e_tiny_cut_quantile(tdgp, oracle):
+    """cut_quantile = 0.5 (the non-flatness score's rendering, non_flatness_score.py:9) through the fused renderer: both marcher calls
+    threshold their activated densities at the global median (tri_plane_renderer.py:366-368); against the reference's image."""
+    cfg = tdgp.config.config_tiny()
+    g = load_golden('e2e_tiny')
+    G = _gen(tdgp, cfg, 21)
+    out = G.synthesis(T(g['ws']), camera_params=_cam(g), noise_mode='const', render_opts=dict(return_depth=True, cut_quantile=0.5),
+                      u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
+    assert_close(N(out.img), g['img_cut'], 1e-5, 'img, cut_quantile 0.5', 1.0)
+    assert_close(N(out.depth), g['depth_cut'], 1e-5, 'depth, cut_quantile 0.5', 1.0)
+    # mip marcher: the threshold is taken over mid-point densities in MERGED order (two merge passes); vs the op-level chain
+    cfg.ray_marcher_type = 'mip'
+    G2 = _gen(tdgp, cfg, 41)
+    a = G2.synthesis(T(g['ws']), camera_params=_cam(g), noise_mode='const', render_opts=dict(return_depth=True, cut_quantile=0.4),
+                     u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
+    sd = tdgp.weights.random_state_dict(cfg, seed=41, exercise_all=True)
+    c = cfg.to_dict()
+    c['cut_quantile'] = 0.4
+    oimg, odepth = oracle.synthesis_forward(sd, c, g['ws'], {k[4:]: v for k, v in g.items() if k.startswith('cam_')}, g['u_coarse'], g['u_fine'], 'const')
+    assert_close(N(a.img), oimg, 1e-5, 'mip img, cut_quantile 0.4, vs oracle', 1.0)
+    assert_close(N(a.depth), odepth, 1e-5, 'mip depth, cut_quantile 0.4, vs oracle', 1.0)
 
 
 def test_batched_demod_equals_per_layer(tdgp):

@@ -129,7 +129,8 @@ def test_unify(oracle):
 
 @pytest.mark.parametrize('tag,kw', [('cl_inf', dict(use_inf_depth=True)), ('cl_noinf', dict(use_inf_depth=False)),
                                     ('cl_lastback', dict(use_inf_depth=True, last_back=True)),
-                                    ('cl_relu', dict(use_inf_depth=True, clamp_mode='relu'))])
+                                    ('cl_relu', dict(use_inf_depth=True, clamp_mode='relu')),
+                                    ('cl_cut', dict(use_inf_depth=True, cut_quantile=0.5))])
 def test_march_classical(oracle, tag, kw):
     g = load_golden('marchers')
     rgb, dep, w, fT = oracle.march_classical(g['colors'], g['densities'], g['depths'], **kw)
@@ -140,7 +141,8 @@ def test_march_classical(oracle, tag, kw):
 
 
 @pytest.mark.parametrize('tag,kw', [('mip_inf', dict(use_inf_depth=True)), ('mip_noinf_white', dict(use_inf_depth=False, white_back=True)),
-                                    ('mip_bias', dict(use_inf_depth=True, density_bias=-1.0))])
+                                    ('mip_bias', dict(use_inf_depth=True, density_bias=-1.0)),
+                                    ('mip_cut', dict(use_inf_depth=True, cut_quantile=0.3))])
 def test_march_mip(oracle, tag, kw):
     g = load_golden('marchers')
     rgb, dep, w, fT = oracle.march_mip(g['colors01'], g['densities'], g['depths'], **kw)
@@ -204,6 +206,20 @@ def test_e2e_mid(oracle, tdgp):
     g, img, depth, _ = _e2e(oracle, tdgp, 'e2e_mid', tdgp.config.config_mid(), 31)
     assert_image_parity(img, g, 'oracle e2e_mid img')
     assert_image_parity(depth, g, 'oracle e2e_mid depth', 'depth')
+
+
+def test_e2e_tiny_cut_quantile(oracle, tdgp):
+    """The non-flatness score's rendering (cut_quantile = 0.5 in both marcher calls, non_flatness_score.py:9)."""
+    cfg = tdgp.config.config_tiny()
+    g = load_golden('e2e_tiny')
+    sd = tdgp.weights.random_state_dict(cfg, seed=21, exercise_all=True)
+    cam = {k[4:]: v for k, v in g.items() if k.startswith('cam_')}
+    c = cfg.to_dict()
+    c['cut_quantile'] = 0.5
+    img, depth = oracle.synthesis_forward(sd, c, g['ws'], cam, g['u_coarse'], g['u_fine'], 'const')
+    assert np.abs(g['img_cut'] - g['img']).max() > 0.1                 # the option changes the image
+    assert_close(img, g['img_cut'], 1e-5, 'img, cut_quantile 0.5', 1.0)
+    assert_close(depth, g['depth_cut'], 1e-5, 'depth, cut_quantile 0.5', 1.0)
 
 
 def test_e2e_tiny_mip(oracle, tdgp):

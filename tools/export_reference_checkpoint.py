@@ -21,9 +21,40 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get('TDGP_REFERENCE', '/root/reference')
 
 
+def unsupported_options(c, fp16_blocks=(), conv_clamp=None):
+    """Generator options that change the forward and that 3dgp_amd does not implement.  A checkpoint trained with any of them would
+    export and load cleanly and then render DIFFERENT images, so the exporter refuses (and records the checked values in
+    generator.json so that `weights.config_from_json` can refuse a hand-edited file too)."""
+    get = lambda path, d=None: _get(c, path, d)         # noqa: E731
+    checked = dict(use_full_box=bool(get('use_full_box', False)), mlp_n_layers=int(get('tri_plane.mlp.n_layers', 2)),
+                   has_view_cond=bool(get('tri_plane.view_cond', get('has_view_cond', False)) or False), camera_cond=bool(get('camera_cond', False)),
+                   fp32_only=bool(get('fp32_only', True)) and not fp16_blocks, num_fp16_res=max(int(get('num_fp16_res', 0) or 0), len(fp16_blocks)),
+                   conv_clamp=None if conv_clamp is None else float(conv_clamp), ray_start_is_auto=isinstance(get('camera.ray.start'), str))
+    bad = []
+    if checked['use_full_box'] or checked['ray_start_is_auto']:
+        bad.append("use_full_box / ray_start='auto' (never resolved by the reference renderer either)")
+    if checked['mlp_n_layers'] != 2:
+        bad.append(f"tri_plane.mlp.n_layers={checked['mlp_n_layers']} (the field kernel is the 2-layer TriPlaneMLP)")
+    if checked['has_view_cond']:
+        bad.append('view-direction conditioning of the tri-plane MLP')
+    if checked['camera_cond']:
+        bad.append('camera_cond (camera-conditioned mapping network)')
+    if not checked['fp32_only'] and checked['num_fp16_res'] > 0:
+        bad.append(f"fp32_only=false with num_fp16_res={checked['num_fp16_res']} (fp16 blocks + conv_clamp=256: the exported fp32 path has no clamp)")
+    return checked, bad
+
+
 def cfg_to_json(G):
     c = G.cfg
     get = lambda o, path, d=None: _get(o, path, d)      # noqa: E731
+    # fp16 is decided per block at construction (networks_epigraf.py:99-108: `num_fp16_res` is a constructor argument that train.py:271-273
+    # zeroes when fp32_only), so the modules themselves are asked
+    dec = G.synthesis.tri_plane_decoder
+    blocks = [getattr(dec, f'b{r}') for r in dec.block_resolutions]
+    fp16_blocks = [int(b.resolution) for b in blocks if getattr(b, 'use_fp16', False)]
+    checked, bad = unsupported_options(c, fp16_blocks, getattr(blocks[-1].conv1, 'conv_clamp', None))
+    if bad:
+        raise NotImplementedError('checkpoint uses generator options 3dgp_amd does not implement: ' + '; '.join(bad))
     out = dict(z_dim=int(G.z_dim), w_dim=int(G.w_dim), c_dim=int(G.c_dim), map_depth=int(get(c, 'map_depth', 2)), cbase=int(c.cbase), cmax=int(c.cmax),
                fmaps=float(get(c, 'fmaps', 1.0)), use_noise=bool(get(c, 'use_noise', True)), tri_plane_res=int(c.tri_plane.res), feat_dim=int(c.tri_plane.feat_dim),
                mlp_hid=int(c.tri_plane.mlp.hid_dim), ray_marcher_type=str(c.ray_marcher_type), num_ray_steps=int(c.num_ray_steps),
@@ -44,6 +75,7 @@ def cfg_to_json(G):
                                      camera=dict(yaw=rng(cam.origin.angles.yaw), pitch=rng(cam.origin.angles.pitch), fov=rng(cam.fov),
                                                  look_at_yaw=rng(cam.look_at.angles.yaw), look_at_pitch=rng(cam.look_at.angles.pitch),
                                                  look_at_radius=rng(cam.look_at.radius)))
+    out['checked_options'] = checked
     return out
 
 

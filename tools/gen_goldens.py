@@ -518,8 +518,15 @@ def gen_marchers():
         ro.update(opts)
         rgb, dep, w, fT = cm(T(colors), T(dens), T(depths), ro)
         arrays.update({f'{tag}_rgb': npy(rgb), f'{tag}_depth': npy(dep), f'{tag}_weights': npy(w), f'{tag}_T': npy(fT)})
+    # cut_quantile = 0.5 (the non-flatness score's setting, non_flatness_score.py:9): densities below the global median are zeroed
+    ro = EasyDict(clamp_mode='softplus', cut_quantile=0.5, density_bias=0.0, last_back=False, white_back=False, use_inf_depth=True)
+    rgb, dep, w, fT = cm(T(colors), T(dens), T(depths), ro)
+    arrays.update({'cl_cut_rgb': npy(rgb), 'cl_cut_depth': npy(dep), 'cl_cut_weights': npy(w), 'cl_cut_T': npy(fT)})
     mm = ref_tpr.MipRayMarcher2()
     colors01 = (1 / (1 + np.exp(-colors))).astype(np.float32)
+    ro = EasyDict(clamp_mode='softplus', cut_quantile=0.3, density_bias=0.0, white_back=False, use_inf_depth=True)
+    rgb, dep, w, fT = mm(T(colors01), T(dens), T(depths), ro)
+    arrays.update({'mip_cut_rgb': npy(rgb), 'mip_cut_depth': npy(dep), 'mip_cut_weights': npy(w), 'mip_cut_T': npy(fT)})
     arrays['colors01'] = colors01
     for tag, opts in [('mip_inf', dict(use_inf_depth=True, white_back=False)), ('mip_noinf_white', dict(use_inf_depth=False, white_back=True)),
                       ('mip_bias', dict(use_inf_depth=True, white_back=False, density_bias=-1.0))]:
@@ -674,6 +681,10 @@ def gen_e2e(tag, cfg, batch, seed, keep_intermediates):
                 x, img = blk(x, img, ws.narrow(1, w_idx, blk.num_conv + blk.num_torgb), noise_mode='const')
                 w_idx += blk.num_conv
                 arrays[f'x{r}'] = npy(x)
+            # the non-flatness score's rendering: cut_quantile = 0.5 through the whole renderer (both marcher calls)
+            with PatchedRNG(rand_like=[T(inp['u_coarse']).reshape(batch, R, S, 1)], rand=[T(inp['u_fine'])]):
+                cut = G.synthesis(ws, camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True, cut_quantile=0.5))
+            arrays.update(img_cut=npy(cut.img), depth_cut=npy(cut.depth))
             # also the 'none' noise mode image (no noise inputs at all)
             with PatchedRNG(rand_like=[T(inp['u_coarse']).reshape(batch, R, S, 1)], rand=[T(inp['u_fine'])]):
                 arrays['img_noise_none'] = npy(G.synthesis(ws, camera_params=cam, noise_mode='none'))
