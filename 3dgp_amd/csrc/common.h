@@ -1,6 +1,7 @@
 // common.h -- shared helpers for the gfx950 kernels of libtdgp_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_bfloat16.h>
 #include <stdint.h>
@@ -30,20 +31,22 @@ void tdgp_set_error(const char* fmt, ...);
         }                                                                      \
     } while (0)
 
-// Optional per-kernel timing (tdgp_profile_enable / tdgp_profile_report): HIP events recorded around every launch
-// on the launch stream, the counterpart of the reference's `misc.profiled_function` ranges (misc.py:101-106).
+// Optional per-kernel timing (tdgp_profile_enable / tdgp_profile_report), the counterpart of the reference's
+// `misc.profiled_function` ranges (misc.py:101-106).  While it is on, every launch goes through hipExtLaunchKernelGGL with a
+// start and a stop event ATTACHED TO THE DISPATCH ITSELF: the pair reads the kernel's own begin / end timestamps on the launch
+// stream -- the same ones rocprofv3's kernel trace reports -- instead of bracketing it with two marker packets, whose dispatch
+// and marker latencies (and the cache write-back a marker triggers) inflated the r01 per-kernel figures by ~4 %.
 bool tdgp_prof_on();
-void tdgp_prof_begin(const char* name, hipStream_t s);
-void tdgp_prof_end(hipStream_t s);
-struct ProfScope {
-    hipStream_t s; bool on;
-    ProfScope(const char* name, hipStream_t st) : s(st), on(tdgp_prof_on()) { if (on) tdgp_prof_begin(name, s); }
-    ~ProfScope() { if (on) tdgp_prof_end(s); }
-};
-#define TDGP_LAUNCH(NAME, KERNEL, GRID, BLOCK, LDS, STREAM, ...)              \
-    do {                                                                      \
-        ProfScope ps_(NAME, STREAM);                                          \
-        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);    \
+void tdgp_prof_events(const char* name, hipEvent_t* a, hipEvent_t* b);
+#define TDGP_LAUNCH(NAME, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                      \
+    do {                                                                                              \
+        if (tdgp_prof_on()) {                                                                         \
+            hipEvent_t pa_, pb_;                                                                      \
+            tdgp_prof_events(NAME, &pa_, &pb_);                                                       \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, pa_, pb_, 0, __VA_ARGS__);        \
+        } else {                                                                                      \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                        \
+        }                                                                                             \
     } while (0)
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -28,22 +28,19 @@ struct ProfEvent { const char* name; hipEvent_t a, b; };
 std::mutex g_mu;
 std::vector<ProfEvent> g_events;
 std::atomic<int> g_on{0};
-thread_local ProfEvent g_cur;
 }  // namespace
 
 bool tdgp_prof_on() { return g_on.load(std::memory_order_relaxed) != 0; }
 
-void tdgp_prof_begin(const char* name, hipStream_t s) {
-    g_cur.name = name;
-    (void)hipEventCreate(&g_cur.a);
-    (void)hipEventCreate(&g_cur.b);
-    (void)hipEventRecord(g_cur.a, s);
-}
-
-void tdgp_prof_end(hipStream_t s) {
-    (void)hipEventRecord(g_cur.b, s);
+// A fresh (start, stop) event pair for one launch, registered under `name`; the caller hands both to hipExtLaunchKernelGGL.
+void tdgp_prof_events(const char* name, hipEvent_t* a, hipEvent_t* b) {
+    ProfEvent e;
+    e.name = name;
+    (void)hipEventCreate(&e.a);
+    (void)hipEventCreate(&e.b);
+    *a = e.a; *b = e.b;
     std::lock_guard<std::mutex> lk(g_mu);
-    g_events.push_back(g_cur);
+    g_events.push_back(e);
 }
 
 static void prof_clear() {

@@ -28,7 +28,7 @@
 // matrix time -- the blend uses v_pk_fma_f32 and the remaining lever is the per-point address arithmetic.
 #include "common.h"
 
-// Compile-time ablations for timing experiments (tools/scratch/build_variant.sh): 1 = no tap loads, 2 = no layer-1 MFMAs,
+// Compile-time ablations for timing experiments (tools/dev/build_variant.sh): 1 = no tap loads, 2 = no layer-1 MFMAs,
 // 4 = no stores, 32 = per-phase cycle counts of one wave (printed).  Always 0 in the shipped library.
 #ifndef TDGP_FIELD_ABL
 #define TDGP_FIELD_ABL 0

@@ -29,7 +29,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-// A/B switches for timing experiments (tools/scratch/build_variant.sh); the defaults are the shipped code.
+// A/B switches for timing experiments (tools/dev/build_variant.sh); the defaults are the shipped code.
 #ifndef TDGP_AB_NO_SCALAR_WV
 #define TDGP_AB_NO_SCALAR_WV 0
 #endif
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// Fast paths of the 3x3 layers.  Measured on this chip (tools/scratch/ubench_overlap.hip): fp32 MFMA and fp32 VALU do NOT
+// Fast paths of the 3x3 layers.  Measured on this chip (tools/dev/ubench_overlap.hip): fp32 MFMA and fp32 VALU do NOT
 // overlap -- an MFMA-only loop runs at 149-155 TFLOP/s, a v_pk_fma-only loop of the same cycle count takes the same time, and
 // the two together take the SUM (or more), whether interleaved in one wave or split across the waves of a SIMD.  Every VALU
 // instruction inside the K loop therefore costs matrix time (4 cycles of 64 for a 32x32x2 step), and the generic kernel above
@@ -876,7 +876,7 @@ struct UpParams {
 };
 
 #ifndef TDGP_UP_ABL
-#define TDGP_UP_ABL 0      // timing experiments (tools/scratch/build_variant.sh): 1 no Z stores, 2 no global staging loads, 4 no LDS fragment reads, 8 no barriers
+#define TDGP_UP_ABL 0      // timing experiments (tools/dev/build_variant.sh): 1 no Z stores, 2 no global staging loads, 4 no LDS fragment reads, 8 no barriers
 #endif
 constexpr int UP_CT_W = 68;     // epilogue LDS tile: 32 channels x 64 floats (+4 pad)
 

@@ -9,11 +9,18 @@ inputs per GPU, inputs and random-init weights resident in HBM before the timed 
 the batch is sharded by image (weak scaling: per-GPU batch fixed), and the FID-style feature block is all-gathered
 over RCCL on a side stream (3dgp_amd/distributed.py) -- the only collective on the path.
 
-Besides the contract fields the line carries
+Protocol: batch 16 per GPU (configs/scripts/inference.yaml:25) is the headline `value`; batch 4
+(training/base.yaml:5) is measured in the same process and reported under `other_batches`; defaults 10 warm-up + 50 timed
+steps.  Besides the contract fields the line carries
   roofline     -- the dominant kernel (by HIP-event time measured here, on the launch stream, through the library's
-                  per-kernel event hooks): algorithmic FLOP per launch / average launch duration vs the fp32 MFMA peak;
+                  per-kernel event hooks: start/stop events attached to each dispatch): algorithmic FLOP per launch / average launch
+                  duration vs the fp32 MFMA peak; `traffic` (HBM bytes per launch), `hbm_gbs` (= traffic / the duration
+                  measured here) and `mfma_busy_pct` from the committed rocprofv3 PMC passes (profiles/pmc_latest.json,
+                  labelled with the commit they were taken at; counters cannot be read from inside this process);
+  whole_forward-- all algorithmic FLOP of the step / ms_per_step vs the same peak (the metric's "fraction of roofline");
   cpu_baseline -- the CPU oracle (oracle/, a port of the reference's CPU/PyTorch path) timed on the host cores
-                  (rank 0, N == 1 only) on a bounded sample of the same workload;
+                  (rank 0, N == 1 only) on a bounded sample of the same workload; cpu_baseline_c1 -- the same for
+                  BASELINE configs[0] (64^2 / 32 steps: the reference's own CPU-runnable case), always;
   kernels      -- per-kernel ms/step breakdown of the same profiled steps.
 """
 import argparse
@@ -63,7 +70,7 @@ def algorithmic_flops(cfg):
                 triplane_field_kernel=(field, 2))
 
 
-def cpu_baseline(tdgp, cfg, n_img=8, budget_s=25.0):
+def cpu_baseline(tdgp, cfg, n_img=8, budget_s=14.0):
     """Time the CPU oracle on the same workload: whole generator forwards (mapping, backbone, all 256^2 rays), one image at
     a time, until `n_img` images or ~`budget_s` seconds of host time (whichever first; at least one image)."""
     import oracle as O
@@ -86,12 +93,33 @@ def cpu_baseline(tdgp, cfg, n_img=8, budget_s=25.0):
                        f'samples) in {t_total:.1f} s; OpenMP C oracle (oracle/tdgp_oracle.c), {cores} threads')
 
 
+def timed_steps(step, barrier, steps, warmup, world, dev, finish=None):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        img = step()
+    if finish is not None:
+        finish()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(img).all()
+    return elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=8, help='images per GPU per step (16: +1 %, 32: +7 % img/s as the low-resolution layers and launch tails amortise)')
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=16, help='images per GPU per step of the headline value (16 = configs/scripts/inference.yaml:25)')
+    ap.add_argument('--other-batches', default='4', help='comma list of further per-GPU batch sizes measured in the same run (4 = training/base.yaml:5); "" = none')
     ap.add_argument('--config', default='c3', choices=['c1', 'c2', 'c3', 'c4'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--depth-adaptor', action='store_true', help='also run the DepthAdaptor inside G.forward (SURVEY 8f rank 1; off = the 8a hot path)')
@@ -118,87 +146,120 @@ def main():
     G = tdgp.generator.Generator(cfg)
     G.load_numpy_state_dict(tdgp.weights.random_state_dict(cfg, seed=0))        # random-init weights, identical on every rank
     G = G.to(dev)
-    inp = tdgp.weights.synthetic_inputs(cfg, batch=args.batch, seed=D.rank_seed(0, rank, world))
     T = lambda a: torch.as_tensor(a).to(dev)   # noqa: E731
-    z, c = T(inp['z']), T(inp['c'])
-    cam = {k: T(v) for k, v in inp['camera'].items()}
-    u_coarse, u_fine = T(inp['u_coarse']), T(inp['u_fine'])
     gather = D.FeatureGatherer() if world > 1 else None
+    # what RCCL actually saw: an all-reduce of ones over the process group, AFTER a real collective (not WORLD_SIZE from the env)
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(one)
+        ranks_seen = int(one.item())
+        assert ranks_seen == torch.distributed.get_world_size() == world
 
-    def step():
-        img = G(z, c, cam, noise_mode='const', u_coarse=u_coarse, u_fine=u_fine)
-        if gather is not None:
-            if gather._pending is not None:
-                gather.wait()
-            gather.gather_async(D.stand_in_features(img))
-        return img
+    def inputs(batch):
+        inp = tdgp.weights.synthetic_inputs(cfg, batch=batch, seed=D.rank_seed(0, rank, world))
+        return dict(z=T(inp['z']), c=T(inp['c']), cam={k: T(v) for k, v in inp['camera'].items()}, u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']))
+
+    def make_step(x):
+        def step():
+            img = G(x['z'], x['c'], x['cam'], noise_mode='const', u_coarse=x['u_coarse'], u_fine=x['u_fine'])
+            if gather is not None:
+                if gather._pending is not None:
+                    gather.wait()
+                gather.gather_async(D.stand_in_features(img))
+            return img
+        return step
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        img = step()
-    if gather is not None and gather._pending is not None:
-        gather.wait()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(img).all()
+    def finish():
+        if gather is not None and gather._pending is not None:
+            gather.wait()
+
+    x = inputs(args.batch)
+    elapsed = timed_steps(make_step(x), barrier, args.steps, args.warmup, world, dev, finish)
 
     # ---- per-kernel timing of the same step (HIP events on the launch stream, inside the library) -------------------
+    # While profiling is on the library launches through hipExtLaunchKernelGGL with a start and a stop event attached to each
+    # dispatch: the pair reads the kernel's own begin/end timestamps (what rocprofv3's kernel trace reports), with no marker
+    # packets around it -- per-kernel averages are directly comparable with profiles/*_kernel_stats.md.
     tdgp._lib.profile_enable(True)
     for _ in range(args.profile_steps):
-        G(z, c, cam, noise_mode='const', u_coarse=u_coarse, u_fine=u_fine)
+        G(x['z'], x['c'], x['cam'], noise_mode='const', u_coarse=x['u_coarse'], u_fine=x['u_fine'])
     torch.cuda.synchronize()
     prof = tdgp._lib.profile_report()
     tdgp._lib.profile_enable(False)
     nprof = max(args.profile_steps, 1)
-    kernels = {k: dict(ms_per_step=round(v['total_ms'] / nprof, 4), launches_per_step=v['launches'] // nprof,
-                       avg_ms=round(v['avg_ms'], 5)) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])}
+    kernels = {}
+    for k, v in prof.items():
+        tot = v['total_ms']
+        kernels[k] = dict(ms_per_step=round(tot / nprof, 4), launches_per_step=v['launches'] // nprof, avg_ms=round(tot / max(v['launches'], 1), 5))
+    kernels = dict(sorted(kernels.items(), key=lambda kv: -kv[1]['ms_per_step']))
     dominant = next(iter(kernels), None)
     flops = algorithmic_flops(cfg)
-    # HBM bytes per launch from the committed PMC passes (tools/profile_bench.sh -> tools/pmc_traffic.py); counters cannot be
-    # collected from inside this process, so `traffic` is only filled when that measurement was taken on this very workload.
-    traffic = None
-    tpath = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get('config') == args.config and tj.get('batch_per_gpu') == args.batch and not args.depth_adaptor and dominant in tj.get('kernels', {}):
-            traffic = tj['kernels'][dominant]['hbm_bytes_per_launch']
+    # HBM bytes per launch and matrix-pipe busy from the committed PMC passes (tools/profile_round.sh -> profiles/pmc_latest.json);
+    # only used when they were taken on this very workload.
+    pmc, pmc_src = {}, None
+    ppath = os.path.join(REPO, 'profiles', 'pmc_latest.json')
+    if os.path.exists(ppath):
+        pj = json.load(open(ppath))
+        if pj.get('config') == args.config and pj.get('batch_per_gpu') == args.batch and not args.depth_adaptor and args.arith == 'f32':
+            pmc, pmc_src = pj.get('kernels', {}), dict(file='profiles/pmc_latest.json', commit=pj.get('commit'), passes=pj.get('source'))
     roofline = None
     if dominant in flops:
         fl_img, launches_img = flops[dominant]
         k = kernels[dominant]
         fl_per_launch = fl_img * args.batch / k['launches_per_step']
         achieved = fl_per_launch / (k['avg_ms'] * 1e-3) / 1e12
+        pk = pmc.get(dominant, {})
+        traffic = pk.get('hbm_bytes_per_launch')
         roofline = dict(kernel=dominant, bound='mfma', achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                         frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
-                        flop_per_launch=fl_per_launch, avg_launch_ms=k['avg_ms'], launches_per_step=k['launches_per_step'])
+                        hbm_gbs=None if traffic is None else round(traffic / (k['avg_ms'] * 1e-3) / 1e9, 1), mfma_busy_pct=pk.get('mfma_busy_pct'),
+                        pmc_source=pmc_src, flop_per_launch=fl_per_launch, avg_launch_ms=k['avg_ms'], launches_per_step=k['launches_per_step'])
+    for k, v in kernels.items():               # the same three figures for every kernel the PMC passes cover
+        pk = pmc.get(k)
+        if pk and v['avg_ms'] > 0:
+            v.update(hbm_gbs=round(pk['hbm_bytes_per_launch'] / (v['avg_ms'] * 1e-3) / 1e9, 1), mfma_busy_pct=pk.get('mfma_busy_pct'))
+        if k in flops and v['avg_ms'] > 0:
+            v['tflops'] = round(flops[k][0] * args.batch / v['launches_per_step'] / (v['avg_ms'] * 1e-3) / 1e12, 2)
+    total_flop_img = sum(f for f, _ in flops.values())
+    ms_step = elapsed / args.steps * 1e3
+    whole = dict(flop_per_image=total_flop_img, achieved=round(total_flop_img * args.batch / (ms_step * 1e-3) / 1e12, 2), peak=PEAK_FP32_MFMA_TFLOPS,
+                 unit='TFLOP/s', frac=round(total_flop_img * args.batch / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                 kernel_ms_sum=round(sum(v['ms_per_step'] for v in kernels.values()), 3))
+
+    others = {}
+    for b in [int(t) for t in args.other_batches.split(',') if t.strip()]:
+        if b == args.batch:
+            continue
+        xb = inputs(b)
+        eb = timed_steps(make_step(xb), barrier, args.steps, args.warmup, world, dev, finish)
+        others[str(b)] = dict(value=round(b * world * args.steps / eb, 3), ms_per_step=round(eb / args.steps * 1e3, 3), batch_per_gpu=b, steps=args.steps,
+                              frac_of_fp32_mfma_ceiling=round(total_flop_img * b / (eb / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
+        del xb
 
     if rank == 0:
         total_imgs = args.batch * world * args.steps
+        names = dict(c1='BASELINE configs[0]: SDFood-like 64x64', c2='BASELINE configs[1]: Dogs 128x128', c3='BASELINE configs[2]: ImageNet 256x256',
+                     c4='BASELINE configs[3]: ImageNet 256x256')
         out = {
             'metric': 'generator-forward img/s @256^2, 64 steps' if args.config in ('c3', 'c4') else f'generator-forward img/s ({args.config})',
             'value': round(total_imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.arith == 'f32' else 'bf16x3->f32 (3x3 and x2 layers), f32 elsewhere', 'data': 'synthetic',
-            'config': {'workload': f'BASELINE configs[2]: ImageNet 256x256, {cfg.num_ray_steps}(+{cfg.num_ray_steps}) ray steps, cmax {cfg.cmax}, '
-                                   f'c_dim {cfg.c_dim}, tri-plane {cfg.tri_plane_res}^2 x {cfg.plane_channels}, full HIP path' if args.config == 'c3'
-                       else args.config, 'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'img_resolution': cfg.img_resolution,
+            'config': {'workload': f'{names[args.config]}, {cfg.num_ray_steps}(+{cfg.num_ray_steps}) ray steps, cmax {cfg.cmax}, '
+                                   f'c_dim {cfg.c_dim}, tri-plane {cfg.tri_plane_res}^2 x {cfg.plane_channels}, full HIP path',
+                       'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'img_resolution': cfg.img_resolution,
                        'num_ray_steps': cfg.num_ray_steps, 'depth_adaptor': bool(args.depth_adaptor), 'parallelism': f'dp{world} (batch-sharded, weights replicated)'},
-            'roofline': roofline, 'kernels': kernels,
+            'rccl_ranks_seen': ranks_seen, 'roofline': roofline, 'whole_forward': whole, 'other_batches': others, 'kernels': kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(tdgp, cfg)
+            out['cpu_baseline_c1'] = out['cpu_baseline'] if args.config == 'c1' else cpu_baseline(tdgp, tdgp.config.config_c1(), n_img=16, budget_s=8.0)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))
