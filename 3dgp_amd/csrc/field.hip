@@ -121,8 +121,11 @@ __device__ __forceinline__ f32x2 div3(f32x2 x) {
 // MFMA k-slot q = c4, so slot s = 4*j + i holds channel 16*j + 4*q + i.  (FQ < 4: scalar loads, channel = q*FQ + s.)
 __host__ __device__ __forceinline__ int feat_of(int s, int q, int FQ) { return FQ % 4 == 0 ? 16 * (s >> 2) + 4 * q + (s & 3) : q * FQ + s; }
 
-template <int FQ, int MT, bool TAPS>
-__global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
+// WALK = true : the table-driven image walk alone (rays of an image, FQ % 4 == 0, planes addressable through one buffer
+//                descriptor) -- the hot path, compiled as its own kernel so that its register budget is its own;
+// WALK = false: every other mode (explicit coordinates, linear point order, the generic image walk).
+template <int FQ, int MT, bool TAPS, bool WALK>
+__device__ __forceinline__ void field_body(const FieldParams& p) {
     constexpr int F = FQ * 4;
     constexpr int HID = MT * 16;
     // MFMA A operands, one float per lane per k-step, stored [step][lane] (conflict-free ds_read_b32, shared by the 4 waves):
@@ -130,13 +133,15 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
     //   layer 2: a1s[mt*4 + r][lane]   = W1[lane&3][mt*16 + 4*(lane>>4) + r] * sqrt(2)/sqrt(HID)     (16-block 4x4x1 MFMA, see below)
     __shared__ float a0s[MT * FQ * 64];
     __shared__ float a1s[MT * 4 * 64];
-    __shared__ float b0s[HID];
-    __shared__ float4 obuf_all[4 * 16 * 9];      // per wave: [16 rays][8 samples (+1 pad)] parked outputs of the ray walk
-    __shared__ uint4 atab_all[(FQ % 4 == 0) ? 4 * 6 * 64 : 1];   // per wave: tap table of 4 samples x 16 rays, [3 planes x {weights, texel offsets}][sample*16 + ray]
+    __shared__ __attribute__((aligned(16))) float b0s[HID];
+    constexpr int NW = 4;
+    constexpr int PW = 8;             // patch = 8 x 8 pixels: one 4 x 4-pixel quad per wave
+    __shared__ float4 obuf_all[NW * 16 * 9];     // per wave: [16 rays][8 samples (+1 pad)] parked outputs of the ray walk
+    __shared__ uint4 atab_all[(FQ % 4 == 0) ? NW * 6 * 64 : 1];   // per wave: tap table of 4 samples x 16 rays, [3 planes x {weights, texel offsets}][sample*16 + ray]
     const float sqrt2 = 1.41421353816986083984375f;    // (float)sqrt(2): lrelu gain, folded into the layer-2 weights
     for (int i = threadIdx.x; i < MT * FQ * 64; i += blockDim.x) {
         const int ln = i & 63, ms = i >> 6, mt = ms / FQ, sidx = ms % FQ;
-        a0s[i] = p.w0[(mt * 16 + (ln & 15)) * F + feat_of(sidx, ln >> 4, FQ)] * p.g0;
+        a0s[i] = (p.w0[(mt * 16 + (ln & 15)) * F + feat_of(sidx, ln >> 4, FQ)] * p.g0) / 3.0f;      // x.mean(dim=1) over the 3 planes folded in (see blend)
     }
     for (int i = threadIdx.x; i < MT * 4 * 64; i += blockDim.x) {
         const int ln = i & 63, ms = i >> 6, mt = ms >> 2, r = ms & 3;
@@ -148,10 +153,9 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
     const int l = lane_id();
     const int pt = l & 15, q = l >> 4;
     const float sx = (float)(p.W - 1) / 2.f, sy = (float)(p.H - 1) / 2.f;
-    const float b1r[4] = {p.b1[0], p.b1[1], p.b1[2], p.b1[3]};      // layer-2 bias: in registers, not reloaded per tile (a load there drags a vmcnt(0) into the loop)
-    f32x4 bias0[MT];                  // layer-1 bias of the hidden units this lane owns (accumulator rows 4*q + r of tile mt)
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++) bias0[mt] = (f32x4){b0s[mt * 16 + 4 * q], b0s[mt * 16 + 4 * q + 1], b0s[mt * 16 + 4 * q + 2], b0s[mt * 16 + 4 * q + 3]};
+    // layer-2 bias: in registers, not reloaded per tile (a load there drags a vmcnt(0) into the loop); it is the initial accumulator of
+    // the q == 0 lanes, so the cross-lane sum over q adds it exactly once
+    const f32x4 o4init = (l >> 4) == 0 ? (f32x4){p.b1[0], p.b1[1], p.b1[2], p.b1[3]} : (f32x4){0.f, 0.f, 0.f, 0.f};
     const int plane_elems = p.H * p.W * F;
 
     // Two lane layouts per 16-point tile:
@@ -215,57 +219,72 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
             }
         }
     };
-    auto blend = [&](float* g) {
-        // two channels per VALU slot (v_pk_fma_f32): the same fma chain per element as the scalar form
+    // ---- the arithmetic of one 16-point tile, cut into PASSES of 16 channels (4 per gathering lane = one 16-B piece of every texel):
+    //   blend_pass : g[16 channels of the pass] = sum over the 3 planes x 4 taps of weight * texel, two channels per VALU slot
+    //                (v_pk_fma_f32), ONE fma chain per channel pair -- 12 instructions per pair, no separate plane sums / division: the
+    //                mean's 1/3 lives in the layer-1 weights.  Vector instructions are paid for in matrix time on this chip (fp32 MFMA
+    //                and VALU share the issue port), so the blend is written at its floor: 6 * FQ packed instructions per tile.  (The
+    //                reference sums per plane and divides by 3: same value to fp32 rounding, different last bit; the parity tests
+    //                bound it.)  The 4 blended values then hop from the gather layout to the MFMA layout (ds_bpermute);
+    //   mlp_pass   : the 4 k-steps of layer 1 that consume those 16 channels, on all MT accumulator tiles;
+    //   mlp_finish : lrelu, layer 2, the sum over the four hidden-unit quarters.
+    // Every path of the kernel runs the same three functions in the same order, so results do not depend on the walk.
+    constexpr int NP = (FQ % 4 == 0) ? FQ / 4 : 1;          // passes per tile
+    constexpr int PP = (FQ % 4 == 0) ? 2 : FQ / 2;          // channel pairs per lane and pass
+    auto blend_pass = [&](auto& T, int base, float* gp) {
 #pragma unroll
-        for (int s = 0; s < FQ / 2; s++) {
-            f32x2 pa[3];
+        for (int s = 0; s < PP; s++) {
+            f32x2 a = T[0][0][base + s] * (f32x2){wgt[0][0], wgt[0][0]};
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
-                const f32x2 w0 = {wgt[pl][0], wgt[pl][0]}, w1 = {wgt[pl][1], wgt[pl][1]}, w2 = {wgt[pl][2], wgt[pl][2]}, w3 = {wgt[pl][3], wgt[pl][3]};
-                pa[pl] = __builtin_elementwise_fma(tap[pl][3][s], w3, __builtin_elementwise_fma(tap[pl][2][s], w2, __builtin_elementwise_fma(tap[pl][1][s], w1, tap[pl][0][s] * w0)));
-            }
-            const f32x2 m = div3((pa[0] + pa[1]) + pa[2]);          // x.mean(dim=1)
-            g[2 * s] = m.x; g[2 * s + 1] = m.y;
+            for (int j = 1; j < 12; j++) a = __builtin_elementwise_fma(T[j >> 2][j & 3][base + s], (f32x2){wgt[j >> 2][j & 3], wgt[j >> 2][j & 3]}, a);
+            gp[2 * s] = a.x; gp[2 * s + 1] = a.y;
         }
         if (FQ % 4 == 0) {                                 // gather layout -> MFMA layout: lane (q, pt) takes from lane 4*pt + q
             const int src = (pt * 4 + q) * 4;
 #pragma unroll
-            for (int s = 0; s < FQ; s++) g[s] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(g[s])));
+            for (int s = 0; s < 2 * PP; s++) gp[s] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(gp[s])));
         }
     };
-    auto mlp = [&](const float* g) -> float4 {
-        // layer 1 on the matrix cores: h^T[hid x 16 pts] = W0s * g^T
-        f32x4 acc[MT];
+    auto mlp_begin = [&](f32x4* acc) {
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) acc[mt] = bias0[mt];           // addmm(b, x, W^T): the bias is the initial accumulator
+        for (int mt = 0; mt < MT; mt++) acc[mt] = *(const f32x4*)(b0s + mt * 16 + 4 * q);    // addmm(b, x, W^T): the bias (rows 4q..4q+3 of tile mt,
+                                                                                             // one 16-B LDS read, not 4*MT resident registers) is the initial accumulator
+    };
+    auto mlp_pass = [&](f32x4* acc, int ps, const float* gp) {     // layer 1 on the matrix cores: h^T[hid x 16 pts] += W0s[:, pass] * g^T[pass]
         if (!(TDGP_FIELD_ABL & 2))
 #pragma unroll
-        for (int s = 0; s < FQ; s++)
+        for (int i = 0; i < 2 * PP; i++)
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0s[(mt * FQ + s) * 64 + l], g[s], acc[mt], 0, 0, 0);
-
-        // bias + lrelu(0.2) lane-locally (each lane owns 4*MT hidden units of ITS point).  Layer 2 (hid -> 4) as sixteen 4x4x1
+            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0s[(mt * FQ + ps * 2 * PP + i) * 64 + l], gp[i], acc[mt], 0, 0, 0);
+    };
+    auto mlp_finish = [&](const f32x4* acc) -> float4 {
+        // lrelu(0.2) lane-locally (each lane owns 4*MT hidden units of ITS point).  Layer 2 (hid -> 4) as sixteen 4x4x1
         // block MFMAs: the instruction multiplies 16 independent (4x1)*(1x4) blocks, block = lane >> 2.  With lane = 16*q + pt the
         // block is (q, pt >> 2): B = the lane's own hidden unit of point pt, A = W1[lane & 3][that unit], so after the 4*MT steps
         // lane (q, pt) holds the (r,g,b,sigma) partial sums of ITS point over the hidden units of quarter q; two cross-lane adds
         // finish them.  8 MFMA cycles per step instead of 32 for a 16x16x4 tile that would be 3/4 padding.
-        f32x4 o4[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        f32x4 o4[2] = {o4init, (f32x4){0.f, 0.f, 0.f, 0.f}};       // the layer-2 bias rides in as the q == 0 lanes' initial accumulator
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+        for (int mt = 0; mt < MT; mt++) {
+            // leaky_relu(v, 0.2) = max(v, 0.2 v): one packed multiply per PAIR + one v_med3 per value.  The third med3 operand is
+            // the largest finite float, not +inf: with +inf the compiler folds the med3 into fmaxf, which then needs the MFMA result
+            // canonicalised first -- a second v_max per value (seen in the r01 ISA).  No inline asm here: a vector instruction the
+            // hazard recognizer cannot see, next to MFMAs, is a wrong-result generator.  The sqrt(2) gain lives in a1s.
+            const f32x2 c02 = {0.2f, 0.2f};
+            const f32x2 lo = (f32x2){acc[mt][0], acc[mt][1]} * c02, hi = (f32x2){acc[mt][2], acc[mt][3]} * c02;
+            const float sc[4] = {lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float v = acc[mt][r];
-                const float h = __builtin_amdgcn_fmed3f(v, 0.2f * v, __builtin_inff());     // leaky_relu(v, 0.2) = max(v, 0.2 v) in ONE v_med3 (fmaxf costs a canonicalising extra max); the sqrt(2) gain lives in a1s
+                const float h = __builtin_amdgcn_fmed3f(acc[mt][r], sc[r], 3.4028234663852886e38f);
                 o4[r & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1s[(mt * 4 + r) * 64 + l], h, o4[r & 1], 0, 0, 0);
             }
-        float o[4];
+        }
+        const f32x2 s01 = (f32x2){o4[0][0], o4[0][1]} + (f32x2){o4[1][0], o4[1][1]}, s23 = (f32x2){o4[0][2], o4[0][3]} + (f32x2){o4[1][2], o4[1][3]};
+        float o[4] = {s01.x, s01.y, s23.x, s23.y};
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            float v = o4[0][c] + o4[1][c];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            o[c] = b1r[c] + v;
+            o[c] += __shfl_xor(o[c], 16, 64);
+            o[c] += __shfl_xor(o[c], 32, 64);
         }
         if (p.marcher == 1) {
 #pragma unroll
@@ -273,11 +292,20 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
         }
         return make_float4(o[0], o[1], o[2], o[3]);        // (r,g,b,sigma) of point pt, valid in every lane of its column
     };
+    auto tile_from_taps = [&]() -> float4 {                // all passes of a tile whose taps sit in tap[][][] (whole texel quarters)
+        f32x4 acc[MT];
+        mlp_begin(acc);
+#pragma unroll
+        for (int ps = 0; ps < NP; ps++) {
+            float gp[2 * PP];
+            blend_pass(tap, ps * PP, gp);
+            mlp_pass(acc, ps, gp);
+        }
+        return mlp_finish(acc);
+    };
     auto eval_tile = [&](float cx, float cy, float cz, const float* __restrict__ bplanes, int64_t ggp, bool gvalid, int64_t gp, bool valid) {
-        float g[FQ];
         issue_taps(cx, cy, cz, bplanes, ggp, gvalid);
-        blend(g);
-        const float4 o = mlp(g);
+        const float4 o = tile_from_taps();
         if (q == 0 && valid && (!(TDGP_FIELD_ABL & 4) || o.x == 123.f)) {
             float4 on = o;
             if (p.snoise) on.w = __fadd_rn(on.w, __fmul_rn(p.snoise[gp], p.snoise_std));
@@ -290,19 +318,19 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
         // all S samples of those rays, so the 16 points of a tile are neighbours in texture space (a few texels apart) and
         // the patch's footprint stays in L1.  Patches are dealt to blocks so that each XCD (block id mod 8 on gfx950) owns a
         // contiguous band of the image and therefore a compact slice of the tri-planes in its private L2.
-        const int pX = (p.ray_w + 7) / 8, pY = (p.ray_h + 7) / 8;
+        const int pX = (p.ray_w + PW - 1) / PW, pY = (p.ray_h + 7) / 8;
         const int npatch = (int)(p.total / p.P) * pX * pY;
         const int nb = gridDim.x, per = nb / 8;
         const int lb = (nb % 8 == 0) ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
         const int wvi = threadIdx.x >> 6;
         float4* obuf = obuf_all + wvi * (16 * 9);
         auto ray_of = [&](int b, int py, int px, int tpt, bool& ok) {       // pixel tpt of this wave's 4x4 quadrant -> ray index
-            const int y = py * 8 + (wvi >> 1) * 4 + (tpt >> 2), x = px * 8 + (wvi & 1) * 4 + (tpt & 3);
+            const int y = py * 8 + ((wvi >> 1) & 1) * 4 + (tpt >> 2), x = px * PW + (wvi & 1) * 4 + (tpt & 3);
             ok = y < p.ray_h && x < p.ray_w;
             return b * (int)p.R + (ok ? y * p.ray_w + x : 0);                   // B*R*S < 2^31 (checked on the host)
         };
-        if constexpr (FQ % 4 == 0) {
-          if (p.planes_bytes != 0) {
+        if constexpr (WALK) {
+          {
             // Table-driven walk.  The four lanes that gather for one point would each repeat that point's coordinate -> tap
             // arithmetic (~135 VALU instructions per 16-point tile, a third of the kernel's vector work, and vector work is paid
             // in matrix time on this chip).  Instead the wave does it ONCE for four consecutive samples with lane = (ray, sample),
@@ -325,36 +353,53 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
                 const float* tp = p.t + (int64_t)gray * p.S;
                 float t_grp = tp[min(gc4, p.S - 1)];
                 auto address_phase = [&](int k0) {
+                    // One (ray, sample) per lane, ~80 vector instructions per 64 points.  The four distinct (coordinate, axis) uses of
+                    // the three planes -- x along W, y along H (plane xy), y along W (plane yz), z along H -- run as two packed pairs;
+                    // every fp32 step is the reference's own (add, multiply, floor, subtract: unfused), so the tap indices stay bit-exact.
                     const int ks = min(k0 + gc4, p.S - 1);
                     const float tt = t_grp;
-                    const float cx = ox + tt * dxr, cy = oy + tt * dyr, cz = oz + tt * dzr;     // :141 (unfused mul, add)
-                    float qc[3];
-                    if (p.scale_is_pow2) { qc[0] = cx * p.inv_scale; qc[1] = cy * p.inv_scale; qc[2] = cz * p.inv_scale; }
-                    else { qc[0] = cx / p.scale; qc[1] = cy / p.scale; qc[2] = cz / p.scale; }
+                    const f32x2 cxy = (f32x2){ox, oy} + (f32x2){tt, tt} * (f32x2){dxr, dyr};     // :141 (unfused mul, add)
+                    const float cz = oz + tt * dzr;
+                    f32x2 qxy; float qz;
+                    if (p.scale_is_pow2) { qxy = cxy * (f32x2){p.inv_scale, p.inv_scale}; qz = cz * p.inv_scale; }
+                    else { qxy = (f32x2){cxy.x / p.scale, cxy.y / p.scale}; qz = cz / p.scale; }
+                    const f32x2 one2 = {1.0f, 1.0f};
+                    const f32x2 iA = ((f32x2){qxy.x, qxy.y} + one2) * (f32x2){sx, sy};          // (x -> W, y -> H)
+                    const f32x2 iB = ((f32x2){qxy.y, qz} + one2) * (f32x2){sx, sy};             // (y -> W, z -> H)
+                    const float iv[4] = {iA.x, iA.y, iB.x, iB.y};
+                    const float lim[4] = {(float)p.W, (float)p.H, (float)p.W, (float)p.H};
+                    const int nn[4] = {p.W, p.H, p.W, p.H};
+                    f32x2 T[4];            // per axis use: (weight of the lower tap, weight of the upper tap), 0 where the tap is outside (zero padding)
+                    int i0[4], ia[4], ib[4];
+#pragma unroll
+                    for (int a = 0; a < 4; a++) {
+                        const float f = floorf(iv[a]);
+                        const float tw = iv[a] - f;
+                        const f32x2 t2 = __builtin_elementwise_fma((f32x2){tw, tw}, (f32x2){-1.0f, 1.0f}, (f32x2){1.0f, 0.0f});   // (1 - tw, tw), each exactly rounded
+                        const float cf = __builtin_amdgcn_fmed3f(f, -2.f, lim[a]);
+                        const int x0 = (int)cf;
+                        i0[a] = x0;
+                        const bool v0 = (unsigned)x0 < (unsigned)nn[a], v1 = (unsigned)(x0 + 1) < (unsigned)nn[a];
+                        T[a] = (f32x2){v0 ? t2.x : 0.f, v1 ? t2.y : 0.f};
+                        ia[a] = min(max(x0, 0), nn[a] - 1);
+                        ib[a] = min(max(x0 + 1, 0), nn[a] - 1);
+                    }
+                    if (TAPS) {
+                        if (p.tap_idx && gok && k0 + gc4 < p.S) {
+                            int32_t* tdst = p.tap_idx + ((int64_t)gray * p.S + ks) * 6;
+                            tdst[0] = i0[0]; tdst[1] = i0[1]; tdst[2] = i0[0]; tdst[3] = i0[3]; tdst[4] = i0[2]; tdst[5] = i0[3];
+                        }
+                    }
+                    const uint32_t rowb = (uint32_t)p.W * (F * 4u);                            // bytes per texel row (< 2^24: W * F * 4)
+                    const int ua[3] = {0, 0, 2}, va[3] = {1, 3, 3};                           // planes (x,y), (x,z), (y,z): width <- first coordinate (:577-581)
 #pragma unroll
                     for (int pl = 0; pl < 3; pl++) {
-                        const float u = qc[pl == 2 ? 1 : 0], v = qc[pl == 0 ? 1 : 2];
-                        const float ix = (u + 1.0f) * sx, iy = (v + 1.0f) * sy;
-                        const float fx = floorf(ix), fy = floorf(iy);
-                        const float tw = ix - fx, te = 1.0f - tw, tn = iy - fy, ts = 1.0f - tn;
-                        const float cfx = fx < -2.f ? -2.f : (fx > (float)p.W ? (float)p.W : fx);
-                        const float cfy = fy < -2.f ? -2.f : (fy > (float)p.H ? (float)p.H : fy);
-                        const int x0 = (int)cfx, y0 = (int)cfy;
-                        if (TAPS) {
-                            if (p.tap_idx && gok && k0 + gc4 < p.S) {
-                                p.tap_idx[(((int64_t)gray * p.S + ks) * 3 + pl) * 2 + 0] = x0;
-                                p.tap_idx[(((int64_t)gray * p.S + ks) * 3 + pl) * 2 + 1] = y0;
-                            }
-                        }
-                        const bool vx0 = (unsigned)x0 < (unsigned)p.W, vx1 = (unsigned)(x0 + 1) < (unsigned)p.W;
-                        const bool vy0 = (unsigned)y0 < (unsigned)p.H, vy1 = (unsigned)(y0 + 1) < (unsigned)p.H;
-                        const float4 w4 = make_float4((vx0 && vy0) ? ts * te : 0.f, (vx1 && vy0) ? ts * tw : 0.f, (vx0 && vy1) ? tn * te : 0.f, (vx1 && vy1) ? tn * tw : 0.f);
-                        const int xa = min(max(x0, 0), p.W - 1), xb = min(max(x0 + 1, 0), p.W - 1);
-                        const int ya = min(max(y0, 0), p.H - 1), yb = min(max(y0 + 1, 0), p.H - 1);
-                        const int ra = ya * p.W, rb = yb * p.W;
-                        atab[(pl * 2 + 0) * 64 + wslot] = make_uint4(__float_as_uint(w4.x), __float_as_uint(w4.y), __float_as_uint(w4.z), __float_as_uint(w4.w));
-                        atab[(pl * 2 + 1) * 64 + wslot] = make_uint4((uint32_t)(ra + xa) * (F * 4u), (uint32_t)(ra + xb) * (F * 4u), (uint32_t)(rb + xa) * (F * 4u),
-                                                                     (uint32_t)(rb + xb) * (F * 4u));
+                        const f32x2 wn = T[ua[pl]] * (f32x2){T[va[pl]].x, T[va[pl]].x};       // (nw, ne) = (te, tw) * ts
+                        const f32x2 ws2 = T[ua[pl]] * (f32x2){T[va[pl]].y, T[va[pl]].y};      // (sw, se) = (te, tw) * tn
+                        const uint32_t ca = (uint32_t)ia[ua[pl]] * (F * 4u), cb = (uint32_t)ib[ua[pl]] * (F * 4u);
+                        const uint32_t ra = __umul24((uint32_t)ia[va[pl]], rowb), rb = __umul24((uint32_t)ib[va[pl]], rowb);
+                        atab[(pl * 2 + 0) * 64 + wslot] = make_uint4(__float_as_uint(wn.x), __float_as_uint(wn.y), __float_as_uint(ws2.x), __float_as_uint(ws2.y));
+                        atab[(pl * 2 + 1) * 64 + wslot] = make_uint4(ra + ca, ra + cb, rb + ca, rb + cb);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -363,6 +408,12 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                     t_grp = tp[min(k0 + 4 + gc4, p.S - 1)];
                 };
+                // Software pipeline over the samples: all 12 texel quarters of sample k+1 (24 x 16 B per lane at F = 32) are put in flight
+                // right after sample k has been blended, and travel while the matrix cores run sample k's MLP.  (Tried and measured in
+                // r02: splitting the tile into two 16-channel passes with only one pass of taps in flight -- 48 instead of 96 tap
+                // registers, three / four waves per SIMD instead of two -- is 5 % FASTER on the coarse pass and 35 % SLOWER on the fine
+                // pass, whose importance samples are scattered in depth: there it is the number of loads in flight per wave that hides
+                // the L2 / MALL latency, not the number of waves.)
                 auto issue_from_table = [&](int j) {                   // sample j of the current group: this lane's point is ray gpt
                     const int rslot = j * 16 + gpt;
 #pragma unroll
@@ -381,27 +432,21 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
                             }
                     }
                 };
-#if TDGP_FIELD_ABL & 32
-                long long tf[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
-#define TF(i) { const long long tn_ = __builtin_readcyclecounter(); tf[i] += tn_ - tprev; tprev = tn_; }
-#else
-#define TF(i)
-#endif
                 address_phase(0);
                 issue_from_table(0);
-                TF(1)
                 for (int k = 0; k < p.S; k++) {
-                    float g[FQ];
-                    blend(g);
-                    TF(0)
+                    float g[NP][2 * PP];
+#pragma unroll
+                    for (int ps = 0; ps < NP; ps++) blend_pass(tap, ps * PP, g[ps]);
                     if (k + 1 < p.S) {
                         if (((k + 1) & 3) == 0) address_phase(k + 1);
-                        TF(1)
                         issue_from_table((k + 1) & 3);
-                        TF(2)
                     }
-                    const float4 o = mlp(g);
-                    TF(3)
+                    f32x4 acc[MT];
+                    mlp_begin(acc);
+#pragma unroll
+                    for (int ps = 0; ps < NP; ps++) mlp_pass(acc, ps, g[ps]);
+                    const float4 o = mlp_finish(acc);
                     if (q == 0) obuf[pt * 9 + (k & 7)] = o;
                     if ((k & 7) == 7 || k + 1 == p.S) {
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -422,17 +467,12 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                     }
-                    TF(4)
                 }
-#if TDGP_FIELD_ABL & 32
-                if (l == 0 && wvi == 0 && (patch == lb) && (blockIdx.x == 0 || blockIdx.x == 1001))
-                    printf("field blk %d S %d: blend(+tap wait) %lld address %lld issue %lld mlp %lld park/flush %lld\n", (int)blockIdx.x, p.S, tf[0], tf[1], tf[2], tf[3], tf[4]);
-#endif
-#undef TF
             }
             return;
           }
         }
+        if constexpr (!WALK)
         for (int patch = lb; patch < npatch; patch += nb) {
             const int px = patch % pX, py = (patch / pX) % pY, b = patch / (pX * pY);       // uniform
             bool gok;
@@ -449,14 +489,19 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
             float tn = p.S > 1 ? tp[1] : 0.f;
             issue_taps(ox + tt * dxr, oy + tt * dyr, oz + tt * dzr, bplanes, (int64_t)gray * p.S, gok);          // :141 (unfused mul, add)
             for (int k = 0; k < p.S; k++) {
-                float g[FQ];
-                blend(g);
+                float g[NP][2 * PP];
+#pragma unroll
+                for (int ps = 0; ps < NP; ps++) blend_pass(tap, ps * PP, g[ps]);
                 if (k + 1 < p.S) {
                     tt = tn;
                     tn = k + 2 < p.S ? tp[k + 2] : 0.f;
                     issue_taps(ox + tt * dxr, oy + tt * dyr, oz + tt * dzr, bplanes, (int64_t)gray * p.S + k + 1, gok);
                 }
-                const float4 o = mlp(g);
+                f32x4 acc[MT];
+                mlp_begin(acc);
+#pragma unroll
+                for (int ps = 0; ps < NP; ps++) mlp_pass(acc, ps, g[ps]);
+                const float4 o = mlp_finish(acc);
                 // Results are parked in a per-wave LDS tile [16 rays][8 samples] and flushed as 128-B runs per ray: stored
                 // directly, the 16 points of a step sit S*16 B apart -- sixteen 16-B fragments of sixteen different lines (the
                 // PMC write traffic was 3.3x the payload).
@@ -484,6 +529,7 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
         }
         return;
     }
+    if constexpr (WALK) return;
     const int64_t ntiles = (p.total + 15) / 16;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -507,6 +553,12 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
         eval_tile(cx, cy, cz, p.planes + (int64_t)b * 3 * plane_elems, ggp, gvalid, gp, valid);
     }
 }
+
+template <int FQ, int MT, bool TAPS>
+__global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) { field_body<FQ, MT, TAPS, false>(p); }
+
+template <int FQ, int MT, bool TAPS>
+__global__ __launch_bounds__(256, 2) void triplane_walk_kernel(FieldParams p) { field_body<FQ, MT, TAPS, true>(p); }
 
 // NCHW planes [B,3F,H,W] -> [B,3,H,W,F] through an LDS tile of 64 pixels x F channels.
 __global__ __launch_bounds__(256) void planes_to_hwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int F, int HW, int64_t ntiles,
@@ -532,10 +584,30 @@ __global__ __launch_bounds__(256) void planes_to_hwc_kernel(const float* __restr
 template <int FQ, int MT, bool TAPS>
 void launch_field_t(const FieldParams& p, hipStream_t s) {
     int64_t want;
+    const bool walk = FQ % 4 == 0 && p.ray_w > 0 && p.planes_bytes != 0;
+    const int threads = 256;
     if (p.ray_w > 0) want = (p.total / p.P) * cdiv(p.ray_w, 8) * cdiv(p.ray_h, 8);      // one 8x8-pixel patch per block
     else want = cdiv64((p.total + 15) / 16, 4);                                          // one 16-point tile per wave
-    int blocks = (int)min((int64_t)(256 * 8), want);         // persistent-ish grid: <= 8 blocks per CU, blocks stride over the work
+    // Persistent grid = exactly the blocks the chip holds at once (LDS-limited: 3 per CU at F = 32, hid = 64), each striding over the
+    // work.  r01 launched 8 per CU: 2048 blocks over 768 slots ran as 2.67 rounds in the time of 3 (11 % of the kernel idle in the
+    // last round); with 768 blocks every block gets within one patch of the same number of patches.
+    static int resident[2] = {0, 0};
+    if (resident[walk] == 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        hipError_t e;
+        if constexpr (FQ % 4 == 0) e = walk ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, triplane_walk_kernel<FQ, MT, TAPS>, 256, 0)
+                                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, triplane_field_kernel<FQ, MT, TAPS>, 256, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, triplane_field_kernel<FQ, MT, TAPS>, 256, 0);
+        if (e != hipSuccess || per_cu < 1) per_cu = 2;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        resident[walk] = per_cu * cus;
+    }
+    int blocks = (int)min((int64_t)resident[walk], want);
     if (blocks > 8) blocks -= blocks % 8;                    // whole rounds of the 8 XCDs (the in-kernel XCD remap needs it)
+    if constexpr (FQ % 4 == 0) {
+        if (walk) { TDGP_LAUNCH("triplane_field_kernel", (triplane_walk_kernel<FQ, MT, TAPS>), dim3(blocks), dim3(threads), 0, s, p); return; }
+    }
     TDGP_LAUNCH("triplane_field_kernel", (triplane_field_kernel<FQ, MT, TAPS>), dim3(blocks), dim3(256), 0, s, p);
 }
 
@@ -580,7 +652,7 @@ TDGP_API int tdgp_triplane_field(const float* planes_hwc, const float* coords, c
     TDGP_CHECK((int64_t)B * P <= INT32_MAX / 4 && (int64_t)3 * H * W * F <= INT32_MAX, TDGP_EINVAL, "triplane_field: tensor too large");
     p.g0 = (float)(1.0 / sqrt((double)F)); p.g1 = (float)(1.0 / sqrt((double)hid));    // weight_gain, layers.py:39
     p.marcher = marcher;
-    { const int64_t pb = (int64_t)B * 3 * H * W * F * 4; p.planes_bytes = pb < ((int64_t)1 << 32) - 65536 ? (uint32_t)pb : 0u; }
+    { const int64_t pb = (int64_t)B * 3 * H * W * F * 4; p.planes_bytes = (pb < ((int64_t)1 << 32) - 65536 && (int64_t)W * F * 4 < (1 << 24)) ? (uint32_t)pb : 0u; }
     p.R = coords ? 0 : P / S; p.ray_w = 0; p.ray_h = 0;
     if (!coords && ray_w > 0) {
         TDGP_CHECK((p.R % ray_w) == 0, TDGP_EINVAL, "triplane_field: ray_w=%d does not divide the %lld rays", ray_w, (long long)p.R);
