@@ -112,3 +112,27 @@ __device__ __forceinline__ double wave_sum_f64(double v) { return wave_last_f64(
 
 // torch's thresholded softplus (beta 1, threshold 20), evaluated in fp64 and rounded once.
 __device__ __forceinline__ float softplus20(float x) { return x > 20.f ? x : (float)log1p(exp((double)x)); }
+
+// fp32 counterparts (the forward ray marchers): the same DPP scans on one register per value, and softplus as the reference's
+// own fp32 formula log1p(exp(x)) on the accurate (<= 1 ulp) OCML routines.
+template <int CTRL, int RMASK>
+__device__ __forceinline__ float dpp_f32(float keep, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(v), CTRL, RMASK, 0xf, false));
+}
+template <bool PROD>
+__device__ __forceinline__ float wave_scan_f32(float v) {
+    const float id = PROD ? 1.0f : 0.0f;
+#define TDGP_SCAN_STEP(CTRL, RMASK) { const float o = dpp_f32<CTRL, RMASK>(id, v); v = PROD ? v * o : v + o; }
+    TDGP_SCAN_STEP(0x111, 0xf)
+    TDGP_SCAN_STEP(0x112, 0xf)
+    TDGP_SCAN_STEP(0x114, 0xf)
+    TDGP_SCAN_STEP(0x118, 0xf)
+    TDGP_SCAN_STEP(0x142, 0xa)
+    TDGP_SCAN_STEP(0x143, 0xc)
+#undef TDGP_SCAN_STEP
+    return v;
+}
+__device__ __forceinline__ float wave_last_f32(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+__device__ __forceinline__ float wave_shr1_f32(float v, float first) { return dpp_f32<0x138, 0xf>(first, v); }
+__device__ __forceinline__ float wave_sum_f32(float v) { return wave_last_f32(wave_scan_f32<false>(v)); }
+__device__ __forceinline__ float softplus20f(float x) { return x > 20.f ? x : log1pf(expf(x)); }

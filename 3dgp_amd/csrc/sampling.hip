@@ -6,11 +6,14 @@
 //   :237-255 sample_importance      :257-295 sample_pdf              :196-206 unify_samples
 //
 // Mapping: ONE 64-lane wavefront per ray (4 rays per 256-thread block), samples across lanes, per-wave LDS
-// scratch, no block-level synchronisation.  Scans (transmittance cumprod, cdf cumsum) are fp64 wave scans
-// rounded to fp32 per prefix, which reproduces torch's sequential-fp64 CPU accumulation;
-// reductions are fp64 wave sums rounded once, except sample_pdf's normaliser, which follows torch's fp32 order bit for bit.  exp/log1p are evaluated in fp64: these kernels are HBM/latency
-// bound (2S*20 B per ray), the fp64 transcendental costs nothing measurable and keeps the importance-sampling
-// integer decisions (searchsorted index, sort permutation) identical to the CPU oracle.
+// scratch, no block-level synchronisation.
+// Arithmetic (r02): the marchers are the reference's own fp32 chain -- delta, softplus = log1p(exp(x)), alpha = 1 - exp(-delta*sigma),
+// transmittance = cumprod, weights, weighted sums -- on fp32 OCML transcendentals (<= 1 ulp), fp32 DPP wave scans and fp32 wave
+// sums.  r01 evaluated the transcendentals, scans and sums in fp64 to be bit-identical to the CPU oracle (which rounds the exact
+// value once); that cost 2-3x the instructions (fp64 exp / log1p, two-register DPP moves, half-rate adds) for an agreement that
+// is not the reference's either (torch's expf is Sleef's 1-ulp routine, its sums fp32 cascades).  What has to be EXACT is kept
+// exact: sample_pdf's normaliser follows torch's summation order, the cdf is torch's sequential-double cumsum rounded per prefix,
+// so for given weights the searchsorted indices and the fine samples equal the reference's bit for bit (the stage-level tests).
 #include "common.h"
 
 #ifndef TDGP_RAY_ABL
@@ -50,26 +53,25 @@ __device__ __forceinline__ float s2t(float s, float t_near, float t_far) { retur
 // ------------------------------------------------------------------------------------------------
 __device__ void march_classical_lds(const float* z, const float* sig, float* w, int S, int flags, float cut_thr, float& final_T, float& wagg) {
     const int l = lane_id();
-    double carry = 1.0, wsum = 0.0;
+    float carry = 1.0f, wsum = 0.0f;
     for (int base = 0; base < S; base += 64) {
         const int i = base + l;
         float alpha = 0.f, fac = 1.0f;
         if (i < S) {
             float delta = (i < S - 1) ? (z[i + 1] - z[i]) : ((flags & 1) ? 1e10f : 1e-3f);
-            float sp = (flags & 8) ? (sig[i] > 0.f ? sig[i] : 0.f) : softplus20(sig[i]);
+            float sp = (flags & 8) ? (sig[i] > 0.f ? sig[i] : 0.f) : softplus20f(sig[i]);
             if (sp < cut_thr) sp = 0.f;                        // cut_quantile (:366-368); cut_thr = 0 never cuts (sp >= 0)
-            alpha = 1.0f - (float)exp((double)(-delta * sp));
+            alpha = 1.0f - expf(-(delta * sp));
             fac = (1.0f - alpha) + 1e-10f;
         }
-        double incl = wave_scan_f64<true>((double)fac) * carry;
-        const double excl = wave_shr1_f64(incl, carry);
-        float wi = alpha * (float)excl;
-        if (i < S) { w[i] = wi; wsum += (double)wi; }
-        carry = wave_last_f64(incl);
+        const float incl = wave_scan_f32<true>(fac) * carry;
+        const float excl = wave_shr1_f32(incl, carry);
+        const float wi = alpha * excl;
+        if (i < S) { w[i] = wi; wsum += wi; }
+        carry = wave_last_f32(incl);
     }
-    wsum = wave_sum_f64(wsum);
-    wagg = (float)wsum;
-    final_T = (float)carry;
+    wagg = wave_sum_f32(wsum);
+    final_T = carry;
     wave_sync();
     if ((flags & 2) && l == 0) w[S - 1] += (1.0f - wagg);
     wave_sync();
@@ -81,7 +83,7 @@ __device__ void march_mip_lds(const float* z, const float* sig, float* w, int S,
                               float& wagg) {
     const int l = lane_id();
     const int M = (flags & 1) ? S : S - 1;
-    double carry = 1.0, wsum = 0.0;
+    float carry = 1.0f, wsum = 0.0f;
     for (int base = 0; base < M; base += 64) {
         const int i = base + l;
         float alpha = 0.f, fac = 1.0f;
@@ -89,21 +91,20 @@ __device__ void march_mip_lds(const float* z, const float* sig, float* w, int S,
             float delta, smid;
             if (i < S - 1) { delta = z[i + 1] - z[i]; smid = (sig[i] + sig[i + 1]) / 2.f; }
             else { delta = 1e10f; smid = sig[S - 1]; }
-            float sp = softplus20(smid + density_bias);
+            float sp = softplus20f(smid + density_bias);
             if (sp < cut_thr) sp = 0.f;                        // cut_quantile (:324-326)
             float dd = sp * delta;
-            alpha = 1.0f - (float)exp((double)(-dd));
+            alpha = 1.0f - expf(-dd);
             fac = (1.0f - alpha) + 1e-10f;
         }
-        double incl = wave_scan_f64<true>((double)fac) * carry;
-        const double excl = wave_shr1_f64(incl, carry);
-        float wi = alpha * (float)excl;
-        if (i < M) { w[i] = wi; wsum += (double)wi; }
-        carry = wave_last_f64(incl);
+        const float incl = wave_scan_f32<true>(fac) * carry;
+        const float excl = wave_shr1_f32(incl, carry);
+        const float wi = alpha * excl;
+        if (i < M) { w[i] = wi; wsum += wi; }
+        carry = wave_last_f32(incl);
     }
-    wsum = wave_sum_f64(wsum);
-    wagg = (float)wsum;
-    final_T = (float)carry;
+    wagg = wave_sum_f32(wsum);
+    final_T = carry;
     wave_sync();
 }
 
@@ -255,9 +256,9 @@ __global__ __launch_bounds__(256) void ray_march_kernel(const float* __restrict_
     if (marcher == 0) march_classical_lds(sc.z, sc.sig, sc.w, S, flags, cut_thr, fT, wagg);
     else march_mip_lds(sc.z, sc.sig, sc.w, S, flags, density_bias, cut_thr, fT, wagg);
     if (weights) for (int i = l; i < M; i += 64) weights[r * M + i] = sc.w[i];
-    // composite: sum_i w_i * c_i  (products rounded to fp32, accumulated in fp64)
+    // composite: sum_i w_i * c_i
     for (int c = 0; c <= C; c++) {          // c == C: depth
-        double acc = 0.0;
+        float acc = 0.0f;
         for (int i = l; i < M; i += 64) {
             float v;
             if (c < C) {
@@ -267,9 +268,9 @@ __global__ __launch_bounds__(256) void ray_march_kernel(const float* __restrict_
                 v = sc.z[i];
                 if (marcher == 1 && i < S - 1) v = (v + sc.z[i + 1]) / 2.f;
             }
-            acc += (double)(sc.w[i] * v);
+            acc += sc.w[i] * v;
         }
-        float out = (float)wave_sum_f64(acc);
+        float out = wave_sum_f32(acc);
         if (marcher == 1 && c < C) {
             if (flags & 4) out = out + 1.0f - wagg;
             out = out * 2.0f - 1.0f;
@@ -500,21 +501,21 @@ __global__ __launch_bounds__(256) void merge_composite_kernel(const float* __res
     if (marcher == 0) march_classical_lds(sc.z, sc.sig, sc.w, M, flags, cut_thr, fT, wagg);
     else march_mip_lds(sc.z, sc.sig, sc.w, M, flags, density_bias, cut_thr, fT, wagg);
     TPH(3)
-    double acc[4] = {0.0, 0.0, 0.0, 0.0}, wacc = 0.0;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, wacc = 0.f;
     for (int i = l; i < Mm; i += 64) {
         const float wi = sc.w[i];
-        wacc += (double)wi;
+        wacc += wi;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             float v = c < 3 ? sc.col[c][i] : sc.z[i];
             if (marcher == 1 && i < M - 1) v = (v + (c < 3 ? sc.col[c][i + 1] : sc.z[i + 1])) / 2.f;
-            acc[c] += (double)(wi * v);
+            acc[c] += wi * v;
         }
     }
     float out[4];
 #pragma unroll
-    for (int c = 0; c < 4; c++) out[c] = (float)wave_sum_f64(acc[c]);
-    const float wtot = (float)wave_sum_f64(wacc);     // weights.sum(2): final weights incl. last_back
+    for (int c = 0; c < 4; c++) out[c] = wave_sum_f32(acc[c]);
+    const float wtot = wave_sum_f32(wacc);            // weights.sum(2): final weights incl. last_back
     if (marcher == 1) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {

@@ -346,8 +346,10 @@ def test_march_classical(tdgp, oracle, tag, kw):
     assert_close(N(dep), g[f'{tag}_depth'], 5e-6, 'depth', 1.0)
     assert_close(N(fT), g[f'{tag}_T'], 2e-6, 'T')
     orgb, odep, ow, ofT = oracle.march_classical(g['colors'], g['densities'], g['depths'], **kw)
-    np.testing.assert_array_equal(N(w), ow)                                       # same fp64 scan, same fp64 exp: bit-exact
-    np.testing.assert_array_equal(N(fT), ofT)
+    # the marchers run the reference's fp32 chain on <= 1-ulp transcendentals and fp32 wave scans; the oracle rounds the exact
+    # value once: a few ulp apart, like torch's own Sleef-based result is from either
+    assert_close(N(w), ow, 1e-6, 'weights vs oracle', 1.0)
+    assert_close(N(fT), ofT, 2e-6, 'T vs oracle')
     assert_close(N(rgb), orgb, 1e-6, 'rgb vs oracle', 1.0)
 
 
