@@ -70,6 +70,12 @@ class GeneratorConfig:
     white_back: bool = False
     density_bias: float = 0.0
     img_resolution: int = 256
+    # Reduced-precision blocks (networks_epigraf.py:82,99-108, networks_stylegan2.py:237): the `num_fp16_res` highest-resolution blocks
+    # of the tri-plane backbone keep their activations and weights in 16 bits -- bfloat16 here (BASELINE configs[4]: "bf16 weights on
+    # CDNA4"), fp32 accumulation -- and every conv output is clamped to +-conv_clamp.  0 / None = `fp32_only` (train.py:271-273), the
+    # setting of every 3dgp config and of the headline metric.
+    num_fp16_res: int = 0
+    conv_clamp: Optional[float] = None
     max_batch_res: int = 128        # kept for API parity (run_batchwise chunking is a no-op for results)
     # training-mode forward: patch-wise rendering resolution (configs/training/patch_beta.yaml `resolution`;
     # None = patch.enabled off -> img_resolution) and the density-noise schedule (configs/model/3dgp.yaml:22-23)
@@ -94,6 +100,13 @@ class GeneratorConfig:
     def channels(self):
         """networks_epigraf.py:98."""
         return {r: min(int(self.cbase * self.fmaps) // r, self.cmax) for r in self.block_resolutions}
+
+    @property
+    def fp16_resolution(self):
+        """networks_epigraf.py:99: blocks at or above this resolution run in reduced precision; None = fp32 only."""
+        if self.num_fp16_res <= 0:
+            return None
+        return max(2 ** (int(math.log2(self.tri_plane_res)) + 1 - self.num_fp16_res), 8)
 
     @property
     def num_ws(self):
@@ -126,6 +139,20 @@ def config_c3():
 def config_c4():
     """As C3 with cmax 1024 / cbase 65536 (README.md:57)."""
     return GeneratorConfig(c_dim=1000, img_resolution=256, num_ray_steps=64, cmax=1024, cbase=65536)
+
+
+def config_c5():
+    """BASELINE configs[4]: ImageNet 256x256, 96(+96) ray steps, the four highest-resolution backbone blocks (64^2 ... 512^2) in bfloat16
+    with fp32 accumulation and conv_clamp 256 -- the reference's `num_fp16_res = 4, conv_clamp = 256` defaults (networks_epigraf.py:82,
+    networks_stylegan2.py:220) with bf16 in the place of fp16; skip image / tri-planes and the renderer stay fp32, as there."""
+    return GeneratorConfig(c_dim=1000, img_resolution=256, num_ray_steps=96, num_fp16_res=4, conv_clamp=256.0)
+
+
+def config_mid_bf16():
+    """The reduced-precision golden (tools/gen_goldens.py:gen_bf16): 64^2 tri-planes of 3 x 8 features, 32 channels, the two
+    highest-resolution blocks (32^2, 64^2: row widths the MFMA fast paths take) in bf16."""
+    return GeneratorConfig(z_dim=32, w_dim=32, c_dim=0, cbase=2048, cmax=32, tri_plane_res=64, feat_dim=8, mlp_hid=16, num_ray_steps=8,
+                           img_resolution=16, num_fp16_res=2, conv_clamp=256.0)
 
 
 def config_tiny():

@@ -376,24 +376,62 @@ class SynthesisBlocksSequence(torch.nn.Module):
             w_idx += blk.num_conv
         return img
 
+    def _run(self, resolutions, x, img, ws, styles, dcoefs, feat, sl=None, **block_kwargs):
+        """Blocks `resolutions` on the batch slice `sl` (None = whole batch) of (ws, styles, dcoefs); x / img are already that slice."""
+        cut = (lambda t: t) if sl is None else (lambda t: t[sl])
+        for res in resolutions:
+            blk = getattr(self, f'b{res}')
+            w_idx, s_idx, d_idx = self._block_index[res]
+            n = blk.num_conv + blk.num_torgb
+            x, img = blk(x, img, cut(ws).narrow(1, w_idx, n), styles=[cut(t) for t in styles[s_idx:s_idx + n]],
+                         dcoefs=[cut(t) for t in dcoefs[d_idx:d_idx + blk.num_conv]], hwc_feat=feat, **block_kwargs)
+        return x, img
+
+    def _index_blocks(self):
+        idx, w_idx, s_idx, d_idx = {}, 0, 0, 0
+        for res in self.block_resolutions:
+            blk = getattr(self, f'b{res}')
+            idx[res] = (w_idx, s_idx, d_idx)
+            w_idx += blk.num_conv
+            s_idx += blk.num_conv + blk.num_torgb
+            d_idx += blk.num_conv
+        return idx
+
     def forward(self, ws, x=None, hwc=False, **block_kwargs):
         """ws [B, num_ws, w_dim] -> planes [B, out_channels, R, R] (NCHW), or HWCPlanes [B,3,R,R,feat] when hwc=True."""
+        planes = None
+        for _, img in self.forward_chunks(ws, x=x, hwc=hwc, chunk=None, **block_kwargs):
+            planes = img
+        return planes
+
+    def forward_chunks(self, ws, x=None, hwc=False, chunk=None, chunk_from=128, **block_kwargs):
+        """Generator over (batch slice, planes of that slice).  chunk = None: one item, the whole batch.  chunk = n: the blocks below
+        `chunk_from` run on the whole batch (they are small and need the batch to fill the chip), the high-resolution blocks run
+        `n` samples at a time, and each slice is yielded as soon as its planes exist -- the caller renders it while its planes and the
+        block activations behind them (67-100 MB per sample at 512^2) are still in the 256 MB Infinity Cache, instead of streaming a
+        batch-sized tensor (1-1.6 GB at B = 16) through HBM between every pair of kernels.  Per-sample results are unchanged (every
+        op is per sample; split-K factors, which depend on the launch size, move the last bit)."""
         assert ws.shape[1] == self.num_ws and ws.shape[2] == self.cfg.w_dim, f'Wrong shape: ws {tuple(ws.shape)}'
         _lib.require_cuda(ws, 'ws')
         ws = ws.to(torch.float32)
+        B = ws.shape[0]
         styles = self.all_styles(ws)
-        dcoefs = self.all_demods(ws.shape[0])
+        dcoefs = self.all_demods(B)
+        if getattr(self, '_block_index', None) is None:
+            self._block_index = self._index_blocks()
         feat = self.out_channels // 3 if hwc else 0
-        img = None
-        w_idx = s_idx = d_idx = 0
-        for res in self.block_resolutions:
-            blk = getattr(self, f'b{res}')
-            n = blk.num_conv + blk.num_torgb
-            x, img = blk(x, img, ws.narrow(1, w_idx, n), styles=styles[s_idx:s_idx + n], dcoefs=dcoefs[d_idx:d_idx + blk.num_conv], hwc_feat=feat, **block_kwargs)
-            w_idx += blk.num_conv
-            s_idx += n
-            d_idx += blk.num_conv
-        return _renderer.HWCPlanes(img) if hwc else img
+        wrap = (lambda t: _renderer.HWCPlanes(t)) if hwc else (lambda t: t)
+        if chunk is None or chunk >= B:
+            x, img = self._run(self.block_resolutions, x, None, ws, styles, dcoefs, feat, **block_kwargs)
+            yield slice(0, B), wrap(img)
+            return
+        head = [r for r in self.block_resolutions if r < chunk_from]
+        tail = [r for r in self.block_resolutions if r >= chunk_from]
+        x, img = self._run(head, x, None, ws, styles, dcoefs, feat, **block_kwargs)
+        for c0 in range(0, B, chunk):
+            sl = slice(c0, min(c0 + chunk, B))
+            _, img_c = self._run(tail, None if x is None else x[sl], None if img is None else img[sl], ws, styles, dcoefs, feat, sl=sl, **block_kwargs)
+            yield sl, wrap(img_c)
 
 
 class SynthesisNetwork(torch.nn.Module):
@@ -417,6 +455,10 @@ class SynthesisNetwork(torch.nn.Module):
         self.camera_adaptor = _adaptors.CameraAdaptor(cfg.camera_adaptor, cfg.z_dim, cfg.c_dim) if cfg.camera_adaptor is not None else None
         self._default_render_options = dict(max_batch_res=cfg.max_batch_res, return_depth=False, return_depth_adapted=False, return_weights=False,
                                             concat_depth=False, cut_quantile=0.0, density_bias=cfg.density_bias)
+        # Schedule of the inference forward (results do not depend on it): the blocks from `chunk_from` up and the renderer run `chunk`
+        # samples at a time so that a sample's high-resolution activations and tri-planes are consumed out of the Infinity Cache
+        # (SynthesisBlocksSequence.forward_chunks).  None = the whole batch through every kernel.
+        self.chunk, self.chunk_from = None, 128
 
     def progressive_update(self, cur_kimg):
         """networks_epigraf.py:191-194: density-noise std decays linearly to 0 over nerf_noise_kimg_growth; the depth adaptor anneals."""
@@ -486,16 +528,38 @@ class SynthesisNetwork(torch.nn.Module):
         if (render_opts['return_depth_adapted'] or render_opts['concat_depth']) and self.depth_adaptor is None:
             raise RuntimeError('return_depth_adapted / concat_depth need cfg.depth_adaptor')
         B = ws.shape[0]
-        planes = self.tri_plane_decoder(ws[:, :self.tri_plane_decoder.num_ws], hwc=True, **block_kwargs)
         h = w = self.train_resolution if self.training else self.test_resolution
         cam = camera_params
         get = (lambda k: cam[k]) if isinstance(cam, dict) else (lambda k: getattr(cam, k))
         c2w = _renderer.compute_cam2world_matrix(cam)
         ray_o, ray_d = _renderer.sample_rays(c2w, fov=get('fov'), resolution=(h, w), patch_params=patch_params, device=ws.device)
         opts = self.rendering_options(render_opts)
-        opts['u_coarse'], opts['u_fine'], opts['n_coarse'], opts['n_fine'] = u_coarse, u_fine, n_coarse, n_fine
         opts['ray_grid_w'] = w                      # rays are the row-major pixels of an h x w image (sample_rays)
-        rgb, depth, _w, _T = self.renderer(planes, self.tri_plane_mlp, ray_o, ray_d, opts)
+        R = h * w
+        draws = dict(u_coarse=(u_coarse, [B, R, -1]), u_fine=(u_fine, [B, R, -1]), n_coarse=(n_coarse, [B, -1]), n_fine=(n_fine, [B, -1]))
+        # cut_quantile thresholds at a quantile over the WHOLE batch (tri_plane_renderer.py:366-368): such a call is rendered in one piece
+        chunk = None if float(opts.get('cut_quantile', 0.0)) > 0.0 else self.chunk
+        rgb = depth = None
+        for sl, planes in self.tri_plane_decoder.forward_chunks(ws[:, :self.tri_plane_decoder.num_ws], hwc=True, chunk=chunk, chunk_from=self.chunk_from,
+                                                                **block_kwargs):
+            whole = sl.start == 0 and sl.stop == B
+            o = dict(opts)
+            for k, (t, shape) in draws.items():          # the explicit draws of this batch slice, in the layouts the renderer takes
+                if t is None:
+                    o[k] = None
+                elif whole:
+                    o[k] = t
+                else:
+                    tc = t.reshape(shape)[sl]
+                    o[k] = tc.reshape(-1, tc.shape[-1]) if k == 'u_fine' else tc
+            rgb_c, depth_c, _w, _T = self.renderer(planes, self.tri_plane_mlp, ray_o[sl], ray_d[sl], o)
+            if whole:
+                rgb, depth = rgb_c, depth_c
+            else:
+                if rgb is None:
+                    rgb = torch.empty([B, R, rgb_c.shape[-1]], dtype=torch.float32, device=ws.device)
+                    depth = torch.empty([B, R, 1], dtype=torch.float32, device=ws.device)
+                rgb[sl], depth[sl] = rgb_c, depth_c
         img = torch.empty([B, self.img_channels, h, w], dtype=torch.float32, device=ws.device)
         with torch.cuda.device(ws.device):
             _lib.call('tdgp_rays_to_image', rgb.data_ptr(), img.data_ptr(), B, h * w, _lib.stream_of(rgb))

@@ -124,6 +124,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--depth-adaptor', action='store_true', help='also run the DepthAdaptor inside G.forward (SURVEY 8f rank 1; off = the 8a hot path)')
     ap.add_argument('--profile-steps', type=int, default=2)
+    ap.add_argument('--chunk', type=int, default=-1, help='samples per pass through the high-resolution blocks + renderer (Infinity-Cache-sized working set); '
+                                                           '0 = whole batch through every kernel; -1 = the package default')
+    ap.add_argument('--chunk-from', type=int, default=0, help='first block resolution that runs chunked (0 = the package default)')
     ap.add_argument('--arith', default='f32', choices=['f32', 'split'],
                     help="arithmetic of the large 3x3 convolutions: f32 = fp32 MFMA (default, the reported metric); split = opt-in 3 x bf16 split operands, "
                          "6 piece products, fp32 accumulation (fp32-grade results; reported with dtype 'bf16x3->f32' and never mixed with the default line)")
@@ -146,6 +149,10 @@ def main():
     G = tdgp.generator.Generator(cfg)
     G.load_numpy_state_dict(tdgp.weights.random_state_dict(cfg, seed=0))        # random-init weights, identical on every rank
     G = G.to(dev)
+    if args.chunk >= 0:
+        G.synthesis.chunk = args.chunk or None
+    if args.chunk_from > 0:
+        G.synthesis.chunk_from = args.chunk_from
     T = lambda a: torch.as_tensor(a).to(dev)   # noqa: E731
     gather = D.FeatureGatherer() if world > 1 else None
     # what RCCL actually saw: an all-reduce of ones over the process group, AFTER a real collective (not WORLD_SIZE from the env)
@@ -254,7 +261,8 @@ def main():
             'config': {'workload': f'{names[args.config]}, {cfg.num_ray_steps}(+{cfg.num_ray_steps}) ray steps, cmax {cfg.cmax}, '
                                    f'c_dim {cfg.c_dim}, tri-plane {cfg.tri_plane_res}^2 x {cfg.plane_channels}, full HIP path',
                        'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'img_resolution': cfg.img_resolution,
-                       'num_ray_steps': cfg.num_ray_steps, 'depth_adaptor': bool(args.depth_adaptor), 'parallelism': f'dp{world} (batch-sharded, weights replicated)'},
+                       'num_ray_steps': cfg.num_ray_steps, 'depth_adaptor': bool(args.depth_adaptor), 'parallelism': f'dp{world} (batch-sharded, weights replicated)',
+                       'schedule': dict(chunk=G.synthesis.chunk, chunk_from=G.synthesis.chunk_from)},
             'rccl_ranks_seen': ranks_seen, 'roofline': roofline, 'whole_forward': whole, 'other_batches': others, 'kernels': kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

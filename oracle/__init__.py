@@ -175,9 +175,36 @@ def normalize_2nd_moment(x):
     return y
 
 
-def modulated_conv2d(x, weight, styles, noise=None, up=1, demodulate=True, resample_filter=None):
+def round_bf16(x):
+    """fp32 array -> the nearest bfloat16 values (round to nearest even), kept as fp32."""
+    x = _f(x)
+    y = np.empty_like(x)
+    lib().orc_round_bf16(_p(x), _p(y), c_i64(x.size))
+    return y
+
+
+def bias_act_bf16(x, b=None, act='linear', alpha=None, gain=None, clamp=None):
+    """`_bias_act_ref` (bias_act.py:91-120) on a bfloat16 tensor as torch's CPU path evaluates it: every elementwise op computes in fp32
+    and rounds its result to bf16 -- bias add (the bias itself rounded first, networks_stylegan2.py:144 `self.bias.to(x.dtype)`),
+    activation, gain, clamp.  (The CUDA plugin rounds once at the end; the fixtures come from the CPU path.)"""
+    x = round_bf16(x)
+    alpha = float(ACT_DEF_ALPHA[act] if alpha is None else alpha)
+    gain = float(ACT_DEF_GAIN[act] if gain is None else gain)
+    if b is not None:
+        x = round_bf16(x + round_bf16(b).reshape(1, -1, *([1] * (x.ndim - 2))))
+    if act != 'linear':
+        x = round_bf16(bias_act(x, None, act=act, alpha=alpha, gain=1.0))
+    if gain != 1:
+        x = round_bf16(x * np.float32(gain))
+    if clamp is not None and clamp >= 0:
+        x = np.clip(x, -np.float32(clamp), np.float32(clamp))
+    return x.astype(np.float32)
+
+
+def modulated_conv2d(x, weight, styles, noise=None, up=1, demodulate=True, resample_filter=None, prec='f32'):
     """Eval/fused modulated conv (networks_stylegan2.py:31-88) for the layer forms on the
-    path: odd k (1, 3; 5 for the depth adaptor), padding=k//2, up in {1,2}, flip_weight=(up==1)."""
+    path: odd k (1, 3; 5 for the depth adaptor), padding=k//2, up in {1,2}, flip_weight=(up==1).
+    prec='bf16': the reduced-precision path with bfloat16 (x must hold bf16 values); see orc_modconv2d."""
     x, weight, styles = _f(x), _f(weight), _f(styles)
     B, cin, H, W = x.shape
     cout, cin2, k, k2 = weight.shape
@@ -191,7 +218,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, demodulate=True, resam
     if up == 2:
         assert f is not None and f.shape == (4, 4)
     lib().orc_modconv2d(_p(x), _p(weight), _p(styles), _p(noise), mode, _p(f), _p(y),
-                        B, cin, cout, H, W, k, up, int(bool(demodulate)))
+                        B, cin, cout, H, W, k, up, int(bool(demodulate)), 1 if prec == 'bf16' else 0)
     return y
 
 

@@ -60,49 +60,71 @@ def mapping_forward(sd, cfg, z, c, truncation_psi=1.0, truncation_cutoff=None):
     return ws
 
 
-def _layer(sd, pfx, x, w, up, noise_mode, f, use_noise):
-    """SynthesisLayer.forward, networks_stylegan2.py:128-145."""
+def _layer(sd, pfx, x, w, up, noise_mode, f, use_noise, bf16=False, clamp=None):
+    """SynthesisLayer.forward, networks_stylegan2.py:128-145.  bf16: the block runs in reduced precision (x holds bf16 values)."""
     styles = O.fc(w, sd[pfx + '.affine.weight'], sd[pfx + '.affine.bias'])
     noise = None
     if use_noise and noise_mode == 'const':
         noise = (sd[pfx + '.noise_const'] * sd[pfx + '.noise_strength']).astype(np.float32)
     elif use_noise and isinstance(noise_mode, dict):        # explicit 'random' noise tensors keyed by layer
         noise = (noise_mode[pfx] * sd[pfx + '.noise_strength']).astype(np.float32)
-    x = O.modulated_conv2d(x, sd[pfx + '.weight'], styles, noise=noise, up=up, demodulate=True, resample_filter=f)
-    return O.bias_act(x, sd[pfx + '.bias'], act='lrelu')
+    x = O.modulated_conv2d(x, sd[pfx + '.weight'], styles, noise=noise, up=up, demodulate=True, resample_filter=f, prec='bf16' if bf16 else 'f32')
+    if bf16:
+        return O.bias_act_bf16(x, sd[pfx + '.bias'], act='lrelu', clamp=clamp)
+    return O.bias_act(x, sd[pfx + '.bias'], act='lrelu', clamp=clamp)
 
 
-def _torgb(sd, pfx, x, w):
+def _torgb(sd, pfx, x, w, bf16=False, clamp=None):
     """ToRGBLayer.forward, networks_stylegan2.py:168-172."""
     cin = sd[pfx + '.weight'].shape[1]
     styles = O.fc(w, sd[pfx + '.affine.weight'], sd[pfx + '.affine.bias'])
     styles = (styles * np.float32(1 / np.sqrt(cin))).astype(np.float32)
-    x = O.modulated_conv2d(x, sd[pfx + '.weight'], styles, demodulate=False)
-    return O.bias_act(x, sd[pfx + '.bias'])
+    x = O.modulated_conv2d(x, sd[pfx + '.weight'], styles, demodulate=False, prec='bf16' if bf16 else 'f32')
+    if bf16:
+        return O.bias_act_bf16(x, sd[pfx + '.bias'], clamp=clamp)       # y.to(float32) afterwards: exact
+    return O.bias_act(x, sd[pfx + '.bias'], clamp=clamp)
+
+
+def fp16_resolution(cfg):
+    """networks_epigraf.py:99: blocks at or above this resolution run in reduced precision (None: fp32_only, train.py:271-273)."""
+    n = int(cfg.get('num_fp16_res', 0) or 0)
+    if n <= 0:
+        return None
+    return max(2 ** (int(np.log2(cfg['tri_plane_res'])) + 1 - n), 8)
 
 
 def synthesis_backbone(sd, cfg, ws, noise_mode='const', return_intermediates=False):
     """SynthesisBlocksSequence.forward (networks_epigraf.py:114-129) over SynthesisBlock.forward
-    (networks_stylegan2.py:231-273), architecture 'skip', fp32."""
+    (networks_stylegan2.py:231-273), architecture 'skip'.  fp32 (`fp32_only`), or -- cfg['num_fp16_res'] > 0, BASELINE configs[4] --
+    the reference's reduced-precision blocks (:237 `dtype = float16 if use_fp16`) with bfloat16, conv_clamp = cfg['conv_clamp']: x is
+    rounded at the block input (:250), every layer follows orc_modconv2d's / bias_act_bf16's rounding points, the ToRGB output is
+    widened to fp32 (:268) and the skip image stays fp32."""
     f = O.setup_filter([1, 3, 3, 1])
     B = ws.shape[0]
     x = img = None
     w_idx = 0
     inter = {}
     root = 'synthesis.tri_plane_decoder'
+    r16 = fp16_resolution(cfg)
     for i, r in enumerate(block_resolutions(cfg)):
         pfx = f'{root}.b{r}'
+        bf16 = r16 is not None and r >= r16
+        clamp = cfg.get('conv_clamp') if r16 is not None else None
         if i == 0:
             x = np.repeat(sd[pfx + '.const'][None], B, axis=0).astype(np.float32)
-            x = _layer(sd, pfx + '.conv1', x, ws[:, w_idx], 1, noise_mode, f, cfg['use_noise'])
+            if bf16:
+                x = O.round_bf16(x)
+            x = _layer(sd, pfx + '.conv1', x, ws[:, w_idx], 1, noise_mode, f, cfg['use_noise'], bf16, clamp)
             nconv = 1
         else:
-            x = _layer(sd, pfx + '.conv0', x, ws[:, w_idx], 2, noise_mode, f, cfg['use_noise'])
-            x = _layer(sd, pfx + '.conv1', x, ws[:, w_idx + 1], 1, noise_mode, f, cfg['use_noise'])
+            if bf16:
+                x = O.round_bf16(x)                   # x.to(dtype), :250
+            x = _layer(sd, pfx + '.conv0', x, ws[:, w_idx], 2, noise_mode, f, cfg['use_noise'], bf16, clamp)
+            x = _layer(sd, pfx + '.conv1', x, ws[:, w_idx + 1], 1, noise_mode, f, cfg['use_noise'], bf16, clamp)
             nconv = 2
         if img is not None:
             img = O.upsample2d(img, f)
-        y = _torgb(sd, pfx + '.torgb', x, ws[:, w_idx + nconv])
+        y = _torgb(sd, pfx + '.torgb', x, ws[:, w_idx + nconv], bf16, clamp)
         img = img + y if img is not None else y
         w_idx += nconv
         if return_intermediates:

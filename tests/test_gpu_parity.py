@@ -742,6 +742,29 @@ def test_full_size_properties(tdgp, full_c3):
     assert torch.equal(img_b, img_b2)
 
 
+def test_chunked_schedule_is_the_same_forward(tdgp, full_c3):
+    """SynthesisNetwork.chunk (high-resolution blocks + renderer a few samples at a time, for Infinity-Cache residency) only re-orders
+    the launches: images agree with the whole-batch forward to split-K rounding, for every chunk size incl. a ragged last chunk."""
+    G, inp = full_c3['G'], full_c3['inp']
+    syn = G.synthesis
+    B = 5
+    inp5 = tdgp.weights.synthetic_inputs(full_c3['cfg'], batch=B, seed=11)
+    ws = G.mapping(T(inp5['z']), T(inp5['c']))
+    cam = {k: T(v) for k, v in inp5['camera'].items()}
+    u1, u2 = T(inp5['u_coarse']), T(inp5['u_fine'])
+    prev = (syn.chunk, syn.chunk_from)
+    try:
+        syn.chunk = None
+        ref = syn(ws, camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True), u_coarse=u1, u_fine=u2)
+        for chunk, cfrom in ((2, 128), (1, 256), (4, 64), (3, 8)):
+            syn.chunk, syn.chunk_from = chunk, cfrom
+            out = syn(ws, camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True), u_coarse=u1, u_fine=u2)
+            assert float((out.img - ref.img).abs().max() / ref.img.abs().max()) < 1e-5, (chunk, cfrom)
+            assert float((out.depth - ref.depth).abs().max()) < 1e-5, (chunk, cfrom)
+    finally:
+        syn.chunk, syn.chunk_from = prev
+
+
 def test_compat_plugins(tdgp, oracle):
     """The pybind-signature plugin objects of 3dgp_amd/compat.py (bias_act.cpp:32 / upfirdn2d.cpp:16 argument orders)."""
     rs = np.random.RandomState(2)

@@ -427,3 +427,57 @@ def test_modconv_grad_oracle(oracle, tag, demod):
     assert_close(dx, g[f'{tag}_dx'], 1e-5, 'dx', 1.0)
     assert_close(dw, g[f'{tag}_dw'], 1e-5, 'dw', 1.0)
     assert_close(ds, g[f'{tag}_ds'], 1e-5, 'ds', 1.0)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[4]: bf16 blocks
+def _bf16_vals(a):
+    """fixture array -> fp32 values (bf16 tensors are stored as their 16 bits)."""
+    return (a.astype(np.uint32) << 16).view(np.float32) if a.dtype == np.uint16 else a
+
+
+def _ulp_bf16(ref):
+    return np.maximum(np.abs(ref), 2.0 ** -126) * 2.0 ** -7        # one bf16 ulp is 2^-7 .. 2^-8 of the value
+
+
+@pytest.mark.parametrize('tag', ['c3', 'up', 'rgb'])
+def test_bf16_modconv(oracle, tag):
+    """modulated_conv2d on bf16 activations (the reference's reduced-precision path run with bfloat16): pre-normalisation, bf16
+    per-sample weights, fp32 accumulation, bf16 outputs -- the oracle follows the same rounding points, so it lands on the SAME bf16
+    value except where an fp32 accumulation-order difference crosses a rounding boundary: <= 1 bf16 ulp, on a small share of elements."""
+    g = load_golden('bf16')
+    k, up, demod = g[f'{tag}_meta']
+    y = oracle.modulated_conv2d(g[f'{tag}_x'], g[f'{tag}_w'], g[f'{tag}_s'], noise=g.get(f'{tag}_noise'), up=int(up), demodulate=bool(demod),
+                                resample_filter=g['f'], prec='bf16')
+    ref = g[f'{tag}_y']
+    assert np.array_equal(y, oracle.round_bf16(y))                                  # bf16 values
+    assert (np.abs(y - ref) <= 1.01 * _ulp_bf16(ref)).all()
+    assert (y != ref).mean() < 0.02, (y != ref).mean()
+    act = oracle.bias_act_bf16(ref, g[f'{tag}_b'], act='lrelu' if demod else 'linear', clamp=256)
+    np.testing.assert_array_equal(act, g[f'{tag}_act'])                             # elementwise chain on identical inputs: exact
+
+
+def test_bf16_backbone_and_image(oracle, tdgp):
+    """The generator with its two highest-resolution blocks in bf16 (config_mid_bf16), block by block against the reference's own run."""
+    cfg = tdgp.config.config_mid_bf16()
+    g = load_golden('bf16')
+    sd = tdgp.weights.random_state_dict(cfg, seed=61, exercise_all=True)
+    c = cfg.to_dict()
+    from oracle import pipeline as P
+    assert P.fp16_resolution(c) == 32
+    planes, inter = P.synthesis_backbone(sd, c, g['ws'], 'const', return_intermediates=True)
+    assert_close(inter['x16'], g['x16'], 5e-6, 'x16 (fp32 block)', 1.0)
+    for r in (32, 64):
+        ref = _bf16_vals(g[f'x{r}'])
+        got = inter[f'x{r}']
+        assert np.array_equal(got, oracle.round_bf16(got))
+        # same rounding points; a flipped rounding upstream moves a few downstream values by a bf16 ulp or two
+        bad = np.abs(got - ref) > 2.01 * _ulp_bf16(ref) + 1e-3 * np.abs(ref).max()
+        assert bad.mean() < 1e-3, (r, bad.mean())
+        assert (got != ref).mean() < 0.1, (r, (got != ref).mean())
+    # the fp32 skip image accumulates the bf16 ToRGB outputs: a flipped rounding is one bf16 ulp of that output (0.4-0.8 % of it)
+    assert_close(planes, g['planes'], 8e-3, 'tri-planes (fp32 skip image fed by bf16 blocks)', 1.0)
+    assert (np.abs(planes - g["planes"]) > 1e-3 * np.abs(g["planes"]).max()).mean() < 1e-2        # ... and it is a 0.3 % minority
+    cam = {k[4:]: v for k, v in g.items() if k.startswith('cam_')}
+    img, depth = P.synthesis_forward(sd, c, g['ws'], cam, g['u_coarse'], g['u_fine'], 'const')
+    assert_close(img, g['img'], 5e-3, 'img', 1.0)
+    assert_close(depth, g['depth'], 2e-3, 'depth', 1.0)

@@ -691,6 +691,89 @@ def gen_e2e(tag, cfg, batch, seed, keep_intermediates):
     save(tag, **arrays)
 
 
+class _CudaFlag(torch.Tensor):
+    """A tensor that reports device type 'cuda': SynthesisBlock.forward forces fp32 off-GPU (networks_stylegan2.py:235-236) and this
+    is the one thing it looks at.  unbind() hands plain tensors on, so nothing downstream sees the flag."""
+    @property
+    def device(self):
+        return types.SimpleNamespace(type='cuda')
+
+    def unbind(self, dim=0):
+        return tuple(t.as_subclass(torch.Tensor) for t in super().unbind(dim))
+
+
+class _Bf16ForFp16:
+    """Run the reference's reduced-precision path with bfloat16: its code spells the dtype `torch.float16` (networks_stylegan2.py:51,237)
+    and looks it up at call time."""
+    def __enter__(self):
+        self.f16 = torch.float16
+        torch.float16 = torch.bfloat16
+
+    def __exit__(self, *exc):
+        torch.float16 = self.f16
+
+
+def gen_bf16():
+    """BASELINE configs[4]'s arithmetic: the reference's own reduced-precision blocks (`use_fp16`, conv_clamp 256) run here on the CPU
+    with bfloat16 -- op level (modulated_conv2d on bf16 activations: pre-normalisation, bf16 per-sample weights, bf16 outputs) and the
+    whole generator with its two highest-resolution blocks in bf16."""
+    g = np.random.RandomState(55)
+    arrays = {}
+    f = ref_upfirdn2d.setup_filter([1, 3, 3, 1])
+    arrays['f'] = npy(f)
+    with _Bf16ForFp16():
+        for tag, (B, cin, cout, H, k, up, demod, noise) in dict(c3=(2, 16, 24, 12, 3, 1, True, True), up=(2, 16, 8, 8, 3, 2, True, True),
+                                                                rgb=(3, 24, 12, 10, 1, 1, False, False)).items():
+            x = T(g.randn(B, cin, H, H).astype(np.float32)).bfloat16()
+            w = T(g.randn(cout, cin, k, k).astype(np.float32))
+            s = T((1.0 + 0.5 * g.randn(B, cin)).astype(np.float32))
+            nz = T((0.3 * g.randn(H * up, H * up)).astype(np.float32)) if noise else None
+            y = ref_sg2.modulated_conv2d(x=x, weight=w, styles=s, noise=nz, up=up, padding=k // 2, resample_filter=f, demodulate=demod,
+                                         flip_weight=(up == 1), fused_modconv=True)
+            assert y.dtype == torch.bfloat16
+            arrays.update({f'{tag}_x': npy(x.float()), f'{tag}_w': npy(w), f'{tag}_s': npy(s), f'{tag}_y': npy(y.float()),
+                           f'{tag}_meta': np.array([k, up, int(demod)])})
+            if noise:
+                arrays[f'{tag}_noise'] = npy(nz)
+            b = T(g.randn(cout).astype(np.float32))
+            act = 'lrelu' if demod else 'linear'
+            arrays[f'{tag}_b'] = npy(b)
+            arrays[f'{tag}_act'] = npy(ref_bias_act.bias_act(y, b.to(y.dtype), act=act, clamp=256).float())
+    cfg = tdgp.config.config_mid_bf16()
+    sd = tdgp.weights.random_state_dict(cfg, seed=61, exercise_all=True)
+    G = Generator(ref_cfg(cfg), img_resolution=cfg.img_resolution, img_channels=3, mapping_kwargs={}, num_fp16_res=cfg.num_fp16_res,
+                  conv_clamp=cfg.conv_clamp, fused_modconv_default='inference_only').eval()
+    G.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    dec = G.synthesis.tri_plane_decoder
+    assert [getattr(dec, f'b{r}').use_fp16 for r in dec.block_resolutions] == [False, False, False, True, True]
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=1, seed=62)
+    cam = TensorGroup(**{k: T(v) for k, v in inp['camera'].items()})
+    R, S = cfg.img_resolution ** 2, cfg.num_ray_steps
+    o_fwd = dec.forward
+    dec.forward = lambda ws, **kw: o_fwd(ws.as_subclass(_CudaFlag), **kw)
+    with torch.no_grad(), _Bf16ForFp16():
+        ws = G.mapping(T(inp['z']), T(inp['c']))
+        planes = dec(ws, noise_mode='const')
+        x = img = None
+        w_idx = 0
+        wsf = ws.as_subclass(_CudaFlag)
+        for r in dec.block_resolutions:                 # per-block activations (bf16 for the last two blocks)
+            blk = getattr(dec, f'b{r}')
+            x, img = blk(x, img, wsf.narrow(1, w_idx, blk.num_conv + blk.num_torgb), noise_mode='const')
+            w_idx += blk.num_conv
+            if r >= 16:
+                # bf16 tensors are stored as their 16 bits (the upper half of the fp32 pattern)
+                arrays[f'x{r}'] = npy(x.float()) if x.dtype == torch.float32 else (npy(x.float()).view(np.uint32) >> 16).astype(np.uint16)
+            arrays[f'x{r}_is_bf16'] = np.array(x.dtype == torch.bfloat16)
+        with PatchedRNG(rand_like=[T(inp['u_coarse']).reshape(1, R, S, 1)], rand=[T(inp['u_fine'])]):
+            out = G.synthesis(ws, camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True))
+    dec.forward = o_fwd
+    assert planes.dtype == torch.float32 and arrays['x64_is_bf16'] and not arrays['x16_is_bf16']
+    arrays.update(z=inp['z'], c=inp['c'], u_coarse=inp['u_coarse'], u_fine=inp['u_fine'], ws=npy(ws), planes=npy(planes), img=npy(out.img), depth=npy(out.depth),
+                  **{'cam_' + k: v for k, v in inp['camera'].items()})
+    save('bf16', **arrays)
+
+
 def ref_camera_cfg(r):
     mm = lambda t: EasyDict(min=t[0], max=t[1])   # noqa: E731
     return EasyDict(origin=EasyDict(angles=EasyDict(yaw=mm(r.yaw), pitch=mm(r.pitch))), fov=mm(r.fov),
@@ -1125,6 +1208,7 @@ def main():
     gen_field()
     gen_sampling()
     gen_sampling_hot()
+    gen_bf16()
     gen_marchers()
     gen_camera()
     gen_mapping()
