@@ -36,6 +36,9 @@ _PROTOTYPES = {
     'tdgp_demod_batch': (c_int, [P, P, P, c_int, c_int, c_int, P]),
     'tdgp_modconv2d': (c_int, [P, P, P, P, P, c_int64, P, POINTER(c_float), P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_float, c_float, c_float, c_int, c_int, P, c_int64, P]),
+    'tdgp_modconv2d_bf16': (c_int, [P, P, P, P, P, c_int64, P, POINTER(c_float), P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, c_float, c_float, c_float, c_int, c_int, P, c_int64, P]),
+    'tdgp_cast_f32_bf16': (c_int, [P, P, c_int64, P]),
     'tdgp_style_affine': (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     'tdgp_cam2world': (c_int, [P, P, P, P, c_int, P]),
     'tdgp_sample_rays': (c_int, [P, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),

@@ -68,6 +68,7 @@ struct EpiParams {
     int B, Cout, Hout, Wout;    // dims of the output tensor
     int out_layout, out_feat;
     int act; float alpha, gain, clamp;
+    int round_bf16;     // ToRGB of a reduced-precision block: conv output and bias_act output rounded to bf16 before the fp32 skip add
 };
 
 struct ConvParams {
@@ -173,16 +174,17 @@ __device__ __forceinline__ void epilogue_store(const EpiParams& e, float v, int 
     if (e.bias) v = v + e.bias[o];
     const int h2 = e.Hout / 2, w2 = e.Wout / 2;
     int64_t addr;
+    float sk = 0.f;
     if (e.out_layout == 0) {
-        if (e.skip) v = v + skip_eval(e.skip + ((int64_t)b * e.Cout + o) * h2 * w2, skip_taps(h2, w2, oy, ox, e.fir), 1);
+        if (e.skip) sk = skip_eval(e.skip + ((int64_t)b * e.Cout + o) * h2 * w2, skip_taps(h2, w2, oy, ox, e.fir), 1);
         addr = (((int64_t)b * e.Cout + o) * e.Hout + oy) * e.Wout + ox;
     } else {
         const int pl = o / e.out_feat, f = o % e.out_feat;
         const int64_t plane = (int64_t)b * (e.Cout / e.out_feat) + pl;
-        if (e.skip) v = v + skip_eval(e.skip + plane * h2 * w2 * e.out_feat + f, skip_taps(h2, w2, oy, ox, e.fir), e.out_feat);
+        if (e.skip) sk = skip_eval(e.skip + plane * h2 * w2 * e.out_feat + f, skip_taps(h2, w2, oy, ox, e.fir), e.out_feat);
         addr = ((plane * e.Hout + oy) * e.Wout + ox) * e.out_feat + f;
     }
-    e.y[addr] = finish_act(e, v);
+    e.y[addr] = finish_act(e, v) + sk;          // img = upsample2d(img) + bias_act(conv): the skip joins AFTER activation / gain / clamp (:265-269)
 }
 
 // Output stage for one 32(channels) x 32(pixels) accumulator tile parked in a per-wave LDS tile ct[32][33].
@@ -256,7 +258,7 @@ __device__ __forceinline__ void epilogue_tile(const EpiParams& e, const SideCach
                 const int o = obase + sel;
                 if (pok && o < e.Cout) {
                     float v = ct[sel * CT_LD + l32];
-                    if (!raw) v = finish_act<ACT>(e, ((v * side_demod(e, sc, pb, o, true) + nz) + side_bias(e, sc, o, true)) + sk[q]);
+                    if (!raw) v = finish_act<ACT>(e, (v * side_demod(e, sc, pb, o, true) + nz) + side_bias(e, sc, o, true)) + sk[q];
                     dst[pix + o * cstride] = v;
                 }
             }
@@ -315,10 +317,10 @@ __device__ __forceinline__ void epilogue_tile(const EpiParams& e, const SideCach
                 float4 v = *(const float4*)&ct[px * CT_LD + 4 * cg];
                 const float d0 = side_demod(e, sc, bq[pass], o, true), d1 = side_demod(e, sc, bq[pass], o + 1, true);
                 const float d2 = side_demod(e, sc, bq[pass], o + 2, true), d3 = side_demod(e, sc, bq[pass], o + 3, true);
-                v.x = finish_act<ACT>(e, ((v.x * d0 + nzq[pass]) + bias4.x) + sk[pass].x);
-                v.y = finish_act<ACT>(e, ((v.y * d1 + nzq[pass]) + bias4.y) + sk[pass].y);
-                v.z = finish_act<ACT>(e, ((v.z * d2 + nzq[pass]) + bias4.z) + sk[pass].z);
-                v.w = finish_act<ACT>(e, ((v.w * d3 + nzq[pass]) + bias4.w) + sk[pass].w);
+                v.x = finish_act<ACT>(e, (v.x * d0 + nzq[pass]) + bias4.x) + sk[pass].x;
+                v.y = finish_act<ACT>(e, (v.y * d1 + nzq[pass]) + bias4.y) + sk[pass].y;
+                v.z = finish_act<ACT>(e, (v.z * d2 + nzq[pass]) + bias4.z) + sk[pass].z;
+                v.w = finish_act<ACT>(e, (v.w * d3 + nzq[pass]) + bias4.w) + sk[pass].w;
                 *(float4*)(e.y + addr[pass]) = v;
             }
         }
@@ -1719,6 +1721,7 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
 // gain / clamp are compiled out when they are 1 / off (PLAIN), and for power-of-two images (POW2: lw = log2 W, lhw = log2 HW)
 // the pixel coordinates come from shifts of the pixel index instead of 16 cross-lane reads.
 typedef float rgb_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int rgb_u32x2 __attribute__((ext_vector_type(2)));
 // G = passes handled together (4: all 16 taps in flight; 2: half the registers, for the multi-tile kernel that keeps the next
 // tile's activations in registers across this stage).
 template <bool SKIP, bool PLAIN, bool POW2, int G>
@@ -1769,7 +1772,22 @@ __device__ __forceinline__ void rgb_output_tile(const EpiParams& e, const float*
 #pragma unroll
     for (int pass = 0; pass < G; pass++) {
         const float4 c4 = *(const float4*)&ct[((g0 + pass) * 8 + pr) * CT_LD + 4 * cg];
-        rgb_f32x2 r01 = (rgb_f32x2){c4.x, c4.y} + b01, r23 = (rgb_f32x2){c4.z, c4.w} + b23;
+        rgb_f32x2 r01, r23;
+        if (!PLAIN) {                           // conv -> (bf16) -> + bias -> * gain -> clamp -> (bf16), then the skip (networks_stylegan2.py:170-171, 265-269)
+            float q[4] = {c4.x, c4.y, c4.z, c4.w};
+            const float bq[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float t = q[i];
+                if (e.round_bf16) t = (float)(__bf16)t;
+                t = (t + (e.round_bf16 ? (float)(__bf16)bq[i] : bq[i])) * e.gain;
+                t = t < -lim ? -lim : (t > lim ? lim : t);
+                q[i] = e.round_bf16 ? (float)(__bf16)t : t;
+            }
+            r01 = (rgb_f32x2){q[0], q[1]}; r23 = (rgb_f32x2){q[2], q[3]};
+        } else {
+            r01 = (rgb_f32x2){c4.x, c4.y} + b01; r23 = (rgb_f32x2){c4.z, c4.w} + b23;
+        }
         if (SKIP) {
             const SkipTaps& t = tp[pass];
             const rgb_f32x2 w00 = {t.w00, t.w00}, w01 = {t.w01, t.w01}, w10 = {t.w10, t.w10}, w11 = {t.w11, t.w11};
@@ -1778,12 +1796,7 @@ __device__ __forceinline__ void rgb_output_tile(const EpiParams& e, const float*
             r01 = r01 + __builtin_elementwise_fma(w11, d01, __builtin_elementwise_fma(w10, cc01, __builtin_elementwise_fma(w01, bb01, w00 * a01)));
             r23 = r23 + __builtin_elementwise_fma(w11, d23, __builtin_elementwise_fma(w10, cc23, __builtin_elementwise_fma(w01, bb23, w00 * a23)));
         }
-        float r[4] = {r01.x, r01.y, r23.x, r23.y};
-        if (!PLAIN) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) { r[i] = r[i] * e.gain; r[i] = r[i] < -lim ? -lim : (r[i] > lim ? lim : r[i]); }
-        }
-        v[pass] = make_float4(r[0], r[1], r[2], r[3]);
+        v[pass] = make_float4(r01.x, r01.y, r23.x, r23.y);
     }
 #pragma unroll
     for (int pass = 0; pass < G; pass++)
@@ -1798,7 +1811,8 @@ __device__ __forceinline__ void rgb_output_tile(const EpiParams& e, const float*
 // vectors along x and transposed in registers to the [pixel][4 channels] LDS layout while the style scale is applied,
 // weights [chunk][Cout][4], fragments = 8-byte LDS reads with immediate offsets, no VALU in the MFMA loop.
 struct RgbParams {
-    const float* x; const float* wp; const float* styles;
+    const float* x;     // activations: fp32, or (XBF) bf16 -- the reduced-precision blocks, modconv_bf16.inc
+    const float* wp; const float* styles;
     EpiParams e;
     int B, Cin, Cout, CoutP, HW, W;
     int64_t P;          // B*H*W
@@ -1813,7 +1827,7 @@ struct RgbParams {
 // RESIDENT: Cin <= 64 -- the whole weight matrix is one LDS stage, loaded once per block, and the block walks `tpb` consecutive
 // tiles with the activations of tile t+1 in flight while tile t is multiplied and stored.
 // FAST: power-of-two image, no clamp, gain 1 (the generator's ToRGB layers) -- the trimmed output stage.
-template <int MT, bool RESIDENT, bool FAST>
+template <int MT, bool RESIDENT, bool FAST, bool XBF = false>
 __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
     constexpr int BM = 32 * MT, BN = 128, NCH = 16;                 // 16 packed chunks = 64 channels per iteration
     constexpr int AS_SZ = NCH * BM * 4, XS_SZ = NCH * BN * 4;
@@ -1845,13 +1859,21 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
                 const int b = (int)(pix / p.HW), inner = (int)(pix - (int64_t)b * p.HW);
                 const int sb = b * p.Cin + 4 * (cq + 8 * k);
                 s_vo[k] = (uint32_t)sb * 4u;
-                x_vo[k] = (uint32_t)(sb * p.HW + inner) * 4u;
+                x_vo[k] = (uint32_t)(sb * p.HW + inner) * (XBF ? 2u : 4u);
             }
         }
     };
-    const uint32_t hw4 = (uint32_t)p.HW * 4u;
+    const uint32_t hw4 = (uint32_t)p.HW * (XBF ? 2u : 4u);
     const bool cin4 = (p.Cin & 3) == 0;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.wp, p.wp_bytes), rs = make_rsrc(p.styles ? p.styles : p.x, p.styles ? p.st_bytes : 0);
+    auto load_x4 = [&](uint32_t vo, uint32_t so) -> float4 {        // 4 consecutive pixels of one channel
+        if constexpr (XBF) {
+            const rgb_u32x2 u = __builtin_amdgcn_raw_buffer_load_b64(rx, vo, so, 0);          // 4 bf16
+            return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+        } else {
+            return buf_load4(rx, vo, so);
+        }
+    };
 
     constexpr int NA = (NCH * BM + 255) / 256;
     uint32_t a_vo[NA];
@@ -1886,7 +1908,7 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
         for (int k = 0; k < 2; k++) {
             // micro-tile channels beyond Cin: the x loads fall into the next sample (finite) or beyond the buffer (0) and meet zero weights
 #pragma unroll
-            for (int j = 0; j < 4; j++) xr[k][j] = buf_load4(rx, x_vo[k], (c0 + j) * hw4);
+            for (int j = 0; j < 4; j++) xr[k][j] = load_x4(x_vo[k], (c0 + j) * hw4);
             if (p.styles) {
                 if (cin4) sr[k] = buf_load4(rs, s_vo[k], c0 * 4u);
                 else sr[k] = make_float4(buf_load1(rs, s_vo[k], c0 * 4u), buf_load1(rs, s_vo[k], c0 * 4u + 4u), buf_load1(rs, s_vo[k], c0 * 4u + 8u), buf_load1(rs, s_vo[k], c0 * 4u + 12u));
@@ -2034,6 +2056,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // -------------------------------------------------------------------------------------------------
 struct FirParams {
     const float* z; const float* dcoef; const float* noise; const float* bias; float* y;
+    uint16_t* y16;      // bf16 output (fir_act_kernel<.., true>): the reduced-precision blocks, modconv_bf16.inc
     int64_t noise_bstride, zslice;
     float fir[16];
     int B, C, ZROWS, P2, GS2, ksplit, OH, OW;      // ZROWS = 2H+2 rows of pitch P2 = 2*G1 (a multiple of 4), alternating between the parity planes
@@ -2042,7 +2065,18 @@ struct FirParams {
 
 // Tile FIR_TH x FIR_TW outputs per block: 32 x 64, or 16 x 128 for wide images (longer contiguous runs per row: 544-B reads,
 // 512-B writes instead of 288 / 256).
-template <int FIR_TH, int FIR_TW>
+typedef float fir_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 fir_b2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float fir_round_bf16(float v) { return (float)(__bf16)v; }
+__device__ __forceinline__ uint32_t fir_pack_bf16(float a, float b) {
+    const fir_b2 h = __builtin_convertvector((fir_f2){a, b}, fir_b2);
+    uint32_t u;
+    __builtin_memcpy(&u, &h, 4);
+    return u;
+}
+// YBF: bf16 output with the reference's rounding points behind the (fp32, unrounded) transposed-convolution intermediate: FIR output,
+// + noise, bias (itself rounded) / activation / gain / clamp.
+template <int FIR_TH, int FIR_TW, bool YBF = false>
 __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
     constexpr int CW = FIR_TW / 4, RPP = 256 / CW;                 // threads per output row, rows per pass
     constexpr int ZP = FIR_TW + 8;                  // window columns ox0-4 .. ox0+67, fetched as aligned 16-B vectors (P2 % 4 == 0)
@@ -2100,7 +2134,7 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
         __syncthreads();
         const int lx = (threadIdx.x % CW) * 4;
         const float d = p.dcoef ? p.dcoef[b * p.C + c] : 1.f;
-        const float bv = p.bias ? p.bias[c] : 0.f;
+        const float bv = p.bias ? (YBF ? fir_round_bf16(p.bias[c]) : p.bias[c]) : 0.f;
 #pragma unroll
         for (int hrow = 0; hrow < FIR_TH / RPP; hrow++) {
             const int ly = threadIdx.x / CW + hrow * RPP;
@@ -2119,20 +2153,29 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
 #pragma unroll
                         for (int kx = 0; kx < 4; kx++) acc[o] = fmaf_(p.fir[ky * 4 + kx], win[o + kx], acc[o]);
                 }
-                float* yp = p.y + (((int64_t)b * p.C + c) * p.OH + oy) * p.OW + ox0 + lx;
+                const int64_t yoff = (((int64_t)b * p.C + c) * p.OH + oy) * p.OW + ox0 + lx;
                 float out[4];
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
                     float v = acc[o] * d;
-                    if (p.noise && ox0 + lx + o < p.OW) v = v + p.noise[b * p.noise_bstride + (int64_t)oy * p.OW + ox0 + lx + o];
+                    if (YBF) v = fir_round_bf16(v);
+                    if (p.noise && ox0 + lx + o < p.OW) { v = v + p.noise[b * p.noise_bstride + (int64_t)oy * p.OW + ox0 + lx + o]; if (YBF) v = fir_round_bf16(v); }
                     v = v + bv;
                     v = act_apply(v, p.act, p.alpha) * p.gain;
                     if (p.clamp >= 0.f) v = v < -p.clamp ? -p.clamp : (v > p.clamp ? p.clamp : v);
                     out[o] = v;
                 }
-                if (ox0 + lx + 3 < p.OW && (p.OW & 3) == 0) *(float4*)yp = make_float4(out[0], out[1], out[2], out[3]);
-                else
-                    for (int o = 0; o < 4 && ox0 + lx + o < p.OW; o++) yp[o] = out[o];
+                if constexpr (YBF) {
+                    uint16_t* yp = p.y16 + yoff;
+                    if (ox0 + lx + 3 < p.OW && (p.OW & 3) == 0) *(uint2*)yp = make_uint2(fir_pack_bf16(out[0], out[1]), fir_pack_bf16(out[2], out[3]));
+                    else
+                        for (int o = 0; o < 4 && ox0 + lx + o < p.OW; o++) yp[o] = (uint16_t)(fir_pack_bf16(out[o], 0.f) & 0xffffu);
+                } else {
+                    float* yp = p.y + yoff;
+                    if (ox0 + lx + 3 < p.OW && (p.OW & 3) == 0) *(float4*)yp = make_float4(out[0], out[1], out[2], out[3]);
+                    else
+                        for (int o = 0; o < 4 && ox0 + lx + o < p.OW; o++) yp[o] = out[o];
+                }
             }
         }
     }
@@ -2155,6 +2198,8 @@ __global__ __launch_bounds__(256) void z_gather_kernel(const float* __restrict__
         }
     }
 }
+
+#include "modconv_bf16.inc"
 
 // d[b,o] = rsqrt(sum_c s[b,c]^2 * wsq[c][o] + 1e-8)      (networks_stylegan2.py:62)
 // block (64 out-channels x 16 channel slices): coalesced wsq rows, 16-way split of the Cin loop, LDS tree at the end.
@@ -2250,7 +2295,7 @@ __global__ __launch_bounds__(256) void style_affine_kernel(const float* __restri
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
-struct PackInfo { int T, KC, CoutP, nchunks, niter16; int64_t wp_floats, wsq_floats, wsplit_floats; };
+struct PackInfo { int T, KC, CoutP, nchunks, niter16, nch32; int64_t wp_floats, wsq_floats, wsplit_floats, wbf_floats; };
 inline PackInfo pack_info(int Cout, int Cin, int k) {
     PackInfo pi;
     pi.T = k * k;
@@ -2261,6 +2306,8 @@ inline PackInfo pack_info(int Cout, int Cin, int k) {
     pi.wsq_floats = (int64_t)Cin * pi.CoutP;
     pi.niter16 = (Cin + 15) / 16;
     pi.wsplit_floats = k == 3 ? (int64_t)pi.niter16 * 9 * 3 * pi.CoutP * 8 : 0;      // split-bf16 copy of the 3x3 weights (opt-in arithmetic)
+    pi.nch32 = (Cin + 31) / 32;
+    pi.wbf_floats = k == 3 ? (int64_t)pi.nch32 * 9 * 2 * pi.CoutP * 8 : 0;          // bf16 copy of the 3x3 weights (reduced-precision blocks)
     return pi;
 }
 
@@ -2359,27 +2406,31 @@ void launch_upconv(const UpParams& u, hipStream_t s) {
     TDGP_LAUNCH("upconv_mfma_kernel", (upconv_mfma_kernel<MTW, NTW, WM, WN, DEEP>), grid, dim3(64 * NW), lds, s, u);
 }
 
-template <int MT, bool RESIDENT, bool FAST>
+template <int MT, bool RESIDENT, bool FAST, bool XBF>
 void launch_torgb_v(const RgbParams& r, hipStream_t s) {
     constexpr int BM = 32 * MT;
     const size_t lds = (size_t)(16 * BM * 4 + 16 * 128 * 4 + BM) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)torgb_mfma_kernel<MT, RESIDENT, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)torgb_mfma_kernel<MT, RESIDENT, FAST, XBF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     // RESIDENT: several consecutive tiles per block once there are more tiles than ~4 rounds of the 512 resident blocks
     RgbParams rr = r;
     const int64_t ntiles = cdiv64(r.P, 128);
     rr.tpb = RESIDENT ? (int)max((int64_t)1, min((int64_t)8, ntiles / 2048)) : 1;
-    TDGP_LAUNCH("torgb_mfma_kernel", (torgb_mfma_kernel<MT, RESIDENT, FAST>), dim3((unsigned)cdiv64(ntiles, rr.tpb)), dim3(256), lds, s, rr);
+    TDGP_LAUNCH("torgb_mfma_kernel", (torgb_mfma_kernel<MT, RESIDENT, FAST, XBF>), dim3((unsigned)cdiv64(ntiles, rr.tpb)), dim3(256), lds, s, rr);
 }
 
-template <int MT>
+template <int MT, bool XBF = false>
 void launch_torgb(const RgbParams& r, hipStream_t s) {
     const bool fast = r.lw >= 0 && r.e.clamp < 0.f && r.e.gain == 1.f;
-    if (r.Cin <= 64) { if (fast) launch_torgb_v<MT, true, true>(r, s); else launch_torgb_v<MT, true, false>(r, s); }
-    else { if (fast) launch_torgb_v<MT, false, true>(r, s); else launch_torgb_v<MT, false, false>(r, s); }
+    if constexpr (XBF) {                                    // the reduced-precision blocks always clamp: one output stage
+        if (r.Cin <= 64) launch_torgb_v<MT, true, false, true>(r, s); else launch_torgb_v<MT, false, false, true>(r, s);
+    } else {
+        if (r.Cin <= 64) { if (fast) launch_torgb_v<MT, true, true, false>(r, s); else launch_torgb_v<MT, true, false, false>(r, s); }
+        else { if (fast) launch_torgb_v<MT, false, true, false>(r, s); else launch_torgb_v<MT, false, false, false>(r, s); }
+    }
 }
 
 // KS x KS stride-1 fast path (W % 32 == 0)
@@ -2445,7 +2496,7 @@ WsLayout ws_layout(int B, int Cin, int Cout, int H, int W, int k, int up) {
 TDGP_API int64_t tdgp_modconv_pack_bytes(int Cout, int Cin, int k) {
     if (Cout < 1 || Cin < 1 || (k != 1 && k != 3 && k != 5)) return -1;
     const PackInfo pi = pack_info(Cout, Cin, k);
-    return (pi.wp_floats + pi.wsq_floats + pi.wsplit_floats) * (int64_t)sizeof(float);
+    return (pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats) * (int64_t)sizeof(float);
 }
 
 TDGP_API int tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int Cin, int k, tdgp_stream_t stream) {
@@ -2459,6 +2510,9 @@ TDGP_API int tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int C
     if (pi.wsplit_floats > 0)
         TDGP_LAUNCH("pack_kernel", pack_split_kernel, dim3((int)min((int64_t)4096, cdiv64(pi.wsplit_floats, 256))), dim3(256), 0, (hipStream_t)stream, weight,
                     (uint32_t*)(wp + pi.wp_floats + pi.wsq_floats), Cout, Cin, pi.CoutP, pi.niter16);
+    if (pi.wbf_floats > 0)
+        TDGP_LAUNCH("pack_kernel", pack_bf16_kernel, dim3((int)min((int64_t)4096, cdiv64(pi.wbf_floats, 256))), dim3(256), 0, (hipStream_t)stream, weight,
+                    (uint32_t*)(wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats), Cout, Cin, pi.CoutP, pi.nch32);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }
@@ -2510,7 +2564,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
     p.x = x; p.wp = wp; p.styles = styles; p.B = B; p.Cin = Cin; p.Cout = Cout; p.CoutP = pi.CoutP; p.Hin = H; p.Win = W;
     p.T = pi.T; p.ksplit = 1; p.partial = nullptr;
     EpiParams& e = p.e;
-    e.B = B; e.Cout = Cout;
+    e.B = B; e.Cout = Cout; e.round_bf16 = 0;
     for (int i = 0; i < 16; i++) e.fir[i] = 0.f;
     if (fir4x4) {
         // fir4x4 is a HOST pointer (the filter is a static 64-byte buffer; reading it on the host keeps the call async)
@@ -2598,7 +2652,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         } else if (pl.cfg == 0) launch_upconv<2, 1, 2, 2, true>(u, s);
         else launch_upconv<2, 1, 1, 4, false>(u, s);
         FirParams f;
-        f.z = z; f.dcoef = dco; f.noise = noise; f.noise_bstride = noise_bstride; f.bias = bias; f.y = y;
+        f.z = z; f.dcoef = dco; f.noise = noise; f.noise_bstride = noise_bstride; f.bias = bias; f.y = y; f.y16 = nullptr;
         for (int i = 0; i < 16; i++) f.fir[i] = e.fir[i];
         f.B = B; f.C = Cout; f.ZROWS = 2 * H + 2; f.P2 = 2 * pl.G1; f.GS2 = 2 * pl.GS; f.ksplit = split ? 1 : pl.ksplit; f.zslice = pl.zslice;
         f.OH = 2 * H; f.OW = 2 * W;
@@ -2611,6 +2665,105 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
             TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<32, 64>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
         }
     }
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}
+
+// Reduced-precision blocks (BASELINE configs[4], modconv_bf16.inc): x is bf16 NCHW; y is bf16 NCHW (3x3 layers) or, for the ToRGB
+// form (k = 1, channel-last planes + fused skip), fp32.  Forms the bf16 MFMA kernels take: 3x3 with Cin % 32 == 0 and, for up = 1,
+// W % 32 == 0; the channel-last ToRGB.  Anything else returns TDGP_EUNSUPPORTED (the caller widens to fp32 and uses tdgp_modconv2d).
+TDGP_API int tdgp_modconv2d_bf16(const void* x, const void* wpack, const float* styles, const float* dcoef_in, const float* noise, int64_t noise_bstride,
+                                 const float* bias, const float* fir4x4, const float* skip, void* y, int B, int Cin, int Cout, int H, int W, int k, int up,
+                                 int demodulate, int act, float alpha, float gain, float clamp, int out_layout, int out_feat, void* workspace,
+                                 int64_t workspace_bytes, tdgp_stream_t stream) {
+    TDGP_CHECK(x && wpack && y, TDGP_EINVAL, "modconv2d_bf16: null pointer");
+    TDGP_CHECK(B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, TDGP_EINVAL, "modconv2d_bf16: bad shape");
+    TDGP_CHECK(act >= 1 && act <= 9, TDGP_EUNSUPPORTED, "modconv2d_bf16: unknown activation %d", act);
+    TDGP_CHECK(!demodulate || styles, TDGP_EINVAL, "modconv2d_bf16: demodulate needs styles");
+    TDGP_CHECK((int64_t)B * Cin * H * W < ((int64_t)1 << 30) && (int64_t)B * Cout * (H * up + 1) * (W * up + 1) <= INT32_MAX, TDGP_EINVAL,
+               "modconv2d_bf16: tensor too large (activations are addressed through 4 GiB buffer descriptors)");
+    const bool rgb = k == 1 && up == 1 && out_layout == 1 && Cout <= 96 && !demodulate && !noise && act == 1 && ((H * W) & 3) == 0 && out_feat >= 4 &&
+                     (out_feat % 4) == 0 && (Cout % out_feat) == 0 && (!skip || (fir4x4 && (H % 2) == 0 && (W % 2) == 0));
+    const bool c3 = k == 3 && up == 1 && out_layout == 0 && !skip && (W & 31) == 0 && (Cin & 31) == 0 && Cin <= 2048;
+    const bool u3 = k == 3 && up == 2 && out_layout == 0 && !skip && fir4x4 && (Cin & 31) == 0;
+    TDGP_CHECK(rgb || c3 || u3, TDGP_EUNSUPPORTED, "modconv2d_bf16: no bf16 kernel for k=%d up=%d Cin=%d W=%d layout=%d", k, up, Cin, W, out_layout);
+    const WsLayout wl = ws_layout(B, Cin, Cout, H, W, k, up);
+    TDGP_CHECK(workspace && workspace_bytes >= wl.total, TDGP_EWORKSPACE, "modconv2d_bf16: workspace %lld < %lld bytes", (long long)workspace_bytes,
+               (long long)wl.total);
+    hipStream_t s = (hipStream_t)stream;
+    const PackInfo pi = pack_info(Cout, Cin, k);
+    const float* wp = (const float*)wpack;
+    const float* wsq = wp + pi.wp_floats;
+    const void* wb = wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats;
+    float* dco = (float*)((char*)workspace + wl.dco);
+    float* z = (float*)((char*)workspace + wl.z);
+    if (demodulate && dcoef_in) dco = const_cast<float*>(dcoef_in);
+    else if (demodulate) TDGP_LAUNCH("demod_kernel", demod_kernel, dim3(cdiv(Cout, 64), B), dim3(1024), 0, s, styles, wsq, dco, B, Cin, Cout, pi.CoutP);
+    else dco = nullptr;
+    EpiParams e;
+    e.B = B; e.Cout = Cout; e.round_bf16 = 1;
+    for (int i = 0; i < 16; i++) e.fir[i] = 0.f;
+    if (fir4x4)
+        for (int ky = 0; ky < 4; ky++)
+            for (int kx = 0; kx < 4; kx++) e.fir[ky * 4 + kx] = fir4x4[(3 - ky) * 4 + (3 - kx)] * 4.0f;
+    e.dcoef = dco; e.noise = noise; e.noise_bstride = noise_bstride; e.bias = bias; e.skip = skip; e.y = (float*)y;
+    e.Hout = H * up; e.Wout = W * up; e.out_layout = out_layout; e.out_feat = out_feat > 0 ? out_feat : 1;
+    e.act = act; e.alpha = alpha; e.gain = gain; e.clamp = clamp;
+    const uint32_t x_bytes = (uint32_t)((int64_t)B * Cin * H * W * 2);
+    if (rgb) {
+        RgbParams r;
+        r.x = (const float*)x; r.wp = wp; r.styles = styles; r.e = e;
+        r.B = B; r.Cin = Cin; r.Cout = Cout; r.CoutP = pi.CoutP; r.HW = H * W; r.W = W; r.P = (int64_t)B * H * W;
+        r.lw = r.lhw = -1;
+        if ((W & (W - 1)) == 0 && (H & (H - 1)) == 0 && (int64_t)B * H * W < ((int64_t)1 << 31) - 512) {
+            r.lw = 0; while ((1 << r.lw) < W) r.lw++;
+            r.lhw = 0; while ((1 << r.lhw) < H * W) r.lhw++;
+        }
+        r.x_bytes = x_bytes; r.wp_bytes = (uint32_t)(pi.wp_floats * 4); r.st_bytes = (uint32_t)((int64_t)B * Cin * 4);
+        if (Cout <= 32) launch_torgb<1, true>(r, s);
+        else if (Cout <= 64) launch_torgb<2, true>(r, s);
+        else launch_torgb<3, true>(r, s);
+    } else if (c3) {
+        ConvBfParams q;
+        q.x = (const uint16_t*)x; q.wb = wb; q.styles = styles; q.e = e; q.y16 = (uint16_t*)y;
+        q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W;
+        q.x_bytes = x_bytes; q.wb_bytes = (uint32_t)(pi.wbf_floats * 4);
+        const size_t lds = (size_t)(9 * 2 * 64 * 32 + 2 * 10 * 34 * 32 + 5 * 64 * 4 + 2 * Cin * 4);
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds - 2 * Cin * 4 + 2 * 2048 * 4)); attr_set = true; }
+        TDGP_LAUNCH("conv_bf16_kernel", conv3_bf16_kernel<true>, dim3((W >> 5) * cdiv(B * (H + 1), 8), cdiv(Cout, 64)), dim3(256), lds, s, q);
+    } else {
+        const UpPlan pl = up_plan(B, Cin, Cout, H, W);
+        UpBfParams q;
+        q.x = (const uint16_t*)x; q.wb = wb; q.styles = styles; q.z = z;
+        q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W; q.G1 = pl.G1; q.GS = pl.GS; q.zslice = pl.zslice;
+        q.x_bytes = x_bytes; q.wb_bytes = (uint32_t)(pi.wbf_floats * 4); q.st_bytes = (uint32_t)((int64_t)B * Cin * 4);
+        const size_t lds = (size_t)(9 * 2 * 64 * 32 + 2 * 2 * 130 * 32);
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)upconv_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+        TDGP_LAUNCH("upconv_bf16_kernel", upconv_bf16_kernel, dim3(cdiv(B * pl.GS, 128), cdiv(Cout, 64)), dim3(256), lds, s, q);
+        FirParams f;
+        f.z = z; f.dcoef = dco; f.noise = noise; f.noise_bstride = noise_bstride; f.bias = bias; f.y = nullptr; f.y16 = (uint16_t*)y;
+        for (int i = 0; i < 16; i++) f.fir[i] = e.fir[i];
+        f.B = B; f.C = Cout; f.ZROWS = 2 * H + 2; f.P2 = 2 * pl.G1; f.GS2 = 2 * pl.GS; f.ksplit = 1; f.zslice = pl.zslice;
+        f.OH = 2 * H; f.OW = 2 * W;
+        f.act = act; f.alpha = alpha; f.gain = gain; f.clamp = clamp;
+        if (f.OW >= 128) {
+            const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, 16) * cdiv(f.OW, 128);
+            TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<16, 128, true>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
+        } else {
+            const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, 32) * cdiv(f.OW, 64);
+            TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<32, 64, true>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
+        }
+    }
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}
+
+TDGP_API int tdgp_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, tdgp_stream_t stream) {
+    TDGP_CHECK((x && y_bf16) || n == 0, TDGP_EINVAL, "cast_f32_bf16: null pointer");
+    if (n <= 0) return TDGP_OK;
+    TDGP_LAUNCH("cast_f32_bf16_kernel", cast_f32_bf16_kernel, dim3((int)min((int64_t)8192, cdiv64(n, 512))), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y_bf16, n);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }

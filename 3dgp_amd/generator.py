@@ -219,12 +219,27 @@ class ToRGBLayer(torch.nn.Module):
                                         clamp=self.conv_clamp, skip=skip, fir=fir, out_layout=out_layout, out_feat=out_feat)
 
 
-class SynthesisBlock(torch.nn.Module):
-    """networks_stylegan2.py:180-276, architecture 'skip', fp32."""
+def _to_dtype(x, dtype):
+    """x.to(dtype) of SynthesisBlock.forward (:250); fp32 -> bf16 through the library's cast (round to nearest even)."""
+    if x.dtype == dtype:
+        return x
+    if dtype == torch.bfloat16 and x.dtype == torch.float32 and x.is_cuda:
+        x = x.contiguous()
+        y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.call('tdgp_cast_f32_bf16', x.data_ptr(), y.data_ptr(), x.numel(), _lib.stream_of(x))
+        return y
+    return x.to(dtype)
 
-    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, use_noise=True, conv_clamp=None):
+
+class SynthesisBlock(torch.nn.Module):
+    """networks_stylegan2.py:180-276, architecture 'skip'.  `use_fp16` (:212, :237): the block keeps its activations in 16 bits --
+    bfloat16 here (BASELINE configs[4]) -- on the bf16 MFMA kernels of tdgp_modconv2d_bf16; the skip image stays fp32 (:268)."""
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, use_noise=True, conv_clamp=None, use_fp16=False):
         super().__init__()
         self.in_channels, self.w_dim, self.resolution, self.img_channels, self.is_last = in_channels, w_dim, resolution, img_channels, is_last
+        self.use_fp16 = use_fp16
         self.register_buffer('resample_filter', _upfirdn2d.setup_filter([1, 3, 3, 1]))
         self.num_conv = 0
         self.num_torgb = 1
@@ -258,10 +273,11 @@ class SynthesisBlock(torch.nn.Module):
         w_iter = iter(ws.unbind(dim=1))
         s_iter = iter(styles) if styles is not None else iter([None] * 3)
         d_iter = iter(dcoefs) if dcoefs is not None else iter([None] * 2)
+        dtype = torch.bfloat16 if self.use_fp16 and not force_fp32 else torch.float32       # :237
         if self.in_channels == 0:
-            x = self.const.to(torch.float32).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+            x = self.const.to(dtype).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
         else:
-            x = self.conv0(x.to(torch.float32), next(w_iter), styles=next(s_iter), dcoef=next(d_iter), **layer_kwargs)
+            x = self.conv0(_to_dtype(x, dtype), next(w_iter), styles=next(s_iter), dcoef=next(d_iter), **layer_kwargs)      # x.to(dtype), :250
         x = self.conv1(x, next(w_iter), styles=next(s_iter), dcoef=next(d_iter), **layer_kwargs)
         fir = _modconv.fir_host_array(self.resample_filter) if img is not None else None
         img = self.torgb(x, next(w_iter), styles=next(s_iter), skip=img, fir=fir, out_layout=1 if hwc_feat else 0, out_feat=hwc_feat)
@@ -280,8 +296,10 @@ class SynthesisBlocksSequence(torch.nn.Module):
         self.num_ws = 0
         for i, res in enumerate(self.block_resolutions):
             is_last = res == cfg.tri_plane_res
+            r16 = cfg.fp16_resolution
             block = SynthesisBlock(ch[res // 2] if i > 0 else 0, ch[res], w_dim=cfg.w_dim, resolution=res, img_channels=out_channels,
-                                   is_last=is_last, use_noise=cfg.use_noise, conv_clamp=None)
+                                   is_last=is_last, use_noise=cfg.use_noise, conv_clamp=cfg.conv_clamp if r16 is not None else None,
+                                   use_fp16=r16 is not None and res >= r16)
             self.num_ws += block.num_conv + (block.num_torgb if is_last else 0)
             setattr(self, f'b{res}', block)
         self._affine_pack = None

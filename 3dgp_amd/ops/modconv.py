@@ -72,11 +72,12 @@ def _packed(weight):
 
 def modconv_forward(x, packed, styles, noise=None, bias=None, up=1, demodulate=True, act='linear', alpha=None, gain=None, clamp=None,
                     fir=None, skip=None, out_layout=0, out_feat=0, dcoef=None):
-    """One call of tdgp_modconv2d.  x [B,Cin,H,W] fp32 NCHW; returns [B,Cout,H*up,W*up] (out_layout 0) or the
+    """One call of tdgp_modconv2d (x fp32) / tdgp_modconv2d_bf16 (x bf16: the reduced-precision blocks).  x [B,Cin,H,W] NCHW; returns [B,Cout,H*up,W*up] (out_layout 0) or the
     channel-last plane tensor [B,Cout/out_feat,H,W,out_feat] (out_layout 1).  `dcoef`: demodulation coefficients [B,Cout] precomputed by
     `demod_batch` (else the call computes them)."""
     _lib.require_cuda(x, 'x')
-    x = _lib.f32c(x)
+    bf16 = x.dtype == torch.bfloat16
+    x = x.contiguous() if bf16 else _lib.f32c(x)
     B, cin, H, W = x.shape
     if cin != packed.cin:
         raise RuntimeError(f'modulated_conv2d: x has {cin} channels, weight expects {packed.cin}')
@@ -102,13 +103,30 @@ def modconv_forward(x, packed, styles, noise=None, bias=None, up=1, demodulate=T
     if skip is not None:
         skip = _lib.f32c(skip)
     cout = packed.cout
+    lib = _lib.load()
+    ws_bytes = lib.tdgp_modconv2d_workspace_bytes(B, cin, cout, H, W, packed.k, up)
+    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=x.device)
+    if bf16:
+        # reduced-precision block (BASELINE configs[4]): bf16 activations in, bf16 out -- except the ToRGB form, whose output joins the
+        # fp32 skip image (networks_stylegan2.py:268).  Shapes the bf16 MFMA kernels do not take are widened and run on the fp32 path.
+        rgb = out_layout == 1
+        takes = (rgb and packed.k == 1 and up == 1) or (packed.k == 3 and out_layout == 0 and skip is None and cin % 32 == 0 and cin <= 2048 and
+                                                         (up == 2 or W % 32 == 0))
+        if not takes:
+            y = modconv_forward(x.float(), packed, styles, noise=noise, bias=bias, up=up, demodulate=demodulate, act=act, alpha=alpha, gain=gain,
+                                clamp=None if clamp < 0 else clamp, fir=fir, skip=skip, out_layout=out_layout, out_feat=out_feat, dcoef=dcoef)
+            return y if rgb else y.to(torch.bfloat16)
+        y = (torch.empty([B, cout // out_feat, H, W, out_feat], dtype=torch.float32, device=x.device) if rgb else
+             torch.empty([B, cout, H * up, W * up], dtype=torch.bfloat16, device=x.device))
+        with torch.cuda.device(x.device):
+            _lib.call('tdgp_modconv2d_bf16', x.data_ptr(), packed.buf.data_ptr(), _lib.ptr(styles), _lib.ptr(dcoef), _lib.ptr(noise), nbs, _lib.ptr(bias), fir,
+                      _lib.ptr(skip), y.data_ptr(), B, cin, cout, H, W, packed.k, up, int(bool(demodulate)), spec.cuda_idx, alpha, gain, clamp,
+                      out_layout, out_feat, ws.data_ptr(), ws_bytes, _lib.stream_of(x))
+        return y
     if out_layout == 0:
         y = torch.empty([B, cout, H * up, W * up], dtype=torch.float32, device=x.device)
     else:
         y = torch.empty([B, cout // out_feat, H, W, out_feat], dtype=torch.float32, device=x.device)
-    lib = _lib.load()
-    ws_bytes = lib.tdgp_modconv2d_workspace_bytes(B, cin, cout, H, W, packed.k, up)
-    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.call('tdgp_modconv2d', x.data_ptr(), packed.buf.data_ptr(), _lib.ptr(styles), _lib.ptr(dcoef), _lib.ptr(noise), nbs, _lib.ptr(bias), fir,
                   _lib.ptr(skip), y.data_ptr(), B, cin, cout, H, W, packed.k, up, int(bool(demodulate)), spec.cuda_idx, alpha, gain, clamp,

@@ -41,33 +41,41 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 PEAK_HBM_GBS = 8000.0
 
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+
+
 def algorithmic_flops(cfg):
     """Algorithmic FLOP per image of the MFMA kernels: 2 * MAC of every conv launch (stride-1 3x3 layers in
-    conv_mfma_kernel, the x2 layers in upconv_mfma_kernel, ToRGB in torgb_mfma_kernel); 5376 per field point."""
+    conv_mfma_kernel, the x2 layers in upconv_mfma_kernel, ToRGB in torgb_mfma_kernel); 5376 per field point.  With reduced-precision
+    blocks (BASELINE configs[4]) the 3x3 layers of those blocks run in conv_bf16_kernel / upconv_bf16_kernel and are priced against
+    the bf16 MFMA peak.  -> {kernel label: (flop per image, launches per image batch, peak TFLOP/s)}"""
     ch = cfg.channels
-    conv = up = rgb = 0
-    launches = up_launches = 0
+    r16 = cfg.fp16_resolution
+    acc = dict(conv_mfma_kernel=[0, 0], upconv_mfma_kernel=[0, 0], torgb_mfma_kernel=[0, 0], conv_bf16_kernel=[0, 0], upconv_bf16_kernel=[0, 0])
     for i, r in enumerate(cfg.block_resolutions):
         c = ch[r]
+        bf = r16 is not None and r >= r16
         if i > 0:
-            up += 2 * ch[r // 2] * c * 9 * (r // 2) ** 2          # stride-2 transposed conv: 9 taps per INPUT pixel
-            up_launches += 1
-        conv += 2 * c * c * 9 * r * r                              # conv1
-        rgb += 2 * c * cfg.plane_channels * r * r                  # ToRGB 1x1
-        launches += 1
+            k = 'upconv_bf16_kernel' if bf else 'upconv_mfma_kernel'
+            acc[k][0] += 2 * ch[r // 2] * c * 9 * (r // 2) ** 2   # stride-2 transposed conv: 9 taps per INPUT pixel
+            acc[k][1] += 1
+        k = 'conv_bf16_kernel' if bf else 'conv_mfma_kernel'
+        acc[k][0] += 2 * c * c * 9 * r * r                         # conv1
+        acc[k][1] += 1
+        acc['torgb_mfma_kernel'][0] += 2 * c * cfg.plane_channels * r * r        # ToRGB 1x1
+        acc['torgb_mfma_kernel'][1] += 1
     da = cfg.depth_adaptor
     if da is not None:                                             # --depth-adaptor: 5x5 Conv2dLayers + the 1x1 head of the last layer
         dims = [1] + [da.hid_dim] * da.num_hid_layers
         for cin, cout in zip(dims[:-1], dims[1:]):
-            conv += 2 * cin * cout * da.kernel_size ** 2 * cfg.img_resolution ** 2
-        conv += 2 * dims[-1] * cfg.img_resolution ** 2
-        launches_da = da.num_hid_layers + 1
-    else:
-        launches_da = 0
+            acc['conv_mfma_kernel'][0] += 2 * cin * cout * da.kernel_size ** 2 * cfg.img_resolution ** 2
+        acc['conv_mfma_kernel'][0] += 2 * dims[-1] * cfg.img_resolution ** 2
+        acc['conv_mfma_kernel'][1] += da.num_hid_layers + 1
     pts = 2 * cfg.img_resolution ** 2 * cfg.num_ray_steps          # coarse + fine
     field = pts * (2 * (cfg.feat_dim * cfg.mlp_hid + 4 * cfg.mlp_hid) + 3 * 4 * 2 * cfg.feat_dim)   # MLP 4608 + bilerp 768 @ (32,64)
-    return dict(conv_mfma_kernel=(conv, launches + launches_da), upconv_mfma_kernel=(up, up_launches), torgb_mfma_kernel=(rgb, launches),
-                triplane_field_kernel=(field, 2))
+    out = {k: (v[0], v[1], PEAK_BF16_MFMA_TFLOPS if 'bf16' in k else PEAK_FP32_MFMA_TFLOPS) for k, v in acc.items() if v[1] > 0}
+    out['triplane_field_kernel'] = (field, 2, PEAK_FP32_MFMA_TFLOPS)
+    return out
 
 
 def cpu_baseline(tdgp, cfg, n_img=8, budget_s=14.0):
@@ -120,7 +128,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=16, help='images per GPU per step of the headline value (16 = configs/scripts/inference.yaml:25)')
     ap.add_argument('--other-batches', default='4', help='comma list of further per-GPU batch sizes measured in the same run (4 = training/base.yaml:5); "" = none')
-    ap.add_argument('--config', default='c3', choices=['c1', 'c2', 'c3', 'c4'])
+    ap.add_argument('--config', default='c3', choices=['c1', 'c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--depth-adaptor', action='store_true', help='also run the DepthAdaptor inside G.forward (SURVEY 8f rank 1; off = the 8a hot path)')
     ap.add_argument('--profile-steps', type=int, default=2)
@@ -217,14 +225,14 @@ def main():
             pmc, pmc_src = pj.get('kernels', {}), dict(file='profiles/pmc_latest.json', commit=pj.get('commit'), passes=pj.get('source'))
     roofline = None
     if dominant in flops:
-        fl_img, launches_img = flops[dominant]
+        fl_img, launches_img, peak = flops[dominant]
         k = kernels[dominant]
         fl_per_launch = fl_img * args.batch / k['launches_per_step']
         achieved = fl_per_launch / (k['avg_ms'] * 1e-3) / 1e12
         pk = pmc.get(dominant, {})
         traffic = pk.get('hbm_bytes_per_launch')
-        roofline = dict(kernel=dominant, bound='mfma', achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                        frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+        roofline = dict(kernel=dominant, bound='mfma', achieved=round(achieved, 3), peak=peak, unit='TFLOP/s',
+                        frac=round(achieved / peak, 4), traffic=traffic,
                         hbm_gbs=None if traffic is None else round(traffic / (k['avg_ms'] * 1e-3) / 1e9, 1), mfma_busy_pct=pk.get('mfma_busy_pct'),
                         pmc_source=pmc_src, flop_per_launch=fl_per_launch, avg_launch_ms=k['avg_ms'], launches_per_step=k['launches_per_step'])
     for k, v in kernels.items():               # the same three figures for every kernel the PMC passes cover
@@ -233,7 +241,7 @@ def main():
             v.update(hbm_gbs=round(pk['hbm_bytes_per_launch'] / (v['avg_ms'] * 1e-3) / 1e9, 1), mfma_busy_pct=pk.get('mfma_busy_pct'))
         if k in flops and v['avg_ms'] > 0:
             v['tflops'] = round(flops[k][0] * args.batch / v['launches_per_step'] / (v['avg_ms'] * 1e-3) / 1e12, 2)
-    total_flop_img = sum(f for f, _ in flops.values())
+    total_flop_img = sum(f for f, _, _ in flops.values())
     ms_step = elapsed / args.steps * 1e3
     whole = dict(flop_per_image=total_flop_img, achieved=round(total_flop_img * args.batch / (ms_step * 1e-3) / 1e12, 2), peak=PEAK_FP32_MFMA_TFLOPS,
                  unit='TFLOP/s', frac=round(total_flop_img * args.batch / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -252,12 +260,14 @@ def main():
     if rank == 0:
         total_imgs = args.batch * world * args.steps
         names = dict(c1='BASELINE configs[0]: SDFood-like 64x64', c2='BASELINE configs[1]: Dogs 128x128', c3='BASELINE configs[2]: ImageNet 256x256',
-                     c4='BASELINE configs[3]: ImageNet 256x256')
+                     c4='BASELINE configs[3]: ImageNet 256x256', c5='BASELINE configs[4]: ImageNet 256x256')
         out = {
-            'metric': 'generator-forward img/s @256^2, 64 steps' if args.config in ('c3', 'c4') else f'generator-forward img/s ({args.config})',
+            'metric': 'generator-forward img/s @256^2, 64 steps' if args.config in ('c3', 'c4') else (
+                'generator-forward img/s @256^2, 96 steps, bf16 blocks' if args.config == 'c5' else f'generator-forward img/s ({args.config})'),
             'value': round(total_imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.arith == 'f32' else 'bf16x3->f32 (3x3 and x2 layers), f32 elsewhere', 'data': 'synthetic',
+            'dtype': ('bf16 (backbone blocks >= %d^2: bf16 activations + weights, fp32 accumulate), f32 elsewhere' % cfg.fp16_resolution) if cfg.fp16_resolution
+                     else ('f32' if args.arith == 'f32' else 'bf16x3->f32 (3x3 and x2 layers), f32 elsewhere'), 'data': 'synthetic',
             'config': {'workload': f'{names[args.config]}, {cfg.num_ray_steps}(+{cfg.num_ray_steps}) ray steps, cmax {cfg.cmax}, '
                                    f'c_dim {cfg.c_dim}, tri-plane {cfg.tri_plane_res}^2 x {cfg.plane_channels}, full HIP path',
                        'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'img_resolution': cfg.img_resolution,

@@ -92,7 +92,7 @@ int tdgp_upfirdn2d(const void* x, const float* f, void* y, int N, int C, int inH
  *   tdgp_modconv_pack_bytes  -> bytes of the packed buffer for (Cout,Cin,k)
  *   tdgp_modconv_pack        -> wpack ([Cin/4][k*k][Cout][4 channels], zero padded, + sum_taps w^2 per (c,o))
  * Forward:
- *   y[b,o] = act( d[b,o] * conv(x[b]*s[b,:], W)[o] + noise + bias[o] ) * gain  (+ skip term)
+ *   y[b,o] = clamp( act( d[b,o] * conv(x[b]*s[b,:], W)[o] + noise + bias[o] ) * gain )  (+ skip term, added after the clamp)
  *   d[b,o] = rsqrt(sum_c s[b,c]^2 * wsq[o,c] + 1e-8) if demodulate else 1
  *   up=2: transposed conv (stride 2) followed by the 4x4 FIR `fir4x4` with gain 4 (pad 1,1,1,1).
  *   fir4x4: HOST pointer to the 16 filter taps (a static 64-byte buffer: upfirdn2d.setup_filter([1,3,3,1])).
@@ -117,6 +117,25 @@ int     tdgp_modconv2d(const float* x, const void* wpack, const float* styles, c
                        float* y, int B, int Cin, int Cout, int H, int W, int k, int up, int demodulate,
                        int act, float alpha, float gain, float clamp, int out_layout, int out_feat,
                        void* workspace, int64_t workspace_bytes, tdgp_stream_t stream);
+
+/* The reduced-precision blocks of the backbone -- BASELINE configs[4]; replaces the reference's `use_fp16` path
+ * (networks_stylegan2.py:50-53, :237 `dtype = float16 if use_fp16`, :286-304 / networks_epigraf.py:99-108 `num_fp16_res`, conv_clamp 256)
+ * with bfloat16 in the place of float16.  Same arguments as tdgp_modconv2d except:
+ *   x: bf16 NCHW [B,Cin,H,W];
+ *   y: bf16 NCHW [B,Cout,H*up,W*up] for the 3x3 layers; for the ToRGB form (k = 1, up = 1, out_layout = 1, optional skip) the fp32
+ *      channel-last planes, as in tdgp_modconv2d (the skip image stays fp32, :268).
+ * bf16 weights x bf16 (style-scaled) activations on v_mfma_f32_32x32x16_bf16, fp32 accumulation; demodulation, noise, bias,
+ * activation, gain, clamp in fp32; the reference's rounding points behind the accumulator (conv output, + noise, bias_act output; the
+ * bias itself is rounded as in `self.bias.to(x.dtype)`), and the skip is added AFTER the clamp.
+ * Forms taken: 3x3 with Cin % 32 == 0 (and W % 32 == 0 for up = 1); the channel-last ToRGB with Cout <= 96.  Anything else returns
+ * TDGP_EUNSUPPORTED: widen x to fp32 and call tdgp_modconv2d.  Workspace: tdgp_modconv2d_workspace_bytes of the same shape.
+ * tdgp_cast_f32_bf16: x.to(bf16) (round to nearest even) at the first reduced-precision block (:250). */
+int     tdgp_modconv2d_bf16(const void* x_bf16, const void* wpack, const float* styles, const float* dcoef, const float* noise,
+                            int64_t noise_bstride, const float* bias, const float* fir4x4, const float* skip,
+                            void* y, int B, int Cin, int Cout, int H, int W, int k, int up, int demodulate,
+                            int act, float alpha, float gain, float clamp, int out_layout, int out_feat,
+                            void* workspace, int64_t workspace_bytes, tdgp_stream_t stream);
+int     tdgp_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, tdgp_stream_t stream);
 
 /* Plain x2 transposed convolution (the adjoint of a 3x3 stride-2 convolution, conv2d_gradfix.py:126-129):
  *   y [B,Cout,2H+1,2W+1] = conv_transpose2d(x * styles[:, :, None, None], w.transpose(0,1), stride=2),   w [Cout,Cin,3,3] packed by

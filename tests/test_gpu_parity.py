@@ -209,16 +209,13 @@ def test_torgb_channel_last_variants(tdgp, oracle, B, cin, crgb, H, W, clamp, ga
     s = (1 + 0.5 * rs.randn(B, cin)).astype(np.float32)
     bias = rs.randn(crgb).astype(np.float32)
     f = oracle.setup_filter([1, 3, 3, 1])
-    ref = oracle.bias_act(oracle.modulated_conv2d(x, w1, s, demodulate=False), bias, act='linear', gain=gain)
+    ref = oracle.bias_act(oracle.modulated_conv2d(x, w1, s, demodulate=False), bias, act='linear', gain=gain, clamp=clamp)
     prev_cl = None
     if skip:
         prev = rs.randn(B, crgb, H // 2, W // 2).astype(np.float32)
-        # order of the fused call: ((conv + bias) + skip) * gain, then clamp (the reference adds the skip after bias_act; with gain 1
-        # and no clamp -- every ToRGB of the generator -- the two coincide, and the test keeps to those cases when a skip is present)
+        # the reference's order (networks_stylegan2.py:170-171, 265-269): y = clamp(gain * (conv + bias)), THEN img = upsample2d(img) + y
         ref = ref + oracle.upsample2d(prev, f)
         prev_cl = T(prev).reshape(B, 3, feat, H // 2, W // 2).permute(0, 1, 3, 4, 2).contiguous()
-    if clamp is not None:
-        ref = np.clip(ref, -clamp, clamp)
     y = mc.modconv_forward(T(x), mc.PackedConv(T(w1)), T(s), bias=T(bias), demodulate=False, act='linear', gain=gain, clamp=clamp, skip=prev_cl,
                            fir=mc.fir_host_array(f) if skip else None, out_layout=1, out_feat=feat)
     assert y.shape == (B, 3, H, W, feat)
@@ -763,6 +760,121 @@ def test_chunked_schedule_is_the_same_forward(tdgp, full_c3):
             assert float((out.depth - ref.depth).abs().max()) < 1e-5, (chunk, cfrom)
     finally:
         syn.chunk, syn.chunk_from = prev
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[4]: bf16 blocks
+# Tolerance of the reduced-precision path.  One bf16 rounding is 2^-9 (0.2 %) of the value; a layer output passes through ~4 of them
+# (operands, conv output, bias_act output) and the HIP kernels round at different points than the reference (style-scaled activations
+# and shared weights instead of per-sample weights, modconv_bf16.inc), so two correct implementations differ by rounding NOISE:
+# bounded here by 1.5e-2 of the tensor scale at the worst element and 2e-3 in the mean -- an indexing or scaling bug is O(1).
+BF16_MAX, BF16_MEAN = 1.5e-2, 2e-3
+
+
+def _assert_bf16_close(got, ref, what, max_tol=BF16_MAX, mean_tol=BF16_MEAN):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref) / scale
+    report_parity('bf16 ' + what, max_err=float(err.max()), mean_err=float(err.mean()))
+    assert err.max() <= max_tol and err.mean() <= mean_tol, f'{what}: max {err.max():.3e} (tol {max_tol:.1e}), mean {err.mean():.3e} (tol {mean_tol:.1e})'
+
+
+@pytest.mark.parametrize('B,cin,cout,H,k,up,noise', [(2, 64, 64, 32, 3, 1, True), (3, 32, 96, 64, 3, 1, False), (2, 96, 40, 32, 3, 1, True),
+                                                      (2, 64, 32, 32, 3, 2, True), (1, 32, 64, 64, 3, 2, False), (2, 128, 130, 16, 3, 2, True),
+                                                      (2, 64, 64, 16, 3, 1, True), (2, 24, 16, 32, 3, 1, False)])
+def test_bf16_modconv_vs_oracle(tdgp, oracle, B, cin, cout, H, k, up, noise):
+    """One reduced-precision synthesis layer (modulated 3x3 conv, stride 1 or x2 + FIR, noise, bias, lrelu * sqrt2, clamp 256) on bf16
+    activations: tdgp_modconv2d_bf16 -- and, for the last two shapes, the widened fp32 fallback -- against the oracle's bf16 path."""
+    rs = np.random.RandomState(B * 100 + cin + up)
+    mc = tdgp.ops.modconv
+    x = oracle.round_bf16(rs.randn(B, cin, H, H).astype(np.float32))
+    w = rs.randn(cout, cin, k, k).astype(np.float32)
+    s = (1.0 + 0.5 * rs.randn(B, cin)).astype(np.float32)
+    bias = rs.randn(cout).astype(np.float32)
+    nz = (0.3 * rs.randn(H * up, H * up)).astype(np.float32) if noise else None
+    f = oracle.setup_filter([1, 3, 3, 1])
+    ref = oracle.bias_act_bf16(oracle.modulated_conv2d(x, w, s, noise=nz, up=up, demodulate=True, resample_filter=f, prec='bf16'), bias, act='lrelu', clamp=256)
+    y = mc.modconv_forward(T(x).to(torch.bfloat16), mc.PackedConv(T(w)), T(s), noise=None if nz is None else T(nz), bias=T(bias), up=up, demodulate=True,
+                           act='lrelu', clamp=256, fir=mc.fir_host_array(f) if up == 2 else None)
+    assert y.dtype == torch.bfloat16 and y.shape == (B, cout, H * up, H * up)
+    _assert_bf16_close(N(y.float()), ref, f'layer {cin}->{cout} @{H} up{up}')
+
+
+@pytest.mark.parametrize('B,cin,crgb,H,skip', [(2, 64, 96, 64, True), (2, 128, 24, 32, True), (1, 32, 96, 32, False)])
+def test_bf16_torgb_vs_oracle(tdgp, oracle, B, cin, crgb, H, skip):
+    """ToRGB of a reduced-precision block: bf16 activations in, clamp 256, the fp32 skip image upsampled and added AFTER the clamp."""
+    rs = np.random.RandomState(cin + crgb)
+    mc = tdgp.ops.modconv
+    feat = crgb // 3
+    x = oracle.round_bf16(rs.randn(B, cin, H, H).astype(np.float32))
+    w1 = rs.randn(crgb, cin, 1, 1).astype(np.float32)
+    s = ((1 + 0.5 * rs.randn(B, cin)) / np.sqrt(cin)).astype(np.float32)
+    bias = rs.randn(crgb).astype(np.float32)
+    f = oracle.setup_filter([1, 3, 3, 1])
+    ref = oracle.bias_act_bf16(oracle.modulated_conv2d(x, w1, s, demodulate=False, prec='bf16'), bias, act='linear', clamp=256)
+    prev_cl = None
+    if skip:
+        prev = rs.randn(B, crgb, H // 2, H // 2).astype(np.float32)
+        ref = ref + oracle.upsample2d(prev, f)
+        prev_cl = T(prev).reshape(B, 3, feat, H // 2, H // 2).permute(0, 1, 3, 4, 2).contiguous()
+    y = mc.modconv_forward(T(x).to(torch.bfloat16), mc.PackedConv(T(w1)), T(s), bias=T(bias), demodulate=False, act='linear', gain=1.0, clamp=256, skip=prev_cl,
+                           fir=mc.fir_host_array(f) if skip else None, out_layout=1, out_feat=feat)
+    assert y.dtype == torch.float32 and y.shape == (B, 3, H, H, feat)
+    _assert_bf16_close(N(y.permute(0, 1, 4, 2, 3).reshape(B, crgb, H, H)), ref, f'torgb {cin}->{crgb} @{H}')
+
+
+def test_bf16_generator_vs_reference_golden(tdgp, oracle):
+    """config_mid_bf16 (blocks 32^2 and 64^2 in bf16, conv_clamp 256): tri-planes and image against the REFERENCE's own reduced-precision
+    run with bfloat16 (tests/golden/bf16.npz), and block by block against the oracle."""
+    cfg = tdgp.config.config_mid_bf16()
+    g = load_golden('bf16')
+    G = _gen(tdgp, cfg, 61)
+    dec = G.synthesis.tri_plane_decoder
+    assert [getattr(dec, f'b{r}').use_fp16 for r in dec.block_resolutions] == [False, False, False, True, True]
+    ws = T(g['ws'])
+    planes = dec(ws, noise_mode='const')
+    _assert_bf16_close(N(planes), g['planes'], 'tri-planes vs the reference')
+    out = G.synthesis(ws, camera_params=_cam(g), noise_mode='const', render_opts=dict(return_depth=True), u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
+    _assert_bf16_close(N(out.img), g['img'], 'image vs the reference', max_tol=3e-2, mean_tol=4e-3)
+    _assert_bf16_close(N(out.depth), g['depth'], 'depth vs the reference', max_tol=2e-2, mean_tol=2e-3)
+    sd = tdgp.weights.random_state_dict(cfg, seed=61, exercise_all=True)
+    from oracle import pipeline as P
+    oplanes = P.synthesis_backbone(sd, cfg.to_dict(), g['ws'], 'const')
+    _assert_bf16_close(N(planes), oplanes, 'tri-planes vs the oracle')
+
+
+def test_config_c5_vs_oracle(tdgp, oracle):
+    """BASELINE configs[4] at its REAL size: 512^2 tri-planes with the 64^2 ... 512^2 blocks in bf16 (one sample against the oracle's bf16
+    backbone), and the 256^2 / 96(+96)-step renderer on a strip of rows against the fp32 oracle renderer on the same planes."""
+    cfg = tdgp.config.config_c5()
+    sd = tdgp.weights.random_state_dict(cfg, seed=113, exercise_all=True)
+    G = tdgp.generator.Generator(cfg)
+    G.load_numpy_state_dict(sd)
+    G = G.to(DEV)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=1, seed=114)
+    ws = G.mapping(T(inp['z']), T(inp['c']))
+    planes = G.synthesis.tri_plane_decoder(ws, noise_mode='const', hwc=True)
+    oracle.set_threads(min(64, __import__('os').cpu_count() or 1))
+    from oracle import pipeline as P
+    ref = P.synthesis_backbone(sd, cfg.to_dict(), N(ws), 'const')
+    planes_nchw = N(planes.t.permute(0, 1, 4, 2, 3).reshape(1, 96, 512, 512))
+    _assert_bf16_close(planes_nchw, ref, 'C5 tri-planes 512^2 vs the oracle')
+    cam = {k: T(v) for k, v in inp['camera'].items()}
+    out = G.synthesis(ws, camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True), u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']))
+    img, depth = N(out.img), N(out.depth)
+    mlp = tuple(sd[f'synthesis.tri_plane_mlp.model.{i}.{n}'] for i in (0, 1) for n in ('weight', 'bias'))
+    c2w = oracle.cam2world(inp['camera']['angles'], inp['camera']['radius'], inp['camera']['look_at'])
+    ro, rd = oracle.sample_rays(c2w, inp['camera']['fov'], 256, 256)
+    R, S = 256 * 256, cfg.num_ray_steps
+    sel = np.concatenate([np.arange(r * 256, (r + 1) * 256) for r in (5, 200)])
+    u1 = inp['u_coarse'].reshape(1, R, S)[:, sel]
+    u2 = inp['u_fine'].reshape(1, R, S)[:, sel].reshape(-1, S)
+    orgb, odepth, _, _ = oracle.importance_render(planes_nchw, mlp, ro[:, sel], rd[:, sel], P.render_options(cfg.to_dict()), u1, u2)   # same (HIP) planes: fp32 renderer
+    got = img.reshape(1, 3, R)[:, :, sel].transpose(0, 2, 1)
+    e_rgb = float(np.abs(got - orgb).max() / np.abs(orgb).max())
+    e_dep = float(np.abs(depth.reshape(1, R)[:, sel] - odepth[..., 0]).max())
+    report_parity('C5 renderer strip vs oracle (2 rows x 256 rays x 96+96 samples, fp32 on the HIP planes)', rgb_range_err=e_rgb, depth_abs_err=e_dep)
+    assert e_rgb < 1e-5 and e_dep < 1e-5, (e_rgb, e_dep)
 
 
 def test_compat_plugins(tdgp, oracle):
