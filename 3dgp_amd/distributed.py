@@ -51,7 +51,10 @@ class FeatureGatherer:
     def __init__(self, group=None, side_stream=True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.stream = torch.cuda.Stream() if (side_stream and torch.cuda.is_available() and self.world > 1) else None
+        # no process group: plain pass-through.  An initialised group of ONE rank still goes through the collective (that is how the
+        # RCCL path -- communicator set-up, side stream, record_stream -- is exercised on a single-GPU box: tests/test_distributed.py)
+        self.collective = dist.is_initialized()
+        self.stream = torch.cuda.Stream() if (side_stream and torch.cuda.is_available() and self.collective) else None
         self._pending = None
 
     def gather(self, y):
@@ -61,7 +64,7 @@ class FeatureGatherer:
 
     def gather_async(self, y):
         assert y.ndim == 2
-        if self.world == 1:
+        if not self.collective:
             self._pending = (y, None)
             return
         y = y.contiguous()

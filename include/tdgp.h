@@ -8,7 +8,9 @@
  *   - every function returns 0 on success or a negative TDGP_E* code; tdgp_last_error() returns a
  *     thread-local message.  Nothing throws across the ABI;
  *   - fp32 unless a `dtype` argument says otherwise (TDGP_F32 / TDGP_F16 / TDGP_BF16);
- *   - re-entrant; no global mutable state.
+ *   - re-entrant.  Process-wide state is limited to: the init-once kernel tables, the two opt-in switches tdgp_set_conv_arith (arithmetic of
+ *     the large 3x3 layers; default 0 = fp32 MFMA) and tdgp_profile_enable (per-kernel event timing; default off), and the launch
+ *     geometry cached per kernel instantiation (resident blocks per CU).  Nothing else is remembered between calls.
  *
  * Each entry point cites the reference interface it replaces (file:line under the reference tree).
  * The reference binds its two native ops through pybind (bias_act.cpp:94, upfirdn2d.cpp:102); the

@@ -95,3 +95,70 @@ def test_single_process_helpers(tdgp):
     assert torch.equal(g.gather(y), y)
     f = D.stand_in_features(torch.randn(2, 3, 64, 64))
     assert f.shape == (2, 2048)
+
+
+# ------------------------------------------------------------------------------------------------ RCCL (needs GPUs)
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_RCCL_ONE_RANK = '''
+import importlib, os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)            # "nccl" is RCCL on ROCm
+D = importlib.import_module("3dgp_amd").distributed
+g = D.FeatureGatherer(side_stream=True)
+assert g.collective and g.stream is not None
+outs = []
+for step in range(4):                                            # the bench's pattern: wait for the previous block, launch the next
+    y = torch.full([64, 2048], float(step), device="cuda") + torch.arange(64, device="cuda")[:, None]
+    if g._pending is not None:
+        outs.append(g.wait())
+    g.gather_async(y)
+    del y                                                        # record_stream keeps the block alive for the side stream
+outs.append(g.wait())
+torch.cuda.synchronize()
+for step, o in enumerate(outs):
+    assert o.shape == (64, 2048) and float(o[5, 7]) == step + 5, (step, float(o[5, 7]))
+one = torch.ones(1, device="cuda")
+dist.all_reduce(one)
+assert int(one.item()) == dist.get_world_size() == 1
+net = torch.nn.Linear(8, 4).cuda()
+net(torch.ones(3, 8, device="cuda")).sum().backward()
+flat = D.allreduce_gradients(net.parameters())
+assert flat is not None and flat.is_cuda and flat.numel() == 36
+dist.barrier()
+dist.destroy_process_group()
+print("rccl ok")
+'''
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_collectives():
+    """The RCCL code path on whatever GPU is there: a one-rank NCCL group still builds a communicator and runs the side-stream
+    all_gather_into_tensor (+ record_stream), the all-reduce behind `rccl_ranks_seen`, the flat-gradient all-reduce and a barrier."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-c', _RCCL_ONE_RANK % (REPO, str(_free_port()))], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and 'rccl ok' in out.stdout, out.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_rccl():
+    """bench.py --gpus 2 under torchrun, the driver's launch line: runs only where two GPUs are visible (the round-end 8-GPU node)."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f'{torch.cuda.device_count()} GPU(s) visible: the two-rank RCCL run needs 2')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '2', '--other-batches', '', '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['rccl_ranks_seen'] == 2 and line['config']['global_batch'] == 4 and line['value'] > 0

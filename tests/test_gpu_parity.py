@@ -119,6 +119,27 @@ def test_upfirdn2d_oracle(tdgp, oracle):
         u.upfirdn2d(T(x), T(f), padding=-8)          # output must be at least 1x1
 
 
+@pytest.mark.parametrize('shape,kw', [((2, 3, 129, 129), dict(padding=[1, 1, 1, 1], gain=4)),                 # F1 at a tileable size: 128^2 out, 16-B stores
+                                      ((1, 2, 70, 201), dict(padding=[1, 1, 1, 1], gain=4)),                   # ragged tiles, scalar loads / stores (odd pitch)
+                                      ((1, 2, 40, 160), dict(padding=[2, 1, 0, 3], gain=1.5, flip_filter=True)),  # asymmetric padding, flipped filter
+                                      ((2, 3, 64, 64), dict(up=2, padding=[2, 1, 2, 1], gain=4)),              # F2: 128^2 out
+                                      ((1, 2, 37, 53), dict(up=2, padding=[2, 1, 2, 1], gain=4)),              # F2, odd sizes
+                                      ((1, 1, 33, 100), dict(up=2, padding=[1, 2, 3, 0], gain=2.0, flip_filter=True))])
+def test_upfirdn2d_lds_tiles(tdgp, oracle, shape, kw):
+    """The LDS-staged 4x4 kernel (planes of >= 16 x 64 outputs: the generator's F1 / F2 forms at their hot sizes) against the oracle:
+    window geometry for both up factors, every padding, ragged edge tiles, vector and scalar load / store paths."""
+    u = tdgp.ops.upfirdn2d
+    rs = np.random.RandomState(shape[2] + shape[3])
+    f = oracle.setup_filter([1, 2, 3, 1]) if kw.get('flip_filter') else oracle.setup_filter([1, 3, 3, 1])       # an asymmetric filter where flipping matters
+    x = rs.randn(*shape).astype(np.float32)
+    ref = oracle.upfirdn2d(x, f, **kw)
+    assert ref.shape[2] >= 16 and ref.shape[3] >= 64
+    assert_close(N(u.upfirdn2d(T(x), T(f), **kw)), ref, 2e-6, f'upfirdn2d {shape} {kw}', 1.0)
+    xs = T(np.concatenate([x, x], axis=3))[:, :, :, 1:shape[3] + 1]                       # same values, a view with an unaligned base and pitch
+    xs_ref = oracle.upfirdn2d(np.ascontiguousarray(np.concatenate([x, x], axis=3)[:, :, :, 1:shape[3] + 1]), f, **kw)
+    assert_close(N(u.upfirdn2d(xs, T(f), **kw)), xs_ref, 2e-6, 'unaligned view', 1.0)
+
+
 # ------------------------------------------------------------------------------------------------ modulated conv
 
 @pytest.mark.parametrize('tag', ['c3_up1', 'c3_up2', 'c3_up2_b1', 'c1_rgb', 'c3_up1_b1_nonoise'])
