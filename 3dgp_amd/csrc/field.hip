@@ -343,7 +343,18 @@ __device__ __forceinline__ void field_body(const FieldParams& p) {
             const __amdgpu_buffer_rsrc_t rpl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.planes), 0, p.planes_bytes, 0x00020000);
             const int wslot = gc4 * 16 + gpt;                           // table slot this lane WRITES (sample j = gc4 of the group, ray gpt)
             for (int patch = lb; patch < npatch; patch += nb) {
-                const int px = patch % pX, py = (patch / pX) % pY, b = patch / (pX * pY);       // uniform
+                // patch id -> (sample, patch row, patch column).  Consecutive ids run through 8 x 8-patch (64 x 64-pixel) squares when the
+                // image allows it: the 64 patches an XCD works on at a time (blocks lb = x * per .. + per - 1 of a round) then cover a compact
+                // square instead of a 256 x 16-pixel band -- its footprint in the (x,z) plane is a quarter of the plane, not all of it, and the
+                // eight private L2s fetch about half as much between them (FETCH_SIZE, profiles/).
+                int px, py, b;
+                if (((pX | pY) & 7) == 0) {
+                    const int per_img = pX * pY, r = patch % per_img, sq = r >> 6, in = r & 63;
+                    b = patch / per_img;
+                    px = (sq % (pX >> 3)) * 8 + (in & 7); py = (sq / (pX >> 3)) * 8 + (in >> 3);
+                } else {
+                    px = patch % pX; py = (patch / pX) % pY; b = patch / (pX * pY);
+                }
                 bool gok, fok;
                 const int gray = ray_of(b, py, px, gpt, gok);      // the ray this lane computes addresses / gathers for
                 const int fray = ray_of(b, py, px, l >> 2, fok);   // the ray whose parked results this lane flushes
