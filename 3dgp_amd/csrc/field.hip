@@ -33,6 +33,9 @@
 #ifndef TDGP_FIELD_ABL
 #define TDGP_FIELD_ABL 0
 #endif
+#ifndef TDGP_WALK_WAVES
+#define TDGP_WALK_WAVES 2      // waves per SIMD the table walk is compiled for (3: 168 registers, 24 spilled -- measured slower)
+#endif
 
 namespace {
 
@@ -569,7 +572,7 @@ template <int FQ, int MT, bool TAPS>
 __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) { field_body<FQ, MT, TAPS, false>(p); }
 
 template <int FQ, int MT, bool TAPS>
-__global__ __launch_bounds__(256, 2) void triplane_walk_kernel(FieldParams p) { field_body<FQ, MT, TAPS, true>(p); }
+__global__ __launch_bounds__(256, TDGP_WALK_WAVES) void triplane_walk_kernel(FieldParams p) { field_body<FQ, MT, TAPS, true>(p); }
 
 // NCHW planes [B,3F,H,W] -> [B,3,H,W,F] through an LDS tile of 64 pixels x F channels.
 __global__ __launch_bounds__(256) void planes_to_hwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int F, int HW, int64_t ntiles,

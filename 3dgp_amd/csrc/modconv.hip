@@ -2685,7 +2685,7 @@ TDGP_API int tdgp_modconv2d_bf16(const void* x, const void* wpack, const float* 
     const bool rgb = k == 1 && up == 1 && out_layout == 1 && Cout <= 96 && !demodulate && !noise && act == 1 && ((H * W) & 3) == 0 && out_feat >= 4 &&
                      (out_feat % 4) == 0 && (Cout % out_feat) == 0 && (!skip || (fir4x4 && (H % 2) == 0 && (W % 2) == 0));
     const bool c3 = k == 3 && up == 1 && out_layout == 0 && !skip && (W & 31) == 0 && (Cin & 31) == 0 && Cin <= 2048;
-    const bool u3 = k == 3 && up == 2 && out_layout == 0 && !skip && fir4x4 && (Cin & 31) == 0;
+    const bool u3 = k == 3 && up == 2 && out_layout == 0 && !skip && fir4x4 && (Cin & 31) == 0 && (W & 1) == 0;
     TDGP_CHECK(rgb || c3 || u3, TDGP_EUNSUPPORTED, "modconv2d_bf16: no bf16 kernel for k=%d up=%d Cin=%d W=%d layout=%d", k, up, Cin, W, out_layout);
     const WsLayout wl = ws_layout(B, Cin, Cout, H, W, k, up);
     TDGP_CHECK(workspace && workspace_bytes >= wl.total, TDGP_EWORKSPACE, "modconv2d_bf16: workspace %lld < %lld bytes", (long long)workspace_bytes,
@@ -2738,9 +2738,11 @@ TDGP_API int tdgp_modconv2d_bf16(const void* x, const void* wpack, const float* 
         q.x = (const uint16_t*)x; q.wb = wb; q.styles = styles; q.z = z;
         q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W; q.G1 = pl.G1; q.GS = pl.GS; q.zslice = pl.zslice;
         q.x_bytes = x_bytes; q.wb_bytes = (uint32_t)(pi.wbf_floats * 4); q.st_bytes = (uint32_t)((int64_t)B * Cin * 4);
-        const size_t lds = (size_t)(9 * 2 * 64 * 32 + 2 * 2 * 130 * 32);
+        const int nsb = std::min(B, (130 + pl.G1) / pl.GS + 2);                 // samples one block's grid points can touch
+        const size_t lds = (size_t)(9 * 2 * 64 * 32 + 2 * 2 * 130 * 32) + (size_t)nsb * Cin * 4;
+        if (lds > 80 * 1024) return TDGP_EUNSUPPORTED;
         static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)upconv_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)upconv_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
         TDGP_LAUNCH("upconv_bf16_kernel", upconv_bf16_kernel, dim3(cdiv(B * pl.GS, 128), cdiv(Cout, 64)), dim3(256), lds, s, q);
         FirParams f;
         f.z = z; f.dcoef = dco; f.noise = noise; f.noise_bstride = noise_bstride; f.bias = bias; f.y = nullptr; f.y16 = (uint16_t*)y;
