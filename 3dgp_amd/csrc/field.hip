@@ -22,10 +22,10 @@
 // Roofline: 2*(F*hid + 4*hid) = 4608 MLP flop + 768 blend flop and 12 taps * F * 4 = 1536 B of L1/L2-served gathers per
 // point; the tri-plane of one image (100.7 MB at 512^2 x 96) is read from HBM once and then lives in
 // L2 / Infinity Cache.  Output traffic 16 B per point.
-// Measured (r01): with the tap loads compiled out the kernel runs at 0.87x of its full time, and that time equals the SUM of
-// its VALU and MFMA issue cycles (~316 VALU x 4 + 48 MFMA = ~2400 cycles per 16-point tile): fp32 MFMA and (packed) fp32
-// VALU have the same 64 flop/clk/SIMD rate on this chip and do not overlap, so every VALU instruction in the loop costs
-// matrix time -- the blend uses v_pk_fma_f32 and the remaining lever is the per-point address arithmetic.
+// Measured (r02, tools/dev/ubench_overlap2.hip): fp32 MFMA and every vector-ALU instruction of ANY wave of a SIMD issue through one
+// port (5-7 cycles of matrix time per VALU instruction, 5.4 for a packed one), LDS and vector-memory instructions overlap.  Per
+// 16-point tile this kernel issues 64 MFMAs (1152 cycles) and ~142 vector instructions (316 in r01) and takes ~2900 cycles per
+// SIMD; 4.95 ms per 67 M points, matrix pipe 43 % busy.  DESIGN.md (e) lists what was tried on top and measured slower.
 #include "common.h"
 
 // Compile-time ablations for timing experiments (tools/dev/build_variant.sh): 1 = no tap loads, 2 = no layer-1 MFMAs,
