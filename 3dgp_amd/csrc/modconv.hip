@@ -2200,6 +2200,7 @@ __global__ __launch_bounds__(256) void z_gather_kernel(const float* __restrict__
 }
 
 #include "modconv_bf16.inc"
+#include "modconv_wino.inc"
 
 // d[b,o] = rsqrt(sum_c s[b,c]^2 * wsq[c][o] + 1e-8)      (networks_stylegan2.py:62)
 // block (64 out-channels x 16 channel slices): coalesced wsq rows, 16-way split of the Cin loop, LDS tree at the end.
@@ -2295,7 +2296,7 @@ __global__ __launch_bounds__(256) void style_affine_kernel(const float* __restri
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
-struct PackInfo { int T, KC, CoutP, nchunks, niter16, nch32; int64_t wp_floats, wsq_floats, wsplit_floats, wbf_floats; };
+struct PackInfo { int T, KC, CoutP, nchunks, niter16, nch32, nch8; int64_t wp_floats, wsq_floats, wsplit_floats, wbf_floats, wino_floats; };
 inline PackInfo pack_info(int Cout, int Cin, int k) {
     PackInfo pi;
     pi.T = k * k;
@@ -2308,6 +2309,8 @@ inline PackInfo pack_info(int Cout, int Cin, int k) {
     pi.wsplit_floats = k == 3 ? (int64_t)pi.niter16 * 9 * 3 * pi.CoutP * 8 : 0;      // split-bf16 copy of the 3x3 weights (opt-in arithmetic)
     pi.nch32 = (Cin + 31) / 32;
     pi.wbf_floats = k == 3 ? (int64_t)pi.nch32 * 9 * 2 * pi.CoutP * 8 : 0;          // bf16 copy of the 3x3 weights (reduced-precision blocks)
+    pi.nch8 = (Cin + 7) / 8;
+    pi.wino_floats = k == 3 ? (int64_t)pi.nch8 * 16 * 2 * pi.CoutP * 4 : 0;          // Winograd-domain weights G g G^T (modconv_wino.inc)
     return pi;
 }
 
@@ -2496,7 +2499,7 @@ WsLayout ws_layout(int B, int Cin, int Cout, int H, int W, int k, int up) {
 TDGP_API int64_t tdgp_modconv_pack_bytes(int Cout, int Cin, int k) {
     if (Cout < 1 || Cin < 1 || (k != 1 && k != 3 && k != 5)) return -1;
     const PackInfo pi = pack_info(Cout, Cin, k);
-    return (pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats) * (int64_t)sizeof(float);
+    return (pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats + pi.wino_floats) * (int64_t)sizeof(float);
 }
 
 TDGP_API int tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int Cin, int k, tdgp_stream_t stream) {
@@ -2513,13 +2516,16 @@ TDGP_API int tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int C
     if (pi.wbf_floats > 0)
         TDGP_LAUNCH("pack_kernel", pack_bf16_kernel, dim3((int)min((int64_t)4096, cdiv64(pi.wbf_floats, 256))), dim3(256), 0, (hipStream_t)stream, weight,
                     (uint32_t*)(wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats), Cout, Cin, pi.CoutP, pi.nch32);
+    if (pi.wino_floats > 0)
+        TDGP_LAUNCH("pack_kernel", pack_wino_kernel, dim3((int)min((int64_t)4096, cdiv64(pi.wino_floats, 256))), dim3(256), 0, (hipStream_t)stream, weight,
+                    wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats, Cout, Cin, pi.CoutP, pi.nch8);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }
 
 static int g_conv_arith = 0;
 TDGP_API int tdgp_set_conv_arith(int mode) {
-    TDGP_CHECK(mode == 0 || mode == 1, TDGP_EINVAL, "set_conv_arith: mode %d (0 = fp32 MFMA, 1 = split-bf16 MFMA with fp32 accumulation)", mode);
+    TDGP_CHECK(mode >= 0 && mode <= 2, TDGP_EINVAL, "set_conv_arith: mode %d (0 = fp32 MFMA, Winograd F(2x2,3x3) where it pays; 1 = split-bf16 MFMA with fp32 accumulation; 2 = fp32 MFMA, direct sums only)", mode);
     const int old = g_conv_arith;
     g_conv_arith = mode;
     return old;
@@ -2528,6 +2534,18 @@ TDGP_API int tdgp_set_conv_arith(int mode) {
 
 TDGP_API int64_t tdgp_modconv2d_workspace_bytes(int B, int Cin, int Cout, int H, int W, int k, int up) {
     return ws_layout(B, Cin, Cout, H, W, k, up).total;
+}
+
+// Winograd kernel (modconv_wino.inc): which stride-1 3x3 layers take it.  TDGP_WINO_MIN_CIN: below it the direct kernel's staging
+// economy wins (K = Cin per position instead of 9 Cin); measured per layer, see DESIGN.md.
+#ifndef TDGP_WINO_MIN_CIN
+#define TDGP_WINO_MIN_CIN 64
+#endif
+inline size_t wino_lds_bytes(int) { return (size_t)(2 * 8192 + 2 * 8192 + 2 * 8 * 10 * 48 + 128) * 4; }
+inline bool wino_ok(int B, int Cin, int Cout, int H, int W) {
+    // (fewer than one block per CU: the direct kernel's split-K fills the chip better)
+    return (W & 31) == 0 && (H & 7) == 0 && (Cin & 7) == 0 && Cin >= TDGP_WINO_MIN_CIN && wino_lds_bytes(Cin) <= 160 * 1024 &&
+           (int64_t)(W >> 5) * (H >> 3) * B * cdiv(Cout, 64) >= 256;
 }
 
 TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styles, const float* dcoef_in, const float* noise, int64_t noise_bstride,
@@ -2599,6 +2617,15 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 static bool attr_set = false;
                 if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds - 2 * Cin * 4 + 2 * 2048 * 4)); attr_set = true; }
                 TDGP_LAUNCH("conv_mfma_kernel", conv3s_mfma_kernel, dim3((W >> 5) * cdiv(B * (H + 1), 8), cdiv(Cout, 64)), dim3(256), lds, s, q);
+            } else if (k == 3 && g_conv_arith == 0 && wino_ok(B, Cin, Cout, H, W) && out_layout == 0 && !skip) {
+                WinoParams q;
+                q.x = x; q.u = wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats; q.styles = styles; q.e = e;
+                q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W;
+                q.x_bytes = c.x_bytes; q.u_bytes = (uint32_t)(pi.wino_floats * 4);
+                const size_t lds = wino_lds_bytes(Cin);
+                static bool attr_set = false;
+                if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+                TDGP_LAUNCH("conv_wino_kernel", conv3_wino_kernel, dim3((W >> 5) * (H >> 3) * B, cdiv(Cout, 64)), dim3(512), lds, s, q);
             } else if (k == 3) {
                 if (Cout > 64) launch_conv3<3, 2, 2, 2, 2>(c, partial, wl.partial_floats, s);
                 else launch_conv3<3, 2, 2, 1, 4>(c, partial, wl.partial_floats, s);

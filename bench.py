@@ -44,14 +44,27 @@ PEAK_HBM_GBS = 8000.0
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
 
 
-def algorithmic_flops(cfg):
+# Fraction of the algorithmic (direct-sum) FLOP a kernel actually executes on the matrix pipe: Winograd F(2x2,3x3) multiplies 16 times
+# per 2x2 outputs where the direct sum multiplies 36 times.  `tflops` stays the algorithmic rate; `tflops_executed` is what
+# the MFMA roofline bounds.
+EXECUTED_FRACTION = {'conv_wino_kernel': 16.0 / 36.0}
+
+
+def winograd_takes(batch, cin, cout, r):
+    """Mirror of wino_ok() in 3dgp_amd/csrc/modconv.hip: which stride-1 3x3 layers the default arithmetic runs as Winograd."""
+    return batch is not None and r % 32 == 0 and cin % 8 == 0 and cin >= 64 and (r // 32) * (r // 8) * batch * ((cout + 63) // 64) >= 256
+
+
+def algorithmic_flops(cfg, batch=None):
     """Algorithmic FLOP per image of the MFMA kernels: 2 * MAC of every conv launch (stride-1 3x3 layers in
-    conv_mfma_kernel, the x2 layers in upconv_mfma_kernel, ToRGB in torgb_mfma_kernel); 5376 per field point.  With reduced-precision
+    conv_mfma_kernel -- or, with `batch` given, conv_wino_kernel for the layers the library runs as Winograd at that batch --, the x2
+    layers in upconv_mfma_kernel, ToRGB in torgb_mfma_kernel); 5376 per field point.  With reduced-precision
     blocks (BASELINE configs[4]) the 3x3 layers of those blocks run in conv_bf16_kernel / upconv_bf16_kernel and are priced against
     the bf16 MFMA peak.  -> {kernel label: (flop per image, launches per image batch, peak TFLOP/s)}"""
     ch = cfg.channels
     r16 = cfg.fp16_resolution
-    acc = dict(conv_mfma_kernel=[0, 0], upconv_mfma_kernel=[0, 0], torgb_mfma_kernel=[0, 0], conv_bf16_kernel=[0, 0], upconv_bf16_kernel=[0, 0])
+    acc = dict(conv_mfma_kernel=[0, 0], conv_wino_kernel=[0, 0], upconv_mfma_kernel=[0, 0], torgb_mfma_kernel=[0, 0], conv_bf16_kernel=[0, 0],
+               upconv_bf16_kernel=[0, 0])
     for i, r in enumerate(cfg.block_resolutions):
         c = ch[r]
         bf = r16 is not None and r >= r16
@@ -59,7 +72,7 @@ def algorithmic_flops(cfg):
             k = 'upconv_bf16_kernel' if bf else 'upconv_mfma_kernel'
             acc[k][0] += 2 * ch[r // 2] * c * 9 * (r // 2) ** 2   # stride-2 transposed conv: 9 taps per INPUT pixel
             acc[k][1] += 1
-        k = 'conv_bf16_kernel' if bf else 'conv_mfma_kernel'
+        k = 'conv_bf16_kernel' if bf else ('conv_wino_kernel' if winograd_takes(batch, c, c, r) else 'conv_mfma_kernel')
         acc[k][0] += 2 * c * c * 9 * r * r                         # conv1
         acc[k][1] += 1
         acc['torgb_mfma_kernel'][0] += 2 * c * cfg.plane_channels * r * r        # ToRGB 1x1
@@ -219,7 +232,7 @@ def main():
         kernels[k] = dict(ms_per_step=round(tot / nprof, 4), launches_per_step=v['launches'] // nprof, avg_ms=round(tot / max(v['launches'], 1), 5))
     kernels = dict(sorted(kernels.items(), key=lambda kv: -kv[1]['ms_per_step']))
     dominant = next(iter(kernels), None)
-    flops = algorithmic_flops(cfg)
+    flops = algorithmic_flops(cfg, args.batch if args.arith == 'f32' else None)
     # HBM bytes per launch and matrix-pipe busy from the committed PMC passes (tools/profile_round.sh -> profiles/pmc_latest.json);
     # only used when they were taken on this very workload.
     pmc, pmc_src = {}, None
@@ -233,7 +246,7 @@ def main():
         fl_img, launches_img, peak = flops[dominant]
         k = kernels[dominant]
         fl_per_launch = fl_img * args.batch / k['launches_per_step']
-        achieved = fl_per_launch / (k['avg_ms'] * 1e-3) / 1e12
+        achieved = fl_per_launch / (k['avg_ms'] * 1e-3) / 1e12 * EXECUTED_FRACTION.get(dominant, 1.0)      # what the matrix pipe executes
         pk = pmc.get(dominant, {})
         traffic = pk.get('hbm_bytes_per_launch')
         roofline = dict(kernel=dominant, bound='mfma', achieved=round(achieved, 3), peak=peak, unit='TFLOP/s',
@@ -246,6 +259,8 @@ def main():
             v.update(hbm_gbs=round(pk['hbm_bytes_per_launch'] / (v['avg_ms'] * 1e-3) / 1e9, 1), mfma_busy_pct=pk.get('mfma_busy_pct'))
         if k in flops and v['avg_ms'] > 0:
             v['tflops'] = round(flops[k][0] * args.batch / v['launches_per_step'] / (v['avg_ms'] * 1e-3) / 1e12, 2)
+            if k in EXECUTED_FRACTION:
+                v['tflops_executed'] = round(v['tflops'] * EXECUTED_FRACTION[k], 2)
     total_flop_img = sum(f for f, _, _ in flops.values())
     ms_step = elapsed / args.steps * 1e3
     whole = dict(flop_per_image=total_flop_img, achieved=round(total_flop_img * args.batch / (ms_step * 1e-3) / 1e12, 2), peak=PEAK_FP32_MFMA_TFLOPS,

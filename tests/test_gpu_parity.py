@@ -178,6 +178,51 @@ def test_modconv_oracle(tdgp, oracle, B, cin, cout, H, k, up):
     assert_close(N(y), ref, 1e-5, 'modconv', 1.0)
 
 
+@pytest.mark.parametrize('B,cin,cout,H,W,kw', [
+    (4, 64, 64, 64, 64, {}),                               # the smallest channel count that takes the Winograd kernel
+    (4, 136, 70, 64, 64, dict(clamp=0.7)),                 # 17 chunks (odd), Cout tail inside a 64-channel block, clamp
+    (2, 72, 130, 64, 128, dict(noise=False)),              # H != W, three output-channel blocks with a tail, no noise
+    (16, 64, 32, 32, 32, dict(styles=False)),              # one block column, unmodulated (Conv2dLayer form), Cout < 64
+])
+def test_modconv_winograd_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
+    """The Winograd F(2x2,3x3) kernel (default arithmetic for the large stride-1 3x3 layers, modconv_wino.inc) against the double-
+    accumulating oracle, and against the direct-sum kernel (`set_conv_arith(2)`) on the same call; the profiler names which ran."""
+    rs = np.random.RandomState(cin * 7 + cout)
+    x = rs.randn(B, cin, H, W).astype(np.float32)
+    w = rs.randn(cout, cin, 3, 3).astype(np.float32)
+    styles = kw.get('styles', True)
+    s = (1 + 0.5 * rs.randn(B, cin)).astype(np.float32) if styles else None
+    noise = (0.3 * rs.randn(H, W)).astype(np.float32) if kw.get('noise', True) else None
+    bias = (0.2 * rs.randn(cout)).astype(np.float32)
+    clamp = kw.get('clamp')
+    oracle.set_threads(min(64, __import__('os').cpu_count() or 1))
+    ref = oracle.modulated_conv2d(x, w, s if styles else np.ones([B, cin], np.float32), noise=noise,            # 2-D: one map for the batch
+                                  up=1, demodulate=styles, resample_filter=oracle.setup_filter([1, 3, 3, 1]))
+    ref = oracle.bias_act(ref, bias, act='lrelu', clamp=clamp)
+    M = tdgp.ops.modconv
+    pk = M._packed(T(w))
+    out = {}
+    for mode in (0, 2):
+        prev = tdgp._lib.set_conv_arith(mode)
+        tdgp._lib.profile_enable(True)
+        try:
+            y = M.modconv_forward(T(x), pk, None if s is None else T(s), noise=None if noise is None else T(noise), bias=T(bias), demodulate=styles,
+                                  act='lrelu', clamp=clamp)
+            torch.cuda.synchronize()
+            names = set(tdgp._lib.profile_report())
+        finally:
+            tdgp._lib.profile_enable(False)
+            tdgp._lib.set_conv_arith(prev)
+        out[mode] = (N(y), names)
+    assert 'conv_wino_kernel' in out[0][1] and 'conv_wino_kernel' not in out[2][1], (out[0][1], out[2][1])
+    scale = np.abs(ref).max()
+    e_w, e_d = np.abs(out[0][0] - ref).max() / scale, np.abs(out[2][0] - ref).max() / scale
+    report_parity(f'winograd 3x3 {cin}->{cout} @{H}x{W}', winograd_vs_oracle=e_w, direct_vs_oracle=e_d,
+                  winograd_vs_direct=np.abs(out[0][0] - out[2][0]).max() / scale)
+    assert e_d <= 5e-6, e_d
+    assert e_w <= 1e-5, e_w            # F(2x2,3x3) in fp32: a few ulp more than the direct sum (transforms add roundings), same order
+
+
 def test_fused_layers_oracle(tdgp, oracle):
     """SynthesisLayer / ToRGB+skip as single fused calls (bias, lrelu*sqrt2, x2 FIR skip, channel-last output)."""
     rs = np.random.RandomState(5)
@@ -624,6 +669,24 @@ def test_full_size_backbone_split_arith(tdgp, oracle, full_c3):
     oracle.set_threads(min(64, __import__('os').cpu_count() or 1))
     ref = oracle.synthesis_backbone(sd, cfg.to_dict(), N(ws)[:1], 'const')
     assert_close(a[:1].transpose(0, 1, 4, 2, 3).reshape(1, 96, 512, 512), ref, 1e-5, 'split tri-planes vs oracle', 1.0)
+
+
+def test_full_size_backbone_direct_sums(tdgp, oracle, full_c3):
+    """`set_conv_arith(2)` (direct fp32 sums in every 3x3 layer, no Winograd): tri-planes agree with the default run to fp32 rounding
+    and with the CPU oracle on one sample -- the two fp32 algorithms are interchangeable at the tolerance of the reduction rows."""
+    G, ws = full_c3['G'], full_c3['ws']
+    prev = tdgp._lib.set_conv_arith(2)
+    try:
+        planes = G.synthesis.tri_plane_decoder(ws, noise_mode='const', hwc=True)
+    finally:
+        tdgp._lib.set_conv_arith(prev)
+    a, b = N(planes.t), N(full_c3['planes'].t)
+    assert not np.array_equal(a, b)
+    assert_close(a, b, 5e-6, 'direct-sum vs default (Winograd) tri-planes', 1.0)
+    cfg, sd = full_c3['cfg'], full_c3['sd']
+    oracle.set_threads(min(64, __import__('os').cpu_count() or 1))
+    ref = oracle.synthesis_backbone(sd, cfg.to_dict(), N(ws)[:1], 'const')
+    assert_close(a[:1].transpose(0, 1, 4, 2, 3).reshape(1, 96, 512, 512), ref, 1e-5, 'direct-sum tri-planes vs oracle', 1.0)
 
 
 def test_full_size_renderer_strip_vs_oracle(tdgp, oracle, full_c3):
