@@ -155,6 +155,22 @@ __device__ __forceinline__ void field_body(const FieldParams& p) {
 
     const int l = lane_id();
     const int pt = l & 15, q = l >> 4;
+    // The table walk runs two waves per SIMD (256 registers each) and uses ~110: its MFMA A operands and the layer-1 bias stay in
+    // registers -- 48 + 4*MT LDS reads per 16-point tile fewer, and in this loop every instruction of any kind costs ~7 cycles of issue
+    // next to the MFMAs.  The generic kernel keeps reading them from LDS (its register budget is set by its other modes).
+    constexpr bool REGW = WALK && MT * FQ <= 32;       // (wider MLPs would spill: they keep the LDS form)
+    float a0r[REGW ? MT * FQ : 1], a1r[REGW ? MT * 4 : 1];
+    f32x4 b0r[REGW ? MT : 1];
+    if constexpr (REGW) {
+#pragma unroll
+        for (int i = 0; i < MT * FQ; i++) a0r[i] = a0s[i * 64 + l];
+#pragma unroll
+        for (int i = 0; i < MT * 4; i++) a1r[i] = a1s[i * 64 + l];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) b0r[mt] = *(const f32x4*)(b0s + mt * 16 + 4 * q);
+    }
+    auto a0 = [&](int i) -> float { if constexpr (REGW) return a0r[i]; else return a0s[i * 64 + l]; };
+    auto a1 = [&](int i) -> float { if constexpr (REGW) return a1r[i]; else return a1s[i * 64 + l]; };
     const float sx = (float)(p.W - 1) / 2.f, sy = (float)(p.H - 1) / 2.f;
     // layer-2 bias: in registers, not reloaded per tile (a load there drags a vmcnt(0) into the loop); it is the initial accumulator of
     // the q == 0 lanes, so the cross-lane sum over q adds it exactly once
@@ -250,7 +266,7 @@ __device__ __forceinline__ void field_body(const FieldParams& p) {
     };
     auto mlp_begin = [&](f32x4* acc) {
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) acc[mt] = *(const f32x4*)(b0s + mt * 16 + 4 * q);    // addmm(b, x, W^T): the bias (rows 4q..4q+3 of tile mt,
+        for (int mt = 0; mt < MT; mt++) { if constexpr (REGW) acc[mt] = b0r[mt]; else acc[mt] = *(const f32x4*)(b0s + mt * 16 + 4 * q); }    // addmm(b, x, W^T): the bias (rows 4q..4q+3 of tile mt,
                                                                                              // one 16-B LDS read, not 4*MT resident registers) is the initial accumulator
     };
     auto mlp_pass = [&](f32x4* acc, int ps, const float* gp) {     // layer 1 on the matrix cores: h^T[hid x 16 pts] += W0s[:, pass] * g^T[pass]
@@ -258,7 +274,7 @@ __device__ __forceinline__ void field_body(const FieldParams& p) {
 #pragma unroll
         for (int i = 0; i < 2 * PP; i++)
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0s[(mt * FQ + ps * 2 * PP + i) * 64 + l], gp[i], acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0(mt * FQ + ps * 2 * PP + i), gp[i], acc[mt], 0, 0, 0);
     };
     auto mlp_finish = [&](const f32x4* acc) -> float4 {
         // lrelu(0.2) lane-locally (each lane owns 4*MT hidden units of ITS point).  Layer 2 (hid -> 4) as sixteen 4x4x1
@@ -279,7 +295,7 @@ __device__ __forceinline__ void field_body(const FieldParams& p) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const float h = __builtin_amdgcn_fmed3f(acc[mt][r], sc[r], 3.4028234663852886e38f);
-                o4[r & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1s[(mt * 4 + r) * 64 + l], h, o4[r & 1], 0, 0, 0);
+                o4[r & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1(mt * 4 + r), h, o4[r & 1], 0, 0, 0);
             }
         }
         const f32x2 s01 = (f32x2){o4[0][0], o4[0][1]} + (f32x2){o4[1][0], o4[1][1]}, s23 = (f32x2){o4[0][2], o4[0][3]} + (f32x2){o4[1][2], o4[1][3]};
