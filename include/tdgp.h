@@ -8,7 +8,7 @@
  *   - every function returns 0 on success or a negative TDGP_E* code; tdgp_last_error() returns a
  *     thread-local message.  Nothing throws across the ABI;
  *   - fp32 unless a `dtype` argument says otherwise (TDGP_F32 / TDGP_F16 / TDGP_BF16);
- *   - re-entrant.  Process-wide state is limited to: the init-once kernel tables, the two opt-in switches tdgp_set_conv_arith (arithmetic of
+ *   - re-entrant.  Process-wide state is limited to: the init-once kernel tables, the two switches tdgp_set_conv_arith (algorithm of
  *     the large 3x3 layers; default 0 = fp32 MFMA) and tdgp_profile_enable (per-kernel event timing; default off), and the launch
  *     geometry cached per kernel instantiation (resident blocks per CU).  Nothing else is remembered between calls.
  *
@@ -146,12 +146,18 @@ int     tdgp_cast_f32_bf16(const float* x, void* y_bf16, int64_t n, tdgp_stream_
 int     tdgp_conv_transpose2d_x2(const float* x, const void* wpack, const float* styles, float* y, int B, int Cin, int Cout,
                                  int H, int W, void* workspace, int64_t workspace_bytes, tdgp_stream_t stream);
 
-/* Arithmetic of the large 3x3 convolutions of tdgp_modconv2d -- stride 1 (W % 32 == 0) and the x2 transposed form, launches of
- * >= 256 tiles with styles present and Cin % 16 == 0: 0 (default) = fp32 MFMA; 1 = every fp32 operand split into three bf16
- * pieces, six piece products per multiply on the bf16 MFMA with fp32 accumulation (fp32-grade results, <= 4e-6 of the exact
- * layer output, not bit-identical to mode 0; layers outside those conditions keep the fp32 kernels).  Process-wide; returns the
- * previous mode (negative on error).  No counterpart in the reference: its convolutions are cuDNN fp32 with TF32 disabled
- * (training_loop.py:76-77). */
+/* Arithmetic of the large 3x3 convolutions of tdgp_modconv2d.  All modes are fp32 in, fp32 accumulate, fp32 out:
+ *   0 (default) = fp32 MFMA; stride-1 layers with W % 32 == 0, H % 8 == 0, Cin % 8 == 0, Cin >= 64 whose launch has at least one
+ *       64-channel x 64-tile block per CU run as Winograd F(2x2,3x3) -- the convolution's exact algebra with 16 instead of 36
+ *       multiplies per 2x2 outputs, transforms and products in fp32 (what cuDNN selects for the reference's fp32 3x3 convolutions,
+ *       training_loop.py:76-77 keeps TF32 off); measured as close to the exactly rounded result as the direct sum (<= 5e-6 of the
+ *       tensor scale).  Every other layer: direct sums;
+ *   2 = fp32 MFMA, direct sums in every layer (the summation structure of a plain convolution; results differ from mode 0 in the last
+ *       bits only);
+ *   1 = (stride 1 with W % 32 == 0 and the x2 transposed form, launches of >= 256 tiles with styles present and Cin % 16 == 0) every
+ *       fp32 operand split into three bf16 pieces, six piece products per multiply on the bf16 MFMA with fp32 accumulation
+ *       (fp32-grade results, <= 4e-6 of the exact layer output; layers outside those conditions keep the fp32 kernels).
+ * Process-wide; returns the previous mode (negative on error). */
 int     tdgp_set_conv_arith(int mode);
 
 /* Demodulation coefficients d[b,o] = rsqrt(sum_c s[b,c]^2 * sum_tap W[o,c,tap]^2 + 1e-8) (networks_stylegan2.py:62) of SEVERAL
