@@ -2092,6 +2092,18 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
         const int oy0 = ty * FIR_TH, ox0 = tx * FIR_TW;
         const float* zp = p.z + ((int64_t)b * p.C + c) * 2 * p.GS2;
         const int nrows = min(FIR_TH, p.OH - oy0) + 3;
+        // side inputs of this thread's outputs, requested together with the window so that their latency is not paid after the barrier
+        const int lx = (threadIdx.x % CW) * 4;
+        const float d = p.dcoef ? p.dcoef[b * p.C + c] : 1.f;
+        const float bv = p.bias ? (YBF ? fir_round_bf16(p.bias[c]) : p.bias[c]) : 0.f;
+        const bool nz_vec = p.noise && ox0 + lx + 3 < p.OW && (p.OW & 3) == 0;
+        float4 nzv[FIR_TH / RPP];
+#pragma unroll
+        for (int hrow = 0; hrow < FIR_TH / RPP; hrow++) {
+            const int oy = oy0 + threadIdx.x / CW + hrow * RPP;
+            nzv[hrow] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nz_vec && oy < p.OH) nzv[hrow] = *(const float4*)(p.noise + b * p.noise_bstride + (int64_t)oy * p.OW + ox0 + lx);
+        }
         __syncthreads();
         if (p.ksplit == 1 && !TDGP_AB_FIR_SERIAL) {
             // no split-K slices to add: all (at most 3) window vectors of a thread are put in flight before the first is written to
@@ -2132,9 +2144,6 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
             *(float4*)&zt[ry * ZP + 4 * j] = v;
         }
         __syncthreads();
-        const int lx = (threadIdx.x % CW) * 4;
-        const float d = p.dcoef ? p.dcoef[b * p.C + c] : 1.f;
-        const float bv = p.bias ? (YBF ? fir_round_bf16(p.bias[c]) : p.bias[c]) : 0.f;
 #pragma unroll
         for (int hrow = 0; hrow < FIR_TH / RPP; hrow++) {
             const int ly = threadIdx.x / CW + hrow * RPP;
@@ -2159,7 +2168,11 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
                 for (int o = 0; o < 4; o++) {
                     float v = acc[o] * d;
                     if (YBF) v = fir_round_bf16(v);
-                    if (p.noise && ox0 + lx + o < p.OW) { v = v + p.noise[b * p.noise_bstride + (int64_t)oy * p.OW + ox0 + lx + o]; if (YBF) v = fir_round_bf16(v); }
+                    if (p.noise && ox0 + lx + o < p.OW) {
+                        const float nq[4] = {nzv[hrow].x, nzv[hrow].y, nzv[hrow].z, nzv[hrow].w};
+                        v = v + (nz_vec ? nq[o] : p.noise[b * p.noise_bstride + (int64_t)oy * p.OW + ox0 + lx + o]);
+                        if (YBF) v = fir_round_bf16(v);
+                    }
                     v = v + bv;
                     v = act_apply(v, p.act, p.alpha) * p.gain;
                     if (p.clamp >= 0.f) v = v < -p.clamp ? -p.clamp : (v > p.clamp ? p.clamp : v);
@@ -2409,10 +2422,14 @@ void launch_upconv(const UpParams& u, hipStream_t s) {
     TDGP_LAUNCH("upconv_mfma_kernel", (upconv_mfma_kernel<MTW, NTW, WM, WN, DEEP>), grid, dim3(64 * NW), lds, s, u);
 }
 
+// timing experiment (tools/dev/build_variant.sh): extra dynamic LDS per block = fewer resident blocks per CU.  0 in the shipped library.
+#ifndef TDGP_RGB_LDS_PAD
+#define TDGP_RGB_LDS_PAD 0
+#endif
 template <int MT, bool RESIDENT, bool FAST, bool XBF>
 void launch_torgb_v(const RgbParams& r, hipStream_t s) {
     constexpr int BM = 32 * MT;
-    const size_t lds = (size_t)(16 * BM * 4 + 16 * 128 * 4 + BM) * sizeof(float);
+    const size_t lds = (size_t)(16 * BM * 4 + 16 * 128 * 4 + BM) * sizeof(float) + TDGP_RGB_LDS_PAD;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)torgb_mfma_kernel<MT, RESIDENT, FAST, XBF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -179,10 +179,10 @@ def test_modconv_oracle(tdgp, oracle, B, cin, cout, H, k, up):
 
 
 @pytest.mark.parametrize('B,cin,cout,H,W,kw', [
-    (4, 64, 64, 64, 64, {}),                               # the smallest channel count that takes the Winograd kernel
-    (4, 136, 70, 64, 64, dict(clamp=0.7)),                 # 17 chunks (odd), Cout tail inside a 64-channel block, clamp
-    (2, 72, 130, 64, 128, dict(noise=False)),              # H != W, three output-channel blocks with a tail, no noise
-    (16, 64, 32, 32, 32, dict(styles=False)),              # one block column, unmodulated (Conv2dLayer form), Cout < 64
+    (16, 64, 64, 64, 64, {}),                              # the smallest channel count that takes the Winograd kernel; exactly 256 blocks
+    (8, 136, 70, 64, 64, dict(clamp=0.7)),                 # 17 chunks (odd), Cout tail inside a 64-channel block, clamp
+    (3, 72, 130, 64, 128, dict(noise=False)),              # H != W, three output-channel blocks with a tail, no noise
+    (16, 64, 32, 64, 64, dict(styles=False)),              # unmodulated (Conv2dLayer form), Cout < 64
 ])
 def test_modconv_winograd_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
     """The Winograd F(2x2,3x3) kernel (default arithmetic for the large stride-1 3x3 layers, modconv_wino.inc) against the double-
@@ -198,6 +198,7 @@ def test_modconv_winograd_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
     oracle.set_threads(min(64, __import__('os').cpu_count() or 1))
     ref = oracle.modulated_conv2d(x, w, s if styles else np.ones([B, cin], np.float32), noise=noise,            # 2-D: one map for the batch
                                   up=1, demodulate=styles, resample_filter=oracle.setup_filter([1, 3, 3, 1]))
+    scale = np.abs(oracle.bias_act(ref, bias, act='lrelu')).max()          # errors are measured against the un-clamped output range
     ref = oracle.bias_act(ref, bias, act='lrelu', clamp=clamp)
     M = tdgp.ops.modconv
     pk = M._packed(T(w))
@@ -215,7 +216,6 @@ def test_modconv_winograd_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
             tdgp._lib.set_conv_arith(prev)
         out[mode] = (N(y), names)
     assert 'conv_wino_kernel' in out[0][1] and 'conv_wino_kernel' not in out[2][1], (out[0][1], out[2][1])
-    scale = np.abs(ref).max()
     e_w, e_d = np.abs(out[0][0] - ref).max() / scale, np.abs(out[2][0] - ref).max() / scale
     report_parity(f'winograd 3x3 {cin}->{cout} @{H}x{W}', winograd_vs_oracle=e_w, direct_vs_oracle=e_d,
                   winograd_vs_direct=np.abs(out[0][0] - out[2][0]).max() / scale)
