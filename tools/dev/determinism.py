@@ -46,19 +46,3 @@ for cfgname, B in (('c3', 2), ('c3', 8), ('c4', 1)):
         for p in G.parameters(): p.requires_grad_(False)
     del G
     torch.cuda.empty_cache()
-
-# discriminator forward / backward / R1
-D = t.discriminator.seeded_discriminator(t.discriminator.DiscriminatorConfig(img_resolution=64, c_dim=0), seed=0).cuda() if hasattr(t.discriminator, 'seeded_discriminator') else None
-if D is not None:
-    img = torch.randn(4, D.cfg.img_channels if hasattr(D, 'cfg') else 3, 64, 64, device='cuda')
-    try:
-        def dfb():
-            x = img.clone().requires_grad_(True)
-            out = D(x, torch.zeros(4, 0, device='cuda'))
-            g, = torch.autograd.grad(out.sum(), x, create_graph=True)
-            pen = g.square().sum()
-            gp = torch.autograd.grad(pen, [p for p in D.parameters()], allow_unused=True)
-            return [out.detach(), g.detach()] + [q for q in gp if q is not None]
-        rep('D forward + R1', dfb, 10)
-    except Exception as e:
-        print('D stress skipped:', repr(e)[:200])
