@@ -2076,7 +2076,9 @@ __device__ __forceinline__ uint32_t fir_pack_bf16(float a, float b) {
 }
 // YBF: bf16 output with the reference's rounding points behind the (fp32, unrounded) transposed-convolution intermediate: FIR output,
 // + noise, bias (itself rounded) / activation / gain / clamp.
-template <int FIR_TH, int FIR_TW, bool YBF = false>
+// LRELU: the generator's form (leaky ReLU with 0 <= alpha <= 1, no clamp) decided at compile time -- the pass is instruction-bound,
+// and the run-time activation switch + clamp test per output were a fifth of its output stage.
+template <int FIR_TH, int FIR_TW, bool YBF = false, bool LRELU = false>
 __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
     constexpr int CW = FIR_TW / 4, RPP = 256 / CW;                 // threads per output row, rows per pass
     constexpr int ZP = FIR_TW + 8;                  // window columns ox0-4 .. ox0+67, fetched as aligned 16-B vectors (P2 % 4 == 0)
@@ -2174,8 +2176,11 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
                         if (YBF) v = fir_round_bf16(v);
                     }
                     v = v + bv;
-                    v = act_apply(v, p.act, p.alpha) * p.gain;
-                    if (p.clamp >= 0.f) v = v < -p.clamp ? -p.clamp : (v > p.clamp ? p.clamp : v);
+                    if constexpr (LRELU) v = __builtin_fmaxf(v, v * p.alpha) * p.gain;        // == (v > 0 ? v : alpha v) * gain for 0 <= alpha <= 1, sign of zero included
+                    else {
+                        v = act_apply(v, p.act, p.alpha) * p.gain;
+                        if (p.clamp >= 0.f) v = v < -p.clamp ? -p.clamp : (v > p.clamp ? p.clamp : v);
+                    }
                     out[o] = v;
                 }
                 if constexpr (YBF) {
@@ -2703,7 +2708,10 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         f.act = act; f.alpha = alpha; f.gain = gain; f.clamp = clamp;
         if (f.OW >= 128 && !TDGP_AB_FIR_SERIAL) {
             const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, 16) * cdiv(f.OW, 128);
-            TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<16, 128>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
+            if (f.act == 3 && f.clamp < 0.f && f.alpha >= 0.f && f.alpha <= 1.f)
+                TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<16, 128, false, true>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
+            else
+                TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<16, 128>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
         } else {
             const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, 32) * cdiv(f.OW, 64);
             TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<32, 64>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
