@@ -130,6 +130,7 @@ template <int ACT = 0>
 __device__ __forceinline__ float finish_act(const EpiParams& e, float v) {
     if constexpr (ACT == 1) return v * e.gain;
     else if constexpr (ACT == 3) return (v > 0.f ? v : v * e.alpha) * e.gain;
+    else if constexpr (ACT == 4) return __builtin_amdgcn_fmed3f(__builtin_fmaxf(v, v * e.alpha) * e.gain, -e.clamp, e.clamp);      // lrelu (0 <= alpha <= 1), clamp >= 0
     else {
         v = act_apply(v, e.act, e.alpha) * e.gain;
         if (e.clamp >= 0.f) v = v < -e.clamp ? -e.clamp : (v > e.clamp ? e.clamp : v);
@@ -138,7 +139,7 @@ __device__ __forceinline__ float finish_act(const EpiParams& e, float v) {
 }
 // which specialisation a launch can use (3 = leaky ReLU written as max(v, alpha * v): needs 0 <= alpha <= 1)
 __device__ __forceinline__ int epi_variant(const EpiParams& e) {
-    if (e.clamp >= 0.f) return 0;
+    if (e.clamp >= 0.f) return (e.act == 3 && e.alpha >= 0.f && e.alpha <= 1.f) ? 4 : 0;       // (4: only where a caller asks for it, see epi_variant_noclamp)
     if (e.act == 1) return 1;
     return (e.act == 3 && e.alpha >= 0.f && e.alpha <= 1.f) ? 3 : 0;
 }
@@ -2076,7 +2077,7 @@ __device__ __forceinline__ uint32_t fir_pack_bf16(float a, float b) {
 }
 // YBF: bf16 output with the reference's rounding points behind the (fp32, unrounded) transposed-convolution intermediate: FIR output,
 // + noise, bias (itself rounded) / activation / gain / clamp.
-// LRELU: the generator's form (leaky ReLU with 0 <= alpha <= 1, no clamp) decided at compile time -- the pass is instruction-bound,
+// LRELU: the generator's form (leaky ReLU with 0 <= alpha <= 1; the clamp, if any, one v_med3) decided at compile time -- the pass is instruction-bound,
 // and the run-time activation switch + clamp test per output were a fifth of its output stage.
 template <int FIR_TH, int FIR_TW, bool YBF = false, bool LRELU = false>
 __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
@@ -2176,7 +2177,10 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
                         if (YBF) v = fir_round_bf16(v);
                     }
                     v = v + bv;
-                    if constexpr (LRELU) v = __builtin_fmaxf(v, v * p.alpha) * p.gain;        // == (v > 0 ? v : alpha v) * gain for 0 <= alpha <= 1, sign of zero included
+                    if constexpr (LRELU) {
+                        v = __builtin_fmaxf(v, v * p.alpha) * p.gain;        // == (v > 0 ? v : alpha v) * gain for 0 <= alpha <= 1, sign of zero included
+                        if (p.clamp >= 0.f) v = __builtin_amdgcn_fmed3f(v, -p.clamp, p.clamp);
+                    }
                     else {
                         v = act_apply(v, p.act, p.alpha) * p.gain;
                         if (p.clamp >= 0.f) v = v < -p.clamp ? -p.clamp : (v > p.clamp ? p.clamp : v);
@@ -2708,7 +2712,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         f.act = act; f.alpha = alpha; f.gain = gain; f.clamp = clamp;
         if (f.OW >= 128 && !TDGP_AB_FIR_SERIAL) {
             const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, 16) * cdiv(f.OW, 128);
-            if (f.act == 3 && f.clamp < 0.f && f.alpha >= 0.f && f.alpha <= 1.f)
+            if (f.act == 3 && f.alpha >= 0.f && f.alpha <= 1.f)
                 TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<16, 128, false, true>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
             else
                 TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<16, 128>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
@@ -2804,7 +2808,10 @@ TDGP_API int tdgp_modconv2d_bf16(const void* x, const void* wpack, const float* 
         f.act = act; f.alpha = alpha; f.gain = gain; f.clamp = clamp;
         if (f.OW >= 128) {
             const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, 16) * cdiv(f.OW, 128);
-            TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<16, 128, true>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
+            if (f.act == 3 && f.alpha >= 0.f && f.alpha <= 1.f)
+                TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<16, 128, true, true>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
+            else
+                TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<16, 128, true>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
         } else {
             const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, 32) * cdiv(f.OW, 64);
             TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<32, 64, true>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
