@@ -344,6 +344,32 @@ __device__ __forceinline__ void wave_bitonic_sort(float& key, int& idx) {
     }
 }
 
+// The same network over 128 (key, index) pairs, two per lane (element e = 64 c + lane): 28 stages, the j = 64 stage is a compare-exchange
+// inside the lane.  For 64 < N <= 128 fine samples (BASELINE configs[4]: 96) instead of the brute-force rank (N broadcasts x 2 slots).
+__device__ __forceinline__ void wave_bitonic_sort2(float (&key)[2], int (&idx)[2]) {
+    const int l = lane_id();
+#pragma unroll
+    for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j == 64) {                                  // k = 128: ascending everywhere; slot 0 keeps the smaller
+                const bool less1 = key[1] < key[0] || (key[1] == key[0] && idx[1] < idx[0]);
+                if (less1) { const float tk = key[0]; key[0] = key[1]; key[1] = tk; const int ti = idx[0]; idx[0] = idx[1]; idx[1] = ti; }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const float pk = __shfl_xor(key[c], j, 64);
+                    const int pi = __shfl_xor(idx[c], j, 64);
+                    const bool asc = k == 128 ? true : (k == 64 ? c == 0 : ((l & k) == 0));     // (e & k) == 0: bit 6 of e is the slot, bit 7 is never set
+                    const bool keep_min = ((l & j) == 0) == asc;
+                    const bool partner_less = pk < key[c] || (pk == key[c] && pi < idx[c]);
+                    if (partner_less == keep_min) { key[c] = pk; idx[c] = pi; }
+                }
+            }
+        }
+    }
+}
+
 // fused: coarse march (s-space) -> importance sampling -> fine depths (t-space), WRITTEN IN ASCENDING DEPTH ORDER.
 // The reference leaves the fine samples in draw order and sorts coarse+fine together later (unify_samples); sorting the
 // fine list here (stable, by (t, draw index)) changes nothing in that final order but makes the j-th fine sample of
@@ -395,6 +421,20 @@ __global__ __launch_bounds__(256) void importance_from_coarse_kernel(const float
 #if TDGP_RAY_ABL & 1
         if (l == 0 && (r == 1000 || r == 200000)) printf("importance ray %lld: load %lld march %lld importance %lld sort %lld store %lld\n", (long long)r, tph[0], tph[1], tph[2], tph[3], tph[4]);
 #endif
+        return;
+    }
+    if (N <= 128) {                 // two samples per lane
+        float key[2] = {tkey[l], l + 64 < N ? tkey[l + 64] : INFINITY};
+        int idx[2] = {l, l + 64};
+        wave_bitonic_sort2(key, idx);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int pos = l + 64 * c;
+            if (pos < N) {
+                tfine[r * N + pos] = key[c];
+                if (fine_perm) fine_perm[r * N + pos] = idx[c];
+            }
+        }
         return;
     }
     int rank[MAXS / 64];

@@ -465,6 +465,34 @@ def test_fused_chain_equals_op_level_chain(tdgp):
         assert_close(N(wsum), N(w2.sum(2)), 1e-6, 'weights.sum', 1.0)
 
 
+@pytest.mark.parametrize('S', [16, 48, 64, 96, 128])
+def test_fused_fine_samples_come_out_sorted(tdgp, S):
+    """importance_from_coarse writes the fine samples depth-sorted (lane sort for N <= 64, the two-per-lane network for N <= 128, brute
+    force beyond) and merge_composite's fast path relies on it -- it falls back to a brute-force rank when the list is NOT sorted, so a
+    broken sort costs time, not correctness, and only this test sees it."""
+    rs = np.random.RandomState(S)
+    B, F, H, hid, hw = 1, 8, 32, 16, 16
+    planes = T(rs.randn(B, 3 * F, H, H))
+    mlp = _mlp(tdgp, rs.randn(hid, F), 0.3 * rs.randn(hid), rs.randn(4, hid), 0.3 * rs.randn(4), 'classical')
+    cam = dict(angles=T([[0.3, 1.2, 0.0]]), radius=T([1.0]), look_at=T(np.zeros((1, 3))))
+    ro, rd = tdgp.renderer.sample_rays(tdgp.renderer.compute_cam2world_matrix(cam), T([30.0]), (hw, hw))
+    R = hw * hw
+    opts = dict(box_size=1.0, num_proposal_steps=S, num_fine_steps=S, clamp_mode='softplus', use_inf_depth=True, ray_start=0.75, ray_end=1.25,
+                u_coarse=T(rs.rand(B, R, S, 1)), u_fine=T(rs.rand(B * R, S)))
+    rend = tdgp.renderer.ImportanceRenderer('classical')
+    _, aux = rend(planes, mlp, ro, rd, opts, return_intermediates=True)
+    tf = N(aux['tdist_fine']).reshape(R, S)
+    assert (np.diff(tf, axis=1) >= 0).all(), 'fine samples not ascending'
+    # the same multiset as the draw-order samples, and fine_perm names the draw each slot came from
+    sf = N(aux['sdist_fine']).reshape(R, S)
+    t_draw = (sf * np.float32(1.25) + (np.float32(1.0) - sf) * np.float32(0.75)).astype(np.float32)
+    fp = N(aux['fine_perm']).reshape(R, S).astype(np.int64)
+    assert (np.sort(fp, axis=1) == np.arange(S)[None]).all()
+    np.testing.assert_allclose(np.take_along_axis(t_draw, fp, axis=1), tf, rtol=0, atol=1e-6)
+    order = np.lexsort((np.broadcast_to(np.arange(S), (R, S)), np.take_along_axis(t_draw, fp, axis=1)))      # already sorted: identity
+    assert (order == np.arange(S)[None]).all()
+
+
 # ------------------------------------------------------------------------------------------------ end to end
 
 def _gen(tdgp, cfg, seed):
