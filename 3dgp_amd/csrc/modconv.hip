@@ -2643,7 +2643,8 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 static bool attr_set = false;
                 if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds - 2 * Cin * 4 + 2 * 2048 * 4)); attr_set = true; }
                 TDGP_LAUNCH("conv_mfma_kernel", conv3s_mfma_kernel, dim3((W >> 5) * cdiv(B * (H + 1), 8), cdiv(Cout, 64)), dim3(256), lds, s, q);
-            } else if (k == 3 && g_conv_arith == 0 && wino_ok(B, Cin, Cout, H, W) && out_layout == 0 && !skip) {
+            } else if (k == 3 && g_conv_arith == 0 && wino_ok(B, Cin, Cout, H, W) && out_layout == 0 && !skip && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 &&
+                       (!noise || (((uintptr_t)noise & 7) == 0 && (noise_bstride & 1) == 0))) {        // 16-byte activation loads, 8-byte noise loads / stores
                 WinoParams q;
                 q.x = x; q.u = wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats; q.styles = styles; q.e = e;
                 q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W;
