@@ -148,7 +148,7 @@ def main():
     ap.add_argument('--chunk', type=int, default=-1, help='samples per pass through the high-resolution blocks + renderer (Infinity-Cache-sized working set); '
                                                            '0 = whole batch through every kernel; -1 = the package default')
     ap.add_argument('--chunk-from', type=int, default=0, help='first block resolution that runs chunked (0 = the package default)')
-    ap.add_argument('--arith', default='f32', choices=['f32', 'split'],
+    ap.add_argument('--arith', default='f32', choices=['f32', 'direct', 'split'],
                     help="arithmetic of the large 3x3 convolutions: f32 = fp32 MFMA (default, the reported metric); split = opt-in 3 x bf16 split operands, "
                          "6 piece products, fp32 accumulation (fp32-grade results; reported with dtype 'bf16x3->f32' and never mixed with the default line)")
     args = ap.parse_args()
@@ -163,6 +163,8 @@ def main():
     tdgp._lib.load()                       # the HIP library must be there: no fallback
     if args.arith == 'split':
         tdgp._lib.set_conv_arith(1)
+    elif args.arith == 'direct':            # fp32 MFMA with direct sums in every 3x3 layer (no Winograd): the A/B of the default
+        tdgp._lib.set_conv_arith(2)
 
     cfg = getattr(tdgp.config, f'config_{args.config}')()
     if args.depth_adaptor:
@@ -287,7 +289,7 @@ def main():
             'value': round(total_imgs / elapsed, 3), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': ('bf16 (backbone blocks >= %d^2: bf16 activations + weights, fp32 accumulate), f32 elsewhere' % cfg.fp16_resolution) if cfg.fp16_resolution
-                     else ('f32' if args.arith == 'f32' else 'bf16x3->f32 (3x3 and x2 layers), f32 elsewhere'), 'data': 'synthetic',
+                     else ('f32' if args.arith in ('f32', 'direct') else 'bf16x3->f32 (3x3 and x2 layers), f32 elsewhere'), 'data': 'synthetic',
             'config': {'workload': f'{names[args.config]}, {cfg.num_ray_steps}(+{cfg.num_ray_steps}) ray steps, cmax {cfg.cmax}, '
                                    f'c_dim {cfg.c_dim}, tri-plane {cfg.tri_plane_res}^2 x {cfg.plane_channels}, full HIP path',
                        'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'img_resolution': cfg.img_resolution,
