@@ -2084,14 +2084,17 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
     constexpr int CW = FIR_TW / 4, RPP = 256 / CW;                 // threads per output row, rows per pass
     constexpr int ZP = FIR_TW + 8;                  // window columns ox0-4 .. ox0+67, fetched as aligned 16-B vectors (P2 % 4 == 0)
     __shared__ __attribute__((aligned(16))) float zt[(FIR_TH + 3) * ZP];
-    const int tilesX = (p.OW + FIR_TW - 1) / FIR_TW, tilesY = (p.OH + FIR_TH - 1) / FIR_TH;
-    const int64_t ntiles = (int64_t)p.B * p.C * tilesY * tilesX;
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int tx = (int)(t % tilesX);
-        int64_t r = t / tilesX;
+    const uint32_t tilesX = (uint32_t)(p.OW + FIR_TW - 1) / FIR_TW, tilesY = (uint32_t)(p.OH + FIR_TH - 1) / FIR_TH;
+    const uint32_t ntiles = (uint32_t)p.B * p.C * tilesY * tilesX;          // < 2^31 (host check)
+    // tile index -> (sample, channel, tile row, tile column) in 32-bit unsigned arithmetic on the scalar unit: the index is wave-uniform, and as
+    // 64-bit divisions this decomposition was the largest single item of the pass's instruction count (SQ counters: 48 vector instructions per output)
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint32_t tu = __builtin_amdgcn_readfirstlane(t);
+        const int tx = (int)(tu % tilesX);
+        uint32_t r = tu / tilesX;
         const int ty = (int)(r % tilesY); r /= tilesY;
-        const int c = (int)(r % p.C);
-        const int b = (int)(r / p.C);
+        const int c = (int)(r % (uint32_t)p.C);
+        const int b = (int)(r / (uint32_t)p.C);
         const int oy0 = ty * FIR_TH, ox0 = tx * FIR_TW;
         const float* zp = p.z + ((int64_t)b * p.C + c) * 2 * p.GS2;
         const int nrows = min(FIR_TH, p.OH - oy0) + 3;
