@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('TDGP_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libtdgp_hip.so')     # override: an alternative build of the same ABI
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libtdgp_hip.so')     # the one library of the product; tests / tools/dev rebind this attribute before load()
 
 P = c_void_p
 _PROTOTYPES = {

@@ -4,8 +4,8 @@ cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 for rep in 1 2; do
   for v in default "$@"; do
-    if [ "$v" == default ]; then unset TDGP_LIB_PATH; else export TDGP_LIB_PATH=tools/dev/variants/$v.so; fi
-    timeout 200 python bench.py --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null | tail -1 | python -c "
+    if [ "$v" == default ]; then L=default; else L=tools/dev/variants/$v.so; fi
+    timeout 200 python tools/dev/with_lib.py $L bench.py --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 k = d['kernels']

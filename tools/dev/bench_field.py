@@ -1,5 +1,5 @@
 """Renderer-only timing at the C3 shape (random planes): per-kernel min/max ms through the library's event hooks.
-   python tools/dev/bench_field.py [B]            (TDGP_LIB_PATH selects a variant library built by tools/dev/build_variant.sh)"""
+   python tools/dev/bench_field.py [B]            (variant libraries: python tools/dev/with_lib.py <so> tools/dev/bench_field.py ...)"""
 import importlib
 import os
 import sys
@@ -30,4 +30,4 @@ for _ in range(reps):
 torch.cuda.synchronize()
 r = t._lib.profile_report()
 t._lib.profile_enable(False)
-print('B', B, os.environ.get('TDGP_LIB_PATH', 'default'), {k: (round(v['min_ms'], 3), round(v['avg_ms'], 3)) for k, v in r.items()})
+print('B', B, t._lib.LIB_PATH, {k: (round(v['min_ms'], 3), round(v['avg_ms'], 3)) for k, v in r.items()})
