@@ -73,7 +73,8 @@ class FeatureGatherer:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 dist.all_gather_into_tensor(out, y, group=self.group)
-            y.record_stream(self.stream)
+            y.record_stream(self.stream)            # both blocks were allocated on the caller's stream and are used on the side stream:
+            out.record_stream(self.stream)          # the caching allocator must not hand them out again before the collective is done
         else:
             dist.all_gather_into_tensor(out, y, group=self.group)
         self._pending = (out.view(self.world, y.shape[0], y.shape[1]), self.stream)

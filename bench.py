@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generator-forward throughput on MI355X: img/s at 256^2, 64 ray steps (BASELINE.json metric), one JSON line.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 and no WORLD_SIZE in the environment: starts its own N ranks, one per
+                                                           GPU, the way scripts/calc_metrics.py:144-149 / src/train.py:100-105 spawn theirs)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = one generator forward (mapping -> tri-plane backbone -> volumetric renderer) over one batch of synthetic
@@ -110,6 +111,10 @@ def cpu_baseline(tdgp, cfg, n_img=8, budget_s=14.0):
         assert np.isfinite(img).all()
         done += 1
     return dict(value=round(done / t_total, 5), unit='img/s', cores=cores, kind='port',
+                thread_cap='min(os.cpu_count(), 32): the oracle\'s OpenMP loops stop scaling past a few dozen threads on 2-socket hosts (TDGP_ORACLE_THREADS overrides)',
+                reference_calibration='BASELINE.md section 2: the reference itself (imported, PyTorch CPU ops + its own upfirdn2d / bias_act fallbacks) ran this '
+                                      'workload at 0.108 img/s on the 8 cores of the build container; this C oracle on the same 8 cores / 8 threads: 0.113 img/s '
+                                      '(measured in round 3) -- the "port" reproduces the reference\'s CPU speed on equal cores',
                 sample=f'{done} whole images (mapping + tri-plane backbone + all {cfg.img_resolution ** 2} rays x {cfg.num_ray_steps}+{cfg.num_ray_steps} '
                        f'samples) in {t_total:.1f} s; OpenMP C oracle (oracle/tdgp_oracle.c), {cores} threads')
 
@@ -134,6 +139,38 @@ def timed_steps(step, barrier, steps, warmup, world, dev, finish=None):
     return elapsed
 
 
+def spawn_ranks(n, script=None, argv=None):
+    """`python bench.py --gpus N` without a launcher: start N copies of this command, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT as torchrun would set them), pass rank 0's JSON line through, fail if any rank fails.  The
+    parent never touches a GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [None] * n
+    try:
+        while any(rc is None for rc in rcs):
+            for r, p in enumerate(procs):
+                rcs[r] = p.poll()
+            if any(rc not in (None, 0) for rc in rcs):      # one rank died: the others would sit in a collective for ever
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+    if bad:
+        sys.exit(f'bench.py: rank(s) failed: {bad}')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -153,10 +190,15 @@ def main():
                          "6 piece products, fp32 accumulation (fp32-grade results; reported with dtype 'bf16x3->f32' and never mixed with the default line)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        assert torch.cuda.is_available() and torch.cuda.device_count() >= args.gpus, \
+            f'--gpus {args.gpus} but {torch.cuda.device_count() if torch.cuda.is_available() else 0} GPU(s) visible'
+        return spawn_ranks(args.gpus)
+
     tdgp = importlib.import_module('3dgp_amd')
     D = tdgp.distributed
     rank, world, local_rank = D.init_from_env('nccl')
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -254,19 +296,34 @@ def main():
         roofline = dict(kernel=dominant, bound='mfma', achieved=round(achieved, 3), peak=peak, unit='TFLOP/s',
                         frac=round(achieved / peak, 4), traffic=traffic,
                         hbm_gbs=None if traffic is None else round(traffic / (k['avg_ms'] * 1e-3) / 1e9, 1), mfma_busy_pct=pk.get('mfma_busy_pct'),
+                        l2_hit_pct=pk.get('l2_hit_pct'), traffic_fetch=pk.get('fetch_bytes_per_launch'), traffic_write=pk.get('write_bytes_per_launch'),
+                        traffic_note=None if traffic is None else 'memory-side bytes of the L2 per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts '
+                                     '128-B requests at 64 B: profiles/r03_pmc_calibration.md); Infinity-Cache hits included',
                         pmc_source=pmc_src, flop_per_launch=fl_per_launch, avg_launch_ms=k['avg_ms'], launches_per_step=k['launches_per_step'])
     for k, v in kernels.items():               # the same three figures for every kernel the PMC passes cover
         pk = pmc.get(k)
         if pk and v['avg_ms'] > 0:
             v.update(hbm_gbs=round(pk['hbm_bytes_per_launch'] / (v['avg_ms'] * 1e-3) / 1e9, 1), mfma_busy_pct=pk.get('mfma_busy_pct'))
+            if 'l2_hit_pct' in pk:
+                v['l2_hit_pct'] = pk['l2_hit_pct']
         if k in flops and v['avg_ms'] > 0:
             v['tflops'] = round(flops[k][0] * args.batch / v['launches_per_step'] / (v['avg_ms'] * 1e-3) / 1e12, 2)
             if k in EXECUTED_FRACTION:
                 v['tflops_executed'] = round(v['tflops'] * EXECUTED_FRACTION[k], 2)
     total_flop_img = sum(f for f, _, _ in flops.values())
+    # what the matrix pipe EXECUTES: the Winograd layers multiply 16/36 of their algorithmic (direct-sum) FLOP.  `frac` (algorithmic) is
+    # the metric's figure; `frac_executed` is the one an MFMA roofline bounds -- both are printed, neither alone.
+    exec_flop_img = sum(f * EXECUTED_FRACTION.get(k, 1.0) for k, (f, _, _) in flops.items())
     ms_step = elapsed / args.steps * 1e3
+    busy_w = [(v['ms_per_step'], v['mfma_busy_pct']) for v in kernels.values() if v.get('mfma_busy_pct') is not None]
+    t_all = sum(v['ms_per_step'] for v in kernels.values())
     whole = dict(flop_per_image=total_flop_img, achieved=round(total_flop_img * args.batch / (ms_step * 1e-3) / 1e12, 2), peak=PEAK_FP32_MFMA_TFLOPS,
                  unit='TFLOP/s', frac=round(total_flop_img * args.batch / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                 flop_executed_per_image=round(exec_flop_img), achieved_executed=round(exec_flop_img * args.batch / (ms_step * 1e-3) / 1e12, 2),
+                 frac_executed=round(exec_flop_img * args.batch / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                 # matrix-pipe busy over the whole step: per-kernel SQ_VALU_MFMA_BUSY (committed PMC pass) weighted by the kernel times measured
+                 # here; kernels without a counter row (ATen / rocBLAS micro-kernels) count as 0 % busy
+                 mfma_busy_pct_time_weighted=round(sum(t * b for t, b in busy_w) / t_all, 1) if busy_w and t_all > 0 else None,
                  kernel_ms_sum=round(sum(v['ms_per_step'] for v in kernels.values()), 3), profiled_step_ms=round(profiled_step_ms, 3))
 
     others = {}

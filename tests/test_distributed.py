@@ -162,3 +162,54 @@ def test_bench_two_ranks_over_rccl():
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['rccl_ranks_seen'] == 2 and line['config']['global_batch'] == 4 and line['value'] > 0
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks_over_rccl():
+    """Plain `python bench.py --gpus 2` (no launcher, no WORLD_SIZE): bench.py starts its two ranks itself and rank 0 reports what RCCL saw."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f'{torch.cuda.device_count()} GPU(s) visible: the two-rank RCCL run needs 2')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '2', '--other-batches', '', '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['rccl_ranks_seen'] == 2 and line['config']['global_batch'] == 4 and line['value'] > 0
+
+
+_SPAWNED_CHILD = '''
+import json, os, sys
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert int(os.environ["LOCAL_RANK"]) == rank and os.environ["MASTER_ADDR"] == "127.0.0.1"
+dist.init_process_group("gloo", rank=rank, world_size=world)
+t = torch.ones(1)
+dist.all_reduce(t)
+if sys.argv[1:] == ["--die"] and rank == 1:
+    os._exit(3)
+dist.barrier()
+if rank == 0:
+    print(json.dumps(dict(ranks_seen=int(t.item()), argv=sys.argv[1:])))
+'''
+
+
+def test_bench_spawn_ranks_plumbing(tmp_path):
+    """bench.spawn_ranks on CPU: N children with torchrun's environment, rank 0's line passes through, a dead rank fails the launch
+    instead of hanging it."""
+    import json
+    import subprocess
+    import sys
+    child = tmp_path / 'child.py'
+    child.write_text(_SPAWNED_CHILD)
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    drive = 'import sys; sys.path.insert(0, %r); import bench; bench.spawn_ranks(2, script=%r, argv=sys.argv[1:])' % (REPO, str(child))
+    out = subprocess.run([sys.executable, '-c', drive, '--x', '1'], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line == dict(ranks_seen=2, argv=['--x', '1'])
+    out = subprocess.run([sys.executable, '-c', drive, '--die'], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and 'rank(s) failed' in out.stderr

@@ -6,11 +6,16 @@ way bench.py's event timing pools them): HBM bytes per launch and matrix-pipe bu
   python tools/pmc_fold.py gpurun_out/r02 gpurun_out/r02/pmc.json --bench gpurun_out/r02/bench.json
   (review, then copy to profiles/pmc_latest.json with the commit the passes were taken at)
 
-Units (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are reported in KiB.  WRITE_SIZE matched the known output size
-of the 64->64 @512^2 layer exactly.  FETCH_SIZE is documented to under-count 16-B/lane streaming reads by 2x on gfx950; the conv
-kernels stage activations with 4-B/lane loads, for which the counter matched the expected bytes (x + halo re-read), so no
-correction factor is applied to them -- `fetch_note` records that.  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCD
-instances x 256 CUs x 4 SIMDs), the gfx94x MfmaUtil formula (ROCm 7.2 ships no gfx950 derived-counter section).
+Units (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are reported in KiB.  Calibrated in round 3 against known byte
+counts (tools/pmc_calibrate.hip, profiles/r03_pmc_calibration.md: 2 GiB buffers read / written exactly once with 4-, 8- and 16-B
+loads per lane, whole-line and half-line gathers, stores of both widths): **FETCH_SIZE reports exactly half the bytes for EVERY read
+shape** -- the L2 issues 128-B read requests (TCC_EA0_RDREQ = bytes / 128, TCC_BUBBLE = TCC_EA0_RDREQ_32B = 0) and rocprofv3's gfx950
+expression tallies them at 64 B -- and WRITE_SIZE is exact (64-B write requests).  So fetch bytes = 2 x FETCH_SIZE x 1024 for every
+kernel (FETCH_FACTOR below; round 2's "4-B/lane loads match uncorrected" was wrong: those kernels over-fetch 2x), cross-checked per
+kernel against TCC_EA0_RDREQ_sum x 128 when that pass is present.  These are bytes at the L2's memory side: Infinity-Cache hits are
+included, so this is an upper bound of the HBM bytes.  L2 hit rate = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum).  MFMA busy =
+SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCD instances x 256 CUs x 4 SIMDs), the gfx94x MfmaUtil formula (ROCm 7.2 ships no
+gfx950 derived-counter section).
 """
 import argparse
 import collections
@@ -19,6 +24,8 @@ import os
 import re
 import subprocess
 
+
+FETCH_FACTOR = 2.0      # calibrated: profiles/r03_pmc_calibration.md
 
 # device function name -> the label the library's event timing (and bench.py) pools it under
 ALIAS = {'conv3_mfma_kernel': 'conv_mfma_kernel', 'conv3_wino_kernel': 'conv_wino_kernel', 'conv3_bf16_kernel': 'conv_bf16_kernel', 'triplane_walk_kernel': 'triplane_field_kernel', 'conv3s_mfma_kernel': 'conv_mfma_kernel', 'upconv3s_mfma_kernel': 'upconv_mfma_kernel'}
@@ -53,12 +60,12 @@ def main():
                 re.search(r'configs\[\d\]', bj['config']['workload']).group(0), 'c3')
         except Exception as e:        # noqa: BLE001
             print('bench.json not parsed:', e)
-    fam = collections.defaultdict(lambda: dict(launches=0, fetch=0.0, write=0.0, mfma=0.0, active=0.0, mlaunches=0))
+    fam = collections.defaultdict(lambda: dict(launches=0, fetch=0.0, write=0.0, mfma=0.0, active=0.0, mlaunches=0, hit=0.0, miss=0.0, req=0.0, rdreq=0.0, rlaunches=0))
     for key, fn, counter in (('fetch', 'pmc_FETCH_SIZE.md', 'FETCH_SIZE'), ('write', 'pmc_WRITE_SIZE.md', 'WRITE_SIZE')):
         for name, (calls, _, cs) in table(os.path.join(a.indir, fn)).items():
             base = name.split('<')[0].strip()
             f = fam[ALIAS.get(base, base)]
-            f[key] += calls * cs[counter] * 1024.0
+            f[key] += calls * cs[counter] * 1024.0 * (FETCH_FACTOR if key == 'fetch' else 1.0)
             if key == 'fetch':
                 f['launches'] += calls
     for name, (calls, _, cs) in table(os.path.join(a.indir, 'pmc_SQ_VALU_MFMA_BUSY_CYCLES.md')).items():
@@ -67,17 +74,32 @@ def main():
         f['mfma'] += calls * cs['SQ_VALU_MFMA_BUSY_CYCLES']
         f['active'] += calls * cs['GRBM_GUI_ACTIVE']
         f['mlaunches'] += calls
+    for name, (calls, _, cs) in table(os.path.join(a.indir, 'pmc_TCC_HIT_sum.md')).items():
+        f = fam[ALIAS.get(name.split('<')[0].strip(), name.split('<')[0].strip())]
+        f['hit'] += calls * cs['TCC_HIT_sum']
+        f['miss'] += calls * cs['TCC_MISS_sum']
+        f['req'] += calls * cs.get('TCC_REQ_sum', 0.0)
+    for name, (calls, _, cs) in table(os.path.join(a.indir, 'pmc_TCC_EA0_RDREQ_sum.md')).items():
+        f = fam[ALIAS.get(name.split('<')[0].strip(), name.split('<')[0].strip())]
+        f['rdreq'] += calls * cs['TCC_EA0_RDREQ_sum']
+        f['rlaunches'] += calls
     try:
         commit = subprocess.check_output(['git', '-C', os.path.dirname(os.path.abspath(__file__)), 'rev-parse', '--short', 'HEAD'], text=True).strip()
     except Exception:                 # noqa: BLE001  (the GPU box has no .git: filled in when the file is committed)
         commit = None
     out = dict(config=cfg, batch_per_gpu=batch, commit=commit,
-               source='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (separate passes), tools/profile_round.sh',
-               fetch_note='KiB units; no 2x gfx950 correction applied (4-B/lane staging loads matched expected bytes uncorrected)', kernels={})
+               source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE / TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum / TCC_EA0_RDREQ_sum (separate passes), tools/profile_round.sh',
+               fetch_factor=FETCH_FACTOR,
+               fetch_note='bytes = FETCH_SIZE x 1024 x 2: on gfx950 FETCH_SIZE tallies the 128-B read requests of the L2 at 64 B for every access width (calibrated on known byte counts, profiles/r03_pmc_calibration.md); WRITE_SIZE is exact; memory-side bytes include Infinity-Cache hits', kernels={})
     for name, f in fam.items():
         n = max(f['launches'], 1)
         k = dict(hbm_bytes_per_launch=round((f['fetch'] + f['write']) / n), fetch_bytes_per_launch=round(f['fetch'] / n),
                  write_bytes_per_launch=round(f['write'] / n), launches_sampled=f['launches'])
+        if f['hit'] + f['miss'] > 0:
+            k['l2_hit_pct'] = round(100.0 * f['hit'] / (f['hit'] + f['miss']), 1)
+            k['l2_requests_per_launch'] = round(f['req'] / n)
+        if f['rlaunches'] > 0:
+            k['fetch_bytes_per_launch_rdreq128'] = round(f['rdreq'] * 128.0 / f['rlaunches'])      # cross-check of the corrected FETCH_SIZE
         if f['active'] > 0:
             k['mfma_busy_pct'] = round(100.0 * f['mfma'] / (f['active'] / 8.0 * 1024.0), 1)
         out['kernels'][name] = k

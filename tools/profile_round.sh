@@ -21,7 +21,7 @@ DB=$(find "$OUT/trace" -name '*.db' | head -1)
 [ -n "$DB" ] && python "$REPO/tools/rocpd_summary.py" "$DB" "$OUT/kernel_stats"
 
 PMCBENCH="python $REPO/bench.py --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --other-batches \"\" $EXTRA"
-for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
+for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum"; do
     N=$(echo $C | cut -d' ' -f1)
     timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_$N" -o pmc -- python "$REPO/bench.py" --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --other-batches "" $EXTRA > "$OUT/pmc_$N.log" 2>&1
     echo "pmc $N rc=$?"
