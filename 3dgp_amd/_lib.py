@@ -103,13 +103,17 @@ def stream_of(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+class Unsupported(RuntimeError):
+    """TDGP_EUNSUPPORTED: a valid request this build has no kernel for (include/tdgp.h).  Returned before anything is launched."""
+
+
 def call(name, *args):
     """Call an entry point; non-zero return -> RuntimeError carrying tdgp_last_error()."""
     lib = load()
     rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.tdgp_last_error()
-        raise RuntimeError(f'{name} failed ({rc}): {msg.decode() if msg else "?"}')
+        raise (Unsupported if rc == -2 else RuntimeError)(f'{name} failed ({rc}): {msg.decode() if msg else "?"}')
 
 
 def require_cuda(t, what):

@@ -76,7 +76,7 @@ class GeneratorConfig:
     # setting of every 3dgp config and of the headline metric.
     num_fp16_res: int = 0
     conv_clamp: Optional[float] = None
-    max_batch_res: int = 128        # kept for API parity (run_batchwise chunking is a no-op for results)
+    max_batch_res: int = 128        # above it an eval forward with cut_quantile > 0 is rendered in the reference's ray chunks (per-chunk quantiles)
     # training-mode forward: patch-wise rendering resolution (configs/training/patch_beta.yaml `resolution`;
     # None = patch.enabled off -> img_resolution) and the density-noise schedule (configs/model/3dgp.yaml:22-23)
     patch_resolution: Optional[int] = None
@@ -159,6 +159,13 @@ def config_tiny():
     """Fixture-sized configuration used by the golden end-to-end vectors."""
     return GeneratorConfig(z_dim=32, w_dim=32, c_dim=0, cbase=256, cmax=16, tri_plane_res=32, feat_dim=8,
                            mlp_hid=16, num_ray_steps=8, img_resolution=16)
+
+
+def config_cut_chunked():
+    """Golden of `cut_quantile` above `max_batch_res` (tools/gen_goldens.py:gen_cut_chunked): the tiny backbone in front of 128^2 rays x
+    96 steps, so that a batch of 4 exceeds the reference's 2**24-element quantile chunk (networks_epigraf.py:235-236)."""
+    return GeneratorConfig(z_dim=32, w_dim=32, c_dim=0, cbase=256, cmax=16, tri_plane_res=32, feat_dim=8,
+                           mlp_hid=16, num_ray_steps=96, img_resolution=128, max_batch_res=64)
 
 
 def config_mid():

@@ -139,7 +139,7 @@ __device__ __forceinline__ float finish_act(const EpiParams& e, float v) {
 }
 // which specialisation a launch can use (3 = leaky ReLU written as max(v, alpha * v): needs 0 <= alpha <= 1)
 __device__ __forceinline__ int epi_variant(const EpiParams& e) {
-    if (e.clamp >= 0.f) return (e.act == 3 && e.alpha >= 0.f && e.alpha <= 1.f) ? 4 : 0;       // (4: only where a caller asks for it, see epi_variant_noclamp)
+    if (e.clamp >= 0.f) return (e.act == 3 && e.alpha >= 0.f && e.alpha <= 1.f) ? 4 : 0;       // (4: only the launches that template on it use it)
     if (e.act == 1) return 1;
     return (e.act == 3 && e.alpha >= 0.f && e.alpha <= 1.f) ? 3 : 0;
 }
@@ -2062,6 +2062,7 @@ struct FirParams {
     float fir[16];
     int B, C, ZROWS, P2, GS2, ksplit, OH, OW;      // ZROWS = 2H+2 rows of pitch P2 = 2*G1 (a multiple of 4), alternating between the parity planes
     int act; float alpha, gain, clamp;
+    int noise_vec;      // host: noise may be fetched as 16-byte vectors (pointer 16-byte aligned, batch stride a multiple of 4 floats)
 };
 
 // Tile FIR_TH x FIR_TW outputs per block: 32 x 64, or 16 x 128 for wide images (longer contiguous runs per row: 544-B reads,
@@ -2102,7 +2103,7 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
         const int lx = (threadIdx.x % CW) * 4;
         const float d = p.dcoef ? p.dcoef[b * p.C + c] : 1.f;
         const float bv = p.bias ? (YBF ? fir_round_bf16(p.bias[c]) : p.bias[c]) : 0.f;
-        const bool nz_vec = p.noise && ox0 + lx + 3 < p.OW && (p.OW & 3) == 0;
+        const bool nz_vec = p.noise_vec && ox0 + lx + 3 < p.OW && (p.OW & 3) == 0;
         float4 nzv[FIR_TH / RPP];
 #pragma unroll
         for (int hrow = 0; hrow < FIR_TH / RPP; hrow++) {
@@ -2710,6 +2711,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         else launch_upconv<2, 1, 1, 4, false>(u, s);
         FirParams f;
         f.z = z; f.dcoef = dco; f.noise = noise; f.noise_bstride = noise_bstride; f.bias = bias; f.y = y; f.y16 = nullptr;
+        f.noise_vec = noise && (((uintptr_t)noise) & 15) == 0 && (noise_bstride & 3) == 0;
         for (int i = 0; i < 16; i++) f.fir[i] = e.fir[i];
         f.B = B; f.C = Cout; f.ZROWS = 2 * H + 2; f.P2 = 2 * pl.G1; f.GS2 = 2 * pl.GS; f.ksplit = split ? 1 : pl.ksplit; f.zslice = pl.zslice;
         f.OH = 2 * H; f.OW = 2 * W;
@@ -2745,8 +2747,17 @@ TDGP_API int tdgp_modconv2d_bf16(const void* x, const void* wpack, const float* 
     const bool rgb = k == 1 && up == 1 && out_layout == 1 && Cout <= 96 && !demodulate && !noise && act == 1 && ((H * W) & 3) == 0 && out_feat >= 4 &&
                      (out_feat % 4) == 0 && (Cout % out_feat) == 0 && (!skip || (fir4x4 && (H % 2) == 0 && (W % 2) == 0));
     const bool c3 = k == 3 && up == 1 && out_layout == 0 && !skip && (W & 31) == 0 && (Cin & 31) == 0 && Cin <= 2048;
-    const bool u3 = k == 3 && up == 2 && out_layout == 0 && !skip && fir4x4 && (Cin & 31) == 0 && (W & 1) == 0;
+    bool u3 = k == 3 && up == 2 && out_layout == 0 && !skip && fir4x4 && (Cin & 31) == 0 && (W & 1) == 0;
+    size_t u3_lds = 0;
+    if (u3) {                                     // every acceptance test before the first launch: the x2 kernel keeps the styles of all samples a block's
+        const UpPlan pl0 = up_plan(B, Cin, Cout, H, W);                                   // grid points can touch in LDS
+        const int nsb0 = std::min(B, (130 + pl0.G1) / pl0.GS + 2);
+        u3_lds = (size_t)(9 * 2 * 64 * 32 + 2 * 2 * 130 * 32) + (size_t)nsb0 * Cin * 4;
+        TDGP_CHECK(u3_lds <= 80 * 1024, TDGP_EUNSUPPORTED, "modconv2d_bf16: x2 layer with Cin=%d, B=%d, H=%d needs %zu bytes of LDS (> 80 KiB)", Cin, B, H, u3_lds);
+    }
     TDGP_CHECK(rgb || c3 || u3, TDGP_EUNSUPPORTED, "modconv2d_bf16: no bf16 kernel for k=%d up=%d Cin=%d W=%d layout=%d", k, up, Cin, W, out_layout);
+    const bool nz16 = !noise || ((((uintptr_t)noise) & 15) == 0 && (noise_bstride & 3) == 0);
+    TDGP_CHECK(nz16, TDGP_EINVAL, "modconv2d_bf16: noise must be 16-byte aligned with a batch stride that is a multiple of 4 floats");
     const WsLayout wl = ws_layout(B, Cin, Cout, H, W, k, up);
     TDGP_CHECK(workspace && workspace_bytes >= wl.total, TDGP_EWORKSPACE, "modconv2d_bf16: workspace %lld < %lld bytes", (long long)workspace_bytes,
                (long long)wl.total);
@@ -2798,14 +2809,13 @@ TDGP_API int tdgp_modconv2d_bf16(const void* x, const void* wpack, const float* 
         q.x = (const uint16_t*)x; q.wb = wb; q.styles = styles; q.z = z;
         q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W; q.G1 = pl.G1; q.GS = pl.GS; q.zslice = pl.zslice;
         q.x_bytes = x_bytes; q.wb_bytes = (uint32_t)(pi.wbf_floats * 4); q.st_bytes = (uint32_t)((int64_t)B * Cin * 4);
-        const int nsb = std::min(B, (130 + pl.G1) / pl.GS + 2);                 // samples one block's grid points can touch
-        const size_t lds = (size_t)(9 * 2 * 64 * 32 + 2 * 2 * 130 * 32) + (size_t)nsb * Cin * 4;
-        if (lds > 80 * 1024) return TDGP_EUNSUPPORTED;
+        const size_t lds = u3_lds;                                              // checked against the 80 KiB budget above
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)upconv_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
         TDGP_LAUNCH("upconv_bf16_kernel", upconv_bf16_kernel, dim3(cdiv(B * pl.GS, 128), cdiv(Cout, 64)), dim3(256), lds, s, q);
         FirParams f;
         f.z = z; f.dcoef = dco; f.noise = noise; f.noise_bstride = noise_bstride; f.bias = bias; f.y = nullptr; f.y16 = (uint16_t*)y;
+        f.noise_vec = noise != nullptr;          // alignment checked at entry
         for (int i = 0; i < 16; i++) f.fir[i] = e.fir[i];
         f.B = B; f.C = Cout; f.ZROWS = 2 * H + 2; f.P2 = 2 * pl.G1; f.GS2 = 2 * pl.GS; f.ksplit = 1; f.zslice = pl.zslice;
         f.OH = 2 * H; f.OW = 2 * W;

@@ -555,8 +555,18 @@ class SynthesisNetwork(torch.nn.Module):
         opts['ray_grid_w'] = w                      # rays are the row-major pixels of an h x w image (sample_rays)
         R = h * w
         draws = dict(u_coarse=(u_coarse, [B, R, -1]), u_fine=(u_fine, [B, R, -1]), n_coarse=(n_coarse, [B, -1]), n_fine=(n_fine, [B, -1]))
-        # cut_quantile thresholds at a quantile over the WHOLE batch (tri_plane_renderer.py:366-368): such a call is rendered in one piece
-        chunk = None if float(opts.get('cut_quantile', 0.0)) > 0.0 else self.chunk
+        # cut_quantile thresholds at a quantile over every ray and sample of ONE renderer call (tri_plane_renderer.py:366-368): never
+        # batch-chunked here.  The reference itself splits such a call -- by RAYS -- when the eval resolution exceeds max_batch_res
+        # (networks_epigraf.py:232-239: run_batchwise over 2**24 // (B * num_ray_steps * 3) rays, "cut_quantile fails on large tensors"),
+        # so each ray chunk takes its own quantiles (and, when the draws are not explicit, its own rand_like / rand pair in that order).
+        cutting = float(opts.get('cut_quantile', 0.0)) > 0.0
+        chunk = None if cutting else self.chunk
+        ray_step = None
+        if cutting and not self.training and (h > render_opts['max_batch_res'] or w > render_opts['max_batch_res']):
+            ray_step = 2 ** 24 // (B * self.cfg.num_ray_steps * 3)
+            assert ray_step >= 1, f'Wrong batch_size: {ray_step}'        # training_utils.py:180
+            if ray_step >= R:
+                ray_step = None                                         # run_batchwise's early exit (:185-186)
         rgb = depth = None
         for sl, planes in self.tri_plane_decoder.forward_chunks(ws[:, :self.tri_plane_decoder.num_ws], hwc=True, chunk=chunk, chunk_from=self.chunk_from,
                                                                 **block_kwargs):
@@ -570,6 +580,19 @@ class SynthesisNetwork(torch.nn.Module):
                 else:
                     tc = t.reshape(shape)[sl]
                     o[k] = tc.reshape(-1, tc.shape[-1]) if k == 'u_fine' else tc
+            if ray_step is not None:
+                assert whole
+                rgb = torch.empty([B, R, self.img_channels], dtype=torch.float32, device=ws.device)
+                depth = torch.empty([B, R, 1], dtype=torch.float32, device=ws.device)
+                for a in range(0, R, ray_step):
+                    rs = slice(a, min(a + ray_step, R))
+                    oc = dict(o, ray_grid_w=0)           # a run of rays, not an image: the field kernel takes the linear point order
+                    for k in ('u_coarse', 'u_fine'):
+                        if o[k] is not None:
+                            tc = o[k].reshape(B, R, -1)[:, rs].contiguous()
+                            oc[k] = tc.reshape(-1, tc.shape[-1]) if k == 'u_fine' else tc
+                    rgb[:, rs], depth[:, rs], _w, _T = self.renderer(planes, self.tri_plane_mlp, ray_o[:, rs].contiguous(), ray_d[:, rs].contiguous(), oc)
+                continue
             rgb_c, depth_c, _w, _T = self.renderer(planes, self.tri_plane_mlp, ray_o[sl], ray_d[sl], o)
             if whole:
                 rgb, depth = rgb_c, depth_c

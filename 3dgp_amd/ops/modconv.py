@@ -110,18 +110,30 @@ def modconv_forward(x, packed, styles, noise=None, bias=None, up=1, demodulate=T
         # reduced-precision block (BASELINE configs[4]): bf16 activations in, bf16 out -- except the ToRGB form, whose output joins the
         # fp32 skip image (networks_stylegan2.py:268).  Shapes the bf16 MFMA kernels do not take are widened and run on the fp32 path.
         rgb = out_layout == 1
-        takes = (rgb and packed.k == 1 and up == 1) or (packed.k == 3 and out_layout == 0 and skip is None and cin % 32 == 0 and cin <= 2048 and
-                                                         (up == 2 or W % 32 == 0))
-        if not takes:
+        # the ToRGB form (1x1, no demodulation; `skip` = the running fp32 image it joins): its result is fp32 in EITHER layout --
+        # `y.to(float32); img.add_(y)`, networks_stylegan2.py:268-269 -- so the NCHW fallback must not round the accumulated image to bf16
+        rgb_form = rgb or (packed.k == 1 and not demodulate) or skip is not None
+        # mirror of the acceptance tests of tdgp_modconv2d_bf16 (modconv.hip): anything else is widened and runs on the fp32 kernels
+        if rgb:
+            takes = (packed.k == 1 and up == 1 and cout <= 96 and out_feat > 0 and out_feat % 4 == 0 and cout % out_feat == 0 and (H * W) % 4 == 0 and
+                     (skip is None or (H % 2 == 0 and W % 2 == 0)))
+        else:
+            takes = (packed.k == 3 and not rgb_form and cin % 32 == 0 and cin <= 2048 and ((up == 2 and W % 2 == 0) or (up == 1 and W % 32 == 0)))
+        def widened():
             y = modconv_forward(x.float(), packed, styles, noise=noise, bias=bias, up=up, demodulate=demodulate, act=act, alpha=alpha, gain=gain,
                                 clamp=None if clamp < 0 else clamp, fir=fir, skip=skip, out_layout=out_layout, out_feat=out_feat, dcoef=dcoef)
-            return y if rgb else y.to(torch.bfloat16)
+            return y if rgb_form else y.to(torch.bfloat16)
+        if not takes:
+            return widened()
         y = (torch.empty([B, cout // out_feat, H, W, out_feat], dtype=torch.float32, device=x.device) if rgb else
              torch.empty([B, cout, H * up, W * up], dtype=torch.bfloat16, device=x.device))
-        with torch.cuda.device(x.device):
-            _lib.call('tdgp_modconv2d_bf16', x.data_ptr(), packed.buf.data_ptr(), _lib.ptr(styles), _lib.ptr(dcoef), _lib.ptr(noise), nbs, _lib.ptr(bias), fir,
-                      _lib.ptr(skip), y.data_ptr(), B, cin, cout, H, W, packed.k, up, int(bool(demodulate)), spec.cuda_idx, alpha, gain, clamp,
-                      out_layout, out_feat, ws.data_ptr(), ws_bytes, _lib.stream_of(x))
+        try:
+            with torch.cuda.device(x.device):
+                _lib.call('tdgp_modconv2d_bf16', x.data_ptr(), packed.buf.data_ptr(), _lib.ptr(styles), _lib.ptr(dcoef), _lib.ptr(noise), nbs, _lib.ptr(bias), fir,
+                          _lib.ptr(skip), y.data_ptr(), B, cin, cout, H, W, packed.k, up, int(bool(demodulate)), spec.cuda_idx, alpha, gain, clamp,
+                          out_layout, out_feat, ws.data_ptr(), ws_bytes, _lib.stream_of(x))
+        except _lib.Unsupported:          # the C side's own acceptance tests (e.g. the x2 kernel's LDS budget at large Cin x B): nothing was launched
+            return widened()
         return y
     if out_layout == 0:
         y = torch.empty([B, cout, H * up, W * up], dtype=torch.float32, device=x.device)

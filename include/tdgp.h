@@ -130,7 +130,9 @@ int     tdgp_modconv2d(const float* x, const void* wpack, const float* styles, c
  * activation, gain, clamp in fp32; the reference's rounding points behind the accumulator (conv output, + noise, bias_act output; the
  * bias itself is rounded as in `self.bias.to(x.dtype)`), and the skip is added AFTER the clamp.
  * Forms taken: 3x3 with Cin % 32 == 0 (and W % 32 == 0 for up = 1); the channel-last ToRGB with Cout <= 96.  Anything else returns
- * TDGP_EUNSUPPORTED: widen x to fp32 and call tdgp_modconv2d.  Workspace: tdgp_modconv2d_workspace_bytes of the same shape.
+ * TDGP_EUNSUPPORTED -- decided before anything is launched: widen x to fp32 and call tdgp_modconv2d.  `noise` must be 16-byte aligned with
+ * a batch stride that is a multiple of 4 floats (TDGP_EINVAL otherwise; tdgp_modconv2d takes any float* and falls back to scalar
+ * loads).  Workspace: tdgp_modconv2d_workspace_bytes of the same shape.
  * tdgp_cast_f32_bf16: x.to(bf16) (round to nearest even) at the first reduced-precision block (:250). */
 int     tdgp_modconv2d_bf16(const void* x_bf16, const void* wpack, const float* styles, const float* dcoef, const float* noise,
                             int64_t noise_bstride, const float* bias, const float* fir4x4, const float* skip,

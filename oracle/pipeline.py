@@ -234,9 +234,20 @@ def synthesis_forward(sd, cfg, ws, camera, u_coarse, u_fine, noise_mode='const',
     ray_o, ray_d = O.sample_rays(c2w, camera['fov'], h, w, tr.get('patch_scales'), tr.get('patch_offsets'))
     mlp = tuple(sd[f'synthesis.tri_plane_mlp.model.{i}.{n}'] for i in (0, 1) for n in ('weight', 'bias'))
     ropts = dict(render_options(cfg), density_noise=tr.get('density_noise', 0.0))
-    (rgb, depth, wsum, fT), rinter = importance_render(planes, mlp, ray_o, ray_d, ropts, u_coarse, u_fine, return_intermediates=True,
-                                                       n_coarse=tr.get('n_coarse'), n_fine=tr.get('n_fine'))
     B = ws.shape[0]
+    mbr = cfg.get('max_batch_res', 128)
+    if training is None and ropts['cut_quantile'] > 0 and (h > mbr or w > mbr) and 2 ** 24 // (B * cfg['num_ray_steps'] * 3) < h * w:
+        # networks_epigraf.py:232-239: above max_batch_res the eval forward renders through run_batchwise over ray chunks of
+        # 2**24 // (B * num_ray_steps * 3) rays (training_utils.py:171-203) -- each chunk takes its OWN quantiles
+        step, R, S = 2 ** 24 // (B * cfg['num_ray_steps'] * 3), h * w, cfg['num_ray_steps']
+        uc, uf = np.asarray(u_coarse).reshape(B, R, S), np.asarray(u_fine).reshape(B, R, S)
+        parts = [importance_render(planes, mlp, ray_o[:, a:a + step], ray_d[:, a:a + step], ropts, np.ascontiguousarray(uc[:, a:a + step]),
+                                   np.ascontiguousarray(uf[:, a:a + step]).reshape(-1, S)) for a in range(0, R, step)]
+        rgb, depth, wsum, fT = (np.concatenate([p[i] for p in parts], axis=1) for i in range(4))
+        rinter = {}
+    else:
+        (rgb, depth, wsum, fT), rinter = importance_render(planes, mlp, ray_o, ray_d, ropts, u_coarse, u_fine, return_intermediates=True,
+                                                           n_coarse=tr.get('n_coarse'), n_fine=tr.get('n_fine'))
     img = np.ascontiguousarray(rgb.reshape(B, h, w, 3).transpose(0, 3, 1, 2))
     depth = depth.reshape(B, 1, h, w)
     if return_intermediates:

@@ -83,6 +83,18 @@ def assert_close(a, b, tol, what='', floor=1e-3):
     assert err <= tol, f'{what}: max-rel {err:.3e} > {tol:.1e}'
 
 
+def assert_close_up_to_threshold_flips(a, b, what, tol=1e-5, flips=2e-4, flip_size=1e-2):
+    """For images behind a hard threshold (the marchers' `cut_quantile`: activated densities below a quantile are zeroed): a sample
+    whose density sits within an ulp of the threshold may fall on the other side in another fp32 evaluation, and its pixel then moves
+    by a visible amount.  All pixels but a fraction `flips` agree to `tol` of the range; the flipped ones stay below `flip_size`."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, f'{what}: shape {a.shape} vs {b.shape}'
+    e = np.abs(a - b) / np.abs(b).max()
+    n = int((e > tol).sum())
+    report_parity(what, range_err_max=float(e.max()), pixels_beyond_tol=n, pixels=int(e.size), p9999=float(np.quantile(e, 0.9999)))
+    assert n <= flips * e.size and e.max() <= flip_size, f'{what}: {n} of {e.size} values beyond {tol:.0e} (max {e.max():.3e})'
+
+
 RGB_TOL = 1e-4        # north-star tolerance: max-rel RGB error vs the reference CPU/PyTorch path
 RANGE_TOL = 1e-5      # stricter, well-conditioned companion: max|delta| / max|ref|
 
@@ -96,7 +108,13 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
          <= max(RGB_TOL, 4 x reference self-noise, 2 x reference-vs-exact)   (self-noise is ONE draw of the reference's own
          run-to-run difference; the maximum over the pixels of a second, independent draw scatters by that much);
       3. when the exactly rounded image is available (`exact` = the fp64-accumulating oracle on the same inputs): the HIP
-         image is no further from it, per pixel, than max(RGB_TOL, 1.5 x the reference's own distance from it).
+         image is no further from it, per pixel, than max(RGB_TOL, 1.5 x the reference's own distance from it);
+      4. when the golden holds `<key>_f64` -- the REFERENCE ITSELF run in float64 on the same ws / rays / draws
+         (tools/gen_goldens.py:gen_e2e; the pin that does not lean on this repo's oracle) -- the image is measured against it next
+         to the reference's own fp32 image: per-pixel max-rel <= max(RGB_TOL, 3 x the reference-fp32-vs-f64 figure) (a maximum
+         over pixels of ulp-level noise amplified 1000x on near-zero pixels scatters by that much between two fp32 evaluations;
+         the reference's fp32 run is 1.7e-4 / 3.0e-4 / 2.9e-4 from its own float64 run on the three goldens, i.e. it does not
+         meet a flat 1e-4 against itself), and the robust statistic, mean |d| / max|ref|, <= 1.25 x the reference's + 1e-8.
 
     Why (2) is not a flat 1e-4: raw 'classical' RGB crosses zero, and with the 1e-3 floor an fp32 rounding error of 1e-7 of
     the image range already reads as 1e-4 on a near-zero pixel.  The floor any fp32 implementation hits is measured two
@@ -120,6 +138,17 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
     if exact is not None:
         b3 = max(pix_tol, 1.5 * figs['reference_vs_exact_sym'])
         assert figs['hip_vs_exact'] <= b3, f"{what}: HIP vs exactly-rounded image {figs['hip_vs_exact']:.3e} > {b3:.3e}"
+    if (key + '_f64') in g:
+        f64 = np.asarray(g[key + '_f64'], np.float64)
+        scale = np.abs(f64).max()
+        ours, refs = max_rel(img, f64), max_rel(ref, f64)
+        ours_mean = float(np.abs(np.asarray(img, np.float64) - f64).mean() / scale)
+        refs_mean = float(np.abs(np.asarray(ref, np.float64) - f64).mean() / scale)
+        report_parity(what + ' vs the reference run in float64', pix_vs_reference_f64=ours, reference_fp32_vs_reference_f64=refs,
+                      mean_err_vs_f64=ours_mean, reference_fp32_mean_err_vs_f64=refs_mean)
+        b4 = max(pix_tol, 3 * refs)
+        assert ours <= b4, f'{what}: max-rel vs the float64 reference {ours:.3e} > {b4:.3e} (the reference\'s fp32 run: {refs:.3e})'
+        assert ours_mean <= 1.25 * refs_mean + 1e-8, f'{what}: mean error vs the float64 reference {ours_mean:.3e} vs the reference\'s own {refs_mean:.3e}'
     return rng, pix, self_noise
 
 # ------------------------------------------------------------------------------------------------ upfirdn2d backward

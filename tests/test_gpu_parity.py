@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_close, assert_image_parity, load_golden, report_parity
+from conftest import assert_close, assert_close_up_to_threshold_flips, assert_image_parity, load_golden, report_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -183,6 +183,8 @@ def test_modconv_oracle(tdgp, oracle, B, cin, cout, H, k, up):
     (8, 136, 70, 64, 64, dict(clamp=0.7)),                 # 17 chunks (odd), Cout tail inside a 64-channel block, clamp
     (3, 72, 130, 64, 128, dict(noise=False)),              # H != W, three output-channel blocks with a tail, no noise
     (16, 64, 32, 64, 64, dict(styles=False)),              # unmodulated (Conv2dLayer form), Cout < 64
+    (16, 64, 64, 64, 64, dict(noise='per_sample')),        # noise_mode='random': one [1,H,W] map per sample (noise_bstride = H*W), metric_utils.py:310
+    (8, 128, 128, 32, 64, dict(noise='per_sample', clamp=0.9)),
 ])
 def test_modconv_winograd_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
     """The Winograd F(2x2,3x3) kernel (default arithmetic for the large stride-1 3x3 layers, modconv_wino.inc) against the double-
@@ -193,6 +195,8 @@ def test_modconv_winograd_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
     styles = kw.get('styles', True)
     s = (1 + 0.5 * rs.randn(B, cin)).astype(np.float32) if styles else None
     noise = (0.3 * rs.randn(H, W)).astype(np.float32) if kw.get('noise', True) else None
+    if kw.get('noise') == 'per_sample':
+        noise = (0.3 * rs.randn(B, 1, H, W)).astype(np.float32)        # networks_stylegan2.py:133-134: randn([B,1,res,res]) * noise_strength
     bias = (0.2 * rs.randn(cout)).astype(np.float32)
     clamp = kw.get('clamp')
     oracle.set_threads(min(64, __import__('os').cpu_count() or 1))
@@ -559,7 +563,11 @@ def test_e2e_tiny(tdgp, oracle):
     npm = int((inter['perm'].cpu().numpy().reshape(-1) != g['perm'].reshape(-1)).sum())
     report_parity('e2e_tiny integer rows through the whole chain', inds_mismatches=ni, inds_total=int(g['inds'].size), perm_mismatches=npm,
                   perm_total=int(g['perm'].size))
-    assert ni <= 2e-3 * g['inds'].size and npm <= 5e-3 * g['perm'].size, (ni, npm)
+    # measured: 0 / 4096 and 0 / 8192 (profiles/*_parity_report.json).  Bound = "a handful, each explained": a mismatching index may only
+    # move to the neighbouring cdf interval (a draw within an ulp of a knot), a mismatching sort slot only swap with its neighbour.
+    hi, gi = inter['inds'].cpu().numpy().reshape(-1).astype(np.int64), g['inds'].reshape(-1).astype(np.int64)
+    assert ni <= 2 and (ni == 0 or np.abs(hi - gi).max() <= 1), (ni, np.abs(hi - gi).max())
+    assert npm <= 4, npm
 
 
 def test_e2e_tiny_cut_quantile(tdgp, oracle):
@@ -583,6 +591,24 @@ def test_e2e_tiny_cut_quantile(tdgp, oracle):
     oimg, odepth = oracle.synthesis_forward(sd, c, g['ws'], {k[4:]: v for k, v in g.items() if k.startswith('cam_')}, g['u_coarse'], g['u_fine'], 'const')
     assert_close(N(a.img), oimg, 1e-5, 'mip img, cut_quantile 0.4, vs oracle', 1.0)
     assert_close(N(a.depth), odepth, 1e-5, 'mip depth, cut_quantile 0.4, vs oracle', 1.0)
+
+
+def test_cut_quantile_above_max_batch_res_is_chunked_by_rays(tdgp):
+    """eval + cut_quantile above max_batch_res = the reference's ray chunks with per-chunk quantiles
+    (networks_epigraf.py:232-239); golden from the reference at 4 x 128^2 x 96 (chunks of 14563 rays)."""
+    cfg = tdgp.config.config_cut_chunked()
+    g = load_golden('cut_chunked')
+    seed, batch, step = (int(v) for v in g['seed'])
+    G = _gen(tdgp, cfg, seed)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=batch, seed=seed)
+    cam = {k: T(v) for k, v in inp['camera'].items()}
+    out = G.synthesis(T(g['ws']), camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True, cut_quantile=0.5),
+                      u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']))
+    assert_close_up_to_threshold_flips(N(out.img), g['img_cut'], 'img, cut_quantile 0.5, ray-chunked')
+    assert_close_up_to_threshold_flips(N(out.depth), g['depth_cut'], 'depth, cut_quantile 0.5, ray-chunked')
+    one = G.synthesis(T(g['ws']), camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True, cut_quantile=0.5, max_batch_res=128),
+                      u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']))
+    assert float((one.img - out.img).abs().max()) > 1e-3 * float(np.abs(g['img_cut']).max())      # a global quantile is a different image
 
 
 def test_batched_demod_equals_per_layer(tdgp):
@@ -893,7 +919,8 @@ def _assert_bf16_close(got, ref, what, max_tol=BF16_MAX, mean_tol=BF16_MEAN):
 
 @pytest.mark.parametrize('B,cin,cout,H,k,up,noise', [(2, 64, 64, 32, 3, 1, True), (3, 32, 96, 64, 3, 1, False), (2, 96, 40, 32, 3, 1, True),
                                                       (2, 64, 32, 32, 3, 2, True), (1, 32, 64, 64, 3, 2, False), (2, 128, 130, 16, 3, 2, True),
-                                                      (2, 64, 64, 16, 3, 1, True), (2, 24, 16, 32, 3, 1, False)])
+                                                      (2, 64, 64, 16, 3, 1, True), (2, 24, 16, 32, 3, 1, False),
+                                                      (3, 64, 64, 32, 3, 1, 'per_sample'), (2, 64, 32, 32, 3, 2, 'per_sample')])
 def test_bf16_modconv_vs_oracle(tdgp, oracle, B, cin, cout, H, k, up, noise):
     """One reduced-precision synthesis layer (modulated 3x3 conv, stride 1 or x2 + FIR, noise, bias, lrelu * sqrt2, clamp 256) on bf16
     activations: tdgp_modconv2d_bf16 -- and, for the last two shapes, the widened fp32 fallback -- against the oracle's bf16 path."""
@@ -904,6 +931,8 @@ def test_bf16_modconv_vs_oracle(tdgp, oracle, B, cin, cout, H, k, up, noise):
     s = (1.0 + 0.5 * rs.randn(B, cin)).astype(np.float32)
     bias = rs.randn(cout).astype(np.float32)
     nz = (0.3 * rs.randn(H * up, H * up)).astype(np.float32) if noise else None
+    if noise == 'per_sample':                  # noise_mode='random' (networks_stylegan2.py:133-134): [B,1,H,W], batch stride H*W
+        nz = (0.3 * rs.randn(B, 1, H * up, H * up)).astype(np.float32)
     f = oracle.setup_filter([1, 3, 3, 1])
     ref = oracle.bias_act_bf16(oracle.modulated_conv2d(x, w, s, noise=nz, up=up, demodulate=True, resample_filter=f, prec='bf16'), bias, act='lrelu', clamp=256)
     y = mc.modconv_forward(T(x).to(torch.bfloat16), mc.PackedConv(T(w)), T(s), noise=None if nz is None else T(nz), bias=T(bias), up=up, demodulate=True,
@@ -953,6 +982,66 @@ def test_bf16_generator_vs_reference_golden(tdgp, oracle):
     from oracle import pipeline as P
     oplanes = P.synthesis_backbone(sd, cfg.to_dict(), g['ws'], 'const')
     _assert_bf16_close(N(planes), oplanes, 'tri-planes vs the oracle')
+
+
+def test_bf16_planes_nchw_equal_channel_last(tdgp):
+    """with reduced-precision blocks the tri-plane image must stay fp32 in BOTH layouts (networks_stylegan2.py:268
+    `y.to(float32); img.add_`): the public NCHW form (hwc=False) takes the widened ToRGB fallback and must neither round the accumulated
+    skip image to bf16 nor return a bf16 tensor."""
+    cfg = tdgp.config.config_mid_bf16()
+    G = _gen(tdgp, cfg, 61)
+    dec = G.synthesis.tri_plane_decoder
+    ws = T(load_golden('bf16')['ws'])
+    nchw = dec(ws, noise_mode='const')
+    hwc = dec(ws, noise_mode='const', hwc=True).t
+    assert nchw.dtype == torch.float32 and hwc.dtype == torch.float32
+    a, b = N(nchw), N(hwc.permute(0, 1, 4, 2, 3).reshape(nchw.shape))
+    # same bf16 activations in, fp32 products and sums in both kernels: equal to fp32 rounding (a bf16-rounded image would be off by 4e-3)
+    assert_close(a, b, 1e-5, 'bf16 blocks: tri-planes NCHW vs channel-last', 1.0)
+
+
+def _recorded_randn(fn):
+    """Run fn() with torch.randn recorded: -> (result, [draws in call order]) -- the per-layer noise maps of noise_mode='random'."""
+    draws, real = [], torch.randn
+
+    def rec(*a, **k):
+        t = real(*a, **k)
+        draws.append(t)
+        return t
+    torch.randn = rec
+    try:
+        return fn(), draws
+    finally:
+        torch.randn = real
+
+
+def test_full_size_backbone_random_noise_vs_oracle(tdgp, oracle, full_c3):
+    """noise_mode='random' -- the default of the FID loop (metric_utils.py:310) -- at the real C3 shapes with non-zero noise strengths:
+    every layer gets its own [B,1,res,res] map (networks_stylegan2.py:133-134), i.e. the per-sample noise path (noise_bstride != 0) of the
+    Winograd kernel, the direct kernel and the x2 FIR pass.  The draws are recorded and handed to the oracle as explicit maps."""
+    cfg, sd, G = full_c3['cfg'], full_c3['sd'], full_c3['G']
+    dec = G.synthesis.tri_plane_decoder
+    ws = full_c3['ws'][:2]
+    tdgp._lib.profile_enable(True)
+    try:
+        planes, draws = _recorded_randn(lambda: dec(ws, noise_mode='random', hwc=True))
+        torch.cuda.synchronize()
+        names = set(tdgp._lib.profile_report())
+    finally:
+        tdgp._lib.profile_enable(False)
+    layers = [l for (l, _, _) in dec._layers() if isinstance(l, tdgp.generator.SynthesisLayer)]
+    assert len(draws) == len(layers) == 15 and all(d.shape == (2, 1, l.resolution, l.resolution) for d, l in zip(draws, layers))
+    assert all(float(sd[f'synthesis.tri_plane_decoder.{n}.noise_strength']) != 0.0 for n in ('b512.conv1', 'b64.conv0'))
+    prefixes = [f'synthesis.tri_plane_decoder.b{l.resolution}.conv{1 if (i == 0 or i % 2 == 0) else 0}' for i, l in enumerate(layers)]
+    assert prefixes[0].endswith('b4.conv1') and prefixes[1].endswith('b8.conv0') and prefixes[-1].endswith('b512.conv1')
+    noise = {pfx: N(d[:1]) for pfx, d in zip(prefixes, draws)}
+    oracle.set_threads(min(64, __import__('os').cpu_count() or 1))
+    ref = oracle.synthesis_backbone(sd, cfg.to_dict(), N(ws)[:1], noise)
+    got = N(planes.t[:1].permute(0, 1, 4, 2, 3).reshape(1, 96, 512, 512))
+    assert_close(got, ref, 1e-5, 'tri-planes 512^2, per-sample random noise', 1.0)
+    const = N(full_c3['planes'].t[:1].permute(0, 1, 4, 2, 3).reshape(1, 96, 512, 512))
+    assert np.abs(got - const).max() > 1e-2 * np.abs(const).max()          # the noise maps matter
+    assert 'conv_wino_kernel' in names and 'fir_act_kernel' in names, names     # B = 2: the 64^2 ... 512^2 stride-1 layers run as Winograd
 
 
 def test_config_c5_vs_oracle(tdgp, oracle):

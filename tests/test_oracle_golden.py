@@ -6,7 +6,7 @@ Integer rows (searchsorted indices, sort permutation): bit-exact on identical in
 import numpy as np
 import pytest
 
-from conftest import assert_close, assert_image_parity, load_golden
+from conftest import assert_close, assert_close_up_to_threshold_flips, assert_image_parity, load_golden
 
 ACTS = ['linear', 'relu', 'lrelu', 'tanh', 'sigmoid', 'elu', 'selu', 'softplus', 'swish']
 
@@ -220,6 +220,26 @@ def test_e2e_tiny_cut_quantile(oracle, tdgp):
     assert np.abs(g['img_cut'] - g['img']).max() > 0.1                 # the option changes the image
     assert_close(img, g['img_cut'], 1e-5, 'img, cut_quantile 0.5', 1.0)
     assert_close(depth, g['depth_cut'], 1e-5, 'depth, cut_quantile 0.5', 1.0)
+
+
+def test_cut_quantile_above_max_batch_res_is_chunked_by_rays(oracle, tdgp):
+    """above max_batch_res the reference renders an eval forward with cut_quantile through run_batchwise over ray chunks of
+    2**24 // (B * num_ray_steps * 3) rays (networks_epigraf.py:232-239) -- quantiles per chunk.  4 x 128^2 rays x 96 steps -> chunks of
+    14563 rays; golden = the reference's image, inputs regenerated from the seed."""
+    cfg = tdgp.config.config_cut_chunked()
+    g = load_golden('cut_chunked')
+    seed, batch, step = (int(v) for v in g['seed'])
+    assert step == 2 ** 24 // (batch * cfg.num_ray_steps * 3) < cfg.img_resolution ** 2
+    sd = tdgp.weights.random_state_dict(cfg, seed=seed, exercise_all=True)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=batch, seed=seed)
+    c = cfg.to_dict()
+    c['cut_quantile'] = 0.5
+    img, depth = oracle.synthesis_forward(sd, c, g['ws'], inp['camera'], inp['u_coarse'], inp['u_fine'], 'const')
+    assert_close_up_to_threshold_flips(img, g['img_cut'], 'oracle img, cut_quantile 0.5, ray-chunked')
+    assert_close_up_to_threshold_flips(depth, g['depth_cut'], 'oracle depth, cut_quantile 0.5, ray-chunked')
+    c['max_batch_res'] = 128                   # not above max_batch_res -> one global quantile: a different image
+    img1, _ = oracle.synthesis_forward(sd, c, g['ws'], inp['camera'], inp['u_coarse'], inp['u_fine'], 'const')
+    assert (np.abs(img1 - g['img_cut']) > 1e-3 * np.abs(g['img_cut']).max()).mean() > 0.2      # ... on most pixels
 
 
 def test_e2e_tiny_mip(oracle, tdgp):

@@ -666,6 +666,29 @@ def gen_e2e(tag, cfg, batch, seed, keep_intermediates):
         torch.backends.mkldnn.enabled = True
         torch.set_num_threads(8)
         arrays.update(img_alt=npy(alt.img), depth_alt=npy(alt.depth))
+        # The reference ITSELF in float64 on the same ws / cameras / draws: the exactly-rounded image the fp32 runs (the reference's
+        # and ours) are both measured against -- the pin of the RGB bound that does not lean on this repo's oracle (VERDICT r02 #4a).
+        G64 = build_ref_generator(cfg, sd).double()
+        # cameras -> c2w -> rays are computed in fp32 as always (rendering_utils.py builds fp32 constants; the rays are bit-identical between
+        # the implementations anyway) and handed to the float64 run: "exact" = exactly rounded given those rays, ws and draws
+        import src.training.networks_epigraf as ref_epi
+        c2w32 = ref_ru.compute_cam2world_matrix(cam)
+        ro32, rd32 = ref_tpr.sample_rays(c2w32, fov=cam.fov, resolution=(cfg.img_resolution,) * 2)
+        o_c2w, o_rays = ref_epi.compute_cam2world_matrix, ref_epi.sample_rays
+        ref_epi.compute_cam2world_matrix = lambda camera_params: c2w32
+        ref_epi.sample_rays = lambda *a, **k: (ro32.double(), rd32.double())
+        torch.set_default_dtype(torch.float64)          # linspace / arange / constants created inside the renderer
+        f32 = torch.float32
+        torch.float32 = torch.float64                   # SynthesisBlock casts to `torch.float32` by name (networks_stylegan2.py:237,250,268) and
+        try:                                            # conv2d_resample.py:73 asserts the FIR's dtype against it: the name means "working precision"
+            with PatchedRNG(rand_like=[T(inp['u_coarse']).reshape(batch, R, S, 1).double()], rand=[T(inp['u_fine']).double()]):
+                o64 = G64.synthesis(ws.double(), camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True))
+        finally:
+            torch.float32 = f32
+            torch.set_default_dtype(torch.float32)
+            ref_epi.compute_cam2world_matrix, ref_epi.sample_rays = o_c2w, o_rays
+        assert o64.img.dtype == torch.float64
+        arrays.update(img_f64=npy(o64.img), depth_f64=npy(o64.depth))
         if keep_intermediates:
             planes = G.synthesis.tri_plane_decoder(ws, noise_mode='const')
             c2w = ref_ru.compute_cam2world_matrix(cam)
@@ -689,6 +712,30 @@ def gen_e2e(tag, cfg, batch, seed, keep_intermediates):
             with PatchedRNG(rand_like=[T(inp['u_coarse']).reshape(batch, R, S, 1)], rand=[T(inp['u_fine'])]):
                 arrays['img_noise_none'] = npy(G.synthesis(ws, camera_params=cam, noise_mode='none'))
     save(tag, **arrays)
+
+
+def gen_cut_chunked():
+    """cut_quantile above max_batch_res in eval: the reference renders through run_batchwise over ray chunks of
+    2**24 // (B * num_ray_steps * 3) rays (networks_epigraf.py:232-239), so torch.quantile -- and the random draws -- are taken PER
+    CHUNK.  Smallest case that really chunks: 4 x 128^2 rays x 96 steps -> chunks of 14563 rays.  Inputs are regenerated from the seed
+    (weights.synthetic_inputs: numpy RandomState), only the outputs are stored."""
+    cfg = tdgp.config.config_cut_chunked()
+    batch, seed = 4, 51
+    sd = tdgp.weights.random_state_dict(cfg, seed=seed, exercise_all=True)
+    G = build_ref_generator(cfg, sd)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=batch, seed=seed)
+    cam = TensorGroup(**{k: T(v) for k, v in inp['camera'].items()})
+    R, S = cfg.img_resolution ** 2, cfg.num_ray_steps
+    step = 2 ** 24 // (batch * S * 3)
+    assert step < R and cfg.img_resolution > cfg.max_batch_res, (step, R)
+    uc, uf = T(inp['u_coarse']).reshape(batch, R, S), T(inp['u_fine']).reshape(batch, R, S)
+    likes = [uc[:, a:a + step].reshape(batch, -1, S, 1) for a in range(0, R, step)]
+    rands = [uf[:, a:a + step].reshape(-1, S) for a in range(0, R, step)]
+    with torch.no_grad():
+        ws = G.mapping(T(inp['z']), T(inp['c']))
+        with PatchedRNG(rand_like=likes, rand=rands):
+            cut = G.synthesis(ws, camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True, cut_quantile=0.5))
+    save('cut_chunked', seed=np.array([seed, batch, step], dtype=np.int64), ws=npy(ws), img_cut=npy(cut.img), depth_cut=npy(cut.depth))
 
 
 class _CudaFlag(torch.Tensor):
@@ -1183,9 +1230,12 @@ def gen_harness():
 
 def main():
     torch.set_num_threads(8)
-    if len(sys.argv) > 1:                      # regenerate selected files only: python tools/gen_goldens.py adaptors
+    if len(sys.argv) > 1:                      # regenerate selected files only: python tools/gen_goldens.py adaptors e2e
         for name in sys.argv[1:]:
-            globals()['gen_' + name]()
+            if name == 'e2e':
+                gen_e2e_all()
+            else:
+                globals()['gen_' + name]()
         return
     gen_adaptors()
     gen_metrics()
@@ -1212,6 +1262,11 @@ def main():
     gen_marchers()
     gen_camera()
     gen_mapping()
+    gen_cut_chunked()
+    gen_e2e_all()
+
+
+def gen_e2e_all():
     gen_e2e('e2e_tiny', tdgp.config.config_tiny(), batch=2, seed=21, keep_intermediates=True)
     gen_e2e('e2e_mid', tdgp.config.config_mid(), batch=2, seed=31, keep_intermediates=False)
     cfg = tdgp.config.config_tiny()
