@@ -114,7 +114,7 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
          to the reference's own fp32 image: per-pixel max-rel <= max(RGB_TOL, 3 x the reference-fp32-vs-f64 figure) (a maximum
          over pixels of ulp-level noise amplified 1000x on near-zero pixels scatters by that much between two fp32 evaluations;
          the reference's fp32 run is 1.7e-4 / 3.0e-4 / 2.9e-4 from its own float64 run on the three goldens, i.e. it does not
-         meet a flat 1e-4 against itself), and the robust statistic, mean |d| / max|ref|, <= 1.25 x the reference's + 1e-8.
+         meet a flat 1e-4 against itself), and the robust statistic, mean |d| / max|ref|, <= 1.25 x the reference's + 6e-8 (half an fp32 ulp of the range).
 
     Why (2) is not a flat 1e-4: raw 'classical' RGB crosses zero, and with the 1e-3 floor an fp32 rounding error of 1e-7 of
     the image range already reads as 1e-4 on a near-zero pixel.  The floor any fp32 implementation hits is measured two
@@ -148,7 +148,8 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
                       mean_err_vs_f64=ours_mean, reference_fp32_mean_err_vs_f64=refs_mean)
         b4 = max(pix_tol, 3 * refs)
         assert ours <= b4, f'{what}: max-rel vs the float64 reference {ours:.3e} > {b4:.3e} (the reference\'s fp32 run: {refs:.3e})'
-        assert ours_mean <= 1.25 * refs_mean + 1e-8, f'{what}: mean error vs the float64 reference {ours_mean:.3e} vs the reference\'s own {refs_mean:.3e}'
+        # + half an fp32 ulp of the range: depth maps sit at that floor on both sides
+        assert ours_mean <= 1.25 * refs_mean + 6e-8, f'{what}: mean error vs the float64 reference {ours_mean:.3e} vs the reference\'s own {refs_mean:.3e}'
     return rng, pix, self_noise
 
 # ------------------------------------------------------------------------------------------------ upfirdn2d backward

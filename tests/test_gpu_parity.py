@@ -184,7 +184,7 @@ def test_modconv_oracle(tdgp, oracle, B, cin, cout, H, k, up):
     (3, 72, 130, 64, 128, dict(noise=False)),              # H != W, three output-channel blocks with a tail, no noise
     (16, 64, 32, 64, 64, dict(styles=False)),              # unmodulated (Conv2dLayer form), Cout < 64
     (16, 64, 64, 64, 64, dict(noise='per_sample')),        # noise_mode='random': one [1,H,W] map per sample (noise_bstride = H*W), metric_utils.py:310
-    (8, 128, 128, 32, 64, dict(noise='per_sample', clamp=0.9)),
+    (16, 128, 128, 32, 64, dict(noise='per_sample', clamp=0.9)),
 ])
 def test_modconv_winograd_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
     """The Winograd F(2x2,3x3) kernel (default arithmetic for the large stride-1 3x3 layers, modconv_wino.inc) against the double-
@@ -996,8 +996,14 @@ def test_bf16_planes_nchw_equal_channel_last(tdgp):
     hwc = dec(ws, noise_mode='const', hwc=True).t
     assert nchw.dtype == torch.float32 and hwc.dtype == torch.float32
     a, b = N(nchw), N(hwc.permute(0, 1, 4, 2, 3).reshape(nchw.shape))
-    # same bf16 activations in, fp32 products and sums in both kernels: equal to fp32 rounding (a bf16-rounded image would be off by 4e-3)
-    assert_close(a, b, 1e-5, 'bf16 blocks: tri-planes NCHW vs channel-last', 1.0)
+    # the channel-last kernel keeps the reference's bf16 rounding points inside ToRGB (weights, style-scaled activations, the pre-skip
+    # term), the widened NCHW fallback multiplies the same bf16 activations in fp32: they agree to bf16 rounding of ONE ToRGB term per
+    # block, and both sit inside the bf16 tolerance against the reference's own reduced-precision run
+    _assert_bf16_close(a, b, 'tri-planes NCHW vs channel-last', max_tol=6e-3, mean_tol=5e-4)
+    _assert_bf16_close(a, load_golden('bf16')['planes'], 'NCHW tri-planes vs the reference')
+    # ... and the image itself was never rounded to bf16: (almost) no value is bf16-representable
+    as_bf16 = N(nchw.to(torch.bfloat16).float())
+    assert (as_bf16 != a).mean() > 0.9
 
 
 def _recorded_randn(fn):
