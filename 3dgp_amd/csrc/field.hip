@@ -590,6 +590,8 @@ __global__ __launch_bounds__(256, 2) void triplane_field_kernel(FieldParams p) {
 template <int FQ, int MT, bool TAPS>
 __global__ __launch_bounds__(256, TDGP_WALK_WAVES) void triplane_walk_kernel(FieldParams p) { field_body<FQ, MT, TAPS, true>(p); }
 
+#include "field_walk2.inc"
+
 // NCHW planes [B,3F,H,W] -> [B,3,H,W,F] through an LDS tile of 64 pixels x F channels.
 __global__ __launch_bounds__(256) void planes_to_hwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int F, int HW, int64_t ntiles,
                                                            int tiles_per_plane) {
@@ -611,10 +613,32 @@ __global__ __launch_bounds__(256) void planes_to_hwc_kernel(const float* __restr
     }
 }
 
+#ifndef TDGP_WALK2
+#define TDGP_WALK2 1           // 0: the one-role table walk (triplane_walk_kernel) everywhere -- A/B builds
+#endif
+
 template <int FQ, int MT, bool TAPS>
 void launch_field_t(const FieldParams& p, hipStream_t s) {
     int64_t want;
     const bool walk = FQ % 4 == 0 && p.ray_w > 0 && p.planes_bytes != 0;
+    if constexpr (FQ % 4 == 0 && FQ <= 8 && TDGP_WALK2) {
+        // producer / consumer walk (field_walk2.inc): whole groups of four samples, a ring that is shorter than a patch's march
+        if (walk && (p.S & 3) == 0 && p.S >= 16) {
+            using L = Walk2Lds<FQ, MT>;
+            static int cus = 0;
+            if (cus == 0) {
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+                (void)hipFuncSetAttribute((const void*)triplane_walk2_kernel<FQ, MT, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
+            }
+            const int64_t npatch = (p.total / p.P) * cdiv(p.ray_w, 8) * cdiv(p.ray_h, 8);
+            int blocks = (int)min((int64_t)cus, npatch);                // one 512-thread block per CU, each striding over the patches
+            if (blocks > 8) blocks -= blocks % 8;
+            TDGP_LAUNCH("triplane_field_kernel", (triplane_walk2_kernel<FQ, MT, TAPS>), dim3(blocks), dim3(512), L::total, s, p);
+            return;
+        }
+    }
     const int threads = 256;
     if (p.ray_w > 0) want = (p.total / p.P) * cdiv(p.ray_w, 8) * cdiv(p.ray_h, 8);      // one 8x8-pixel patch per block
     else want = cdiv64((p.total + 15) / 16, 4);                                          // one 16-point tile per wave

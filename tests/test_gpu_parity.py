@@ -350,6 +350,38 @@ def test_field_hot_shape(tdgp, oracle):
     assert tdgp.renderer.simple_tri_plane_renderer(T(planes), T(coords[:, :0]), _mlp(tdgp, *ws, 'classical'), scale=0.5)['rgb'].shape == (B, 0, 3)
 
 
+@pytest.mark.parametrize('B,h,w,S,F,hid,marcher', [(2, 16, 24, 16, 32, 64, 'classical'), (3, 20, 12, 32, 32, 64, 'mip'), (1, 64, 64, 64, 32, 64, 'classical'),
+                                                     (2, 9, 17, 20, 16, 32, 'classical'), (1, 24, 24, 24, 32, 128, 'classical'), (2, 32, 32, 96, 32, 64, 'classical'),
+                                                     (2, 128, 136, 16, 32, 64, 'classical')])
+def test_field_image_walk_equals_linear_order(tdgp, B, h, w, S, F, hid, marcher):
+    """The image walk (ray_w > 0; the producer / consumer kernel of field_walk2.inc when S % 4 == 0 and S >= 16) runs the same arithmetic
+    in the same order as the linear-point-order kernel: (r, g, b, sigma) bit for bit, the tap-index rows too -- including ray images that
+    are not whole 8x8 patches, depths that leave the cube (zero padding), density noise, and more patches than blocks."""
+    rs = np.random.RandomState(S * 7 + h)
+    H = 48
+    planes = T(rs.randn(B, 3 * F, H, H))
+    mlp = _mlp(tdgp, rs.randn(hid, F), 0.3 * rs.randn(hid), rs.randn(4, hid), 0.3 * rs.randn(4), marcher)
+    cam = dict(angles=T(np.stack([rs.uniform(-1, 1, B), rs.uniform(1.0, 2.0, B), np.zeros(B)], 1)), radius=T(np.ones(B)), look_at=T(np.zeros((B, 3))))
+    ro, rd = tdgp.renderer.sample_rays(tdgp.renderer.compute_cam2world_matrix(cam), T(rs.uniform(15, 45, B)), (w, h))
+    R = h * w
+    assert ro.shape == (B, R, 3)
+    t = T(np.sort(rs.uniform(0.4, 1.6, (B, R, S)), axis=2))                   # beyond the cube at both ends
+    hw = tdgp.renderer.planes_to_hwc(planes)
+    mp = tdgp.renderer._mlp_params(mlp)
+    n = T(rs.randn(B, R * S))
+    for kw in (dict(), dict(sigma_noise=n, density_noise=0.8)):
+        lin = tdgp.renderer._field(hw, mp, 0.5, ray_o=ro, ray_d=rd, t=t, ray_w=0, **kw)
+        img = tdgp.renderer._field(hw, mp, 0.5, ray_o=ro, ray_d=rd, t=t, ray_w=w, **kw)
+        np.testing.assert_array_equal(N(img), N(lin))
+    taps_l = torch.full([B, R * S, 3, 2], -7, dtype=torch.int32, device=DEV)
+    taps_i = torch.full([B, R * S, 3, 2], -7, dtype=torch.int32, device=DEV)
+    lin = tdgp.renderer._field(hw, mp, 0.5, ray_o=ro, ray_d=rd, t=t, ray_w=0, tap_idx=taps_l)
+    img = tdgp.renderer._field(hw, mp, 0.5, ray_o=ro, ray_d=rd, t=t, ray_w=w, tap_idx=taps_i)
+    np.testing.assert_array_equal(N(img), N(lin))
+    np.testing.assert_array_equal(taps_i.cpu().numpy(), taps_l.cpu().numpy())
+    assert int((taps_i == -7).sum()) == 0
+
+
 # ------------------------------------------------------------------------------------------------ sampling stages
 
 @pytest.mark.parametrize('marcher', ['classical', 'mip'])
