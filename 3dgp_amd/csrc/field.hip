@@ -632,7 +632,8 @@ void launch_field_t(const FieldParams& p, hipStream_t s) {
                 if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
                 (void)hipFuncSetAttribute((const void*)triplane_walk2_kernel<FQ, MT, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
             }
-            const int64_t npatch = (p.total / p.P) * cdiv(p.ray_w, 8) * cdiv(p.ray_h, 8);
+            const int ps = ((p.S & 15) == 0 && TDGP_WALK2_DEPTHSPLIT) ? 4 : 8;       // patch side (field_walk2.inc: DEPTHSPLIT)
+            const int64_t npatch = (p.total / p.P) * cdiv(p.ray_w, ps) * cdiv(p.ray_h, ps);
             int blocks = (int)min((int64_t)cus, npatch);                // one 512-thread block per CU, each striding over the patches
             if (blocks > 8) blocks -= blocks % 8;
             TDGP_LAUNCH("triplane_field_kernel", (triplane_walk2_kernel<FQ, MT, TAPS>), dim3(blocks), dim3(512), L::total, s, p);
