@@ -13,6 +13,7 @@ The directory name starts with a digit, so import it with ``importlib.import_mod
   inference            generate / generate_trajectory / camera trajectories
   compat               `src.*` module aliases so reference-style call sites resolve to this package
   distributed          batch-sharded multi-GPU generation (one process per GPU, RCCL all-gather of features)
+  graphs               the whole generator forward as one captured HIP graph per (batch, options)
 """
 from . import config, weights  # noqa: F401  (numpy only)
 from .config import GeneratorConfig  # noqa: F401
@@ -20,7 +21,7 @@ from .config import GeneratorConfig  # noqa: F401
 
 def __getattr__(name):
     # torch-dependent submodules are imported on first use
-    if name in ('_lib', 'ops', 'renderer', 'generator', 'adaptors', 'metrics', 'inference', 'discriminator', 'training', 'compat', 'distributed', 'build'):
+    if name in ('_lib', 'ops', 'renderer', 'generator', 'adaptors', 'metrics', 'inference', 'discriminator', 'training', 'compat', 'distributed', 'build', 'graphs'):
         import importlib
         return importlib.import_module(f'{__name__}.{name}')
     raise AttributeError(name)

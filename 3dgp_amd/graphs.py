@@ -1,0 +1,76 @@
+"""The generator forward as ONE captured HIP graph per (batch, options).
+
+At the batch the reference's FID loop generates with (metric_utils.py:305 `batch_gen = 4`) a forward is ~110 launches of 10-300 us
+each -- the library's kernels plus the mapping network's rocBLAS GEMMs and ~20 ATen micro-kernels (pow / mean / rsqrt / lerp / cat) -- and
+the host's launch path, not the GPU, paces it.  Captured once (hipStreamBeginCapture on the stream the forward runs on: the library takes
+its stream from the caller, include/tdgp.h) and replayed, the same kernels run back to back from one submission.  Nothing is skipped or
+cached: a replay executes every kernel of the forward on whatever the static input buffers hold at that moment.
+
+    gg = GraphedGenerator(G, batch=4)              # warm-up + capture
+    img = gg(z, c, camera_params)                  # copies the inputs into the static buffers, replays, returns the static output
+    gg.load(z, c, camera_params); gg.replay()      # the two halves separately (bench.py: inputs resident before the timed region)
+
+With `explicit_draws=False` the renderer's uniform draws (and `noise_mode='random'` maps) are made on the device INSIDE the graph, from
+torch's graph-safe Philox state: every replay draws fresh numbers, as the eager forward does.
+"""
+import torch
+
+
+class GraphedGenerator:
+    def __init__(self, G, batch, noise_mode='const', explicit_draws=False, truncation_psi=1, truncation_cutoff=None, render_opts=None, warmup=2):
+        dev = next(G.parameters()).device
+        assert dev.type == 'cuda', 'GraphedGenerator needs the generator on the GPU'
+        cfg = G.cfg
+        self.G, self.batch = G, batch
+        self.kw = dict(noise_mode=noise_mode, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        if render_opts:
+            if float(render_opts.get('cut_quantile', 0.0)) > 0.0:
+                raise NotImplementedError('cut_quantile reads a threshold back to the host (torch.quantile -> float): not capturable')
+            self.kw['render_opts'] = dict(render_opts)
+        R, S = cfg.img_resolution ** 2, cfg.num_ray_steps
+        f = dict(dtype=torch.float32, device=dev)
+        self.z = torch.zeros([batch, cfg.z_dim], **f)
+        self.c = torch.zeros([batch, cfg.c_dim], **f)
+        self.cam = dict(angles=torch.zeros([batch, 3], **f), fov=torch.full([batch], 20.0, **f), radius=torch.ones([batch], **f),
+                        look_at=torch.zeros([batch, 3], **f))
+        self.cam['angles'][:, 1] = 1.5707964          # a valid camera until load() is called (pitch 90 deg = the equator)
+        self.u_coarse = torch.rand([batch, R, S], **f) if explicit_draws else None
+        self.u_fine = torch.rand([batch * R, S], **f) if explicit_draws else None
+        # warm-up on a side stream (weight packing, demodulation tables, rocBLAS handles, allocator pools), then capture
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                self._forward()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._forward()
+
+    def _forward(self):
+        return self.G(self.z, self.c, self.cam, u_coarse=self.u_coarse, u_fine=self.u_fine, **self.kw)
+
+    def load(self, z, c, camera_params, u_coarse=None, u_fine=None):
+        """Copy one batch of inputs into the graph's static buffers (device-to-device when they are resident already)."""
+        get = (lambda k: camera_params[k]) if isinstance(camera_params, dict) else (lambda k: getattr(camera_params, k))
+        self.z.copy_(z)
+        self.c.copy_(c)
+        for k in self.cam:
+            self.cam[k].copy_(get(k))
+        if self.u_coarse is not None:
+            if u_coarse is None or u_fine is None:
+                raise RuntimeError('this graph was captured with explicit draws: pass u_coarse and u_fine')
+            self.u_coarse.copy_(u_coarse.reshape(self.u_coarse.shape))
+            self.u_fine.copy_(u_fine.reshape(self.u_fine.shape))
+        elif u_coarse is not None or u_fine is not None:
+            raise RuntimeError('this graph draws on the device (explicit_draws=False)')
+
+    def replay(self):
+        """Run the captured forward on the current contents of the static buffers; returns the static output (overwritten by the next replay)."""
+        self.graph.replay()
+        return self.out
+
+    def __call__(self, z, c, camera_params, u_coarse=None, u_fine=None):
+        self.load(z, c, camera_params, u_coarse, u_fine)
+        return self.replay()

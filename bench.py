@@ -185,10 +185,16 @@ def main():
     ap.add_argument('--chunk', type=int, default=-1, help='samples per pass through the high-resolution blocks + renderer (Infinity-Cache-sized working set); '
                                                            '0 = whole batch through every kernel; -1 = the package default')
     ap.add_argument('--chunk-from', type=int, default=0, help='first block resolution that runs chunked (0 = the package default)')
+    ap.add_argument('--graph', action='store_true', help='headline = replays of the forward captured as one HIP graph (3dgp_amd/graphs.py) instead of eager launches '
+                                                          '(one host call per kernel).  The other mode is timed and reported next to it either way; measured r03: the two '
+                                                          'agree to 0.3 % at B = 16 and B = 4 -- the forward is not launch-bound')
+    ap.add_argument('--fid-loop', action='store_true', help="also time the reference's FID generation loop shape (metric_utils.py:288-319): 64 images per rank as 16 "
+                                                             'sub-batches of 4 with device-side draws, one feature block (and, N > 1, one RCCL all-gather) per 64')
     ap.add_argument('--arith', default='f32', choices=['f32', 'direct', 'split'],
                     help="arithmetic of the large 3x3 convolutions: f32 = fp32 MFMA (default, the reported metric); split = opt-in 3 x bf16 split operands, "
                          "6 piece products, fp32 accumulation (fp32-grade results; reported with dtype 'bf16x3->f32' and never mixed with the default line)")
     args = ap.parse_args()
+    args.no_graph = not args.graph
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         assert torch.cuda.is_available() and torch.cuda.device_count() >= args.gpus, \
@@ -232,9 +238,21 @@ def main():
         inp = tdgp.weights.synthetic_inputs(cfg, batch=batch, seed=D.rank_seed(0, rank, world))
         return dict(z=T(inp['z']), c=T(inp['c']), cam={k: T(v) for k, v in inp['camera'].items()}, u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']))
 
-    def make_step(x):
+    graphs = {}
+
+    def graphed(batch):
+        """The captured forward for this batch size, its static buffers holding the (resident) synthetic inputs."""
+        if batch not in graphs:
+            graphs[batch] = tdgp.graphs.GraphedGenerator(G, batch, noise_mode='const', explicit_draws=True)
+        return graphs[batch]
+
+    def make_step(x, use_graph=None):
+        use_graph = (not args.no_graph) if use_graph is None else use_graph
+        if use_graph:
+            gg = graphed(x['z'].shape[0])
+            gg.load(x['z'], x['c'], x['cam'], x['u_coarse'], x['u_fine'])          # inputs resident in the graph's buffers before the timed region
         def step():
-            img = G(x['z'], x['c'], x['cam'], noise_mode='const', u_coarse=x['u_coarse'], u_fine=x['u_fine'])
+            img = gg.replay() if use_graph else G(x['z'], x['c'], x['cam'], noise_mode='const', u_coarse=x['u_coarse'], u_fine=x['u_fine'])
             if gather is not None:
                 if gather._pending is not None:
                     gather.wait()
@@ -253,6 +271,8 @@ def main():
 
     x = inputs(args.batch)
     elapsed = timed_steps(make_step(x), barrier, args.steps, args.warmup, world, dev, finish)
+    # the other launch mode next to the headline (eager when the headline replays a graph, and the other way round)
+    alt_elapsed = timed_steps(make_step(x, use_graph=args.no_graph), barrier, args.steps, args.warmup, world, dev, finish)
 
     # ---- per-kernel timing of the same step (HIP events on the launch stream, inside the library) -------------------
     # While profiling is on the library launches through hipExtLaunchKernelGGL with a start and a stop event attached to each
@@ -332,9 +352,41 @@ def main():
             continue
         xb = inputs(b)
         eb = timed_steps(make_step(xb), barrier, args.steps, args.warmup, world, dev, finish)
+        eb_alt = timed_steps(make_step(xb, use_graph=args.no_graph), barrier, args.steps, args.warmup, world, dev, finish)
         others[str(b)] = dict(value=round(b * world * args.steps / eb, 3), ms_per_step=round(eb / args.steps * 1e3, 3), batch_per_gpu=b, steps=args.steps,
-                              frac_of_fp32_mfma_ceiling=round(total_flop_img * b / (eb / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
+                              frac_of_fp32_mfma_ceiling=round(total_flop_img * b / (eb / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                              launch='eager' if args.no_graph else 'hip graph replay',
+                              **{('graph_value' if args.no_graph else 'eager_value'): round(b * world * args.steps / eb_alt, 3)})
         del xb
+
+    fid_loop = None
+    if args.fid_loop:
+        # metric_utils.py:288-319 (compute_feature_stats_for_generator): batch_size 64 per rank, generated as 64 // batch_gen forwards of
+        # batch_gen = 4 with noise_mode='random' and the renderer's own draws, concatenated, passed through the detector (stand-in: a fixed
+        # pooling to [64, 2048], the Inception pickle is a URL download) and appended -- one all-gather of the [64, 2048] block per 64 images.
+        gen, per = 4, 64
+        gg = tdgp.graphs.GraphedGenerator(G, gen, noise_mode='random', explicit_draws=False) if not args.no_graph else None
+        zs = [inputs(gen) for _ in range(2)]
+
+        def fid_step():
+            imgs = []
+            for i in range(per // gen):
+                xi = zs[i & 1]
+                if gg is not None:
+                    imgs.append(gg(xi['z'], xi['c'], xi['cam']).clone())
+                else:
+                    imgs.append(G(xi['z'], xi['c'], xi['cam'], noise_mode='random'))
+            feats = D.stand_in_features(torch.cat(imgs))
+            if gather is not None:
+                if gather._pending is not None:
+                    gather.wait()
+                gather.gather_async(feats)
+            return imgs[-1]
+        nfid = max(args.steps // 8, 3)
+        ef = timed_steps(fid_step, barrier, nfid, 1, world, dev, finish)
+        fid_loop = dict(value=round(per * world * nfid / ef, 3), unit='img/s', images_per_rank_per_step=per, sub_batch=gen, steps=nfid,
+                        ms_per_64=round(ef / nfid * 1e3, 3), noise_mode='random', draws='device (inside the graph)' if gg is not None else 'device',
+                        launch='hip graph replay' if gg is not None else 'eager', reference='metric_utils.py:288-319')
 
     if rank == 0:
         total_imgs = args.batch * world * args.steps
@@ -352,6 +404,8 @@ def main():
                        'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'img_resolution': cfg.img_resolution,
                        'num_ray_steps': cfg.num_ray_steps, 'depth_adaptor': bool(args.depth_adaptor), 'parallelism': f'dp{world} (batch-sharded, weights replicated)',
                        'schedule': dict(chunk=G.synthesis.chunk, chunk_from=G.synthesis.chunk_from)},
+            'launch': 'eager' if args.no_graph else 'hip graph replay (3dgp_amd/graphs.py: every kernel of the forward, one submission per step)',
+            ('graph_value' if args.no_graph else 'eager_value'): round(total_imgs / alt_elapsed, 3), 'fid_loop': fid_loop,
             'rccl_ranks_seen': ranks_seen, 'roofline': roofline, 'whole_forward': whole, 'other_batches': others, 'kernels': kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

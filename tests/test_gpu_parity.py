@@ -643,6 +643,28 @@ def test_cut_quantile_above_max_batch_res_is_chunked_by_rays(tdgp):
     assert float((one.img - out.img).abs().max()) > 1e-3 * float(np.abs(g['img_cut']).max())      # a global quantile is a different image
 
 
+def test_graph_replay_equals_eager_forward(tdgp):
+    """3dgp_amd/graphs.py: the whole forward captured as one HIP graph.  A replay runs the very kernels of the eager forward on the
+    static buffers: same image bit for bit, for new inputs too (nothing is cached across replays); with device-side draws every replay
+    renders a different image."""
+    cfg = tdgp.config.config_mid()
+    G = _gen(tdgp, cfg, 31)
+    gg = tdgp.graphs.GraphedGenerator(G, 2, noise_mode='const', explicit_draws=True)
+    for seed in (1, 2):
+        inp = tdgp.weights.synthetic_inputs(cfg, batch=2, seed=seed)
+        cam = {k: T(v) for k, v in inp['camera'].items()}
+        eager = G(T(inp['z']), T(inp['c']), cam, noise_mode='const', u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']))
+        replay = gg(T(inp['z']), T(inp['c']), cam, T(inp['u_coarse']), T(inp['u_fine']))
+        assert torch.equal(eager, replay)
+    gd = tdgp.graphs.GraphedGenerator(G, 2, noise_mode='random', explicit_draws=False)
+    a = gd(T(inp['z']), T(inp['c']), cam).clone()
+    b = gd(T(inp['z']), T(inp['c']), cam).clone()
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
+    assert float((a - b).abs().max()) < 0.5 * float(a.abs().max())          # same scene, different draws
+    with pytest.raises(RuntimeError):
+        gd(T(inp['z']), T(inp['c']), cam, T(inp['u_coarse']), T(inp['u_fine']))
+
+
 def test_batched_demod_equals_per_layer(tdgp):
     """tdgp_demod_batch (all layers' demodulation coefficients in one launch) is the same arithmetic as the per-call path of
     tdgp_modconv2d: coefficient tables and the backbone output must agree bit for bit."""
