@@ -48,7 +48,7 @@ _PROTOTYPES = {
                                     c_int, P]),
     'tdgp_ray_march': (c_int, [P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, P]),
     'tdgp_triplane_field_grad_workspace_bytes': (c_int64, [c_int, c_int64, c_int, c_int]),
-    'tdgp_triplane_field_grad': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, P]),
+    'tdgp_triplane_field_grad': (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int64, c_int, c_int, c_int, c_int, c_float, c_int, P]),
     'tdgp_ray_march_grad': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, P]),
     'tdgp_sample_importance': (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, P]),
     'tdgp_unify_samples': (c_int, [P, P, P, c_int, P, P, P, c_int, P, P, P, P, c_int64, c_int, P]),

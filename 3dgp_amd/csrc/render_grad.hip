@@ -171,6 +171,7 @@ struct FieldGradParams {
     const float* w0; const float* b0; const float* w1; const float* b1;
     const float* d_out;        // [B,P,4]
     float* d_planes;           // [B,3,H,W,F], accumulated into (caller zeroes) or null
+    float* d_coords;           // [B,P,3] gradient w.r.t. the sample positions, written; or null
     float* partial;            // [gridDim.x][npart]
     int64_t total, P;
     int F, hid, H, W, marcher, npart;
@@ -224,6 +225,8 @@ __global__ __launch_bounds__(64 * NW) void triplane_field_grad_kernel(FieldGradP
         const float q[3] = {cp[0] / p.scale, cp[1] / p.scale, cp[2] / p.scale};
         float tw_[3][4];
         int to_[3][4];
+        float fr_[3][2];                                      // (tw, tn): fractional position inside the texel cell, per plane
+        int in_[3];                                           // in-range mask of the four taps (bit t), per plane
         float gsum[16];
 #pragma unroll
         for (int c = 0; c < 16; c++) gsum[c] = 0.f;
@@ -237,12 +240,14 @@ __global__ __launch_bounds__(64 * NW) void triplane_field_grad_kernel(FieldGradP
             const int x0 = (int)cfx, y0 = (int)cfy;
             const float wgt[4] = {ts * te, ts * twx, tn * te, tn * twx};
             const float* plane = p.planes + ((int64_t)b * 3 + pl) * p.H * p.W * p.F;
+            fr_[pl][0] = twx; fr_[pl][1] = tn; in_[pl] = 0;
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int x = x0 + (t & 1), y = y0 + (t >> 1);
                 const bool in = valid && x >= 0 && x < p.W && y >= 0 && y < p.H;
                 tw_[pl][t] = in ? wgt[t] : 0.f;
                 to_[pl][t] = in ? (y * p.W + x) * p.F : 0;
+                in_[pl] |= in ? (1 << t) : 0;
             }
 #pragma unroll
             for (int c = 0; c < 16; c++) acc3[pl][c] = 0.f;
@@ -348,11 +353,57 @@ __global__ __launch_bounds__(64 * NW) void triplane_field_grad_kernel(FieldGradP
         // Transposed through LDS so that ONE atomic instruction adds the 32 channels of one tap (a 128-B line) per half-wave:
         // issued from the accumulator layout (lane = point) every instruction touched 64 different lines and the kernel ran at
         // the L2's atomic line rate (82 ms for 8.4 M points).
+        if (p.d_planes || p.d_coords) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) gl[l32 * FG_PITCH + (r & 3) + 8 * (r >> 2) + 4 * half] = dg[r];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- 6a. gradient w.r.t. the sample position (grid_sampler's grid gradient; what a camera is trained through, loss.py:69-83):
+        //     d ix = sum_c dg_c/3 [(ne - nw) ts + (se - sw) tn],   d iy = sum_c dg_c/3 [(sw - nw) te + (se - ne) tw]
+        // taps outside the plane read as zero (torch grid_sampler_2d_backward), then x (size - 1) / 2 (align_corners) and / scale.
+        // lane = (point, channel half): the taps are fetched again (cache hits: this wave gathered them a moment ago).
+        if (p.d_coords) {
+            float dq[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                const float* plane = p.planes + ((int64_t)b * 3 + pl) * p.H * p.W * p.F;
+                const float twx = fr_[pl][0], tn = fr_[pl][1], te = 1.0f - twx, ts = 1.0f - tn;
+                float gix = 0.f, giy = 0.f;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; c4++) {
+                    if (4 * c4 < fh) {
+                        float4 tv[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            tv[t] = *(const float4*)(plane + to_[pl][t] + half * fh + 4 * c4);
+                            if (!((in_[pl] >> t) & 1)) tv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                        const float* gq = gl + l32 * FG_PITCH + half * fh + 4 * c4;
+                        const float gv[4] = {gq[0], gq[1], gq[2], gq[3]};
+                        const float nw[4] = {tv[0].x, tv[0].y, tv[0].z, tv[0].w}, ne[4] = {tv[1].x, tv[1].y, tv[1].z, tv[1].w};
+                        const float sw[4] = {tv[2].x, tv[2].y, tv[2].z, tv[2].w}, se[4] = {tv[3].x, tv[3].y, tv[3].z, tv[3].w};
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            gix = fmaf_(gv[i], (ne[i] - nw[i]) * ts + (se[i] - sw[i]) * tn, gix);
+                            giy = fmaf_(gv[i], (sw[i] - nw[i]) * te + (se[i] - ne[i]) * twx, giy);
+                        }
+                    }
+                }
+                gix += __shfl_xor(gix, 32, 64);
+                giy += __shfl_xor(giy, 32, 64);
+                dq[pl == 2 ? 1 : 0] += gix * sx;                 // planes (x,y), (x,z), (y,z): width <- first coordinate
+                dq[pl == 0 ? 1 : 2] += giy * sy;
+            }
+            if (half == 0 && valid) {
+                const float k = 1.0f / (3.0f * p.scale);
+                float* dc = p.d_coords + gpc * 3;
+                dc[0] = dq[0] * k; dc[1] = dq[1] * k; dc[2] = dq[2] * k;
+            }
+        }
         if (p.d_planes) {
             int* tab_off = (int*)hl;                             // [32 pts][12 taps] float offset into d_planes (h / dh_pre are dead now)
             float* tab_w = hl + 32 * 12;
-#pragma unroll
-            for (int r = 0; r < 16; r++) gl[l32 * FG_PITCH + (r & 3) + 8 * (r >> 2) + 4 * half] = dg[r];
 #pragma unroll
             for (int pl = 0; pl < 3; pl++)
 #pragma unroll
@@ -431,8 +482,8 @@ TDGP_API int64_t tdgp_triplane_field_grad_workspace_bytes(int B, int64_t P, int 
 }
 
 TDGP_API int tdgp_triplane_field_grad(const float* planes_hwc, const float* coords, const float* w0, const float* b0, const float* w1, const float* b1,
-                                      const float* d_out, float* d_planes_hwc, float* d_w0, float* d_b0, float* d_w1, float* d_b1, void* workspace,
-                                      int64_t workspace_bytes, int B, int64_t P, int F, int H, int W, int hid, float scale, int marcher,
+                                      const float* d_out, float* d_planes_hwc, float* d_w0, float* d_b0, float* d_w1, float* d_b1, float* d_coords,
+                                      void* workspace, int64_t workspace_bytes, int B, int64_t P, int F, int H, int W, int hid, float scale, int marcher,
                                       tdgp_stream_t stream) {
     TDGP_CHECK(planes_hwc && coords && w0 && b0 && w1 && b1 && d_out && d_w0 && d_b0 && d_w1 && d_b1, TDGP_EINVAL, "triplane_field_grad: null pointer");
     TDGP_CHECK(B >= 1 && P >= 1 && H >= 2 && W >= 2, TDGP_EINVAL, "triplane_field_grad: bad shape");
@@ -443,7 +494,7 @@ TDGP_API int tdgp_triplane_field_grad(const float* planes_hwc, const float* coor
     const int64_t need = tdgp_triplane_field_grad_workspace_bytes(B, P, F, hid);
     TDGP_CHECK(workspace && workspace_bytes >= need, TDGP_EINVAL, "triplane_field_grad: workspace of %lld bytes needed", (long long)need);
     FieldGradParams p;
-    p.planes = planes_hwc; p.coords = coords; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1; p.d_out = d_out; p.d_planes = d_planes_hwc;
+    p.planes = planes_hwc; p.coords = coords; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.b1 = b1; p.d_out = d_out; p.d_planes = d_planes_hwc; p.d_coords = d_coords;
     p.partial = (float*)workspace; p.total = (int64_t)B * P; p.P = P; p.F = F; p.hid = hid; p.H = H; p.W = W; p.marcher = marcher;
     p.npart = hid * F + hid + 4 * hid + 4;
     p.scale = scale; p.g0 = (float)(1.0 / sqrt((double)F)); p.g1 = (float)(1.0 / sqrt((double)hid));

@@ -504,8 +504,9 @@ class SynthesisNetwork(torch.nn.Module):
                          **block_kwargs):
         """The same forward as a differentiable graph: gradients reach every parameter of the tri-plane
         backbone, the tri-plane MLP and `ws`.  Backbone = chain of the autograd ops (modulated convolutions, bias_act, upfirdn2d),
-        renderer = one autograd node (`renderer.render_autograd`), depth adaptor = conv2d_gradfix + bias_act.  Cameras / rays carry no
-        gradient (the camera adaptor is applied by the caller, as in loss.py:76-77, and its own parameters get none through the rays)."""
+        renderer = one autograd node (`renderer.render_autograd`), depth adaptor = conv2d_gradfix + bias_act.  When a camera parameter
+        requires a gradient (the camera adaptor applied by the caller, loss.py:76-77) the rays are built by `renderer.camera_rays_autograd`
+        and the renderer node returns d(rays) from the field kernel's coordinate gradient; otherwise rays come from the fused kernels."""
         render_opts = {**self._default_render_options, **render_opts}
         if (render_opts['return_depth_adapted'] or render_opts['concat_depth']) and self.depth_adaptor is None:
             raise RuntimeError('return_depth_adapted / concat_depth need cfg.depth_adaptor')
@@ -514,9 +515,13 @@ class SynthesisNetwork(torch.nn.Module):
         h = w = self.train_resolution if self.training else self.test_resolution
         cam = camera_params
         get = (lambda k: cam[k]) if isinstance(cam, dict) else (lambda k: getattr(cam, k))
-        with torch.no_grad():
-            c2w = _renderer.compute_cam2world_matrix(cam)
-            ray_o, ray_d = _renderer.sample_rays(c2w, fov=get('fov'), resolution=(h, w), patch_params=patch_params, device=ws.device)
+        cam_trained = any(isinstance(get(k), torch.Tensor) and get(k).requires_grad for k in ('angles', 'fov', 'radius', 'look_at'))
+        if cam_trained:                          # cameras from a trained CameraAdaptor (loss.py:76-77): rays as a differentiable graph
+            ray_o, ray_d = _renderer.camera_rays_autograd(cam, (h, w), patch_params=patch_params)
+        else:
+            with torch.no_grad():
+                c2w = _renderer.compute_cam2world_matrix(cam)
+                ray_o, ray_d = _renderer.sample_rays(c2w, fov=get('fov'), resolution=(h, w), patch_params=patch_params, device=ws.device)
         opts = self.rendering_options(render_opts)
         opts['u_coarse'], opts['u_fine'], opts['n_coarse'], opts['n_fine'] = u_coarse, u_fine, n_coarse, n_fine
         opts['ray_grid_w'] = w

@@ -93,6 +93,47 @@ def compute_cam2world_matrix(camera_params):
     return c2w
 
 
+def camera_rays_autograd(camera_params, resolution, patch_params=None):
+    """(ray_o, ray_d) [B, h*w, 3] as a differentiable function of the camera parameters: the arithmetic of tdgp_cam2world +
+    tdgp_sample_rays (reference: rendering_utils.py:194-218, tri_plane_renderer.py:487-527) written with tensor ops, so that autograd
+    carries d(rays) back to angles / radius / look_at / fov -- the path a trained camera adaptor needs (loss.py:76-77; the fused kernels
+    are used whenever no camera parameter requires a gradient).  Cameras sit on a sphere: position = radius * (sin(pitch) sin(-yaw),
+    cos(pitch), sin(pitch) cos(yaw)), the look-at point likewise from `look_at` = (yaw, pitch, radius); the camera looks down -z with the
+    world's +y as its up hint; pixel (row, col) of an h x w image shoots through x = -1 + 2 col / (w - 1), y = 1 - 2 row / (h - 1),
+    z = -1 / tan(fov / 2), optionally restricted to a patch (scale, offset in [0, 1] units)."""
+    get = (lambda k: camera_params[k]) if isinstance(camera_params, dict) else (lambda k: getattr(camera_params, k))
+    angles, radius, look_at, fov = get('angles').float(), get('radius').float(), get('look_at').float(), get('fov')
+    B, dev = angles.shape[0], angles.device
+    w, h = resolution
+
+    def on_sphere(yaw, pitch, r):
+        sp = torch.sin(pitch)
+        return torch.stack([r * sp * torch.sin(-yaw), r * torch.cos(pitch), r * sp * torch.cos(yaw)], dim=-1)
+
+    def unit(v):
+        return v / torch.norm(v, dim=-1, keepdim=True)
+
+    eye = on_sphere(angles[:, 0], angles[:, 1], radius)                        # [B,3]
+    target = on_sphere(look_at[:, 0], look_at[:, 1], look_at[:, 2])
+    fwd = unit(unit(target - eye))                                             # (the reference normalises twice)
+    hint = torch.tensor([0.0, 1.0, 0.0], device=dev).expand_as(fwd)
+    left = unit(torch.cross(hint, fwd, dim=-1))
+    up = unit(torch.cross(fwd, left, dim=-1))
+    rot = torch.stack([-left, up, -fwd], dim=-1)                               # [B,3,3]: camera axes as columns
+    xs = torch.linspace(-1, 1, w, device=dev).repeat(h).unsqueeze(0)           # [1, h*w], column index fastest
+    ys = torch.linspace(1, -1, h, device=dev).repeat_interleave(w).unsqueeze(0)
+    if patch_params is not None:
+        sc, of = patch_params['scales'].float(), patch_params['offsets'].float()
+        xs = (xs + 1.0) * sc[:, 0:1] - 1.0 + of[:, 0:1] * 2.0
+        ys = (ys + 1.0) * sc[:, 1:2] - 1.0 + of[:, 1:2] * 2.0
+    fov_t = fov.float().reshape(-1, 1) if isinstance(fov, torch.Tensor) else torch.full([1, 1], float(fov), device=dev)
+    z = -torch.ones([fov_t.shape[0], h * w], device=dev) / torch.tan(fov_t / 360 * 2 * np.pi * 0.5)
+    d_cam = unit(torch.stack([xs.expand(B, -1), ys.expand(B, -1), z.expand(B, -1)], dim=2))       # [B, h*w, 3]
+    ray_d = torch.bmm(d_cam, rot.transpose(1, 2))                              # rot @ d for every pixel
+    ray_o = eye.unsqueeze(1).expand(B, h * w, 3)
+    return ray_o, ray_d
+
+
 def sample_rays(c2w, fov, resolution, patch_params=None, device=None):
     """-> (ray_o_world, ray_d_world), each [B, h*w, 3]; ray r <-> pixel (r // w, r % w).
     `w, h = resolution` exactly as the reference unpacks it (tri_plane_renderer.py:496)."""
@@ -217,10 +258,11 @@ def simple_tri_plane_renderer(x, coords, mlp, scale=1.0, return_taps=False, sigm
     return out
 
 
-def simple_tri_plane_renderer_backward(x, coords, mlp, d_rgb, d_sigma, scale=1.0, planes_grad=True):
+def simple_tri_plane_renderer_backward(x, coords, mlp, d_rgb, d_sigma, scale=1.0, planes_grad=True, coords_grad=False):
     """Gradients of `simple_tri_plane_renderer` (tri_plane_renderer.py:560-588 + TriPlaneMLP) for incoming d_rgb [B,P,3], d_sigma
-    [B,P,1]: returns (d_planes in the field layout [B,3,H,W,F] or None, d_w0, d_b0, d_w1, d_b1).  tdgp_triplane_field_grad: forward
-    values are recomputed; the plane gradient is a scatter with fp32 atomics (as torch's grid_sampler backward)."""
+    [B,P,1]: returns (d_planes in the field layout [B,3,H,W,F] or None, d_w0, d_b0, d_w1, d_b1) and, with `coords_grad`, d_coords
+    [B,P,3] (grid_sampler's grid gradient through the plane mean and `coords / scale`).  tdgp_triplane_field_grad: forward values are
+    recomputed; the plane gradient is a scatter with fp32 atomics (as torch's grid_sampler backward)."""
     planes = planes_to_hwc(x)
     _lib.require_cuda(coords, 'coords')
     coords = _lib.f32c(coords)
@@ -232,13 +274,14 @@ def simple_tri_plane_renderer_backward(x, coords, mlp, d_rgb, d_sigma, scale=1.0
     d_planes = torch.zeros_like(p) if planes_grad else None
     hid = w0.shape[0]
     d_w0, d_b0, d_w1, d_b1 = torch.empty_like(w0), torch.empty_like(b0), torch.empty_like(w1), torch.empty_like(b1)
+    d_coords = torch.empty([B, P, 3], dtype=torch.float32, device=p.device) if coords_grad else None
     nbytes = int(_lib.load().tdgp_triplane_field_grad_workspace_bytes(B, P, F, hid))
     ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=p.device)
     with torch.cuda.device(p.device):
         _lib.call('tdgp_triplane_field_grad', p.data_ptr(), coords.data_ptr(), w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(),
-                  d_out.data_ptr(), _lib.ptr(d_planes), d_w0.data_ptr(), d_b0.data_ptr(), d_w1.data_ptr(), d_b1.data_ptr(), ws.data_ptr(), nbytes,
-                  B, P, F, H, W, hid, float(scale), MARCHER_IDS[marcher], _lib.stream_of(p))
-    return d_planes, d_w0, d_b0, d_w1, d_b1
+                  d_out.data_ptr(), _lib.ptr(d_planes), d_w0.data_ptr(), d_b0.data_ptr(), d_w1.data_ptr(), d_b1.data_ptr(), _lib.ptr(d_coords),
+                  ws.data_ptr(), nbytes, B, P, F, H, W, hid, float(scale), MARCHER_IDS[marcher], _lib.stream_of(p))
+    return (d_planes, d_w0, d_b0, d_w1, d_b1, d_coords) if coords_grad else (d_planes, d_w0, d_b0, d_w1, d_b1)
 
 
 def planes_from_hwc(t):
@@ -362,9 +405,11 @@ class ImportanceRenderer(torch.nn.Module):
                                          sigma_noise=rendering_options.get('sigma_noise'), density_noise=float(rendering_options.get('density_noise', 0.0)))
 
     # -- gradient of the whole chain -----------------------------------------------------------------------------------
-    def backward(self, planes, decoder, ray_origins, ray_directions, rendering_options, d_rgb, d_depth=None):
+    def backward(self, planes, decoder, ray_origins, ray_directions, rendering_options, d_rgb, d_depth=None, rays_grad=False):
         """Gradients of `forward` (tri_plane_renderer.py:126-170 under autograd) w.r.t. the planes and the decoder's tensors for
-        incoming d_rgb [B,R,3] / d_depth [B,R,1]: returns dict(planes=[B,3F,H,W], w0, b0, w1, b1).
+        incoming d_rgb [B,R,3] / d_depth [B,R,1]: returns dict(planes=[B,3F,H,W], w0, b0, w1, b1) and, with `rays_grad`, ray_o / ray_d
+        [B,R,3] -- the gradient that reaches the cameras (points = origin + t * direction, :141; the field kernel's coordinate gradient
+        summed over a ray's samples).
 
         The importance samples carry no gradient (`sample_importance` runs under no_grad, :241), so the path is
         march(unified, sorted) -> gather by the sort permutation -> {coarse, fine} field -> planes / MLP: the forward is replayed
@@ -403,10 +448,20 @@ class ImportanceRenderer(torch.nn.Module):
             g_c, g_s = ray_march_backward(cc, dc, sd, opts, marcher, d_rgb, d_depth)
             passes = [(pts_c, g_c, g_s)]
         total = None
-        for pts, gc, gs in passes:
-            res = simple_tri_plane_renderer_backward(hw, pts, decoder, gc.reshape(B, -1, 3), gs.reshape(B, -1, 1), scale=scale)
+        d_ro = d_rd = None
+        for (pts, gc, gs), tt in zip(passes, (td, tf) if N > 0 else (td,)):
+            res = simple_tri_plane_renderer_backward(hw, pts, decoder, gc.reshape(B, -1, 3), gs.reshape(B, -1, 1), scale=scale, coords_grad=rays_grad)
+            if rays_grad:
+                # points = origin + t * direction (tri_plane_renderer.py:141): the depths are data (stratified draws / detached importance samples)
+                dpts = res[5].reshape(B, R, -1, 3)
+                d_ro = dpts.sum(2) if d_ro is None else d_ro + dpts.sum(2)
+                d_rd = (dpts * tt).sum(2) if d_rd is None else d_rd + (dpts * tt).sum(2)
+                res = res[:5]
             total = list(res) if total is None else [a + b for a, b in zip(total, res)]
-        return dict(planes=planes_from_hwc(total[0]), w0=total[1], b0=total[2], w1=total[3], b1=total[4])
+        out = dict(planes=planes_from_hwc(total[0]), w0=total[1], b0=total[2], w1=total[3], b1=total[4])
+        if rays_grad:
+            out.update(ray_o=d_ro, ray_d=d_rd)
+        return out
 
     # -- the whole chain ---------------------------------------------------------------------------------------------
     def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, return_intermediates=False):
@@ -511,9 +566,9 @@ class _RenderFunction(torch.autograd.Function):
                 opts['n_coarse'] = torch.randn([B, R * S, 1], device=dev)
             if N > 0 and opts.get('n_fine') is None:
                 opts['n_fine'] = torch.randn([B, R * N, 1], device=dev)
-        rgb, depth, _w, _t = renderer.forward(planes.detach(), decoder, ray_o, ray_d, opts)
+        rgb, depth, _w, _t = renderer.forward(planes.detach(), decoder, ray_o.detach(), ray_d.detach(), opts)
         ctx.save_for_backward(planes)
-        ctx.state = (renderer, decoder, ray_o, ray_d, opts)
+        ctx.state = (renderer, decoder, ray_o.detach(), ray_d.detach(), opts)
         return rgb, depth
 
     @staticmethod
@@ -522,12 +577,15 @@ class _RenderFunction(torch.autograd.Function):
         renderer, decoder, ray_o, ray_d, opts = ctx.state
         if d_rgb is None:
             d_rgb = torch.zeros([ray_o.shape[0], ray_o.shape[1], 3], device=ray_o.device)
-        res = renderer.backward(planes.detach(), decoder, ray_o, ray_d, opts, d_rgb.contiguous(), None if d_depth is None else d_depth.contiguous())
-        return res['planes'], res['w0'], res['b0'], res['w1'], res['b1'], None, None, None, None, None
+        rays_grad = ctx.needs_input_grad[7] or ctx.needs_input_grad[8]           # cameras being trained (loss.py:76-77 with learn_camera_dist)
+        res = renderer.backward(planes.detach(), decoder, ray_o, ray_d, opts, d_rgb.contiguous(), None if d_depth is None else d_depth.contiguous(),
+                                rays_grad=rays_grad)
+        return res['planes'], res['w0'], res['b0'], res['w1'], res['b1'], None, None, res.get('ray_o'), res.get('ray_d'), None
 
 
 def render_autograd(renderer, planes, decoder, ray_origins, ray_directions, rendering_options):
-    """(rgb [B,R,3], depth [B,R,1]) with gradients flowing to `planes` ([B,3F,H,W]) and the decoder's four tensors."""
+    """(rgb [B,R,3], depth [B,R,1]) with gradients flowing to `planes` ([B,3F,H,W]), the decoder's four tensors and -- when they carry
+    a graph (camera_rays_autograd) -- the ray origins / directions."""
     m = decoder.model
-    return _RenderFunction.apply(planes, m[0].weight, m[0].bias, m[1].weight, m[1].bias, renderer, decoder, ray_origins.detach(), ray_directions.detach(),
+    return _RenderFunction.apply(planes, m[0].weight, m[0].bias, m[1].weight, m[1].bias, renderer, decoder, ray_origins, ray_directions,
                                  rendering_options)

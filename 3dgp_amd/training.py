@@ -102,12 +102,8 @@ def maybe_blur(img, blur_sigma):
 class StyleGAN2Loss:
     def __init__(self, G, D, device, r1_gamma=10.0, patch_cfg=None, use_depth=False, adv_loss_type='non_saturating', blur_init_sigma=0, blur_fade_kimg=0,
                  blur_real_depth_sigma=0.0, logits_clamp_val=1e7, learn_camera_dist=False, synthesis_kwargs=None):
-        if learn_camera_dist:
-            # The reference trains the camera adaptor THROUGH compute_cam2world_matrix / sample_rays / the sample coordinates
-            # (loss.py:76-77, tri_plane_renderer.py:141).  Here rays are generated without a graph and the field kernel has no
-            # coordinate gradient, so the adaptor would silently stay at its initialisation: refuse instead of training a frozen one.
-            raise NotImplementedError('learn_camera_dist=True needs gradients through ray generation and the sample coordinates, which the '
-                                      'accelerated renderer does not provide (camera adaptor: forward only, SURVEY.md 8f rank 1)')
+        if learn_camera_dist and getattr(G.synthesis, 'camera_adaptor', None) is None:
+            raise RuntimeError('learn_camera_dist=True needs a generator built with cfg.camera_adaptor')
         self.G, self.D, self.device = G, D, device
         self.r1_gamma, self.use_depth, self.adv_loss_type = r1_gamma, use_depth, adv_loss_type
         self.blur_init_sigma, self.blur_fade_kimg, self.blur_real_depth_sigma = blur_init_sigma, blur_fade_kimg, blur_real_depth_sigma
@@ -134,6 +130,8 @@ class StyleGAN2Loss:
         ws = self.G.mapping(z, c, update_emas=update_emas)
         patch_params = sample_patch_params(len(z), self.patch_cfg, device=z.device) if self.patch_cfg.enabled else {}
         patch_kwargs = dict(patch_params=patch_params) if self.patch_cfg.enabled else {}
+        if self.learn_camera_dist:                 # loss.py:76-77: the adaptor is trained through ray generation and the sample positions
+            camera_params = self.G.synthesis.camera_adaptor(camera_params, z, c)
         out = self.G.synthesis.forward_autograd(ws, camera_params, render_opts=dict(concat_depth=self.use_depth, return_depth=True), **patch_kwargs,
                                                 **self.synthesis_kwargs)
         out.ws = ws

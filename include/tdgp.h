@@ -258,13 +258,17 @@ int tdgp_triplane_field(const float* planes_hwc, const float* coords, const floa
  * (tri_plane_renderer.py:560-588 -- grid_sample backward --, networks_epigraf.py:46-68) w.r.t. the planes and the four MLP tensors.
  * d_out [B,P,4] = gradient w.r.t. (r,g,b,sigma) as tdgp_triplane_field returns them.  d_planes_hwc [B,3,H,W,F] is ACCUMULATED
  * into with fp32 atomics (zero it first; NULL skips it; like torch's grid_sampler backward its last bits vary run to run);
- * d_w0 [hid,F], d_b0 [hid], d_w1 [4,hid], d_b1 [4] are written, deterministically.  Requires F in {8,16,24,32}, hid <= 64.
+ * d_w0 [hid,F], d_b0 [hid], d_w1 [4,hid], d_b1 [4] are written, deterministically.  d_coords [B,P,3] (NULL skips it) receives the
+ * gradient w.r.t. the sample positions -- grid_sampler's grid gradient (taps outside a plane read as zero, x (size - 1) / 2 for
+ * align_corners) through the plane mean and `coords / scale`: what the camera parameters are trained through (loss.py:69-83 applies the
+ * camera adaptor inside run_G; rendering_utils.py:194-218 and tri_plane_renderer.py:487-527 are differentiable in the reference).
+ * Requires F in {8,16,24,32}, hid <= 64.
  * workspace: tdgp_triplane_field_grad_workspace_bytes(B, P, F, hid) bytes. */
 int64_t tdgp_triplane_field_grad_workspace_bytes(int B, int64_t P, int F, int hid);
 int     tdgp_triplane_field_grad(const float* planes_hwc, const float* coords, const float* w0, const float* b0,
                                  const float* w1, const float* b1, const float* d_out, float* d_planes_hwc, float* d_w0,
-                                 float* d_b0, float* d_w1, float* d_b1, void* workspace, int64_t workspace_bytes, int B,
-                                 int64_t P, int F, int H, int W, int hid, float scale, int marcher, tdgp_stream_t stream);
+                                 float* d_b0, float* d_w1, float* d_b1, float* d_coords, void* workspace, int64_t workspace_bytes,
+                                 int B, int64_t P, int F, int H, int W, int hid, float scale, int marcher, tdgp_stream_t stream);
 
 /* Generic marcher on [rays,S,C] colours, [rays,S] densities/depths (any S <= 256, C <= 8).
  * weights: [rays,S] (classical, or mip with inf depth) / [rays,S-1] (mip without); may be NULL.

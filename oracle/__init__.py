@@ -222,16 +222,18 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, demodulate=True, resam
     return y
 
 
-def triplane_field_grad(planes, coords, w0, b0, w1, b1, d_rgb, d_sigma, scale=1.0, mlp_mode='classical'):
+def triplane_field_grad(planes, coords, w0, b0, w1, b1, d_rgb, d_sigma, scale=1.0, mlp_mode='classical', return_coords=False):
     """(d_planes [B,3F,H,W], d_w0, d_b0, d_w1, d_b1) of triplane_field for incoming d_rgb [B,P,3], d_sigma [B,P,1] (autograd through
-    tri_plane_renderer.py:560-588 + networks_epigraf.py:46-68), double arithmetic."""
+    tri_plane_renderer.py:560-588 + networks_epigraf.py:46-68), double arithmetic.  return_coords: also d_coords [B,P,3], the gradient
+    w.r.t. the sample positions (what the camera parameters are trained through, loss.py:69-83)."""
     planes, coords, w0, b0, w1, b1, d_rgb, d_sigma = (_f(a) for a in (planes, coords, w0, b0, w1, b1, d_rgb, d_sigma))
     B, c3, H, W = planes.shape
     F, hid, P = c3 // 3, w0.shape[0], coords.shape[1]
     dp, dw0, db0, dw1, db1 = np.empty_like(planes), np.empty_like(w0), np.empty_like(b0), np.empty_like(w1), np.empty_like(b1)
+    dc = np.empty([B, P, 3], dtype=np.float32) if return_coords else None
     lib().orc_triplane_field_grad(_p(planes), _p(coords), _p(w0), _p(b0), _p(w1), _p(b1), _p(d_rgb), _p(d_sigma), _p(dp), _p(dw0), _p(db0), _p(dw1),
-                                  _p(db1), B, c_i64(P), F, H, W, hid, c_float(scale), 1 if mlp_mode == 'mip' else 0)
-    return dp, dw0, db0, dw1, db1
+                                  _p(db1), _p(dc) if return_coords else None, B, c_i64(P), F, H, W, hid, c_float(scale), 1 if mlp_mode == 'mip' else 0)
+    return (dp, dw0, db0, dw1, db1, dc) if return_coords else (dp, dw0, db0, dw1, db1)
 
 
 def ray_march_grad(colors, densities, depths, d_rgb, d_depth=None, d_weights=None, mode='classical', use_inf_depth=True, last_back=False,

@@ -1431,6 +1431,34 @@ def test_field_grad(tdgp, oracle, tag, marcher):
     assert_close(N(res2[0]), N(res[0]), 1e-5, 'd_planes run to run', 1.0)
 
 
+@pytest.mark.parametrize('tag', ['small', 'hot'])
+@pytest.mark.parametrize('marcher', ['classical', 'mip'])
+def test_field_grad_wrt_coords(tdgp, oracle, tag, marcher):
+    """The gradient w.r.t. the sample positions (grid_sampler's grid gradient through the plane mean and coords / scale; what a camera is
+    trained through, loss.py:69-83) against autograd through the reference's simple_tri_plane_renderer; the other outputs unchanged by it;
+    and on points outside the cube (zero padding on both sides of a cell) against the double-precision oracle."""
+    g = load_golden('field_grad')
+    k = f'{tag}_{marcher}_'
+    ws = [g[k + n] for n in ('w0', 'b0', 'w1', 'b1')]
+    mlp = _mlp(tdgp, *ws, marcher)
+    R = tdgp.renderer
+    args = (T(g[f'{tag}_planes']), T(g[f'{tag}_coords']), mlp, T(g[f'{tag}_d_rgb']), T(g[f'{tag}_d_sigma']))
+    res = R.simple_tri_plane_renderer_backward(*args, scale=0.5, coords_grad=True)
+    assert_close(N(res[5]), g[k + 'd_coords'], 5e-5, 'd_coords', 1.0)
+    plain = R.simple_tri_plane_renderer_backward(*args, scale=0.5)
+    for a, b in zip(res[1:5], plain[1:]):
+        assert torch.equal(a, b)
+    only = R.simple_tri_plane_renderer_backward(*args, scale=0.5, planes_grad=False, coords_grad=True)
+    assert only[0] is None and torch.equal(only[5], res[5])
+    rs = np.random.RandomState(5)
+    B, P = g[f'{tag}_planes'].shape[0], 16 * 41 + 3
+    coords = rs.uniform(-0.75, 0.75, (B, P, 3)).astype(np.float32)               # the cube is [-0.5, 0.5]^3 here: a third of the points are outside
+    d_rgb, d_sigma = rs.randn(B, P, 3).astype(np.float32), rs.randn(B, P, 1).astype(np.float32)
+    ref = oracle.triplane_field_grad(g[f'{tag}_planes'], coords, *ws, d_rgb, d_sigma, scale=0.5, mlp_mode=marcher, return_coords=True)
+    got = R.simple_tri_plane_renderer_backward(T(g[f'{tag}_planes']), T(coords), mlp, T(d_rgb), T(d_sigma), scale=0.5, coords_grad=True)
+    assert_close(N(got[5]), ref[5], 1e-4, 'd_coords incl. zero padding', 1.0)
+
+
 def test_field_grad_large(tdgp, oracle):
     """Many tiles per wave, a ragged last tile, several blocks: vs the double-precision oracle."""
     rs = np.random.RandomState(77)
@@ -1530,6 +1558,42 @@ def test_synthesis_forward_autograd(tdgp):
     assert_close(N(img), N(out.img.detach()), 2e-5, 'fused vs autograd path', 1.0)
 
 
+@pytest.mark.parametrize('patch', [False, True])
+def test_camera_gradients(tdgp, patch):
+    """The loss differentiated w.r.t. the CAMERA (angles, fov, radius, look_at) -- rays as a differentiable graph
+    (renderer.camera_rays_autograd), d(rays) from the field kernel's coordinate gradient -- against autograd through the reference's
+    G.synthesis (rendering_utils.py:194-218, tri_plane_renderer.py:487-527 under autograd): what loss.py:76-77 trains the camera adaptor
+    through.  Full image and patch rays."""
+    g = load_golden('synthesis_grad')
+    cfg = tdgp.config.config_tiny()
+    G = _gen(tdgp, cfg, 101)
+    cam = {k: v.clone().requires_grad_(True) for k, v in _cam(g).items()}
+    pp = dict(scales=T(g['patch_scales']), offsets=T(g['patch_offsets'])) if patch else None
+    out = G.synthesis.forward_autograd(T(g['ws']), camera_params=cam, patch_params=pp, noise_mode='const', u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']),
+                                       render_opts=dict(return_depth=True))
+    ref_img = g['img_patch'] if patch else g['img']
+    assert_close(N(out.img.detach()), ref_img, 2e-5, 'image from the differentiable rays', 1.0)
+    keys = ('angles', 'fov', 'radius', 'look_at')
+    grads = torch.autograd.grad([out.img, out.depth], [cam[k] for k in keys], [T(g['d_img']), T(g['d_depth'])], allow_unused=True)
+    tag = '_patch' if patch else ''
+    for k, gr in zip(keys, grads):
+        ref = g[f'd_cam{tag}_{k}']
+        got = np.zeros_like(ref) if gr is None else N(gr)
+        report_parity(f'camera gradient{tag} {k}', err=float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)))
+        assert_close(got, ref, 1e-3, f'd {k}', 1.0)
+    # the camera adaptor is now trainable through the renderer: its parameters receive gradients
+    acfg = tdgp.config.configs_adaptor_goldens()[0][1]
+    GA = _gen(tdgp, acfg, 77)
+    for p_ in GA.parameters():
+        p_.requires_grad_(True)
+    z, c = T(g['z']), T(g['c'])
+    cam_a = GA.synthesis.camera_adaptor(_cam(g), z, c)
+    o = GA.synthesis.forward_autograd(T(g['ws']), camera_params=cam_a, noise_mode='const', u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
+    (o * T(g['d_img'])).sum().backward()
+    ga = [p_.grad for n_, p_ in GA.synthesis.camera_adaptor.named_parameters()]
+    assert all(x is not None and torch.isfinite(x).all() for x in ga) and sum(float(x.abs().sum()) for x in ga) > 0
+
+
 @pytest.mark.parametrize('tag', ['plain', 'full', 'extra'])
 def test_discriminator_gpu(tdgp, tag):
     """The discriminator on the HIP ops (stride-1 and stride-2 convolutions forward and backward, upfirdn2d, bias_act): logits,
@@ -1617,6 +1681,40 @@ def test_stylegan2_loss_phases(tdgp):
         assert float(loss.stats['Loss/D/r1_penalty'].min()) > 0
     finally:
         TR.sample_patch_params = orig
+
+
+def test_loss_trains_the_camera_adaptor(tdgp):
+    """`learn_camera_dist=True` (loss.py:76-77): run_G applies the camera adaptor and the Gmain phase leaves finite, non-zero gradients in
+    its parameters -- through ray generation and the field kernel's coordinate gradient; without the flag the adaptor gets none.  A
+    generator without an adaptor refuses the flag."""
+    TR = tdgp.training
+    cfg = tdgp.config.configs_adaptor_goldens()[0][1]
+    cfg.use_noise = False
+    G = _gen(tdgp, cfg, 301).train()
+    dcfg = tdgp.discriminator.DiscriminatorConfig(c_dim=0, cbase=256, cmax=16)
+    use_depth = cfg.depth_adaptor is not None
+    D = tdgp.discriminator.seeded_discriminator(dcfg, cfg.img_resolution, 4 if use_depth else 3, seed=302).to(DEV).train()
+    B = 2
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=B, seed=303)
+    c0 = torch.zeros(B, 0, device=DEV)
+    gen = tdgp.generator.TensorGroup(z=T(inp['z']), c=c0, camera_params=tdgp.generator.TensorGroup(**{k: T(v) for k, v in inp['camera'].items()}))
+    real = tdgp.generator.TensorGroup(img=torch.randn(B, 3, cfg.img_resolution, cfg.img_resolution, device=DEV), c=c0,
+                                      depth=torch.zeros(B, 1, cfg.img_resolution, cfg.img_resolution, device=DEV))
+    for flag in (True, False):
+        loss = TR.StyleGAN2Loss(G, D, DEV, r1_gamma=0.0, use_depth=use_depth, learn_camera_dist=flag,
+                                synthesis_kwargs=dict(u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine'])))
+        G.zero_grad(set_to_none=True)
+        G.requires_grad_(True)
+        D.requires_grad_(False)
+        loss.accumulate_gradients('Gmain', real, gen, gain=1, cur_nimg=0)
+        grads = [p.grad for p in G.synthesis.camera_adaptor.parameters()]
+        if flag:
+            assert all(x is not None and torch.isfinite(x).all() for x in grads) and sum(float(x.abs().sum()) for x in grads) > 0
+        else:
+            assert all(x is None or float(x.abs().sum()) == 0.0 for x in grads)
+    plain = _gen(tdgp, tdgp.config.config_tiny(), 1)
+    with pytest.raises(RuntimeError):
+        TR.StyleGAN2Loss(plain, D, DEV, learn_camera_dist=True)
 
 
 def test_conv_transpose2d_x2(tdgp):

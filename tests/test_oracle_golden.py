@@ -167,6 +167,40 @@ def test_camera_and_rays(oracle):
     assert_close(d, g['ray_d_scalar_fov'], 2e-6, 'ray_d scalar fov', 1.0)
 
 
+def test_camera_rays_autograd_reproduces_the_rays(tdgp):
+    """renderer.camera_rays_autograd (pure tensor ops, runs on the CPU): the differentiable restatement of cam2world + sample_rays gives
+    the reference's rays (goldens from rendering_utils.py:194-218 / tri_plane_renderer.py:487-527), incl. patch rays and a scalar fov."""
+    import torch
+    g = load_golden('camera')
+    cam = {k: torch.from_numpy(g[k]) for k in ('angles', 'radius', 'look_at', 'fov')}
+    R = tdgp.renderer
+    for hw in [(8, 8), (5, 7), (16, 16)]:
+        o, d = R.camera_rays_autograd(cam, hw)                 # `w, h = resolution` as the reference unpacks it
+        assert_close(o.numpy(), g['ray_o_%dx%d' % hw], 2e-6, 'ray_o')
+        assert_close(d.numpy(), g['ray_d_%dx%d' % hw], 2e-6, 'ray_d', 1.0)
+    pp = dict(scales=torch.from_numpy(g['patch_scales']), offsets=torch.from_numpy(g['patch_offsets']))
+    o, d = R.camera_rays_autograd(cam, (6, 6), patch_params=pp)
+    assert_close(d.numpy(), g['ray_d_patch'], 2e-6, 'ray_d patch', 1.0)
+    o, d = R.camera_rays_autograd(dict(cam, fov=18.0), (4, 4))
+    assert_close(d.numpy(), g['ray_d_scalar_fov'], 2e-6, 'ray_d scalar fov', 1.0)
+    # ... and carries gradients to every camera parameter
+    camg = {k: v.clone().requires_grad_(True) for k, v in cam.items()}
+    o, d = R.camera_rays_autograd(camg, (5, 7))
+    grads = torch.autograd.grad((o * 0.3).sum() + (d * torch.linspace(-1, 1, d.numel()).reshape(d.shape)).sum(), list(camg.values()))
+    assert all(torch.isfinite(x).all() and float(x.abs().sum()) > 0 for x in grads)
+
+
+def test_field_grad_wrt_coords_oracle(oracle):
+    """oracle.triplane_field_grad(return_coords=True) against autograd through the reference's simple_tri_plane_renderer."""
+    g = load_golden('field_grad')
+    for tag in ('small', 'hot'):
+        for marcher in ('classical', 'mip'):
+            k = f'{tag}_{marcher}_'
+            r = oracle.triplane_field_grad(g[f'{tag}_planes'], g[f'{tag}_coords'], g[k + 'w0'], g[k + 'b0'], g[k + 'w1'], g[k + 'b1'], g[f'{tag}_d_rgb'],
+                                           g[f'{tag}_d_sigma'], scale=0.5, mlp_mode=marcher, return_coords=True)
+            assert_close(r[5], g[k + 'd_coords'], 2e-6, 'd_coords', 1.0)
+
+
 def test_mapping(oracle, tdgp):
     g = load_golden('mapping')
     for tag, cfg in [('c0', tdgp.config.config_tiny()), ('c10', tdgp.config.config_mid())]:

@@ -384,12 +384,13 @@ def gen_field_grad():
                 mlp.model[0].bias.copy_(T(g.randn(hid).astype(np.float32) * 0.3))
                 mlp.model[1].bias.copy_(T(g.randn(4).astype(np.float32) * 0.3))
             x = T(planes).requires_grad_(True)
-            out = ref_tpr.simple_tri_plane_renderer(x, T(coords), mlp, scale=0.5)
+            cc = T(coords).requires_grad_(True)          # round 3: the gradient w.r.t. the sample positions too (camera training, loss.py:69-83)
+            out = ref_tpr.simple_tri_plane_renderer(x, cc, mlp, scale=0.5)
             params = [mlp.model[0].weight, mlp.model[0].bias, mlp.model[1].weight, mlp.model[1].bias]
-            grads = torch.autograd.grad([out['rgb'], out['sigma']], [x] + params, [T(d_rgb), T(d_sigma)])
+            grads = torch.autograd.grad([out['rgb'], out['sigma']], [x] + params + [cc], [T(d_rgb), T(d_sigma)])
             for name, t in zip(('w0', 'b0', 'w1', 'b1'), params):
                 arrays[f'{tag}_{marcher}_{name}'] = npy(t)
-            for name, t in zip(('d_planes', 'd_w0', 'd_b0', 'd_w1', 'd_b1'), grads):
+            for name, t in zip(('d_planes', 'd_w0', 'd_b0', 'd_w1', 'd_b1', 'd_coords'), grads):
                 arrays[f'{tag}_{marcher}_{name}'] = npy(t)
     save('field_grad', **arrays)
 
@@ -993,6 +994,18 @@ def gen_synthesis_grad():
     for n, gr in zip(names, grads[1:]):
         if gr is not None:
             arrays['grad::synthesis.' + n] = npy(gr)
+    # round 3: the same loss differentiated w.r.t. the CAMERA (rendering_utils.py:194-218 and tri_plane_renderer.py:487-527 are
+    # differentiable in the reference: this is the path loss.py:76-77 trains the camera adaptor through), full image and a patch
+    for tag, pp in (('', None), ('_patch', dict(scales=T(np.array([[0.6, 0.7], [0.9, 0.5]], np.float32)), offsets=T(np.array([[0.2, 0.1], [0.05, 0.3]], np.float32))))):
+        camg = TensorGroup(**{k: T(v).clone().requires_grad_(True) for k, v in inp['camera'].items()})
+        with PatchedRNG(rand_like=[T(inp['u_coarse']).reshape(B, R, S, 1)], rand=[T(inp['u_fine'])]):
+            o2 = G.synthesis(ws0, camera_params=camg, patch_params=pp, noise_mode='const', render_opts=dict(return_depth=True))
+        keys = ('angles', 'fov', 'radius', 'look_at')
+        cg = torch.autograd.grad([o2.img, o2.depth], [camg[k] for k in keys], [T(d_img), T(d_depth)], allow_unused=True)
+        for k, gr in zip(keys, cg):
+            arrays[f'd_cam{tag}_{k}'] = npy(gr) if gr is not None else np.zeros_like(inp['camera'][k])
+        if pp is not None:
+            arrays.update(patch_scales=npy(pp['scales']), patch_offsets=npy(pp['offsets']), img_patch=npy(o2.img))
     save('synthesis_grad', **arrays)
 
 
