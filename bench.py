@@ -278,6 +278,10 @@ def main():
     # While profiling is on the library launches through hipExtLaunchKernelGGL with a start and a stop event attached to each
     # dispatch: the pair reads the kernel's own begin/end timestamps (what rocprofv3's kernel trace reports), with no marker
     # packets around it -- per-kernel averages are directly comparable with profiles/*_kernel_stats.md.
+    # (per-kernel durations are taken on ONE stream: in the timed steps the ToRGB layers run on a second stream beside the next block's x2
+    #  layer, and two kernels sharing the chip would each be charged the other's time)
+    dec = G.synthesis.tri_plane_decoder
+    overlap_was, dec.overlap_torgb = dec.overlap_torgb, False
     tdgp._lib.profile_enable(True)
     torch.cuda.synchronize()
     t_prof = time.perf_counter()
@@ -289,6 +293,7 @@ def main():
     profiled_step_ms = (time.perf_counter() - t_prof) / max(args.profile_steps, 1) * 1e3
     prof = tdgp._lib.profile_report()
     tdgp._lib.profile_enable(False)
+    dec.overlap_torgb = overlap_was
     nprof = max(args.profile_steps, 1)
     kernels = {}
     for k, v in prof.items():
@@ -403,7 +408,7 @@ def main():
                                    f'c_dim {cfg.c_dim}, tri-plane {cfg.tri_plane_res}^2 x {cfg.plane_channels}, full HIP path',
                        'batch_per_gpu': args.batch, 'global_batch': args.batch * world, 'img_resolution': cfg.img_resolution,
                        'num_ray_steps': cfg.num_ray_steps, 'depth_adaptor': bool(args.depth_adaptor), 'parallelism': f'dp{world} (batch-sharded, weights replicated)',
-                       'schedule': dict(chunk=G.synthesis.chunk, chunk_from=G.synthesis.chunk_from)},
+                       'schedule': dict(chunk=G.synthesis.chunk, chunk_from=G.synthesis.chunk_from, torgb_on_second_stream=bool(overlap_was))},
             'launch': 'eager' if args.no_graph else 'hip graph replay (3dgp_amd/graphs.py: every kernel of the forward, one submission per step)',
             ('graph_value' if args.no_graph else 'eager_value'): round(total_imgs / alt_elapsed, 3), 'fid_loop': fid_loop,
             'rccl_ranks_seen': ranks_seen, 'roofline': roofline, 'whole_forward': whole, 'other_batches': others, 'kernels': kernels,
