@@ -4,8 +4,9 @@ Reference: `src/training/loss.py:33-330` (StyleGAN2Loss: run_G, run_D, accumulat
 Dreg / Dall, maybe_blur), `src/training/training_utils.py:22-167` (patch sampling and extraction), `training_loop.py:325-347`
 (the optimiser step around the gradient exchange).  What is here is the adversarial core every 3dgp run executes: non-saturating
 (or hinge) losses, R1 on real patches, patch-wise training with patch-conditioned discriminator, RGB-D discriminator input through
-the depth adaptor, image / depth blur schedules.  Not here: the camera-adaptor regularisers (Lipschitz, EMD -- the latter needs the
-POT solver), knowledge distillation, path-length regularisation (`pl_weight: 0` in every 3dgp config), ADA.
+the depth adaptor, image / depth blur schedules, and the three camera-adaptor regularisers of `learn_camera_dist` (Lipschitz, earth
+mover's distance to the prior, force-mean; loss.py:142-222).  Not here: knowledge distillation, path-length regularisation
+(`pl_weight: 0` in every 3dgp config), ADA.
 
 All device work runs on the library's kernels through the autograd ops (`G.forward_autograd`, `discriminator.Discriminator`);
 the arithmetic in this file is the reference's eager tensor arithmetic.
@@ -35,6 +36,96 @@ class PatchConfig:
     mbstd_group_size: int = 4
     min_scale: float = 1.0                 # set by progressive_update
     beta: float = 0.001
+
+
+@dataclass
+class CameraRegConfig:
+    """configs/model/3dgp.yaml:55-63,75 (`camera_adaptor.lipschitz_weights`, `.emd`, `.force_mean_weight`) with the yaml's defaults.
+    `prior` is the `camera:` config node the prior is drawn from (dict in the reference's layout, see metrics.sample_camera_params),
+    or a callable (num_samples, device) -> camera parameters for tests."""
+    prior: object = None
+    lipschitz_enabled: bool = False
+    lipschitz_angles: float = 1.0
+    lipschitz_radius: float = 1.0
+    lipschitz_fov: float = 1.0
+    lipschitz_look_at: float = 1.0
+    lipschitz_num_samples: int = 256       # loss.py:146 (hard-coded there)
+    emd_enabled: bool = True
+    emd_anneal_kimg: float = 10000
+    emd_num_samples: int = 64
+    emd_origin: float = 2.0
+    emd_radius: float = 0.0
+    emd_fov: float = 0.0001
+    emd_look_at: float = 0.0001
+    force_mean_weight: float = 10.0
+    force_mean_num_samples: int = 256      # loss.py:228
+    mean_angles: object = None             # [yaw, pitch, roll] the force-mean term pulls to; None = analytic mean of `prior`
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# camera-adaptor regularisers, loss.py:142-238
+# ----------------------------------------------------------------------------------------------------------------------
+def sample_random_c(batch_size, c_dim, device):
+    """training_utils.py:207-214: uniformly random one-hot labels."""
+    c = torch.zeros(batch_size, c_dim, device=device)
+    if c_dim > 0:
+        c[torch.arange(batch_size), torch.randint(low=0, high=c_dim, device=device, size=(batch_size,))] = 1.0
+    return c
+
+
+def emd2_1d(a, b):
+    """Squared-Euclidean earth mover's distance between two equally sized, uniformly weighted 1-D samples.
+
+    The reference calls POT (`ot.dist` -> squared distances, `ot.emd2` with weights 1/n; loss.py:195-197; POT is not vendored with
+    it).  For a convex cost on the line the optimal plan of that linear programme is the monotone matching, so the value is
+    mean((sort(a) - sort(b))^2) and -- `emd2` back-propagates through the cost matrix with the plan held fixed -- so are the
+    gradients.  tests/test_training.py checks both against the assignment-problem solution of the same cost matrix."""
+    assert a.ndim == 1 and a.shape == b.shape
+    return (a.sort().values - b.sort().values).square().mean()
+
+
+def _weigh_camera_regs(adaptor, regs, origin, radius, fov, look_at):
+    """loss.py:170-175 / :208-214: per-component weights; the roll angle does not count."""
+    r = adaptor.roll_camera_params(regs)
+    return (r.angles[:, :2] * origin).sum() + (r.radius * radius).sum() + (r.fov * fov).sum() + (r.look_at * look_at).sum()
+
+
+def _prior_and_posterior(adaptor, prior, num_samples, z_dim, c_dim, device, z=None, c=None):
+    """loss.py:146-156: draw z, c and prior cameras, make the raw [N, 8] prior a leaf and push it through the adaptor."""
+    from .metrics import sample_camera_params
+    z = torch.randn(num_samples, z_dim, device=device) if z is None else z
+    c = sample_random_c(num_samples, c_dim, device) if c is None else c
+    cp = prior(num_samples, device) if callable(prior) else sample_camera_params(prior, num_samples, device=device)
+    prior_raw = adaptor.unroll_camera_params(cp).detach().requires_grad_(True)
+    posterior_raw = adaptor.unroll_camera_params(adaptor(adaptor.roll_camera_params(prior_raw), z, c))
+    return prior_raw, posterior_raw
+
+
+def camera_lipschitz_regs(adaptor, prior_raw, posterior_raw):
+    """loss.py:157-159: g_i = |d posterior_i / d prior_i| per sample (diagonal of the adaptor's Jacobian, one autograd pass per
+    component, graph kept: the regulariser is trained through the second derivative), reg_i = mean(g_i + 1 / (g_i + 1e-4)).  [1, 8]"""
+    grads = [torch.autograd.grad(outputs=[posterior_raw[:, i].sum()], inputs=[prior_raw], create_graph=True, only_inputs=True)[0][:, i]
+             for i in range(posterior_raw.shape[1])]
+    g = torch.stack(grads, dim=1).abs()
+    return (g + 1.0 / (g + 1e-4)).mean(dim=0, keepdim=True)
+
+
+def camera_emd_regs(prior_raw, posterior_raw):
+    """loss.py:195-198: one 1-D transport problem per camera component.  [1, 8]"""
+    return torch.stack([emd2_1d(posterior_raw[:, i], prior_raw[:, i]) for i in range(posterior_raw.shape[1])]).unsqueeze(0)
+
+
+def mean_angles_of_prior(angles_cfg):
+    """rendering_utils.py:180-190."""
+    from .metrics import _g
+    dist = _g(angles_cfg, 'dist')
+    if dist in ('spherical_uniform', 'truncnorm', 'uniform'):
+        return [(_g(angles_cfg, 'yaw.max') + _g(angles_cfg, 'yaw.min')) * 0.5, (_g(angles_cfg, 'pitch.max') + _g(angles_cfg, 'pitch.min')) * 0.5, 0.0]
+    if dist == 'normal':
+        return [_g(angles_cfg, 'yaw.mean'), _g(angles_cfg, 'pitch.mean'), 0.0]
+    if dist == 'custom':
+        raise ValueError('Cannot compute the mean value analytically for a custom angles distribution.')
+    raise NotImplementedError(f'Uknown distribution: `{dist}`')
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -101,7 +192,7 @@ def maybe_blur(img, blur_sigma):
 # ----------------------------------------------------------------------------------------------------------------------
 class StyleGAN2Loss:
     def __init__(self, G, D, device, r1_gamma=10.0, patch_cfg=None, use_depth=False, adv_loss_type='non_saturating', blur_init_sigma=0, blur_fade_kimg=0,
-                 blur_real_depth_sigma=0.0, logits_clamp_val=1e7, learn_camera_dist=False, synthesis_kwargs=None):
+                 blur_real_depth_sigma=0.0, logits_clamp_val=1e7, learn_camera_dist=False, camera_reg=None, synthesis_kwargs=None):
         if learn_camera_dist and getattr(G.synthesis, 'camera_adaptor', None) is None:
             raise RuntimeError('learn_camera_dist=True needs a generator built with cfg.camera_adaptor')
         self.G, self.D, self.device = G, D, device
@@ -110,6 +201,10 @@ class StyleGAN2Loss:
         self.logits_clamp_val, self.learn_camera_dist = logits_clamp_val, learn_camera_dist
         self.patch_cfg = patch_cfg if patch_cfg is not None else PatchConfig(enabled=False)
         self.synthesis_kwargs = dict(synthesis_kwargs or {})          # e.g. explicit renderer draws for the parity tests
+        # the regularisers need a prior to draw from; without one (camera_reg=None) only the adversarial loss reaches the adaptor
+        self.camera_reg = camera_reg if learn_camera_dist else None
+        if self.camera_reg is not None and self.camera_reg.prior is None:
+            raise RuntimeError('camera_reg needs the camera prior (CameraRegConfig.prior)')
         self.stats = {}
         self.progressive_update(0)
 
@@ -124,6 +219,42 @@ class StyleGAN2Loss:
                 p.min_scale = p.min_scale_trg
             else:
                 raise NotImplementedError(f'Uknown patch distribution: {p.distribution}')
+        r = self.camera_reg                        # loss.py:64-67: the EMD term fades IN over emd.anneal_kimg
+        self.emd_multiplier = linear_schedule(cur_kimg, 0.0, 1.0, r.emd_anneal_kimg) if r is not None else 0.0
+
+    def camera_regularisers(self):
+        """loss.py:142-238: the three terms added to the Gmain loss when the camera distribution is learned.  Returns a scalar
+        tensor (0.0 when nothing is enabled); each term draws its own z / c / prior cameras, in the reference's order."""
+        r, G = self.camera_reg, self.G
+        total = 0.0
+        if r is None:
+            return total
+        A = G.synthesis.camera_adaptor
+        if r.lipschitz_enabled:
+            prior_raw, post_raw = _prior_and_posterior(A, r.prior, r.lipschitz_num_samples, G.z_dim, G.c_dim, self.device)
+            regs = camera_lipschitz_regs(A, prior_raw, post_raw)
+            self._report_camera_regs('Dist_lipschitz_reg', A.roll_camera_params(regs))
+            total = total + _weigh_camera_regs(A, regs + regs.max() * 0.0, r.lipschitz_angles, r.lipschitz_radius, r.lipschitz_fov, r.lipschitz_look_at)
+        if r.emd_enabled and self.emd_multiplier > 0.0:
+            prior_raw, post_raw = _prior_and_posterior(A, r.prior, r.emd_num_samples, G.z_dim, G.c_dim, self.device)
+            regs = camera_emd_regs(prior_raw, post_raw)
+            self._report_camera_regs('Dist_emd_reg', A.roll_camera_params(regs))
+            emd = self.emd_multiplier * _weigh_camera_regs(A, regs + regs.max() * 0.0, r.emd_origin, r.emd_radius, r.emd_fov, r.emd_look_at)
+            self.stats['Loss/camera_dist/emd_loss'] = emd.detach()
+            total = total + emd
+        if A.cfg.adjust_angles and r.force_mean_weight > 0:
+            from .metrics import _g
+            mean_angles = torch.tensor(r.mean_angles if r.mean_angles is not None else mean_angles_of_prior(_g(r.prior, 'origin.angles'))).to(self.device)
+            _, post_raw = _prior_and_posterior(A, r.prior, r.force_mean_num_samples, G.z_dim, G.c_dim, self.device)
+            raw = (post_raw[:, :3].mean(dim=0) - mean_angles + 1e-8).square().sum().sqrt()
+            self.stats['Loss/camera_dist/force_mean'] = (r.force_mean_weight * raw).detach()
+            total = total + r.force_mean_weight * raw + 0.0 * post_raw.max()
+        return total
+
+    def _report_camera_regs(self, prefix, regs):
+        for name, v in (('yaw', regs.angles[:, 0]), ('pitch', regs.angles[:, 1]), ('fov', regs.fov), ('radius', regs.radius),
+                        ('look_at_yaw', regs.look_at[:, 0]), ('look_at_pitch', regs.look_at[:, 1]), ('look_at_radius', regs.look_at[:, 2])):
+            self.stats[f'{prefix}/{name}'] = v.detach()
 
     def run_G(self, z, c, camera_params, update_emas=False):
         """loss.py:71-86 (style mixing is off in every 3dgp config)."""
@@ -176,7 +307,7 @@ class StyleGAN2Loss:
             loss_Gmain = self._g_loss(gen_logits)
             self.stats['Loss/G/loss'] = loss_Gmain.detach()
             self.stats['Loss/scores/fake'] = gen_logits.detach()
-            loss_Gmain.mean().mul(gain).backward()
+            (loss_Gmain + self.camera_regularisers()).mean().mul(gain).backward()     # loss.py:240-241
 
         loss_Dgen = 0
         if phase in ['Dmain', 'Dall']:                                    # minimise logits of generated images

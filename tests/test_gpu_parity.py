@@ -1710,8 +1710,26 @@ def test_loss_trains_the_camera_adaptor(tdgp):
         grads = [p.grad for p in G.synthesis.camera_adaptor.parameters()]
         if flag:
             assert all(x is not None and torch.isfinite(x).all() for x in grads) and sum(float(x.abs().sum()) for x in grads) > 0
+            grads_adv = [x.clone() for x in grads]
         else:
             assert all(x is None or float(x.abs().sum()) == 0.0 for x in grads)
+    # with the regularisers of loss.py:142-238 on top (Lipschitz through bias_act's second-order kernel, EMD, force-mean): they add to
+    # the adaptor's gradients and to nothing else
+    base = [x.clone() for x in G.synthesis.camera_adaptor.parameters()]
+    reg = TR.CameraRegConfig(prior=tdgp.metrics.camera_base(), lipschitz_enabled=True, emd_anneal_kimg=1, lipschitz_num_samples=32, force_mean_num_samples=32)
+    loss = TR.StyleGAN2Loss(G, D, DEV, r1_gamma=0.0, use_depth=use_depth, learn_camera_dist=True, camera_reg=reg,
+                            synthesis_kwargs=dict(u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine'])))
+    loss.progressive_update(2)
+    assert loss.emd_multiplier == 1.0
+    G.zero_grad(set_to_none=True)
+    G.requires_grad_(True)
+    loss.accumulate_gradients('Gmain', real, gen, gain=1, cur_nimg=0)
+    grads_reg = [p.grad for p in G.synthesis.camera_adaptor.parameters()]
+    assert all(torch.isfinite(x).all() for x in grads_reg)
+    assert any(float((a - b).abs().max()) > 0 for a, b in zip(grads_reg, grads_adv))
+    for k in ('Loss/camera_dist/emd_loss', 'Loss/camera_dist/force_mean', 'Dist_lipschitz_reg/yaw', 'Dist_emd_reg/fov'):
+        assert k in loss.stats and torch.isfinite(loss.stats[k]).all(), k
+    assert all(torch.equal(a, b) for a, b in zip(base, G.synthesis.camera_adaptor.parameters()))
     plain = _gen(tdgp, tdgp.config.config_tiny(), 1)
     with pytest.raises(RuntimeError):
         TR.StyleGAN2Loss(plain, D, DEV, learn_camera_dist=True)

@@ -1,0 +1,147 @@
+"""Camera-adaptor regularisers of `learn_camera_dist` (loss.py:142-238) against vectors captured from the reference's
+CameraAdaptor (tests/golden/camera_regs.npz, tools/gen_goldens.py:gen_camera_regs) and, for the transport term, against the
+assignment-problem solution of the cost matrix the reference hands to POT."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, load_golden
+
+DEVICES = ['cpu', pytest.param('cuda', marks=pytest.mark.gpu)]
+WEIGHTS = dict(angles=0.7, radius=0.3, fov=1.3, look_at=0.2)
+
+
+def _adaptor(tdgp, idx, device):
+    tag, cfg = tdgp.config.configs_adaptor_goldens()[idx]
+    sd = tdgp.weights.random_state_dict(cfg, seed=51, exercise_all=True)
+    A = tdgp.adaptors.CameraAdaptor(cfg.camera_adaptor, cfg.z_dim, cfg.c_dim)
+    pfx = 'synthesis.camera_adaptor.'
+    A.load_state_dict({k[len(pfx):]: torch.as_tensor(v) for k, v in sd.items() if k.startswith(pfx)}, strict=True)
+    return tag, cfg, A.to(device).train()
+
+
+def _inputs(g, tag, cfg, device):
+    t = lambda a: torch.as_tensor(a).to(device)          # noqa: E731
+    z = t(g[f'{tag}_z'])
+    c = t(g[f'{tag}_c']) if cfg.c_dim > 0 else torch.zeros(len(z), 0, device=device)
+    cam = {k: t(g[f'{tag}_cam_{k}']) for k in ('angles', 'fov', 'radius', 'look_at')}
+    return z, c, cam
+
+
+@pytest.mark.parametrize('device', DEVICES)
+@pytest.mark.parametrize('idx', [0, 1])
+def test_lipschitz_regulariser(tdgp, idx, device):
+    """loss.py:146-175: diagonal of the adaptor's Jacobian, reg = mean(g + 1 / (g + 1e-4)), weighted sum, and -- through the second
+    derivative of the softplus layers (bias_act's second-order kernel on the GPU) -- the gradients left in the adaptor's parameters."""
+    TR = tdgp.training
+    g = load_golden('camera_regs')
+    tag, cfg, A = _adaptor(tdgp, idx, device)
+    z, c, cam = _inputs(g, tag, cfg, device)
+    prior_raw, post_raw = TR._prior_and_posterior(A, lambda n, dev: cam, len(z), cfg.z_dim, cfg.c_dim, device, z=z, c=c)
+    regs = TR.camera_lipschitz_regs(A, prior_raw, post_raw)
+    assert_close(regs.detach().cpu().numpy(), g[f'{tag}_lipschitz_regs'], 2e-5, 'lipschitz regs', 1.0)
+    loss = TR._weigh_camera_regs(A, regs + regs.max() * 0.0, WEIGHTS['angles'], WEIGHTS['radius'], WEIGHTS['fov'], WEIGHTS['look_at'])
+    assert_close(np.asarray(loss.item()), g[f'{tag}_lipschitz_loss'], 2e-5, 'lipschitz loss', 1.0)
+    loss.backward()
+    seen = 0
+    for n, p in A.named_parameters():
+        key = f'{tag}_lip::{n}'
+        if key in g:
+            assert p.grad is not None, n
+            assert_close(p.grad.cpu().numpy(), g[key], 5e-4, n, float(np.abs(g[key]).max()) + 1e-12)
+            seen += 1
+    assert seen >= 8
+
+
+@pytest.mark.parametrize('device', DEVICES)
+@pytest.mark.parametrize('idx', [0, 1])
+def test_force_mean_regulariser(tdgp, idx, device):
+    """loss.py:224-235 through StyleGAN2Loss.camera_regularisers (only this term enabled): value and parameter gradients."""
+    TR = tdgp.training
+    g = load_golden('camera_regs')
+    tag, cfg, A = _adaptor(tdgp, idx, device)
+    z, c, cam = _inputs(g, tag, cfg, device)
+
+    class _G:                                            # what camera_regularisers reads of the generator
+        z_dim, c_dim = cfg.z_dim, cfg.c_dim
+        synthesis = type('S', (), dict(camera_adaptor=A))()
+
+    reg = TR.CameraRegConfig(prior=lambda n, dev: cam, lipschitz_enabled=False, emd_enabled=False, force_mean_weight=10.0,
+                             force_mean_num_samples=len(z), mean_angles=[0.1, 1.5, 0.0])
+    loss = TR.StyleGAN2Loss(_G(), None, device, learn_camera_dist=True, camera_reg=reg)
+    orig = TR._prior_and_posterior
+    TR._prior_and_posterior = lambda *a, **k: orig(*a, **dict(k, z=z, c=c))        # the term draws its own z / c: pin them
+    try:
+        total = loss.camera_regularisers()
+    finally:
+        TR._prior_and_posterior = orig
+    assert_close(np.asarray(total.item()), g[f'{tag}_force_mean'], 1e-5, 'force mean', 1.0)
+    assert_close(loss.stats['Loss/camera_dist/force_mean'].cpu().numpy(), g[f'{tag}_force_mean'], 1e-5, 'reported', 1.0)
+    total.backward()
+    for n, p in A.named_parameters():
+        key = f'{tag}_fm::{n}'
+        if key in g:
+            assert_close(p.grad.cpu().numpy(), g[key], 2e-4, n, float(np.abs(g[key]).max()) + 1e-12)
+
+
+def test_emd_is_the_transport_optimum():
+    """The reference's EMD term is POT's `emd2(1/n, 1/n, dist(a, b))` (loss.py:195-197): the optimum of the transport LP with uniform
+    marginals of equal size, which is attained at a permutation (Birkhoff), i.e. the assignment problem / n.  The sorted matching
+    must give that value and the gradients emd2 propagates (the optimal plan applied to dM/da, dM/db)."""
+    from scipy.optimize import linear_sum_assignment
+    import importlib
+    TR = importlib.import_module('3dgp_amd.training')
+    rs = np.random.RandomState(5)
+    for n in (1, 2, 7, 64):
+        a = torch.tensor(rs.randn(n) * 2 + 0.3, dtype=torch.float64, requires_grad=True)
+        b = torch.tensor(rs.rand(n) * 3 - 1, dtype=torch.float64, requires_grad=True)
+        val = TR.emd2_1d(a, b)
+        M = (a.detach().numpy()[:, None] - b.detach().numpy()[None, :]) ** 2
+        rows, cols = linear_sum_assignment(M)
+        assert abs(val.item() - M[rows, cols].sum() / n) <= 1e-12 * max(1.0, abs(val.item()))
+        val.backward()
+        ga, gb = np.zeros(n), np.zeros(n)
+        av, bv = a.detach().numpy(), b.detach().numpy()
+        ga[rows] = 2 * (av[rows] - bv[cols]) / n
+        gb[cols] = -2 * (av[rows] - bv[cols]) / n
+        np.testing.assert_allclose(a.grad.numpy(), ga, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(b.grad.numpy(), gb, rtol=0, atol=1e-12)
+
+
+def test_emd_regs_and_schedule(tdgp):
+    """camera_emd_regs is one transport problem per camera component; the term fades in over emd.anneal_kimg (loss.py:64-67) and is
+    skipped at multiplier 0; roll is never weighted (loss.py:213)."""
+    TR = tdgp.training
+    _, cfg, A = _adaptor(tdgp, 0, 'cpu')
+    rs = np.random.RandomState(9)
+    prior, post = torch.tensor(rs.randn(16, 8), dtype=torch.float32), torch.tensor(rs.randn(16, 8), dtype=torch.float32)
+    regs = TR.camera_emd_regs(prior, post)
+    assert regs.shape == (1, 8)
+    for i in range(8):
+        assert abs(regs[0, i].item() - TR.emd2_1d(post[:, i], prior[:, i]).item()) < 1e-7
+    w = TR._weigh_camera_regs(A, regs, 2.0, 0.5, 1e-4, 1e-4)
+    want = 2.0 * (regs[0, 0] + regs[0, 1]) + 0.5 * regs[0, 4] + 1e-4 * regs[0, 3] + 1e-4 * regs[0, 5:8].sum()
+    assert abs(w.item() - want.item()) < 1e-6
+
+    class _G:
+        z_dim, c_dim = cfg.z_dim, cfg.c_dim
+        synthesis = type('S', (), dict(camera_adaptor=A))()
+
+    cam = tdgp.metrics.camera_base()
+    reg = TR.CameraRegConfig(prior=cam, emd_anneal_kimg=100, emd_num_samples=16, force_mean_weight=0.0)
+    loss = TR.StyleGAN2Loss(_G(), None, 'cpu', learn_camera_dist=True, camera_reg=reg)
+    assert loss.emd_multiplier == 0.0 and loss.camera_regularisers() == 0.0
+    loss.progressive_update(50)
+    assert loss.emd_multiplier == 0.5
+    torch.manual_seed(1)
+    np.random.seed(1)
+    half = loss.camera_regularisers()
+    loss.progressive_update(1000)
+    torch.manual_seed(1)
+    np.random.seed(1)
+    full = loss.camera_regularisers()
+    assert full.item() > 0 and abs(half.item() * 2 - full.item()) <= 1e-6 * full.item()
+    full.backward()
+    assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in A.parameters())
+    with pytest.raises(RuntimeError):
+        TR.StyleGAN2Loss(_G(), None, 'cpu', learn_camera_dist=True, camera_reg=TR.CameraRegConfig(prior=None))

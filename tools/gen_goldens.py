@@ -868,6 +868,48 @@ def gen_adaptors():
     save('adaptors', **arrays)
 
 
+def gen_camera_regs():
+    """Camera-adaptor regularisers of `learn_camera_dist` (loss.py:142-178 Lipschitz, :224-235 force-mean) on the reference's CameraAdaptor:
+    the per-component terms and the gradients they leave in the adaptor's parameters.  The loss lines sit inline in
+    StyleGAN2Loss.accumulate_gradients, so the few lines of arithmetic around the adaptor are restated here; the adaptor, its forward,
+    the Jacobian through it and roll / unroll are the reference's own.  (The EMD term needs POT, which is not vendored: it is pinned in
+    tests/test_training.py against the assignment-problem solution instead.)"""
+    from src.training.networks_camera_adaptor import CameraAdaptor
+    arrays = {}
+    weights = dict(angles=0.7, radius=0.3, fov=1.3, look_at=0.2)
+    for tag, cfg in tdgp.config.configs_adaptor_goldens():
+        sd = tdgp.weights.random_state_dict(cfg, seed=51, exercise_all=True)
+        ca = cfg.camera_adaptor
+        rca = CameraAdaptor(EasyDict(camera=ref_camera_cfg(ca.camera), residual=ca.residual, lr_multiplier=ca.lr_multiplier, z_dim=cfg.z_dim, c_dim=cfg.c_dim,
+                                     hid_dim=ca.hid_dim, embed_dim=ca.embed_dim,
+                                     adjust=EasyDict(angles=ca.adjust_angles, radius=ca.adjust_radius, fov=ca.adjust_fov, look_at=ca.adjust_look_at))).train()
+        pfx = 'synthesis.camera_adaptor.'
+        rca.load_state_dict({k[len(pfx):]: T(v) for k, v in sd.items() if k.startswith(pfx)}, strict=True)
+        inp = tdgp.weights.synthetic_inputs(cfg, batch=24, seed=57)
+        z, c = T(inp['z']), (T(inp['c']) if cfg.c_dim > 0 else torch.zeros(24, 0))
+        prior = TensorGroup(**{k: T(v) for k, v in inp['camera'].items()})
+        prior_raw = rca.unroll_camera_params(prior).requires_grad_(True)
+        post_raw = rca.unroll_camera_params(rca(rca.roll_camera_params(prior_raw), z, c))
+        grad_i = lambda i: torch.autograd.grad(outputs=[post_raw[:, i].sum()], inputs=[prior_raw], create_graph=True, only_inputs=True)[0][:, i]   # noqa: E731
+        norms = torch.stack([grad_i(i) for i in range(post_raw.shape[1])], dim=1).abs()
+        regs = (norms + 1.0 / (norms + 1e-4)).mean(dim=0, keepdim=True)
+        r = rca.roll_camera_params(regs + regs.max() * 0.0)
+        loss_lip = (r.angles * weights['angles'])[:, :2].sum() + (r.radius * weights['radius']).sum() + (r.fov * weights['fov']).sum() + (r.look_at * weights['look_at']).sum()
+        rca.zero_grad(set_to_none=True)
+        loss_lip.backward()
+        arrays.update({f'{tag}_z': inp['z'], f'{tag}_c': inp['c'], **{f'{tag}_cam_{k}': v for k, v in inp['camera'].items()},
+                       f'{tag}_jac_diag': npy(norms), f'{tag}_lipschitz_regs': npy(regs), f'{tag}_lipschitz_loss': npy(loss_lip)})
+        arrays.update({f'{tag}_lip::{n}': npy(p.grad) for n, p in rca.named_parameters() if p.grad is not None})
+        mean_angles = torch.tensor([0.1, 1.5, 0.0])
+        post = rca(prior, z, c)
+        raw = (post.angles.mean(dim=0) - mean_angles + 1e-8).square().sum().sqrt()
+        rca.zero_grad(set_to_none=True)
+        (10.0 * raw + 0.0 * post.max()).backward()
+        arrays[f'{tag}_force_mean'] = npy(10.0 * raw)
+        arrays.update({f'{tag}_fm::{n}': npy(p.grad) for n, p in rca.named_parameters() if p.grad is not None})
+    save('camera_regs', **arrays)
+
+
 def gen_metrics():
     """FeatureStats accumulation (metric_utils.py:104-169) and the camera prior sampler (rendering_utils.py:146-152)."""
     from src.metrics.metric_utils import FeatureStats
@@ -1251,6 +1293,7 @@ def main():
                 globals()['gen_' + name]()
         return
     gen_adaptors()
+    gen_camera_regs()
     gen_metrics()
     gen_trajectories()
     gen_harness()
