@@ -135,4 +135,20 @@ __device__ __forceinline__ float wave_scan_f32(float v) {
 __device__ __forceinline__ float wave_last_f32(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 __device__ __forceinline__ float wave_shr1_f32(float v, float first) { return dpp_f32<0x138, 0xf>(first, v); }
 __device__ __forceinline__ float wave_sum_f32(float v) { return wave_last_f32(wave_scan_f32<false>(v)); }
-__device__ __forceinline__ float softplus20f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+// softplus (beta 1, threshold 20) of the forward marchers: max(x, 0) + log1p(t), t = exp(-|x|) <= 1, with log1p(t) = log(u) + (t - (u - 1)) / u
+// for u = fl(1 + t) (the second term restores what the rounding of 1 + t dropped; u - 1 is exact).  About 40 vector instructions.
+// The literal log1pf(expf(x)) of r02 is 131 -- OCML's log1pf alone is 121, all double-float arithmetic -- and that was a third of
+// every instruction the two per-ray kernels issue (they are bound by their VALU count, profiles/r02_pmc_sq_mix.md).  Measured on
+// gfx950 over [-30, 22] against the exactly rounded value (tools/dev/softplus_acc.hip): max 2.7 ulp / mean 0.33 ulp here, 1.6 / 0.26
+// for log1pf(expf(x)), 1.5 / 0.28 for torch's own CPU softplus (Sleef): the same noise floor the reference itself sits on.
+#ifndef TDGP_SOFTPLUS_OCML
+#define TDGP_SOFTPLUS_OCML 0        // 1: the literal log1pf(expf(x)) (A/B timing and accuracy comparisons)
+#endif
+__device__ __forceinline__ float softplus20f(float x) {
+    if (TDGP_SOFTPLUS_OCML) return x > 20.f ? x : log1pf(expf(x));
+    const float t = expf(-fabsf(x));
+    const float u = 1.0f + t;
+    const float l1 = logf(u) + (t - (u - 1.0f)) * __builtin_amdgcn_rcpf(u);
+    const float r = fmaxf(x, 0.0f) + l1;
+    return x > 20.f ? x : r;
+}

@@ -464,12 +464,13 @@ def test_march_mip(tdgp, tag, kw):
     assert_close(N(fT), g[f'{tag}_T'], 2e-6, 'T')
 
 
-def test_fused_chain_equals_op_level_chain(tdgp):
+@pytest.mark.parametrize('S', [16, 32, 48])
+def test_fused_chain_equals_op_level_chain(tdgp, S):
     """ImportanceRenderer.forward (fused kernels, fine samples pre-sorted, sorted-merge fast path) must equal the same chain
     issued stage by stage through the reference-named methods (sample_stratified -> run_model -> ray_marcher ->
     sample_importance -> run_model -> unify_samples -> ray_marcher), for both marchers."""
     rs = np.random.RandomState(3)
-    B, F, H, hid, hw, S = 2, 8, 32, 16, 12, 16
+    B, F, H, hid, hw = 2, 8, 32, 16, 12
     planes = T(rs.randn(B, 3 * F, H, H))
     for marcher in ('classical', 'mip'):
         mlp = _mlp(tdgp, rs.randn(hid, F), 0.3 * rs.randn(hid), rs.randn(4, hid), 0.3 * rs.randn(4), marcher)
@@ -499,6 +500,66 @@ def test_fused_chain_equals_op_level_chain(tdgp):
         np.testing.assert_array_equal(N(depth), N(depth2))
         np.testing.assert_array_equal(N(fT), N(fT2))
         assert_close(N(wsum), N(w2.sum(2)), 1e-6, 'weights.sum', 1.0)
+
+
+def _merge_case(tdgp, rs, rays, S, sorted_lists, flags_kw, cut=0.0, with_perm2=False):
+    """tdgp_merge_composite on explicit lists vs the op-level chain unify_samples -> ray marcher, everything bit for bit."""
+    L = tdgp._lib
+    t1 = rs.uniform(0.75, 1.25, (rays, S)).astype(np.float32)
+    t2 = rs.uniform(0.75, 1.25, (rays, S)).astype(np.float32)
+    if sorted_lists:
+        t1.sort(axis=1)
+        t2.sort(axis=1)
+        t2[:, ::5] = t1[:, ::5]                                       # ties between the lists: coarse first
+        t2.sort(axis=1)
+    else:
+        t1[::3].sort(axis=1)                                          # a mix of ascending and arbitrary lists inside one tile
+        t2[1::2].sort(axis=1)
+        if rays > 5:
+            t1[5, 3] = t1[5, 7]                                       # ties inside a list
+    c1, c2 = rs.randn(rays, S, 4).astype(np.float32), rs.randn(rays, S, 4).astype(np.float32)
+    c1[..., 3] *= 4
+    c2[..., 3] *= 4
+    perm2 = np.stack([rs.permutation(S) for _ in range(rays)]).astype(np.int32) if with_perm2 else None
+    flags = tdgp.renderer._marcher_flags(dict(flags_kw), 'classical')
+    dt1, dt2, dc1, dc2 = T(t1), T(t2), T(c1), T(c2)
+    rgb, dep, wsum, fT = (torch.empty(rays, n, device=DEV) for n in (3, 1, 1, 1))
+    perm = torch.empty(rays, 2 * S, dtype=torch.int32, device=DEV)
+    dperm2 = torch.as_tensor(perm2).to(DEV) if with_perm2 else None
+    L.call('tdgp_merge_composite', dc1.data_ptr(), dt1.data_ptr(), S, dc2.data_ptr(), dt2.data_ptr(), S, rgb.data_ptr(), dep.data_ptr(), wsum.data_ptr(),
+           fT.data_ptr(), perm.data_ptr(), L.ptr(dperm2), rays, 0, flags, 0.0, float(cut), L.stream_of(dt1))
+    rend = tdgp.renderer.ImportanceRenderer('classical')
+    sh = lambda a, c: a.reshape(1, rays, S, c)                        # noqa: E731
+    d, c, sg, uperm = rend.unify_samples(sh(dt1, 1), sh(dc1[..., :3].contiguous(), 3), sh(dc1[..., 3].contiguous(), 1),
+                                         sh(dt2, 1), sh(dc2[..., :3].contiguous(), 3), sh(dc2[..., 3].contiguous(), 1), return_perm=True)
+    orgb = torch.empty(1, rays, 3, device=DEV)
+    odep, ow, ofT = torch.empty(1, rays, 1, device=DEV), torch.empty(1, rays, 2 * S, 1, device=DEV), torch.empty(1, rays, device=DEV)
+    L.call('tdgp_ray_march', c.data_ptr(), sg.data_ptr(), d.data_ptr(), orgb.data_ptr(), odep.data_ptr(), ow.data_ptr(), ofT.data_ptr(), rays, 2 * S, 3, 0,
+           flags, 0.0, float(cut), L.stream_of(dt1))
+    tag = f'S={S} rays={rays} sorted={sorted_lists} {flags_kw} cut={cut}'
+    want_perm = uperm.reshape(rays, 2 * S).cpu().numpy().astype(np.int64)
+    if with_perm2:
+        want_perm = np.where(want_perm < S, want_perm, S + np.take_along_axis(perm2.astype(np.int64), np.clip(want_perm - S, 0, S - 1), axis=1))
+    np.testing.assert_array_equal(perm.cpu().numpy().astype(np.int64), want_perm, err_msg=tag)
+    np.testing.assert_array_equal(N(rgb), N(orgb).reshape(rays, 3), err_msg=tag)
+    np.testing.assert_array_equal(N(dep), N(odep).reshape(rays, 1), err_msg=tag)
+    np.testing.assert_array_equal(N(fT).reshape(-1), N(ofT).reshape(-1), err_msg=tag)
+    assert_close(N(wsum).reshape(-1), N(ow).reshape(rays, 2 * S).astype(np.float64).sum(1), 2e-6, 'weights.sum ' + tag, 1.0)
+
+
+@pytest.mark.parametrize('S', [16, 32, 48, 64, 96])
+def test_merge_composite_equals_unify_then_march(tdgp, S):
+    """The fused merge + march + composite against the op-level chain, bit for bit, at the shapes that take the ray-tile kernel
+    (sampling_tile.inc: S in 32 / 48 / 64 / 96, lane-per-ray merge, prefix product and sums walked in the wave trees' own order) and one
+    that stays on the wave-per-ray kernel (16): ascending lists with ties across them, lists that are NOT ascending (repair path; mixed
+    with ascending ones inside a tile), a tile that is not full, every marcher flag, a cut threshold, and the permutation with and
+    without the fine list's own draw permutation."""
+    rs = np.random.RandomState(100 + S)
+    _merge_case(tdgp, rs, 256, S, True, dict(use_inf_depth=True), with_perm2=True)
+    _merge_case(tdgp, rs, 150, S, True, dict(use_inf_depth=False, last_back=True))
+    _merge_case(tdgp, rs, 70, S, True, dict(use_inf_depth=True, clamp_mode='relu'), cut=0.3)
+    _merge_case(tdgp, rs, 200, S, False, dict(use_inf_depth=True), with_perm2=True)
+    _merge_case(tdgp, rs, 1, S, False, dict(use_inf_depth=True, last_back=True))
 
 
 @pytest.mark.parametrize('S', [16, 48, 64, 96, 128])

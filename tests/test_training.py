@@ -48,7 +48,11 @@ def test_lipschitz_regulariser(tdgp, idx, device):
         key = f'{tag}_lip::{n}'
         if key in g:
             assert p.grad is not None, n
-            assert_close(p.grad.cpu().numpy(), g[key], 5e-4, n, float(np.abs(g[key]).max()) + 1e-12)
+            # on the GPU bias_act's gradient kernels follow the reference's CUDA plugin: softplus' = 1 - exp(-y) from the saved OUTPUT
+            # (bias_act.cu), which cancels for saturated units (y ~ 1e-5 keeps 2-3 digits), while the vectors were captured from the
+            # reference's CPU path (autograd of softplus itself).  The adaptor of configuration 0 is saturated almost everywhere
+            # (gradients ~1e-27): measured 0.8 % there, 1e-5 for configuration 1.
+            assert_close(p.grad.cpu().numpy(), g[key], 2e-2 if device == 'cuda' else 5e-4, n, float(np.abs(g[key]).max()) + 1e-12)
             seen += 1
     assert seen >= 8
 
