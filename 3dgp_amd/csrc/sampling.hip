@@ -153,8 +153,8 @@ __device__ float torch_order_sum_lds(const float* w1, int n, float eps) {
 // tri_plane_renderer.py:237-295.  Clobbers sc.w / sc.cdf / sc.bins.
 // Lane j produces sample j (strided by 64).  `emit(j, sample, ind, below, above)` consumes the results.
 // ------------------------------------------------------------------------------------------------
-template <typename SC, typename Emit>
-__device__ void importance_lds(SC& sc, int S, int Wn, const float* u, int N, int mip, Emit emit) {
+template <typename SC, typename GetU, typename Emit>
+__device__ void importance_lds(SC& sc, int S, int Wn, GetU getu, int N, int mip, Emit emit) {
     const int l = lane_id();
     const float eps = 1e-5f;
     float* w = sc.w;
@@ -198,7 +198,7 @@ __device__ void importance_lds(SC& sc, int S, int Wn, const float* u, int N, int
     }
     wave_sync();
     for (int j = l; j < N; j += 64) {
-        const float uu = u[j];
+        const float uu = getu(j);
         int lo = 0, hi = nc;                       // searchsorted(right=True): first index with cdf > u
         while (lo < hi) {
             int mid = (lo + hi) >> 1;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void sample_importance_kernel(const float* __r
     for (int i = l; i < S; i += 64) sc.z[i] = z[r * S + i];
     for (int i = l; i < Wn; i += 64) sc.w[i] = weights[r * Wn + i];
     wave_sync();
-    importance_lds(sc, S, Wn, u + r * N, N, mip, [&](int j, float smp, int ind, int bl, int ab) {
+    importance_lds(sc, S, Wn, [&](int j) { return u[r * N + j]; }, N, mip, [&](int j, float smp, int ind, int bl, int ab) {
         samples[r * N + j] = smp;
         if (inds) { inds[r * N + j] = ind; below[r * N + j] = bl; above[r * N + j] = ab; }
     });
@@ -393,6 +393,10 @@ __global__ __launch_bounds__(256) void importance_from_coarse_kernel(const float
 #define TPH(i)
 #endif
     for (int i = l; i < S; i += 64) { sc.z[i] = sdist[r * S + i]; sc.sig[i] = rgbs[(r * S + i) * 4 + 3]; }
+    // the draws are not needed before the cdf exists: their loads go out now and land during the march
+    float upre[MS / 64];
+#pragma unroll
+    for (int c = 0; c < MS / 64; c++) upre[c] = (l + 64 * c < N) ? u_fine[r * N + l + 64 * c] : 0.f;
     wave_sync();
     TPH(0)
     float fT, wagg;
@@ -401,7 +405,10 @@ __global__ __launch_bounds__(256) void importance_from_coarse_kernel(const float
     else { march_mip_lds(sc.z, sc.sig, sc.w, S, flags, density_bias, cut_thr, fT, wagg); Wn = (flags & 1) ? S : S - 1; }
     TPH(1)
     float* tkey = sc.col[0];
-    importance_lds(sc, S, Wn, u_fine + r * N, N, marcher, [&](int j, float smp, int ind, int, int) {
+    importance_lds(sc, S, Wn, [&](int j) { float v = upre[0];
+#pragma unroll
+                                          for (int c = 1; c < MS / 64; c++) v = (j >> 6) == c ? upre[c] : v;
+                                          return v; }, N, marcher, [&](int j, float smp, int ind, int, int) {
         tkey[j] = s2t(smp, t_near, t_far);
         if (sfine) sfine[r * N + j] = smp;
         if (inds) inds[r * N + j] = ind;
@@ -491,8 +498,17 @@ __global__ __launch_bounds__(256) void merge_composite_kernel(const float* __res
 #if TDGP_RAY_ABL & 1
     long long tph[6], t0_ = __builtin_readcyclecounter();
 #endif
-    // keys -> sc.cdf (scratch), ranks, scatter into sorted sc.z / sc.sig / sc.col
-    for (int i = l; i < M; i += 64) sc.cdf[i] = i < S1 ? t1[r * S1 + i] : t2[r * S2 + (i - S1)];
+    // keys -> sc.cdf (scratch), ranks, scatter into sorted sc.z / sc.sig / sc.col.  The colours do not depend on the ranks: their
+    // loads go out with the keys' and land while the ranks are searched.
+    float4 cval[MS / 64];
+#pragma unroll
+    for (int cc = 0; cc < MS / 64; cc++) {
+        const int i = l + 64 * cc;
+        if (i < M) {
+            sc.cdf[i] = i < S1 ? t1[r * S1 + i] : t2[r * S2 + (i - S1)];
+            cval[cc] = i < S1 ? ((const float4*)rgbs1)[r * S1 + i] : ((const float4*)rgbs2)[r * S2 + (i - S1)];
+        }
+    }
     wave_sync();
     // both lists already ascending (stratified coarse samples; fine samples sorted by importance_from_coarse)?  Then the
     // stable merge position is the element's own index plus a binary search in the OTHER list; otherwise (arbitrary caller
@@ -505,31 +521,48 @@ __global__ __launch_bounds__(256) void merge_composite_kernel(const float* __res
     if (__any(bad)) {
         stable_ranks(sc.cdf, M, rank);
     } else {
+        // the searches of a lane's slots advance together, a fixed number of branch-free steps: one chain of dependent LDS reads
+        // instead of one per slot (this phase was 40 % of the kernel's time when each slot ran its own while loop)
+        constexpr int NSL = MS / 64;
+        float v[NSL];
+        int lo[NSL], hi[NSL], ob[NSL];
+        bool fine[NSL];
 #pragma unroll
-        for (int cc = 0; cc < MAXS / 64; cc++) {
+        for (int cc = 0; cc < NSL; cc++) {
             const int i = l + 64 * cc;
-            rank[cc] = 0;
-            if (i < M) {
-                const float v = sc.cdf[i];
-                const bool fine = i >= S1;
-                const float* other = fine ? sc.cdf : sc.cdf + S1;
-                int lo = 0, hi = fine ? S1 : S2;
-                while (lo < hi) {                  // fine: #coarse <= v (coarse wins ties);  coarse: #fine < v
-                    const int mid = (lo + hi) >> 1;
-                    const float o = other[mid];
-                    if (fine ? (o <= v) : (o < v)) lo = mid + 1; else hi = mid;
-                }
-                rank[cc] = (fine ? i - S1 : i) + lo;
+            v[cc] = i < M ? sc.cdf[i] : 0.f;
+            fine[cc] = i >= S1;
+            ob[cc] = fine[cc] ? 0 : S1;                // first element of the OTHER list
+            lo[cc] = 0;
+            hi[cc] = i < M ? (fine[cc] ? S1 : S2) : 0;
+        }
+        const int steps = 32 - __clz(S1 > S2 ? S1 : S2);
+        for (int it = 0; it < steps; it++) {
+#pragma unroll
+            for (int cc = 0; cc < NSL; cc++) {         // fine: #coarse <= v (coarse wins ties);  coarse: #fine < v
+                const bool open = lo[cc] < hi[cc];
+                const int mid = (lo[cc] + hi[cc]) >> 1;
+                const float o = sc.cdf[ob[cc] + (open ? mid : 0)];
+                const bool right = fine[cc] ? (o <= v[cc]) : (o < v[cc]);
+                lo[cc] = (open && right) ? mid + 1 : lo[cc];
+                hi[cc] = (open && !right) ? mid : hi[cc];
             }
+        }
+#pragma unroll
+        for (int cc = 0; cc < MAXS / 64; cc++) rank[cc] = 0;
+#pragma unroll
+        for (int cc = 0; cc < NSL; cc++) {
+            const int i = l + 64 * cc;
+            rank[cc] = (fine[cc] ? i - S1 : i) + lo[cc];
         }
     }
     TPH(1)
 #pragma unroll
-    for (int cc = 0; cc < MAXS / 64; cc++) {
+    for (int cc = 0; cc < MS / 64; cc++) {
         const int i = l + 64 * cc;
         if (i >= M) continue;
         const int pos = rank[cc];
-        const float4 v = i < S1 ? ((const float4*)rgbs1)[r * S1 + i] : ((const float4*)rgbs2)[r * S2 + (i - S1)];
+        const float4 v = cval[cc];
         sc.z[pos] = sc.cdf[i];
         sc.col[0][pos] = v.x; sc.col[1][pos] = v.y; sc.col[2][pos] = v.z; sc.sig[pos] = v.w;
         if (perm) perm[r * M + pos] = i < S1 ? i : S1 + (perm2 ? perm2[r * S2 + (i - S1)] : i - S1);
@@ -631,7 +664,7 @@ TDGP_API int tdgp_importance_from_coarse(const float* rgbs_coarse, const float* 
                                          float* sdist_fine, int32_t* inds, int32_t* fine_perm, int64_t rays, int S, int N, int marcher, int flags,
                                          float density_bias, float cut_threshold, float t_near, float t_far, tdgp_stream_t stream) {
     TDGP_CHECK(rgbs_coarse && sdist && u_fine && tdist_fine, TDGP_EINVAL, "importance_from_coarse: null pointer");
-    TDGP_CHECK(S >= 4 && S <= MAXS && N >= 1, TDGP_EUNSUPPORTED, "importance_from_coarse: bad S=%d N=%d", S, N);
+    TDGP_CHECK(S >= 4 && S <= MAXS && N >= 1 && N <= MAXS, TDGP_EUNSUPPORTED, "importance_from_coarse: bad S=%d N=%d (both at most %d)", S, N, MAXS);
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "importance_from_coarse: unknown ray marcher %d", marcher);
     if (rays == 0) return TDGP_OK;
     if (S <= 128 && N <= 128)
