@@ -28,7 +28,7 @@ constexpr int RAYS_PER_BLOCK = 4;
 // Per-wave LDS scratch.  MS = capacity in samples; the fused kernels pick 128 when the ray fits (4.1 KB per wave -> 8 waves
 // per SIMD instead of 4: these kernels are chains of dependent LDS / cross-lane steps, occupancy is what hides them).
 template <int MS>
-struct WaveScratchT {
+struct alignas(16) WaveScratchT {
     float z[MS];        // depths (s- or t-space)
     float sig[MS];      // densities
     float w[MS + 4];    // weights / pdf scratch
@@ -417,6 +417,32 @@ __global__ __launch_bounds__(256) void importance_from_coarse_kernel(const float
     TPH(2)
     if (N <= 64) {                  // one sample per lane: sort across the lanes, store coalesced
         float key = l < N ? tkey[l] : INFINITY;
+        // Distinct keys (all but measure-zero rays): the sorted slot of a key is the number of smaller keys -- 16 broadcast LDS reads
+        // and 128 compare / add-carry instructions with no dependent chain, where the network below is 21 stages of two dependent
+        // cross-lane permutes each (it was 30 % of this kernel's time).  Equal keys collide on a slot, which the read-back sees: those
+        // rays take the network, whose (key, draw index) order is the stable sort.
+        {
+            if (l >= N) tkey[l] = INFINITY;
+            wave_sync();
+            int cnt = 0;
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) {
+                const float4 k4 = *(const float4*)&tkey[4 * jj];
+                cnt += (k4.x < key ? 1 : 0) + (k4.y < key ? 1 : 0) + (k4.z < key ? 1 : 0) + (k4.w < key ? 1 : 0);
+            }
+            int* slot = (int*)sc.bins;                      // free since importance_lds returned
+            if (l < N) slot[cnt] = l;
+            wave_sync();
+            const bool mine = l >= N || slot[cnt] == l;
+            if (__all(mine)) {
+                if (l < N) {
+                    const int src = slot[l];
+                    tfine[r * N + l] = tkey[src];
+                    if (fine_perm) fine_perm[r * N + l] = src;
+                }
+                return;
+            }
+        }
         int idx = l;
         wave_bitonic_sort(key, idx);
         TPH(3)
@@ -432,6 +458,35 @@ __global__ __launch_bounds__(256) void importance_from_coarse_kernel(const float
     }
     if (N <= 128) {                 // two samples per lane
         float key[2] = {tkey[l], l + 64 < N ? tkey[l + 64] : INFINITY};
+        {                           // distinct keys: slot = number of smaller keys, as above (MS >= 128 entries behind tkey)
+            if (l + 64 >= N) tkey[l + 64] = INFINITY;
+            wave_sync();
+            int cnt[2] = {0, 0};
+#pragma unroll 8
+            for (int jj = 0; jj < 32; jj++) {
+                const float4 k4 = *(const float4*)&tkey[4 * jj];
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+                    cnt[c] += (k4.x < key[c] ? 1 : 0) + (k4.y < key[c] ? 1 : 0) + (k4.z < key[c] ? 1 : 0) + (k4.w < key[c] ? 1 : 0);
+            }
+            int* slot = (int*)sc.bins;
+            slot[cnt[0]] = l;
+            if (l + 64 < N) slot[cnt[1]] = l + 64;
+            wave_sync();
+            const bool mine = slot[cnt[0]] == l && (l + 64 >= N || slot[cnt[1]] == l + 64);
+            if (__all(mine)) {
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const int pos = l + 64 * c;
+                    if (pos < N) {
+                        const int src = slot[pos];
+                        tfine[r * N + pos] = tkey[src];
+                        if (fine_perm) fine_perm[r * N + pos] = src;
+                    }
+                }
+                return;
+            }
+        }
         int idx[2] = {l, l + 64};
         wave_bitonic_sort2(key, idx);
 #pragma unroll

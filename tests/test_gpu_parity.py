@@ -574,8 +574,11 @@ def test_fused_fine_samples_come_out_sorted(tdgp, S):
     cam = dict(angles=T([[0.3, 1.2, 0.0]]), radius=T([1.0]), look_at=T(np.zeros((1, 3))))
     ro, rd = tdgp.renderer.sample_rays(tdgp.renderer.compute_cam2world_matrix(cam), T([30.0]), (hw, hw))
     R = hw * hw
+    u_fine = rs.rand(B * R, S).astype(np.float32)
+    u_fine[::3, 5] = u_fine[::3, 2]                 # equal draws -> equal depths: the counting sort's slots collide and those rays take the
+    u_fine[1::7, S - 1] = u_fine[1::7, 0]           # network, whose (depth, draw index) order the last assertion checks
     opts = dict(box_size=1.0, num_proposal_steps=S, num_fine_steps=S, clamp_mode='softplus', use_inf_depth=True, ray_start=0.75, ray_end=1.25,
-                u_coarse=T(rs.rand(B, R, S, 1)), u_fine=T(rs.rand(B * R, S)))
+                u_coarse=T(rs.rand(B, R, S, 1)), u_fine=T(u_fine))
     rend = tdgp.renderer.ImportanceRenderer('classical')
     _, aux = rend(planes, mlp, ro, rd, opts, return_intermediates=True)
     tf = N(aux['tdist_fine']).reshape(R, S)
