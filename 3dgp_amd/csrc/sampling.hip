@@ -742,6 +742,9 @@ TDGP_API int tdgp_merge_composite(const float* rgbs_coarse, const float* t_coars
     if (S1 + S2 <= 128)
         TDGP_LAUNCH("merge_composite_kernel", merge_composite_kernel<128>, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, t_coarse, S1,
                            rgbs_fine, t_fine, S2, rgb, depth, wsum, final_T, perm, fine_perm, rays, marcher, flags, density_bias, cut_threshold);
+    else if (S1 + S2 <= 192)        // BASELINE configs[4]: 96 + 96 samples -- three lane slots and 6.2 KB of scratch per wave instead of four and 8.2 KB
+        TDGP_LAUNCH("merge_composite_kernel", merge_composite_kernel<192>, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, t_coarse, S1,
+                           rgbs_fine, t_fine, S2, rgb, depth, wsum, final_T, perm, fine_perm, rays, marcher, flags, density_bias, cut_threshold);
     else
         TDGP_LAUNCH("merge_composite_kernel", merge_composite_kernel<MAXS>, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, t_coarse, S1,
                            rgbs_fine, t_fine, S2, rgb, depth, wsum, final_T, perm, fine_perm, rays, marcher, flags, density_bias, cut_threshold);
