@@ -239,6 +239,11 @@ __global__ __launch_bounds__(256) void stratified_kernel(const float* __restrict
     }
 }
 
+__global__ __launch_bounds__(256) void density_activation_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int relu, float bias) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = relu ? (x[i] > 0.f ? x[i] : 0.f) : softplus20f(x[i] + bias);
+}
+
 // generic marcher: colours [rays,S,C], densities [rays,S], depths [rays,S]
 __global__ __launch_bounds__(256) void ray_march_kernel(const float* __restrict__ colors, const float* __restrict__ dens,
                                                        const float* __restrict__ depths, float* __restrict__ rgb, float* __restrict__ depth_o,
@@ -676,6 +681,16 @@ TDGP_API int tdgp_sample_stratified(const float* u, float* sdist, float* tdist, 
     if (n == 0) return TDGP_OK;
     TDGP_LAUNCH("stratified_kernel", stratified_kernel, dim3((int)min((int64_t)8192, cdiv64(n, 256))), dim3(256), 0, (hipStream_t)stream, u, sdist, tdist, n, S,
                        marcher, t_near, t_far);
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}
+
+TDGP_API int tdgp_density_activation(const float* sigma, float* out, int64_t n, int flags, float density_bias, tdgp_stream_t stream) {
+    TDGP_CHECK(sigma && out, TDGP_EINVAL, "density_activation: null pointer");
+    TDGP_CHECK(n >= 0, TDGP_EINVAL, "density_activation: negative length");
+    if (n == 0) return TDGP_OK;
+    TDGP_LAUNCH("density_activation_kernel", density_activation_kernel, dim3((int)min((int64_t)8192, cdiv64(n, 256))), dim3(256), 0, (hipStream_t)stream, sigma, out, n,
+                (flags & 8) ? 1 : 0, density_bias);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }

@@ -69,13 +69,18 @@ def _cut_threshold(sigma, opts, marcher, flags):
     q = float(opts.get('cut_quantile', 0.0))
     if q <= 0.0:
         return 0.0
-    if marcher == 'classical':
-        dens = torch.relu(sigma) if (flags & 8) else torch.nn.functional.softplus(sigma)
-    else:
+    # the activated densities come from the marchers' own routine (tdgp_density_activation): the reference thresholds the very tensor it
+    # took the quantile of (`x < quantile(x)`), and a softplus that differs from the kernels' by an ulp would flip the samples that sit at
+    # the quantile
+    bias = 0.0
+    if marcher == 'mip':
         mid = (sigma[:, :-1] + sigma[:, 1:]) / 2
-        if flags & 1:
-            mid = torch.cat([mid, sigma[:, -1:]], dim=1)
-        dens = torch.nn.functional.softplus(mid + float(opts.get('density_bias', 0.0)))
+        sigma = torch.cat([mid, sigma[:, -1:]], dim=1) if flags & 1 else mid
+        bias = float(opts.get('density_bias', 0.0))
+    sigma = _lib.f32c(sigma)
+    dens = torch.empty_like(sigma)
+    with torch.cuda.device(sigma.device):
+        _lib.call('tdgp_density_activation', sigma.data_ptr(), dens.data_ptr(), sigma.numel(), flags, bias, _lib.stream_of(sigma))
     return float(_quantile(dens, q))
 
 

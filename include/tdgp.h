@@ -233,6 +233,11 @@ int tdgp_sample_rays(const float* c2w, const float* fov, int fov_stride, const f
 int tdgp_sample_stratified(const float* u, float* sdist, float* tdist, int64_t rays, int S, int marcher,
                            float t_near, float t_far, tdgp_stream_t stream);
 
+/* The marchers' density activation as a function of its own: out[i] = max(x, 0) when flags bit 3 (relu clamp) is set, else the softplus
+ * of x = sigma[i] + density_bias -- the routine the march kernels apply, so that a threshold taken over `out` (the cut_quantile option,
+ * tri_plane_renderer.py:324-326, :366-368: `x < quantile(x)` on the activated densities) compares like with like. */
+int tdgp_density_activation(const float* sigma, float* out, int64_t n, int flags, float density_bias, tdgp_stream_t stream);
+
 /* NCHW planes [B,3F,H,W] -> plane-major channel-last [B,3,H,W,F] (the field kernel's layout). */
 int tdgp_planes_to_hwc(const float* planes_nchw, float* planes_hwc, int B, int F, int H, int W,
                        tdgp_stream_t stream);

@@ -452,6 +452,38 @@ def test_march_classical(tdgp, oracle, tag, kw):
     assert_close(N(rgb), orgb, 1e-6, 'rgb vs oracle', 1.0)
 
 
+def test_density_activation(tdgp):
+    """tdgp_density_activation = the marchers' own softplus (max(x,0) + compensated log1p(exp(-|x|)); threshold 20) / relu: within 3 ulp of
+    the exactly rounded softplus over the whole range (measured max 2.7, tools/dev/softplus_acc.hip; torch's CPU softplus: 1.5), relu exact,
+    and it is what the cut threshold is taken over: a march with cut_quantile zeroes exactly the samples whose activation is below the
+    quantile of the activations this entry returns."""
+    L = tdgp._lib
+    rs = np.random.RandomState(8)
+    x = np.concatenate([np.linspace(-30, 25, 200001), rs.randn(100000) * 5]).astype(np.float32)
+    dx = T(x)
+    out = torch.empty_like(dx)
+    L.call('tdgp_density_activation', dx.data_ptr(), out.data_ptr(), dx.numel(), 0, 0.0, L.stream_of(dx))
+    true = np.where(x > 20, x.astype(np.float64), np.log1p(np.exp(x.astype(np.float64))))
+    ulp = np.spacing(np.abs(true.astype(np.float32))).astype(np.float64)
+    assert (np.abs(N(out).astype(np.float64) - true) / ulp).max() <= 3.0
+    L.call('tdgp_density_activation', dx.data_ptr(), out.data_ptr(), dx.numel(), 8, 0.0, L.stream_of(dx))
+    np.testing.assert_array_equal(N(out), np.maximum(x, 0))
+    L.call('tdgp_density_activation', dx.data_ptr(), out.data_ptr(), dx.numel(), 0, -1.5, L.stream_of(dx))
+    ref = torch.empty_like(dx)
+    sh = T((x + np.float32(-1.5)).astype(np.float32))
+    L.call('tdgp_density_activation', sh.data_ptr(), ref.data_ptr(), dx.numel(), 0, 0.0, L.stream_of(dx))
+    np.testing.assert_array_equal(N(out), N(ref))                                   # the bias is added in fp32, as the mip marcher adds it
+    # self-consistency of the cut: weights vanish exactly where activation < quantile(activation)
+    g = load_golden('marchers')
+    dens = T(g['densities'])
+    act = torch.empty_like(dens)
+    L.call('tdgp_density_activation', dens.data_ptr(), act.data_ptr(), dens.numel(), 0, 0.0, L.stream_of(dens))
+    thr = float(torch.quantile(act.reshape(-1), 0.5))
+    _, _, w, _ = tdgp.renderer.ClassicalRayMarcher()(T(g['colors']), dens, T(g['depths']), dict(use_inf_depth=True, cut_quantile=0.5))
+    cut = N(act).reshape(-1) < thr
+    assert (N(w).reshape(-1)[cut] == 0).all() and cut.sum() == cut.size // 2
+
+
 @pytest.mark.parametrize('tag,kw', [('mip_inf', dict(use_inf_depth=True)), ('mip_noinf_white', dict(use_inf_depth=False, white_back=True)),
                                     ('mip_bias', dict(use_inf_depth=True, density_bias=-1.0)),
                                     ('mip_cut', dict(use_inf_depth=True, cut_quantile=0.3))])
