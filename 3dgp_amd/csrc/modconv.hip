@@ -1822,6 +1822,9 @@ struct RgbParams {
     int lw, lhw;        // log2 W, log2 H*W when both are powers of two, else -1
 };
 
+#ifndef TDGP_FIR_ADJ
+#define TDGP_FIR_ADJ 1      // FIR pass of the wide x2 layers: 4 adjacent rows per thread (0: two rows eight apart, the r02 form)
+#endif
 #ifndef TDGP_RGB_ABL
 #define TDGP_RGB_ABL 0     // 16: per-phase cycle counts of one wave, printed (timing experiments only)
 #endif
@@ -2080,7 +2083,7 @@ __device__ __forceinline__ uint32_t fir_pack_bf16(float a, float b) {
 // + noise, bias (itself rounded) / activation / gain / clamp.
 // LRELU: the generator's form (leaky ReLU with 0 <= alpha <= 1; the clamp, if any, one v_med3) decided at compile time -- the pass is instruction-bound,
 // and the run-time activation switch + clamp test per output were a fifth of its output stage.
-template <int FIR_TH, int FIR_TW, bool YBF = false, bool LRELU = false>
+template <int FIR_TH, int FIR_TW, bool YBF = false, bool LRELU = false, bool ADJ = false>
 __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
     constexpr int CW = FIR_TW / 4, RPP = 256 / CW;                 // threads per output row, rows per pass
     constexpr int ZP = FIR_TW + 8;                  // window columns ox0-4 .. ox0+67, fetched as aligned 16-B vectors (P2 % 4 == 0)
@@ -2107,7 +2110,7 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
         float4 nzv[FIR_TH / RPP];
 #pragma unroll
         for (int hrow = 0; hrow < FIR_TH / RPP; hrow++) {
-            const int oy = oy0 + threadIdx.x / CW + hrow * RPP;
+            const int oy = oy0 + (ADJ ? (threadIdx.x / CW) * (FIR_TH / RPP) + hrow : threadIdx.x / CW + hrow * RPP);
             nzv[hrow] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (nz_vec && oy < p.OH) nzv[hrow] = *(const float4*)(p.noise + b * p.noise_bstride + (int64_t)oy * p.OW + ox0 + lx);
         }
@@ -2151,12 +2154,43 @@ __global__ __launch_bounds__(256) void fir_act_kernel(FirParams p) {
             *(float4*)&zt[ry * ZP + 4 * j] = v;
         }
         __syncthreads();
+        // ADJ: a thread's rows are ADJACENT (a (RPT+3) x 7 window serves RPT x 4 outputs: 3 (RPT + 3) window reads instead of 12 RPT), each
+        // output still summing its 16 taps in the order ky, kx of the other form
+        constexpr int RPT = FIR_TH / RPP;
+        float accs[ADJ ? RPT : 1][4];
+        if constexpr (ADJ) {
+#pragma unroll
+            for (int rr = 0; rr < RPT; rr++)
+#pragma unroll
+                for (int o = 0; o < 4; o++) accs[rr][o] = 0.f;
+            const int ly0 = (threadIdx.x / CW) * RPT;
+#pragma unroll
+            for (int wy = 0; wy < RPT + 3; wy++) {
+                const float4 wa = *(const float4*)&zt[(ly0 + wy) * ZP + lx], wb = *(const float4*)&zt[(ly0 + wy) * ZP + lx + 4],
+                             wc = *(const float4*)&zt[(ly0 + wy) * ZP + lx + 8];
+                const float win[7] = {wa.w, wb.x, wb.y, wb.z, wb.w, wc.x, wc.y};
+#pragma unroll
+                for (int rr = 0; rr < RPT; rr++) {
+                    const int ky = wy - rr;
+                    if (ky >= 0 && ky < 4) {
+#pragma unroll
+                        for (int o = 0; o < 4; o++)
+#pragma unroll
+                            for (int kx = 0; kx < 4; kx++) accs[rr][o] = fmaf_(p.fir[ky * 4 + kx], win[o + kx], accs[rr][o]);
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int hrow = 0; hrow < FIR_TH / RPP; hrow++) {
-            const int ly = threadIdx.x / CW + hrow * RPP;
+            const int ly = ADJ ? (threadIdx.x / CW) * RPT + hrow : threadIdx.x / CW + hrow * RPP;
             const int oy = oy0 + ly;
             if (oy < p.OH && ox0 + lx < p.OW) {
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (ADJ) {
+#pragma unroll
+                    for (int o = 0; o < 4; o++) acc[o] = accs[hrow][o];
+                } else
 #pragma unroll
                 for (int ky = 0; ky < 4; ky++) {
                     // window columns lx+3 .. lx+9 out of three aligned 16-B LDS reads (lx .. lx+11): scalar reads at a 4-float lane
@@ -2719,7 +2753,10 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
         f.B = B; f.C = Cout; f.ZROWS = 2 * H + 2; f.P2 = 2 * pl.G1; f.GS2 = 2 * pl.GS; f.ksplit = split ? 1 : pl.ksplit; f.zslice = pl.zslice;
         f.OH = 2 * H; f.OW = 2 * W;
         f.act = act; f.alpha = alpha; f.gain = gain; f.clamp = clamp;
-        if (f.OW >= 128 && !TDGP_AB_FIR_SERIAL) {
+        if (TDGP_FIR_ADJ && f.OW >= 128 && (f.OH & 31) == 0 && f.ksplit == 1 && f.act == 3 && f.alpha >= 0.f && f.alpha <= 1.f) {
+            const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, 32) * cdiv(f.OW, 128);
+            TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<32, 128, false, true, true>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
+        } else if (f.OW >= 128 && !TDGP_AB_FIR_SERIAL) {
             const int64_t ntiles = (int64_t)B * Cout * cdiv(f.OH, 16) * cdiv(f.OW, 128);
             if (f.act == 3 && f.alpha >= 0.f && f.alpha <= 1.f)
                 TDGP_LAUNCH("fir_act_kernel", (fir_act_kernel<16, 128, false, true>), dim3((int)min((int64_t)(256 * 32), ntiles)), dim3(256), 0, s, f);
