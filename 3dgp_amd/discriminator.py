@@ -272,12 +272,12 @@ class Discriminator(torch.nn.Module):
         return x.squeeze(1), f
 
 
-def seeded_discriminator(cfg, input_resolution, img_channels, seed):
+def seeded_discriminator(cfg, input_resolution, img_channels, seed, epilogue_kwargs={}):
     """Deterministic random weights (CPU generator): the module's own initialisation under `seed`, biases moved off zero.  The
     golden vectors of tools/gen_goldens.py:gen_discriminator are computed with exactly these weights loaded into the reference."""
     state = torch.random.get_rng_state()
     torch.manual_seed(seed)
-    D = Discriminator(cfg, input_resolution=input_resolution, img_channels=img_channels)
+    D = Discriminator(cfg, input_resolution=input_resolution, img_channels=img_channels, epilogue_kwargs=dict(epilogue_kwargs))
     with torch.no_grad():
         for n, p in D.named_parameters():
             if n.endswith('bias'):

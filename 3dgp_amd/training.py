@@ -5,8 +5,9 @@ Dreg / Dall, maybe_blur), `src/training/training_utils.py:22-167` (patch samplin
 (the optimiser step around the gradient exchange).  What is here is the adversarial core every 3dgp run executes: non-saturating
 (or hinge) losses, R1 on real patches, patch-wise training with patch-conditioned discriminator, RGB-D discriminator input through
 the depth adaptor, image / depth blur schedules, and the three camera-adaptor regularisers of `learn_camera_dist` (Lipschitz, earth
-mover's distance to the prior, force-mean; loss.py:142-222).  Not here: knowledge distillation, path-length regularisation
-(`pl_weight: 0` in every 3dgp config), ADA.
+mover's distance to the prior, force-mean; loss.py:142-222), and the discriminator's knowledge-distillation term (features predicted
+from real images pulled to the dataset's precomputed embeddings, loss.py:279-314).  Not here: path-length regularisation (`pl_weight: 0`
+in every 3dgp config), ADA.
 
 All device work runs on the library's kernels through the autograd ops (`G.forward_autograd`, `discriminator.Discriminator`);
 the arithmetic in this file is the reference's eager tensor arithmetic.
@@ -192,7 +193,8 @@ def maybe_blur(img, blur_sigma):
 # ----------------------------------------------------------------------------------------------------------------------
 class StyleGAN2Loss:
     def __init__(self, G, D, device, r1_gamma=10.0, patch_cfg=None, use_depth=False, adv_loss_type='non_saturating', blur_init_sigma=0, blur_fade_kimg=0,
-                 blur_real_depth_sigma=0.0, logits_clamp_val=1e7, learn_camera_dist=False, camera_reg=None, synthesis_kwargs=None):
+                 blur_real_depth_sigma=0.0, logits_clamp_val=1e7, learn_camera_dist=False, camera_reg=None, kd_weight=0.0, kd_anneal_kimg=100000,
+                 kd_loss_type='l2', synthesis_kwargs=None):
         if learn_camera_dist and getattr(G.synthesis, 'camera_adaptor', None) is None:
             raise RuntimeError('learn_camera_dist=True needs a generator built with cfg.camera_adaptor')
         self.G, self.D, self.device = G, D, device
@@ -201,6 +203,7 @@ class StyleGAN2Loss:
         self.logits_clamp_val, self.learn_camera_dist = logits_clamp_val, learn_camera_dist
         self.patch_cfg = patch_cfg if patch_cfg is not None else PatchConfig(enabled=False)
         self.synthesis_kwargs = dict(synthesis_kwargs or {})          # e.g. explicit renderer draws for the parity tests
+        self.kd_weight, self.kd_anneal_kimg, self.kd_loss_type = kd_weight, kd_anneal_kimg, kd_loss_type       # configs/model/base.yaml:82 (3dgp.yaml:91: weight 1)
         # the regularisers need a prior to draw from; without one (camera_reg=None) only the adversarial loss reaches the adaptor
         self.camera_reg = camera_reg if learn_camera_dist else None
         if self.camera_reg is not None and self.camera_reg.prior is None:
@@ -219,6 +222,7 @@ class StyleGAN2Loss:
                 p.min_scale = p.min_scale_trg
             else:
                 raise NotImplementedError(f'Uknown patch distribution: {p.distribution}')
+        self.D_kd_weight = linear_schedule(cur_kimg, self.kd_weight, 0.0, self.kd_anneal_kimg)     # loss.py:63: fades OUT
         r = self.camera_reg                        # loss.py:64-67: the EMD term fades IN over emd.anneal_kimg
         self.emd_multiplier = linear_schedule(cur_kimg, 0.0, 1.0, r.emd_anneal_kimg) if r is not None else 0.0
 
@@ -279,6 +283,13 @@ class StyleGAN2Loss:
         kwargs.pop('camera_angles', None)                               # camera_cond is off in every 3dgp config
         return self.D(img, c, update_emas=update_emas, **kwargs)
 
+    def compute_sample_weights(self, patch_params, scale_pow=1):
+        """loss.py:107-114: larger patches weigh more in the distillation distance."""
+        if not self.patch_cfg.enabled:
+            return 1.0
+        raw = patch_params['scales'].mean(dim=1) ** scale_pow
+        return raw / (raw.mean(dim=0) + 1e-8)
+
     def extract_patches(self, img):
         patch_params = sample_patch_params(len(img), self.patch_cfg, device=img.device)
         return extract_patches(img, patch_params, resolution=self.patch_cfg.resolution), patch_params
@@ -327,7 +338,8 @@ class StyleGAN2Loss:
         if phase in ['Dmain', 'Dreg', 'Dall']:                            # maximise logits of real images, R1
             real_img, patch_params = self.extract_patches(real_img) if self.patch_cfg.enabled else (real_img, None)
             real_img_tmp = real_img.detach().requires_grad_(phase in ['Dreg', 'Dall'])
-            real_logits, _ = self.run_D(real_img_tmp, real_data.c, blur_sigma=blur_sigma, patch_params=patch_params)
+            do_Dkd = self.D_kd_weight > 0 and phase in ['Dmain', 'Dall']
+            real_logits, real_feats = self.run_D(real_img_tmp, real_data.c, blur_sigma=blur_sigma, patch_params=patch_params, predict_feat=do_Dkd)
             self.stats['Loss/scores/real'] = real_logits.detach()
             loss_Dreal = 0.0
             if phase in ['Dmain', 'Dall']:
@@ -339,6 +351,20 @@ class StyleGAN2Loss:
                 else:
                     raise NotImplementedError(f'Unknown loss: {self.adv_loss_type}')
                 self.stats['Loss/D/loss'] = (loss_Dgen + loss_Dreal).detach()
+            loss_Dkd = 0.0
+            if do_Dkd:                                                     # loss.py:301-311: distance of the predicted features to the embeddings
+                if self.kd_loss_type == 'l2':
+                    distances = (real_feats - real_data.embs).norm(dim=1)
+                elif self.kd_loss_type == 'kl':
+                    distances = torch.nn.functional.kl_div(real_feats.log_softmax(dim=1), real_data.embs.softmax(dim=1), reduction='none').sum(dim=1)
+                else:
+                    raise NotImplementedError(f'Unknown loss type: {self.kd_loss_type}')
+                distances = distances * self.compute_sample_weights(patch_params)
+                loss_Dkd = distances * self.D_kd_weight
+                self.stats['Loss/kd/D_dist'] = distances.detach()
+                self.stats['Loss/kd/D_loss'] = loss_Dkd.detach()
+            else:
+                assert real_feats is None, 'There is no sense in predicting features from D'
             loss_Dr1 = 0.0
             if phase in ['Dreg', 'Dall']:
                 from .ops import conv2d_gradfix as _cg
@@ -347,7 +373,7 @@ class StyleGAN2Loss:
                 r1_penalty = r1_grads.square().sum([1, 2, 3])
                 loss_Dr1 = r1_penalty * (self.r1_gamma / 2)
                 self.stats['Loss/D/r1_penalty'] = r1_penalty.detach()
-            (loss_Dreal + loss_Dr1).mean().mul(gain).backward()
+            (loss_Dreal + loss_Dr1 + loss_Dkd).mean().mul(gain).backward()
 
 
 def optimizer_step(module, opt, world=None, grad_clip=None):

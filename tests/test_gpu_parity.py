@@ -1779,6 +1779,61 @@ def test_stylegan2_loss_phases(tdgp):
         TR.sample_patch_params = orig
 
 
+@pytest.mark.parametrize('kind', ['l2', 'kl'])
+def test_stylegan2_loss_knowledge_distillation(tdgp, kind):
+    """The discriminator's distillation term (loss.py:279-314: features predicted from the real patches pulled to the dataset's
+    embeddings, l2 or kl distance, weighted by patch size, faded out over kd.discr.anneal_kimg) inside phase Dmain: the schedule value
+    and every gradient left in D -- feature head included -- against the reference's StyleGAN2Loss on the same weights and draws."""
+    g = load_golden('loss_kd')
+    TR = tdgp.training
+    cfg = tdgp.config.config_tiny()
+    cfg.use_noise = False
+    cfg.patch_resolution = 16
+    dcfg = tdgp.discriminator.DiscriminatorConfig(c_dim=0, cbase=256, cmax=16, patch_params_cond=True, hyper_mod=True, mbstd_group_size=2)
+    G = _gen(tdgp, cfg, 201).train()
+    D = tdgp.discriminator.seeded_discriminator(dcfg, 16, 3, seed=212, epilogue_kwargs=dict(feat_predict_dim=6)).to(DEV).train()
+    pcfg = TR.PatchConfig(enabled=True, distribution='uniform', resolution=16, min_scale_trg=0.5, max_scale=1.0, anneal_kimg=10, mbstd_group_size=2)
+    loss = TR.StyleGAN2Loss(G, D, DEV, r1_gamma=2.0, patch_cfg=pcfg, kd_weight=0.7, kd_anneal_kimg=100, kd_loss_type=kind,
+                            synthesis_kwargs=dict(u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine'])))
+    assert loss.D_kd_weight == 0.7
+    loss.progressive_update(25)
+    assert abs(loss.D_kd_weight - float(g[f'{kind}_kd_weight'])) < 1e-7
+    queue = [dict(scales=T(g[f'pp{i}_scales']), offsets=T(g[f'pp{i}_offsets'])) for i in range(2)]
+    orig = TR.sample_patch_params
+    TR.sample_patch_params = lambda n, pc, device='cpu': queue.pop(0)
+    B = 4
+    c0 = torch.zeros(B, 0, device=DEV)
+    try:
+        G.requires_grad_(False)
+        D.requires_grad_(True)
+        D.zero_grad(set_to_none=True)
+        real = tdgp.generator.TensorGroup(img=T(g['real']), c=c0, depth=torch.zeros(B, 1, 32, 32, device=DEV), embs=T(g['embs']))
+        gen = tdgp.generator.TensorGroup(z=T(g['z']), c=c0, camera_params=tdgp.generator.TensorGroup(**_cam(g)))
+        loss.accumulate_gradients('Dmain', real, gen, gain=1, cur_nimg=0)
+        assert not queue
+    finally:
+        TR.sample_patch_params = orig
+    params = dict(D.named_parameters())
+    n_checked, head = 0, 0
+    for k in g.keys():
+        if not k.startswith(kind + '::'):
+            continue
+        parts = k.split('::')
+        gr = params[parts[-1]].grad
+        assert gr is not None, parts[-1]
+        gr = gr.cpu()
+        got = gr.sum(1) if parts[1] == 'rows' else gr.sum(0) if parts[1] == 'cols' else gr
+        err = float(np.abs(got.numpy() - g[k]).max() / max(np.abs(g[k]).max(), 1e-12))
+        assert err <= 2e-3, (kind, parts[-1], err)
+        n_checked += 1
+        head += 'feat_out' in parts[-1]
+    assert n_checked >= 30 and head >= 4
+    assert torch.isfinite(loss.stats['Loss/kd/D_dist']).all() and float(loss.stats['Loss/kd/D_loss'].abs().sum()) > 0
+    # weight 0 (every 3dgp config but the distilled ones): no feature head is evaluated
+    plain = TR.StyleGAN2Loss(G, D, DEV, r1_gamma=2.0, patch_cfg=pcfg)
+    assert plain.D_kd_weight == 0.0
+
+
 def test_loss_trains_the_camera_adaptor(tdgp):
     """`learn_camera_dist=True` (loss.py:76-77): run_G applies the camera adaptor and the Gmain phase leaves finite, non-zero gradients in
     its parameters -- through ray generation and the field kernel's coordinate gradient; without the flag the adaptor gets none.  A

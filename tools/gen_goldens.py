@@ -1211,6 +1211,77 @@ def gen_loss():
     save('loss', **arrays)
 
 
+def gen_loss_kd():
+    """The discriminator's knowledge-distillation term (loss.py:279-314) through the reference's own StyleGAN2Loss: phase Dmain with
+    kd.discr.weight 0.7 at kimg 0, l2 and kl distances, patch-size sample weights -- the gradients left in D (feature head included)."""
+    ot = types.ModuleType('ot')
+    sys.modules.setdefault('ot', ot)
+    from src.training import loss as ref_loss
+    from src.training.networks_discriminator import Discriminator as RefD
+    cfg, dcfg = loss_golden_setup()
+    B, S, res = 4, cfg.num_ray_steps, cfg.patch_resolution
+    R = res * res
+    FD = 6
+    sd = tdgp.weights.random_state_dict(cfg, seed=201, exercise_all=True)
+    rc = ref_cfg(cfg)
+    rc.patch = EasyDict(enabled=True, resolution=res)
+    rc.nerf_noise_std_init, rc.nerf_noise_kimg_growth = 0.0, 1
+    G = Generator(rc, img_resolution=cfg.img_resolution, img_channels=3, mapping_kwargs={}, num_fp16_res=0, conv_clamp=None, fused_modconv_default='inference_only')
+    G.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    G.train()
+    mineD = tdgp.discriminator.seeded_discriminator(dcfg, res, 3, seed=212, epilogue_kwargs=dict(feat_predict_dim=FD))
+    rd = EasyDict(c_dim=0, cbase=dcfg.cbase, cmax=dcfg.cmax, fmaps=1.0, num_additional_start_blocks=0, patch=EasyDict(patch_params_cond=True), hyper_mod=True,
+                  camera_cond=False, camera_cond_drop_p=0.0, mbstd_group_size=2, logits_clamp_val=1e7)
+    D = RefD(rd, input_resolution=res, img_channels=3, num_fp16_res=0, conv_clamp=None, epilogue_kwargs=dict(mbstd_group_size=2, feat_predict_dim=FD))
+    D.load_state_dict(mineD.state_dict(), strict=True)
+    D.train()
+    g = np.random.RandomState(213)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=B, seed=204)
+    u1, u2 = g.rand(B, R, S, 1).astype(np.float32), g.rand(B * R, S).astype(np.float32)
+    real = g.randn(B, 3, 32, 32).astype(np.float32)
+    embs = g.randn(B, FD).astype(np.float32)
+    sx = g.uniform(0.5, 1.0, (2, B // 2)).astype(np.float32)
+    pps = []
+    for i in range(2):
+        sc = np.repeat(np.stack([sx[i], sx[i]], 1), 2, axis=0)
+        pps.append(dict(scales=sc, offsets=(np.repeat(g.rand(B // 2, 2).astype(np.float32), 2, axis=0) * (1 - sc)).astype(np.float32)))
+    arrays = dict(z=inp['z'], u_coarse=u1, u_fine=u2, real=real, embs=embs, **{'cam_' + k: v for k, v in inp['camera'].items()})
+    for i, pp in enumerate(pps):
+        arrays[f'pp{i}_scales'], arrays[f'pp{i}_offsets'] = pp['scales'], pp['offsets']
+    queue = []
+    ref_loss.sample_patch_params = lambda n, pcfg, device='cpu': {k: T(v) for k, v in queue.pop(0).items()}
+    cam = TensorGroup(**{k: T(v) for k, v in inp['camera'].items()})
+    c0 = torch.zeros(B, 0)
+    for kind in ('l2', 'kl'):
+        full = EasyDict(model=EasyDict(loss_kwargs=EasyDict(blur_init_sigma=0, blur_fade_kimg=0, adv_loss_type='non_saturating', pl_weight=0.0, pl_start_kimg=0,
+                                                           kd=EasyDict(discr=EasyDict(weight=0.7, anneal_kimg=100, loss_type=kind))),
+                                   generator=EasyDict(camera_cond_spoof_p=0.5), discriminator=rd),
+                        training=EasyDict(patch=EasyDict(enabled=True, distribution='uniform', min_scale_trg=0.5, max_scale=1.0, anneal_kimg=10, resolution=res,
+                                                         mbstd_group_size=2, patch_params_cond=True),
+                                          learn_camera_dist=False, use_depth=False, blur_real_depth_sigma=0.0))
+        loss = ref_loss.StyleGAN2Loss(full, 'cpu', G, D, augment_pipe=None, r1_gamma=2.0)
+        loss.progressive_update(25)                                  # a quarter into the fade-out: weight 0.525
+        for m in (G, D):
+            m.zero_grad(set_to_none=True)
+        G.requires_grad_(False)
+        D.requires_grad_(True)
+        queue[:] = [pps[0], pps[1]]
+        real_data = TensorGroup(img=T(real), c=c0, depth=torch.zeros(B, 1, 32, 32), camera_angles=cam.angles, embs=T(embs))
+        gen_data = TensorGroup(z=T(inp['z']), c=c0, camera_params=cam, camera_angles_cond=cam.angles)
+        with PatchedRNG(rand_like=[T(u1)], rand=[T(u2)]):
+            loss.accumulate_gradients(phase='Dmain', real_data=real_data, gen_data=gen_data, gain=1, cur_nimg=0)
+        assert not queue
+        arrays[f'{kind}_kd_weight'] = np.float32(loss.D_kd_weight)
+        for n, p in D.named_parameters():
+            if p.grad is not None:
+                v = npy(p.grad)
+                if v.size > 20000:
+                    arrays[f'{kind}::rows::{n}'], arrays[f'{kind}::cols::{n}'] = v.sum(1), v.sum(0)
+                else:
+                    arrays[f'{kind}::{n}'] = v
+    save('loss_kd', **arrays)
+
+
 class _GoldenDataset:
     """Stand-in for the reference's ImageFolder dataset in iterate_random_conditioning: labels and camera angles are pure
     functions of the item index."""
@@ -1300,6 +1371,7 @@ def main():
     gen_synthesis_grad()
     gen_discriminator()
     gen_loss()
+    gen_loss_kd()
     gen_train_forward()
     gen_bias_act()
     gen_bias_act_grad()
