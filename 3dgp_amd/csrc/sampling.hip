@@ -136,7 +136,7 @@ __device__ float torch_order_sum_lds(const float* w1, int n, float eps) {
         float fin = 0.f;
         for (int k = nv * 8; k < n; k++) fin = __fadd_rn(fin, __fadd_rn(w1[k], eps));
 #pragma unroll
-        for (int c = 0; c < 8; c++) fin = __fadd_rn(fin, __shfl(p, c, 64));
+        for (int c = 0; c < 8; c++) fin = __fadd_rn(fin, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), c)));      // lanes 0..7: scalar reads, no LDS permute
         return fin;
     }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
