@@ -188,6 +188,8 @@ def main():
     ap.add_argument('--graph', action='store_true', help='headline = replays of the forward captured as one HIP graph (3dgp_amd/graphs.py) instead of eager launches '
                                                           '(one host call per kernel).  The other mode is timed and reported next to it either way; measured r03: the two '
                                                           'agree to 0.3 % at B = 16 and B = 4 -- the forward is not launch-bound')
+    ap.add_argument('--fid-lanes', type=int, default=1, help='--fid-loop: run the 16 sub-batch forwards of a 64-image block as this many concurrent graph replays (one '
+                    'captured graph and one stream per lane); 1 = one after the other, the order the reference issues them in')
     ap.add_argument('--fid-loop', action='store_true', help="also time the reference's FID generation loop shape (metric_utils.py:288-319): 64 images per rank as 16 "
                                                              'sub-batches of 4 with device-side draws, one feature block (and, N > 1, one RCCL all-gather) per 64')
     ap.add_argument('--arith', default='f32', choices=['f32', 'direct', 'split'],
@@ -370,17 +372,33 @@ def main():
         # batch_gen = 4 with noise_mode='random' and the renderer's own draws, concatenated, passed through the detector (stand-in: a fixed
         # pooling to [64, 2048], the Inception pickle is a URL download) and appended -- one all-gather of the [64, 2048] block per 64 images.
         gen, per = 4, 64
-        gg = tdgp.graphs.GraphedGenerator(G, gen, noise_mode='random', explicit_draws=False) if not args.no_graph else None
+        lanes = max(1, args.fid_lanes) if not args.no_graph else 1
+        ggs = [tdgp.graphs.GraphedGenerator(G, gen, noise_mode='random', explicit_draws=False) for _ in range(lanes)] if not args.no_graph else []
+        gg = ggs[0] if ggs else None
+        lane_streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)] if lanes > 1 else []
         zs = [inputs(gen) for _ in range(2)]
 
         def fid_step():
             imgs = []
-            for i in range(per // gen):
-                xi = zs[i & 1]
-                if gg is not None:
-                    imgs.append(gg(xi['z'], xi['c'], xi['cam']).clone())
-                else:
-                    imgs.append(G(xi['z'], xi['c'], xi['cam'], noise_mode='random'))
+            if lanes > 1:
+                # the block's 16 forwards are independent: `lanes` of them are in flight at a time, each a replay of its lane's own graph on its
+                # lane's stream -- the low-resolution layers of a 4-image forward fill a fraction of the chip, the lanes fill the rest
+                main = torch.cuda.current_stream(dev)
+                for st in lane_streams:
+                    st.wait_stream(main)
+                for i in range(per // gen):
+                    xi = zs[i & 1]
+                    with torch.cuda.stream(lane_streams[i % lanes]):
+                        imgs.append(ggs[i % lanes](xi['z'], xi['c'], xi['cam']).clone())
+                for st in lane_streams:
+                    main.wait_stream(st)
+            else:
+                for i in range(per // gen):
+                    xi = zs[i & 1]
+                    if gg is not None:
+                        imgs.append(gg(xi['z'], xi['c'], xi['cam']).clone())
+                    else:
+                        imgs.append(G(xi['z'], xi['c'], xi['cam'], noise_mode='random'))
             feats = D.stand_in_features(torch.cat(imgs))
             if gather is not None:
                 if gather._pending is not None:
@@ -391,7 +409,7 @@ def main():
         ef = timed_steps(fid_step, barrier, nfid, 1, world, dev, finish)
         fid_loop = dict(value=round(per * world * nfid / ef, 3), unit='img/s', images_per_rank_per_step=per, sub_batch=gen, steps=nfid,
                         ms_per_64=round(ef / nfid * 1e3, 3), noise_mode='random', draws='device (inside the graph)' if gg is not None else 'device',
-                        launch='hip graph replay' if gg is not None else 'eager', reference='metric_utils.py:288-319')
+                        launch='hip graph replay' if gg is not None else 'eager', lanes=lanes, reference='metric_utils.py:288-319')
 
     if rank == 0:
         total_imgs = args.batch * world * args.steps
