@@ -2690,6 +2690,16 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 const size_t lds = wino_lds_bytes(Cin);
                 static bool attr_set = false;
                 if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+                if (TDGP_WINO_PERSIST) {
+                    static int cus = 0;
+                    if (cus == 0) {
+                        int dev = 0;
+                        (void)hipGetDevice(&dev);
+                        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+                    }
+                    const int64_t nitems = (int64_t)(W >> 5) * (H >> 3) * B * cdiv(Cout, 64);
+                    TDGP_LAUNCH("conv_wino_kernel", conv3_wino_kernel, dim3((unsigned)min((int64_t)cus, nitems)), dim3(512), lds, s, q);
+                } else
                 TDGP_LAUNCH("conv_wino_kernel", conv3_wino_kernel, dim3((W >> 5) * (H >> 3) * B, cdiv(Cout, 64)), dim3(512), lds, s, q);
             } else if (k == 3) {
                 if (Cout > 64) launch_conv3<3, 2, 2, 2, 2>(c, partial, wl.partial_floats, s);
