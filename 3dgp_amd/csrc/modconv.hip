@@ -1765,8 +1765,14 @@ __device__ __forceinline__ void rgb_output_tile(const EpiParams& e, const float*
         if (SKIP) {
             tp[pass] = skip_taps(h2, w2, oy, ox, e.fir);
             const float* sp = e.skip + (int64_t)plane * h2 * w2 * e.out_feat + f;
+#if TDGP_RGB_ABL & 32                   // timing experiment: the taps from LDS (whatever sits there) -- what an LDS-staged texel tile could cost at best
+            const float4* lt = (const float4*)bias_lds;
+            ta[pass] = lt[(tp[pass].i00 * 3 + cg) & 63]; tb[pass] = lt[(tp[pass].i01 * 3 + cg) & 63];
+            tc[pass] = lt[(tp[pass].i10 * 3 + cg) & 63]; td[pass] = lt[(tp[pass].i11 * 3 + cg) & 63];
+#else
             ta[pass] = *(const float4*)(sp + (int64_t)tp[pass].i00 * e.out_feat); tb[pass] = *(const float4*)(sp + (int64_t)tp[pass].i01 * e.out_feat);
             tc[pass] = *(const float4*)(sp + (int64_t)tp[pass].i10 * e.out_feat); td[pass] = *(const float4*)(sp + (int64_t)tp[pass].i11 * e.out_feat);
+#endif
         }
     }
     float4 v[G];
@@ -1826,7 +1832,7 @@ struct RgbParams {
 #define TDGP_FIR_ADJ 1      // FIR pass of the wide x2 layers: 4 adjacent rows per thread (0: two rows eight apart, the r02 form)
 #endif
 #ifndef TDGP_RGB_ABL
-#define TDGP_RGB_ABL 0     // 16: per-phase cycle counts of one wave, printed (timing experiments only)
+#define TDGP_RGB_ABL 0     // 16: per-phase cycle counts of one wave, printed; 32: skip taps from LDS (timing experiments only)
 #endif
 // RESIDENT: Cin <= 64 -- the whole weight matrix is one LDS stage, loaded once per block, and the block walks `tpb` consecutive
 // tiles with the activations of tile t+1 in flight while tile t is multiplied and stored.
