@@ -20,6 +20,7 @@ _PROTOTYPES = {
     'tdgp_last_error': (c_char_p, []),
     'tdgp_profile_enable': (c_int, [c_int]),
     'tdgp_profile_report': (c_int64, [c_char_p, c_int64]),
+    'tdgp_device_fault': (c_int, [c_int]),
     'tdgp_bias_act': (c_int, [P, P, P, c_int64, c_int, c_int64, c_int, c_float, c_float, c_float, c_int, P]),
     'tdgp_bias_act_grad': (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int64, c_int, c_int, c_float, c_float, c_float, c_int, P]),
     'tdgp_upfirdn2d': (c_int, [P, P, P, c_int, c_int, c_int, c_int, POINTER(c_int64), c_int, c_int, POINTER(c_int64),
@@ -145,6 +146,11 @@ def profile_report():
         name, n, tot, mn, mx = line.split()
         out[name] = dict(launches=int(n), total_ms=float(tot), avg_ms=float(tot) / max(int(n), 1), min_ms=float(mn), max_ms=float(mx))
     return out
+
+
+def device_fault(clear=False):
+    """The library's device-fault word (include/tdgp.h: a bounded in-kernel wait that ran out); read it after synchronising."""
+    return int(load().tdgp_device_fault(int(bool(clear))))
 
 
 def set_conv_arith(mode):

@@ -34,6 +34,22 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def verify_field_isa(asm_path):
+    """Run isa_check over the assembly of field.hip; raises (and removes the listing, so the next build checks again) on a violation."""
+    sys.path.insert(0, HERE)
+    try:
+        import isa_check
+    finally:
+        sys.path.pop(0)
+    res = isa_check.check_walk2_asm(open(asm_path).read())
+    bad = [(k, why, ins) for k, (_, v) in res.items() for why, ins in v]
+    if not res or bad:
+        os.remove(asm_path)
+        raise RuntimeError('ISA check of triplane_walk2_kernel failed (3dgp_amd/isa_check.py): ' +
+                           ('no walk2 instantiation found in the listing' if not res else '; '.join(f'{k}: {why} | {ins}' for k, why, ins in bad[:8])))
+    return res
+
+
 def build_native(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link libtdgp_hip.so.  Returns the library path."""
     hipcc = _hipcc()
@@ -57,8 +73,23 @@ def build_native(force=False, verbose=False):
             raise RuntimeError(f'hipcc failed for {s}:\n{r.stderr}')
         return o
 
-    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+    # field.hip carries hand-issued loads whose safety is a property of the generated code (isa_check.py): whenever it is recompiled its
+    # assembly is produced next to the object and checked; a violation fails the build.
+    field_src, field_asm = os.path.join(CSRC, 'field.hip'), os.path.join(objdir, 'field.s')
+    check_field = any(s == field_src for s, _ in jobs) or _stale(field_asm, [field_src] + hdrs)
+
+    def asm_one(_):
+        r = subprocess.run([hipcc] + FLAGS + ['-S', '--cuda-device-only', '-o', field_asm, field_src], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc -S failed for {field_src}:\n{r.stderr}')
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs) + 1))) as ex:
+        fut = ex.submit(asm_one, None) if check_field else None
         list(ex.map(compile_one, jobs))
+        if fut is not None:
+            fut.result()
+    if check_field:
+        verify_field_isa(field_asm)
     objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs

@@ -49,6 +49,37 @@ void tdgp_prof_events(const char* name, hipEvent_t* a, hipEvent_t* b);
         }                                                                                             \
     } while (0)
 
+// Per-DEVICE one-time setup: function attributes (the raised dynamic-LDS cap) and the CU count belong to a device, not to the
+// process -- a `static bool` guard left the second GPU driven from one process without its attribute and sized its persistent grids by the
+// first GPU's CU count.  The guard is a bit per device ordinal, set AFTER the statement ran (two racing threads both run it: idempotent).
+#include <atomic>
+#define TDGP_ONCE_PER_DEVICE(...)                                                              \
+    do {                                                                                       \
+        static std::atomic<uint64_t> done_[4];                                                 \
+        int dev_ = 0;                                                                          \
+        (void)hipGetDevice(&dev_);                                                             \
+        const uint64_t bit_ = 1ull << (dev_ & 63);                                             \
+        std::atomic<uint64_t>& w_ = done_[(dev_ >> 6) & 3];                                    \
+        if (!(w_.load(std::memory_order_acquire) & bit_)) {                                    \
+            __VA_ARGS__;                                                                       \
+            w_.fetch_or(bit_, std::memory_order_release);                                      \
+        }                                                                                      \
+    } while (0)
+int tdgp_cu_count();
+// Device-fault word: one int in pinned, device-visible HOST memory per process.  A kernel whose bounded wait ran out (the
+// producer / consumer ring of field_walk2.inc) ORs a bit into it instead of finishing silently with wrong results; every field / per-ray
+// entry point reads it on the host (a plain load, no synchronisation) and fails with TDGP_ELAUNCH until tdgp_device_fault(1) clears it.
+int* tdgp_fault_word();       // host == device address (pinned, mapped); nullptr if the allocation failed
+#define TDGP_FAULT_CHECK(what)                                                                                                        \
+    do {                                                                                                                              \
+        int* fw_ = tdgp_fault_word();                                                                                                 \
+        if (fw_ && __atomic_load_n(fw_, __ATOMIC_RELAXED) != 0) {                                                                     \
+            tdgp_set_error("%s: an earlier launch reported a device fault (code %d: a bounded in-kernel wait ran out; its results are "   \
+                           "invalid) -- tdgp_device_fault(1) reads and clears it", what, *fw_);                                       \
+            return TDGP_ELAUNCH;                                                                                                      \
+        }                                                                                                                             \
+    } while (0)          // compute units of the CURRENT device (cached per device ordinal, thread-safe)
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -1,6 +1,8 @@
 // core.hip -- version / error plumbing of the C ABI.
 #include "common.h"
 #include <string.h>
+#include <atomic>
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -9,6 +11,43 @@ void tdgp_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int tdgp_cu_count() {
+    static std::atomic<int> cache[256];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<int>& c = cache[dev & 255];
+    int v = c.load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+        c.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+int* tdgp_fault_word() {
+    static std::atomic<int*> word{nullptr};
+    static std::mutex mu;
+    int* w = word.load(std::memory_order_acquire);
+    if (w) return w;
+    std::lock_guard<std::mutex> lk(mu);
+    w = word.load(std::memory_order_acquire);
+    if (!w) {
+        void* hp = nullptr;
+        // 64 bytes of pinned, mapped, coherent host memory: the one allocation the library makes (not device memory; never freed)
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || !hp) { (void)hipGetLastError(); return nullptr; }
+        *(volatile int*)hp = 0;
+        w = (int*)hp;
+        word.store(w, std::memory_order_release);
+    }
+    return w;
+}
+
+TDGP_API int tdgp_device_fault(int clear) {
+    int* w = tdgp_fault_word();
+    if (!w) return 0;
+    return clear ? __atomic_exchange_n(w, 0, __ATOMIC_RELAXED) : __atomic_load_n(w, __ATOMIC_RELAXED);
 }
 
 TDGP_API int tdgp_version(void) { return 100; }

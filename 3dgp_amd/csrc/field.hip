@@ -62,6 +62,7 @@ struct FieldParams {
     int ray_h, ray_w;      // > 0: rays form a [B, ray_h, ray_w] image -> waves walk 4x4-pixel tiles (cache locality); 0: linear point order
     int64_t R;             // rays per sample
     uint32_t planes_bytes; // B*3*H*W*F*4 when it fits a buffer descriptor (< 4 GiB), else 0
+    int* fault;            // the library's device-fault word (pinned host memory) or null
 };
 
 template <int N>
@@ -625,13 +626,8 @@ void launch_field_t(const FieldParams& p, hipStream_t s) {
         // producer / consumer walk (field_walk2.inc): whole groups of four samples, a ring that is shorter than a patch's march
         if (walk && (p.S & 3) == 0 && p.S >= 16) {
             using L = Walk2Lds<FQ, MT>;
-            static int cus = 0;
-            if (cus == 0) {
-                int dev = 0;
-                (void)hipGetDevice(&dev);
-                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-                (void)hipFuncSetAttribute((const void*)triplane_walk2_kernel<FQ, MT, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
-            }
+            const int cus = tdgp_cu_count();
+            TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)triplane_walk2_kernel<FQ, MT, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, L::total));
             const int ps = ((p.S & 15) == 0 && TDGP_WALK2_DEPTHSPLIT) ? 4 : 8;       // patch side (field_walk2.inc: DEPTHSPLIT)
             const int64_t npatch = (p.total / p.P) * cdiv(p.ray_w, ps) * cdiv(p.ray_h, ps);
             int blocks = (int)min((int64_t)cus, npatch);                // one 512-thread block per CU, each striding over the patches
@@ -646,19 +642,18 @@ void launch_field_t(const FieldParams& p, hipStream_t s) {
     // Persistent grid = exactly the blocks the chip holds at once (LDS-limited: 3 per CU at F = 32, hid = 64), each striding over the
     // work.  r01 launched 8 per CU: 2048 blocks over 768 slots ran as 2.67 rounds in the time of 3 (11 % of the kernel idle in the
     // last round); with 768 blocks every block gets within one patch of the same number of patches.
-    static int resident[2] = {0, 0};
-    if (resident[walk] == 0) {
-        int per_cu = 0, dev = 0, cus = 0;
+    static std::atomic<int> resident_pc[2];                  // blocks per CU the occupancy query allows (a property of the kernel, not of the device ordinal)
+    int per_cu = resident_pc[walk].load(std::memory_order_relaxed);
+    if (per_cu == 0) {
         hipError_t e;
         if constexpr (FQ % 4 == 0) e = walk ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, triplane_walk_kernel<FQ, MT, TAPS>, 256, 0)
                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, triplane_field_kernel<FQ, MT, TAPS>, 256, 0);
         else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, triplane_field_kernel<FQ, MT, TAPS>, 256, 0);
         if (e != hipSuccess || per_cu < 1) per_cu = 2;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        resident[walk] = per_cu * cus;
+        resident_pc[walk].store(per_cu, std::memory_order_relaxed);
     }
-    int blocks = (int)min((int64_t)resident[walk], want);
+    const int resident_blocks = per_cu * tdgp_cu_count();
+    int blocks = (int)min((int64_t)resident_blocks, want);
     if (blocks > 8) blocks -= blocks % 8;                    // whole rounds of the 8 XCDs (the in-kernel XCD remap needs it)
     if constexpr (FQ % 4 == 0) {
         if (walk) { TDGP_LAUNCH("triplane_field_kernel", (triplane_walk_kernel<FQ, MT, TAPS>), dim3(blocks), dim3(threads), 0, s, p); return; }
@@ -697,6 +692,7 @@ TDGP_API int tdgp_triplane_field(const float* planes_hwc, const float* coords, c
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "triplane_field: unknown ray marcher %d", marcher);
     TDGP_CHECK(coords || (P % S) == 0, TDGP_EINVAL, "triplane_field: P must be a multiple of S in ray mode");
     TDGP_CHECK(!(density_noise > 0.f) || sigma_noise, TDGP_EINVAL, "triplane_field: density_noise > 0 needs the sigma_noise draws");
+    TDGP_FAULT_CHECK("triplane_field");
     if (B == 0 || P == 0) return TDGP_OK;
     FieldParams p;
     p.planes = planes_hwc; p.coords = coords; p.ray_o = ray_o; p.ray_d = ray_d; p.t = t;
@@ -713,6 +709,7 @@ TDGP_API int tdgp_triplane_field(const float* planes_hwc, const float* coords, c
         TDGP_CHECK((p.R % ray_w) == 0, TDGP_EINVAL, "triplane_field: ray_w=%d does not divide the %lld rays", ray_w, (long long)p.R);
         p.ray_w = ray_w; p.ray_h = (int)(p.R / ray_w);
     }
+    p.fault = tdgp_fault_word();
     hipStream_t s = (hipStream_t)stream;
     bool ok = true;
 #define FIELD_CASE(FF, HH) else if (F == FF && hid == HH) launch_field<FF / 4, HH / 16>(p, s);

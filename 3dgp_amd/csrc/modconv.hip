@@ -2402,11 +2402,7 @@ int launch_conv(ConvParams& p, float* partial, int64_t partial_floats, hipStream
     constexpr int HALO = MAXT == 25 ? 2 : 1;
     constexpr int XS_MAX = (BN / 4 + 2 * HALO) * (4 + 2 * HALO) > (BN / 32 + 2 * HALO) * (32 + 2 * HALO) ? (BN / 4 + 2 * HALO) * (4 + 2 * HALO) : (BN / 32 + 2 * HALO) * (32 + 2 * HALO);
     const size_t lds = (size_t)(2 * (MAXT * KCS * BM + KCS * XS_MAX + 64) + 32 + 5 * BM) * sizeof(float);
-    static bool attr_set = false;   // raise the dynamic-LDS cap once per instantiation
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_mfma_kernel<MTW, NTW, WM, WN, KCS, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv_mfma_kernel<MTW, NTW, WM, WN, KCS, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););   // raise the dynamic-LDS cap once per instantiation and device
     const int gx = px_tiles(p, NT), gy = cdiv(p.Cout, BM);
     const int niter = cdiv(cdiv(p.Cin, KC3), KCS / KC3);
     const int64_t slice = (int64_t)p.e.B * p.e.Cout * p.e.Hout * p.e.Wout;
@@ -2466,11 +2462,7 @@ void launch_upconv(const UpParams& u, hipStream_t s) {
     constexpr int BM = 32 * MTW * WM, BN = 32 * NTW * WN, NW = WM * WN;
     constexpr int stage = 2 * (9 * BM * 4 + 2 * (BN + 2) * 4), epi = NW * 32 * UP_CT_W;
     const size_t lds = (size_t)(stage > epi ? stage : epi) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)upconv_mfma_kernel<MTW, NTW, WM, WN, DEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)upconv_mfma_kernel<MTW, NTW, WM, WN, DEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
     dim3 grid(cdiv(u.B * u.GS, BN), cdiv(u.Cout, BM), u.ksplit);
     TDGP_LAUNCH("upconv_mfma_kernel", (upconv_mfma_kernel<MTW, NTW, WM, WN, DEEP>), grid, dim3(64 * NW), lds, s, u);
 }
@@ -2483,11 +2475,7 @@ template <int MT, bool RESIDENT, bool FAST, bool XBF>
 void launch_torgb_v(const RgbParams& r, hipStream_t s) {
     constexpr int BM = 32 * MT;
     const size_t lds = (size_t)(16 * BM * 4 + 16 * 128 * 4 + BM) * sizeof(float) + TDGP_RGB_LDS_PAD;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)torgb_mfma_kernel<MT, RESIDENT, FAST, XBF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)torgb_mfma_kernel<MT, RESIDENT, FAST, XBF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
     // RESIDENT: several consecutive tiles per block once there are more tiles than ~4 rounds of the 512 resident blocks
     RgbParams rr = r;
     const int64_t ntiles = cdiv64(r.P, 128);
@@ -2512,11 +2500,7 @@ int launch_conv3(Conv3Params& p, float* partial, int64_t partial_floats, hipStre
     constexpr int BM = 32 * MTW * WM, NT = NTW * WN, R = KS / 2;
     constexpr int stage = 2 * (KS * KS * BM * 4 + (NT + 2 * R) * (32 + 2 * R) * 4) + 5 * BM, epi = 4 * 32 * CT_LD;
     const size_t lds = (size_t)(stage > epi ? stage : epi) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<KS, MTW, NTW, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3_mfma_kernel<KS, MTW, NTW, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
     const int gx = (p.W >> 5) * cdiv(p.B * (p.H + R), NT), gy = cdiv(p.Cout, BM);
     const int niter = cdiv(p.Cin, 4);
     const int64_t slice = (int64_t)p.B * p.Cout * p.H * p.W;
@@ -2684,8 +2668,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W;
                 q.x_bytes = c.x_bytes; q.wsp_bytes = (uint32_t)(pi.wsplit_floats * 4); q.st_bytes = c.st_bytes;
                 const size_t lds = (size_t)(2 * 3 * 3 * 64 * 32 + 3 * 10 * 34 * 32 + 5 * 64 * 4 + 2 * Cin * 4);
-                static bool attr_set = false;
-                if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds - 2 * Cin * 4 + 2 * 2048 * 4)); attr_set = true; }
+                TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds - 2 * Cin * 4 + 2 * 2048 * 4)););
                 TDGP_LAUNCH("conv_mfma_kernel", conv3s_mfma_kernel, dim3((W >> 5) * cdiv(B * (H + 1), 8), cdiv(Cout, 64)), dim3(256), lds, s, q);
             } else if (k == 3 && g_conv_arith == 0 && wino_ok(B, Cin, Cout, H, W) && out_layout == 0 && !skip && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 &&
                        (!noise || (((uintptr_t)noise & 7) == 0 && (noise_bstride & 1) == 0))) {        // 16-byte activation loads, 8-byte noise loads / stores
@@ -2694,15 +2677,9 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W;
                 q.x_bytes = c.x_bytes; q.u_bytes = (uint32_t)(pi.wino_floats * 4);
                 const size_t lds = wino_lds_bytes(Cin);
-                static bool attr_set = false;
-                if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+                TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024););
                 if (TDGP_WINO_PERSIST) {
-                    static int cus = 0;
-                    if (cus == 0) {
-                        int dev = 0;
-                        (void)hipGetDevice(&dev);
-                        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-                    }
+                    const int cus = tdgp_cu_count();
                     const int64_t nitems = (int64_t)(W >> 5) * (H >> 3) * B * cdiv(Cout, 64);
                     TDGP_LAUNCH("conv_wino_kernel", conv3_wino_kernel, dim3((unsigned)min((int64_t)cus, nitems)), dim3(512), lds, s, q);
                 } else
@@ -2754,8 +2731,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
             q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W; q.G1 = pl.G1; q.GS = pl.GS; q.zslice = pl.zslice;
             q.x_bytes = u.x_bytes; q.wsp_bytes = (uint32_t)(pi.wsplit_floats * 4);
             const size_t lds = (size_t)(2 * 3 * 3 * 64 * 32 + 3 * 2 * 130 * 32 + (2 * 8 * 256 + 8 * 64) * 4 + 2 * 64 * 4);
-            static bool attr_set = false;
-            if (!attr_set) { (void)hipFuncSetAttribute((const void*)upconv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+            TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)upconv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
             TDGP_LAUNCH("upconv_mfma_kernel", upconv3s_mfma_kernel, dim3(cdiv(B * pl.GS, 128), cdiv(Cout, 64)), dim3(256), lds, s, q);
         }
         // (Round 3, measured and not kept: 8-wave blocks -- 128 x 128 for Cout > 64, 64 x 256 below -- so that one staged weight chunk serves twice the
@@ -2856,8 +2832,7 @@ TDGP_API int tdgp_modconv2d_bf16(const void* x, const void* wpack, const float* 
         q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W;
         q.x_bytes = x_bytes; q.wb_bytes = (uint32_t)(pi.wbf_floats * 4);
         const size_t lds = (size_t)(9 * 2 * 64 * 32 + 2 * 10 * 34 * 32 + 5 * 64 * 4 + 2 * Cin * 4);
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds - 2 * Cin * 4 + 2 * 2048 * 4)); attr_set = true; }
+        TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds - 2 * Cin * 4 + 2 * 2048 * 4)););
         TDGP_LAUNCH("conv_bf16_kernel", conv3_bf16_kernel<true>, dim3((W >> 5) * cdiv(B * (H + 1), 8), cdiv(Cout, 64)), dim3(256), lds, s, q);
     } else {
         const UpPlan pl = up_plan(B, Cin, Cout, H, W);
@@ -2866,8 +2841,7 @@ TDGP_API int tdgp_modconv2d_bf16(const void* x, const void* wpack, const float* 
         q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W; q.G1 = pl.G1; q.GS = pl.GS; q.zslice = pl.zslice;
         q.x_bytes = x_bytes; q.wb_bytes = (uint32_t)(pi.wbf_floats * 4); q.st_bytes = (uint32_t)((int64_t)B * Cin * 4);
         const size_t lds = u3_lds;                                              // checked against the 80 KiB budget above
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)upconv_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_set = true; }
+        TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)upconv_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024););
         TDGP_LAUNCH("upconv_bf16_kernel", upconv_bf16_kernel, dim3(cdiv(B * pl.GS, 128), cdiv(Cout, 64)), dim3(256), lds, s, q);
         FirParams f;
         f.z = z; f.dcoef = dco; f.noise = noise; f.noise_bstride = noise_bstride; f.bias = bias; f.y = nullptr; f.y16 = (uint16_t*)y;

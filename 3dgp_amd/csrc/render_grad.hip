@@ -506,12 +506,10 @@ TDGP_API int tdgp_triplane_field_grad(const float* planes_hwc, const float* coor
     const size_t lds = (size_t)(HP * FG_PITCH + 4 * HP + HP + NW * wave_floats) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     if (MT == 1) {
-        static bool a1 = false;
-        if (!a1) { (void)hipFuncSetAttribute((const void*)triplane_field_grad_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; }
+        TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)triplane_field_grad_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
         TDGP_LAUNCH("triplane_field_grad_kernel", (triplane_field_grad_kernel<1, 4>), dim3(nb), dim3(256), lds, s, p);
     } else {
-        static bool a2 = false;
-        if (!a2) { (void)hipFuncSetAttribute((const void*)triplane_field_grad_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a2 = true; }
+        TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)triplane_field_grad_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
         TDGP_LAUNCH("triplane_field_grad_kernel", (triplane_field_grad_kernel<2, 2>), dim3(nb), dim3(128), lds, s, p);
     }
     TDGP_LAUNCH("field_grad_reduce_kernel", field_grad_reduce_kernel, dim3(cdiv(p.npart, 256)), dim3(256), 0, s, (const float*)workspace, nb, p.npart, hid * F,

@@ -701,6 +701,7 @@ TDGP_API int tdgp_ray_march(const float* colors, const float* densities, const f
     TDGP_CHECK(S >= 2 && S <= MAXS, TDGP_EUNSUPPORTED, "ray_march: S=%d outside [2,%d]", S, MAXS);
     TDGP_CHECK(C >= 1 && C <= 8, TDGP_EUNSUPPORTED, "ray_march: C=%d outside [1,8]", C);
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "ray_march: unknown ray marcher %d", marcher);
+    TDGP_FAULT_CHECK("ray_march");
     if (rays == 0) return TDGP_OK;
     TDGP_LAUNCH("ray_march_kernel", ray_march_kernel, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, colors, densities, depths, rgb, depth, weights,
                        final_T, rays, S, C, marcher, flags, density_bias, cut_threshold);
@@ -736,6 +737,7 @@ TDGP_API int tdgp_importance_from_coarse(const float* rgbs_coarse, const float* 
     TDGP_CHECK(rgbs_coarse && sdist && u_fine && tdist_fine, TDGP_EINVAL, "importance_from_coarse: null pointer");
     TDGP_CHECK(S >= 4 && S <= MAXS && N >= 1 && N <= MAXS, TDGP_EUNSUPPORTED, "importance_from_coarse: bad S=%d N=%d (both at most %d)", S, N, MAXS);
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "importance_from_coarse: unknown ray marcher %d", marcher);
+    TDGP_FAULT_CHECK("importance_from_coarse");
     if (rays == 0) return TDGP_OK;
     if (S <= 128 && N <= 128)
         TDGP_LAUNCH("importance_from_coarse_kernel", importance_from_coarse_kernel<128>, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, sdist,
@@ -753,6 +755,7 @@ TDGP_API int tdgp_merge_composite(const float* rgbs_coarse, const float* t_coars
     TDGP_CHECK(rgbs_coarse && t_coarse && rgbs_fine && t_fine && rgb && depth, TDGP_EINVAL, "merge_composite: null pointer");
     TDGP_CHECK(S1 >= 1 && S2 >= 1 && S1 + S2 <= MAXS, TDGP_EUNSUPPORTED, "merge_composite: S1+S2=%d > %d", S1 + S2, MAXS);
     TDGP_CHECK(marcher == 0 || marcher == 1, TDGP_EINVAL, "merge_composite: unknown ray marcher %d", marcher);
+    TDGP_FAULT_CHECK("merge_composite");
     if (rays == 0) return TDGP_OK;
     if (S1 + S2 <= 128)
         TDGP_LAUNCH("merge_composite_kernel", merge_composite_kernel<128>, dim3(ray_blocks(rays)), dim3(256), 0, (hipStream_t)stream, rgbs_coarse, t_coarse, S1,

@@ -297,6 +297,19 @@ class SynthesisBlock(torch.nn.Module):
         return x, img
 
 
+_SIDE_STREAMS = {}           # (device type, index) -> torch.cuda.Stream; process-wide, never part of a module's state
+
+
+def side_stream_of(device):
+    """One side stream per GPU for work that overlaps the main stream (ToRGB beside the next block's x2 layer)."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(idx)
+    if st is None:
+        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=torch.device('cuda', idx))
+    return st
+
+
 class SynthesisBlocksSequence(torch.nn.Module):
     """networks_epigraf.py:73-129: 4x4 const -> ... -> tri_plane.res; returns the (3*feat)-channel plane image."""
 
@@ -421,11 +434,12 @@ class SynthesisBlocksSequence(torch.nn.Module):
     overlap_torgb = True         # ToRGB layers on a second stream beside the next block's x2 layer (measured r03: B = 16 +0.5 %, B = 4 +2.8 %; same bits)
 
     def _side(self, t):
+        """The stream the ToRGB layers run on, per DEVICE and outside the module: a `torch.cuda.Stream` in `__dict__` would make the
+        generator un-picklable / un-deep-copyable after its first forward (training_loop.py:459 and metric_utils.py:293,328 deep-copy G)
+        and would pin the overlap to the first device the module ran on."""
         if not self.overlap_torgb:
             return None
-        if getattr(self, '_side_stream', None) is None:
-            self._side_stream = torch.cuda.Stream(device=t.device)
-        return self._side_stream
+        return side_stream_of(t.device)
 
     def _index_blocks(self):
         idx, w_idx, s_idx, d_idx = {}, 0, 0, 0

@@ -62,6 +62,17 @@ class CameraRegConfig:
     force_mean_num_samples: int = 256      # loss.py:228
     mean_angles: object = None             # [yaw, pitch, roll] the force-mean term pulls to; None = analytic mean of `prior`
 
+    @classmethod
+    def disabled(cls):
+        """'No regularisers' said out loud: the adversarial loss alone reaches the camera adaptor.  The reference has no such mode by
+        default (3dgp.yaml: emd.enabled, force_mean_weight 10) -- `StyleGAN2Loss(learn_camera_dist=True)` therefore refuses
+        `camera_reg=None` and takes this instead when a caller really wants it."""
+        return cls(prior=None, lipschitz_enabled=False, emd_enabled=False, force_mean_weight=0.0)
+
+    @property
+    def any_enabled(self):
+        return bool(self.lipschitz_enabled or self.emd_enabled or self.force_mean_weight > 0)
+
 
 # ----------------------------------------------------------------------------------------------------------------------
 # camera-adaptor regularisers, loss.py:142-238
@@ -204,9 +215,14 @@ class StyleGAN2Loss:
         self.patch_cfg = patch_cfg if patch_cfg is not None else PatchConfig(enabled=False)
         self.synthesis_kwargs = dict(synthesis_kwargs or {})          # e.g. explicit renderer draws for the parity tests
         self.kd_weight, self.kd_anneal_kimg, self.kd_loss_type = kd_weight, kd_anneal_kimg, kd_loss_type       # configs/model/base.yaml:82 (3dgp.yaml:91: weight 1)
-        # the regularisers need a prior to draw from; without one (camera_reg=None) only the adversarial loss reaches the adaptor
+        # The reference ALWAYS adds the EMD and force-mean terms when the camera distribution is learned (loss.py:186-238 under the 3dgp.yaml
+        # defaults): silently training the adaptor through the adversarial loss alone would be a different model, so the
+        # regularisers are required -- or switched off explicitly with CameraRegConfig.disabled().
+        if learn_camera_dist and camera_reg is None:
+            raise RuntimeError('learn_camera_dist=True needs camera_reg: CameraRegConfig(prior=<camera config node>) for the reference\'s regularisers '
+                               '(loss.py:142-238), or CameraRegConfig.disabled() to train the adaptor through the adversarial loss alone')
         self.camera_reg = camera_reg if learn_camera_dist else None
-        if self.camera_reg is not None and self.camera_reg.prior is None:
+        if self.camera_reg is not None and self.camera_reg.any_enabled and self.camera_reg.prior is None:
             raise RuntimeError('camera_reg needs the camera prior (CameraRegConfig.prior)')
         self.stats = {}
         self.progressive_update(0)

@@ -10,7 +10,8 @@
  *   - fp32 unless a `dtype` argument says otherwise (TDGP_F32 / TDGP_F16 / TDGP_BF16);
  *   - re-entrant.  Process-wide state is limited to: the init-once kernel tables, the two switches tdgp_set_conv_arith (algorithm of
  *     the large 3x3 layers; default 0 = fp32 MFMA) and tdgp_profile_enable (per-kernel event timing; default off), and the launch
- *     geometry cached per kernel instantiation (resident blocks per CU).  Nothing else is remembered between calls.
+ *     geometry cached per kernel instantiation and device (resident blocks per CU, CU count, raised LDS caps), and the device-fault
+ *     word (tdgp_device_fault).  Nothing else is remembered between calls.
  *
  * Each entry point cites the reference interface it replaces (file:line under the reference tree).
  * The reference binds its two native ops through pybind (bias_act.cpp:94, upfirdn2d.cpp:102); the
@@ -47,6 +48,15 @@ const char* tdgp_last_error(void);
  * lines into a HOST buffer, returning the bytes needed.  tdgp_profile_enable(0/1) also clears previous records. */
 int     tdgp_profile_enable(int on);
 int64_t tdgp_profile_report(char* buf, int64_t cap);
+
+/* Device-fault word.  The producer / consumer field kernel bounds its in-kernel waits (a protocol bug or a multi-millisecond stall under
+ * a debugger / thread-trace profiler must never hang the GPU); a wait that runs out ORs a code into one int of pinned HOST memory (the
+ * single allocation this library makes: 64 bytes, hipHostMalloc, on first use) instead of completing silently with wrong numbers.
+ * tdgp_device_fault(0) returns the word, tdgp_device_fault(1) returns and clears it -- meaningful after the stream has been synchronised
+ * by the caller.  While it is non-zero tdgp_triplane_field / tdgp_importance_from_coarse / tdgp_merge_composite / tdgp_ray_march return
+ * TDGP_ELAUNCH (checked on the host at entry, no synchronisation).  No reference counterpart (its ops cannot time out).
+ * codes: 1 = field ring, producer side; 2 = field ring, consumer side. */
+int     tdgp_device_fault(int clear);
 
 /* ---------------------------------------------------------------------------------------------
  * bias_act forward:  y = clamp(gain * act(x + b[(i / stepB) % sizeB]))

@@ -105,3 +105,35 @@ def test_state_dict_layout_matches_reference_names(tdgp):
     keys = set(G.state_dict())
     assert 'synthesis.tri_plane_decoder.b4.const' in keys and 'synthesis.tri_plane_decoder.b8.conv0.affine.weight' in keys
     assert 'synthesis.tri_plane_mlp.model.1.bias' in keys and 'mapping.w_avg' in keys and 'mapping.embed.weight' in keys
+
+
+def test_walk2_isa_check_runs_in_the_build(tdgp):
+    """the hand-issued tap loads of triplane_walk2_kernel rely on a property of the GENERATED code (3dgp_amd/isa_check.py).  The
+    build runs the check whenever field.hip is recompiled and keeps the listing it checked; here the same check is re-run on that listing
+    (produced now if a pre-built tree was copied without it), every instantiation must be present and clean."""
+    import importlib
+    build = importlib.import_module('3dgp_amd.build')
+    asm = os.path.join(build.CSRC, 'build', 'field.s')
+    if not os.path.exists(asm):
+        subprocess.check_call([build._hipcc()] + build.FLAGS + ['-S', '--cuda-device-only', '-o', asm, os.path.join(build.CSRC, 'field.hip')], stderr=subprocess.DEVNULL)
+    res = build.verify_field_isa(asm)
+    assert len(res) >= 2 and all(not bad for _, bad in res.values())
+    main = [k for k in res if 'ILi8ELi4ELb0E' in k]            # the C3 instantiation: feat 32, hid 64, no tap output
+    assert main and res[main[0]][0]['tap_loads'] == 48 and res[main[0]][0]['compiler_vmcnt_waits'] == []
+    # and the checker does catch a violation: an instruction reading a tap register right after its load
+    isa = importlib.import_module('3dgp_amd.isa_check')
+    lines = open(asm).read().splitlines()
+    i0 = next(i for i, ln in enumerate(lines) if re.match(r'^_ZN\S*triplane_walk2_kernelILi8ELi4ELb0E\S*:', ln))
+    i1 = next(j for j in range(i0, len(lines)) if lines[j].strip().startswith('.amdhsa_kernel'))
+    body = lines[i0:i1]
+    heads = [i for i, ln in enumerate(body) if 'Loop Header: Depth=1' in ln]
+    k = next(i for i in range(heads[-1], len(body)) if body[i].strip().startswith('buffer_load_dwordx4'))
+    dst = re.search(r'v\[(\d+):\d+\]', body[k]).group(1)
+    body.insert(k + 1, f'\tv_add_f32_e32 v0, v{dst}, v{dst}')
+    _, bad = isa.check_kernel(body, 8)
+    assert bad and 'touches the destination' in bad[0][0]
+
+
+def test_device_fault_word_is_exported_and_quiet(tdgp):
+    """include/tdgp.h tdgp_device_fault: readable without a GPU (no fault word can be allocated -> 0), never raises."""
+    assert tdgp._lib.device_fault() == 0 and tdgp._lib.device_fault(clear=True) == 0

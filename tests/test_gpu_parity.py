@@ -1852,7 +1852,7 @@ def test_loss_trains_the_camera_adaptor(tdgp):
     real = tdgp.generator.TensorGroup(img=torch.randn(B, 3, cfg.img_resolution, cfg.img_resolution, device=DEV), c=c0,
                                       depth=torch.zeros(B, 1, cfg.img_resolution, cfg.img_resolution, device=DEV))
     for flag in (True, False):
-        loss = TR.StyleGAN2Loss(G, D, DEV, r1_gamma=0.0, use_depth=use_depth, learn_camera_dist=flag,
+        loss = TR.StyleGAN2Loss(G, D, DEV, r1_gamma=0.0, use_depth=use_depth, learn_camera_dist=flag, camera_reg=TR.CameraRegConfig.disabled() if flag else None,
                                 synthesis_kwargs=dict(u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine'])))
         G.zero_grad(set_to_none=True)
         G.requires_grad_(True)

@@ -149,3 +149,13 @@ def test_emd_regs_and_schedule(tdgp):
     assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in A.parameters())
     with pytest.raises(RuntimeError):
         TR.StyleGAN2Loss(_G(), None, 'cpu', learn_camera_dist=True, camera_reg=TR.CameraRegConfig(prior=None))
+
+
+def test_learn_camera_dist_requires_an_explicit_regulariser_choice():
+    """the reference always regularises a learned camera distribution (loss.py:186-238 under 3dgp.yaml); `camera_reg=None` would
+    silently train the adaptor through the adversarial loss alone -> refused; the explicit 'none' is CameraRegConfig.disabled()."""
+    with pytest.raises(RuntimeError, match='camera_reg'):
+        TR.StyleGAN2Loss(_G(), None, 'cpu', learn_camera_dist=True)
+    loss = TR.StyleGAN2Loss(_G(), None, 'cpu', learn_camera_dist=True, camera_reg=TR.CameraRegConfig.disabled())
+    assert loss.camera_regularisers() == 0.0
+    assert TR.StyleGAN2Loss(_G(), None, 'cpu', learn_camera_dist=False).camera_reg is None
