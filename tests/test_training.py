@@ -151,9 +151,16 @@ def test_emd_regs_and_schedule(tdgp):
         TR.StyleGAN2Loss(_G(), None, 'cpu', learn_camera_dist=True, camera_reg=TR.CameraRegConfig(prior=None))
 
 
-def test_learn_camera_dist_requires_an_explicit_regulariser_choice():
+def test_learn_camera_dist_requires_an_explicit_regulariser_choice(tdgp):
     """the reference always regularises a learned camera distribution (loss.py:186-238 under 3dgp.yaml); `camera_reg=None` would
     silently train the adaptor through the adversarial loss alone -> refused; the explicit 'none' is CameraRegConfig.disabled()."""
+    TR = tdgp.training
+    _, cfg, A = _adaptor(tdgp, 0, 'cpu')
+
+    class _G:
+        z_dim, c_dim = cfg.z_dim, cfg.c_dim
+        synthesis = type('S', (), dict(camera_adaptor=A))()
+
     with pytest.raises(RuntimeError, match='camera_reg'):
         TR.StyleGAN2Loss(_G(), None, 'cpu', learn_camera_dist=True)
     loss = TR.StyleGAN2Loss(_G(), None, 'cpu', learn_camera_dist=True, camera_reg=TR.CameraRegConfig.disabled())
