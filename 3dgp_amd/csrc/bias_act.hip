@@ -12,37 +12,53 @@
 
 namespace {
 
-template <int ACT>
-__device__ __forceinline__ float act_fn(float x, float alpha) {
+// The compute type S is float for fp32 / fp16 / bf16 tensors and double for fp64 ones (bias_act.cpp:77 dispatches
+// AT_DISPATCH_FLOATING_TYPES_AND_HALF; bias_act.cu:17-19: scalar_t = double for double tensors).  The overload set below picks the
+// matching OCML routine; the float instantiations are the ones the generator path uses.
+__device__ __forceinline__ float m_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ double m_tanh(double x) { return tanh(x); }
+__device__ __forceinline__ float m_exp(float x) { return expf(x); }
+__device__ __forceinline__ double m_exp(double x) { return exp(x); }
+__device__ __forceinline__ float m_expm1(float x) { return expm1f(x); }
+__device__ __forceinline__ double m_expm1(double x) { return expm1(x); }
+__device__ __forceinline__ float m_log1p(float x) { return log1pf(x); }
+__device__ __forceinline__ double m_log1p(double x) { return log1p(x); }
+
+template <int ACT, typename S>
+__device__ __forceinline__ S act_fn(S x, S alpha) {
     if (ACT == 1) return x;
-    if (ACT == 2) return x > 0.f ? x : 0.f;
-    if (ACT == 3) return x > 0.f ? x : x * alpha;
-    if (ACT == 4) return tanhf(x);
-    if (ACT == 5) return 1.0f / (1.0f + expf(-x));
-    if (ACT == 6) return x > 0.f ? x : expm1f(x);
+    if (ACT == 2) return x > S(0) ? x : S(0);
+    if (ACT == 3) return x > S(0) ? x : x * alpha;
+    if (ACT == 4) return m_tanh(x);
+    if (ACT == 5) return S(1) / (S(1) + m_exp(-x));
+    if (ACT == 6) return x > S(0) ? x : m_expm1(x);
     if (ACT == 7) {
-        const float scale = 1.0507009873554804934193349852946f;
-        const float al = 1.6732632423543772848170429916717f;
-        return x > 0.f ? scale * x : (scale * al) * expm1f(x);
+        const S scale = (S)1.0507009873554804934193349852946;
+        const S al = (S)1.6732632423543772848170429916717;
+        return x > S(0) ? scale * x : (scale * al) * m_expm1(x);
     }
-    if (ACT == 8) return x > 20.f ? x : log1pf(expf(x));
-    if (ACT == 9) return (1.0f / (1.0f + expf(-x))) * x;
+    if (ACT == 8) return x > S(20) ? x : m_log1p(m_exp(x));
+    if (ACT == 9) return (S(1) / (S(1) + m_exp(-x))) * x;
     return x;
 }
 
-template <int ACT>
-__device__ __forceinline__ float finish(float v, float alpha, float gain, float clamp) {
-    v = act_fn<ACT>(v, alpha);
+template <int ACT, typename S>
+__device__ __forceinline__ S finish(S v, S alpha, S gain, S clamp) {
+    v = act_fn<ACT, S>(v, alpha);
     v = v * gain;
-    if (clamp >= 0.f) v = v < -clamp ? -clamp : (v > clamp ? clamp : v);   // NaN falls through (torch.clamp)
+    if (clamp >= S(0)) v = v < -clamp ? -clamp : (v > clamp ? clamp : v);   // NaN falls through (torch.clamp)
     return v;
 }
 
-template <typename T> __device__ __forceinline__ float ld(const T* p, int64_t i);
+template <typename T> struct Compute { typedef float type; };
+template <> struct Compute<double> { typedef double type; };
+template <typename T> __device__ __forceinline__ typename Compute<T>::type ld(const T* p, int64_t i);
+template <> __device__ __forceinline__ double ld<double>(const double* p, int64_t i) { return p[i]; }
 template <> __device__ __forceinline__ float ld<float>(const float* p, int64_t i) { return p[i]; }
 template <> __device__ __forceinline__ float ld<__half>(const __half* p, int64_t i) { return __half2float(p[i]); }
 template <> __device__ __forceinline__ float ld<hip_bfloat16>(const hip_bfloat16* p, int64_t i) { return (float)p[i]; }
-template <typename T> __device__ __forceinline__ void st(T* p, int64_t i, float v);
+template <typename T> __device__ __forceinline__ void st(T* p, int64_t i, typename Compute<T>::type v);
+template <> __device__ __forceinline__ void st<double>(double* p, int64_t i, double v) { p[i] = v; }
 template <> __device__ __forceinline__ void st<float>(float* p, int64_t i, float v) { p[i] = v; }
 template <> __device__ __forceinline__ void st<__half>(__half* p, int64_t i, float v) { p[i] = __float2half(v); }
 template <> __device__ __forceinline__ void st<hip_bfloat16>(hip_bfloat16* p, int64_t i, float v) { p[i] = hip_bfloat16(v); }
@@ -67,10 +83,10 @@ __global__ __launch_bounds__(256) void bias_act_f32x4(const float4* __restrict__
             }
         }
         float4 o;
-        o.x = finish<ACT>(v.x + b0, alpha, gain, clamp);
-        o.y = finish<ACT>(v.y + b1, alpha, gain, clamp);
-        o.z = finish<ACT>(v.z + b2, alpha, gain, clamp);
-        o.w = finish<ACT>(v.w + b3, alpha, gain, clamp);
+        o.x = finish<ACT, float>(v.x + b0, alpha, gain, clamp);
+        o.y = finish<ACT, float>(v.y + b1, alpha, gain, clamp);
+        o.z = finish<ACT, float>(v.z + b2, alpha, gain, clamp);
+        o.w = finish<ACT, float>(v.w + b3, alpha, gain, clamp);
         y[i] = o;
     }
 }
@@ -81,9 +97,10 @@ __global__ __launch_bounds__(256) void bias_act_scalar(const T* __restrict__ x, 
                                                        int64_t start, int64_t n, int sizeB, int64_t stepB,
                                                        float alpha, float gain, float clamp) {
     for (int64_t i = start + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float v = ld<T>(x, i);
+        typedef typename Compute<T>::type S;
+        S v = ld<T>(x, i);
         if (b) v = v + ld<T>(b, (i / stepB) % sizeB);
-        st<T>(y, i, finish<ACT>(v, alpha, gain, clamp));
+        st<T>(y, i, finish<ACT, S>(v, (S)alpha, (S)gain, (S)clamp));
     }
 }
 
@@ -110,6 +127,10 @@ int launch(const void* x, const void* b, void* y, int64_t n, int sizeB, int64_t 
             TDGP_LAUNCH("bias_act_scalar", (bias_act_scalar<ACT, float>), dim3(blocks), dim3(256), 0, s, (const float*)x, (const float*)b,
                                (float*)y, done, n, sizeB, stepB, alpha, gain, clamp);
         }
+    } else if (dtype == TDGP_F64) {
+        const int blocks = (int)min((int64_t)maxBlocks, cdiv64(n, 256));
+        TDGP_LAUNCH("bias_act_scalar", (bias_act_scalar<ACT, double>), dim3(blocks), dim3(256), 0, s, (const double*)x, (const double*)b,
+                           (double*)y, (int64_t)0, n, sizeB, stepB, alpha, gain, clamp);
     } else if (dtype == TDGP_F16) {
         const int blocks = (int)min((int64_t)maxBlocks, cdiv64(n, 256));
         TDGP_LAUNCH("bias_act_scalar", (bias_act_scalar<ACT, __half>), dim3(blocks), dim3(256), 0, s, (const __half*)x, (const __half*)b,
@@ -129,7 +150,7 @@ TDGP_API int tdgp_bias_act(const void* x, const void* b, void* y, int64_t n, int
     // precondition set of bias_act.cpp:35-51
     TDGP_CHECK(x && y, TDGP_EINVAL, "bias_act: x and y must be device pointers");
     TDGP_CHECK(n >= 0 && n <= INT32_MAX, TDGP_EINVAL, "bias_act: x is too large");
-    TDGP_CHECK(dtype >= TDGP_F32 && dtype <= TDGP_BF16, TDGP_EINVAL, "bias_act: unsupported dtype %d", dtype);
+    TDGP_CHECK(dtype >= TDGP_F32 && dtype <= TDGP_F64, TDGP_EINVAL, "bias_act: unsupported dtype %d", dtype);
     TDGP_CHECK(act >= 1 && act <= 9, TDGP_EUNSUPPORTED, "bias_act: no kernel found for the specified activation func (%d)", act);
     TDGP_CHECK(!b || (sizeB >= 1 && stepB >= 1), TDGP_EINVAL, "bias_act: b has wrong number of elements / stride");
     if (n == 0) return TDGP_OK;
@@ -150,40 +171,43 @@ namespace {
 // grad 1:  y = dy_in * gain * act'(xref + b)          (x carries the incoming gradient; the derivative is written in terms of
 // grad 2:  y = d2_in * dy * gain * act''(xref + b)     yy = yref / gain for the activations that save y, of xref for swish)
 // and, with a clamp, zero wherever the forward output yref sat outside (-clamp, clamp).
-template <int ACT>
-__device__ __forceinline__ float act_grad(int G, float x, float xref, float yy, float alpha) {
-    const float seluScale = 1.0507009873554804934193349852946f, seluAlpha = 1.6732632423543772848170429916717f;
-    if (ACT == 1) return G == 1 ? x : 0.f;
-    if (ACT == 2) return G == 1 ? (yy > 0.f ? x : 0.f) : 0.f;
-    if (ACT == 3) return G == 1 ? (yy > 0.f ? x : x * alpha) : 0.f;
-    if (ACT == 4) return G == 1 ? x * (1.f - yy * yy) : x * (1.f - yy * yy) * (-2.f * yy);
-    if (ACT == 5) return G == 1 ? x * yy * (1.f - yy) : x * yy * (1.f - yy) * (1.f - 2.f * yy);
-    if (ACT == 6) return G == 1 ? (yy >= 0.f ? x : x * (yy + 1.f)) : (yy >= 0.f ? 0.f : x * (yy + 1.f));
-    if (ACT == 7) return G == 1 ? (yy >= 0.f ? x * seluScale : x * (yy + seluScale * seluAlpha)) : (yy >= 0.f ? 0.f : x * (yy + seluScale * seluAlpha));
-    if (ACT == 8) { const float c = expf(-yy); return G == 1 ? x * (1.f - c) : x * c * (1.f - c); }
+template <int ACT, typename S>
+__device__ __forceinline__ S act_grad(int G, S x, S xref, S yy, S alpha) {
+    const S seluScale = (S)1.0507009873554804934193349852946, seluAlpha = (S)1.6732632423543772848170429916717;
+    const S one = 1, two = 2, zero = 0;
+    if (ACT == 1) return G == 1 ? x : zero;
+    if (ACT == 2) return G == 1 ? (yy > zero ? x : zero) : zero;
+    if (ACT == 3) return G == 1 ? (yy > zero ? x : x * alpha) : zero;
+    if (ACT == 4) return G == 1 ? x * (one - yy * yy) : x * (one - yy * yy) * (-two * yy);
+    if (ACT == 5) return G == 1 ? x * yy * (one - yy) : x * yy * (one - yy) * (one - two * yy);
+    if (ACT == 6) return G == 1 ? (yy >= zero ? x : x * (yy + one)) : (yy >= zero ? zero : x * (yy + one));
+    if (ACT == 7) return G == 1 ? (yy >= zero ? x * seluScale : x * (yy + seluScale * seluAlpha)) : (yy >= zero ? zero : x * (yy + seluScale * seluAlpha));
+    if (ACT == 8) { const S c = m_exp(-yy); return G == 1 ? x * (one - c) : x * c * (one - c); }
     if (ACT == 9) {
-        const float c = expf(xref), d = c + 1.f;
-        if (G == 1) return xref > 40.f ? x : x * c * (xref + d) / (d * d);
-        return xref > 40.f ? 0.f : x * c * (xref * (2.f - d) + 2.f * d) / (d * d * d);
+        const S c = m_exp(xref), d = c + one;
+        if (G == 1) return xref > S(40) ? x : x * c * (xref + d) / (d * d);
+        return xref > S(40) ? zero : x * c * (xref * (two - d) + two * d) / (d * d * d);
     }
-    return 0.f;
+    return zero;
 }
 
 template <int ACT, typename T>
 __global__ __launch_bounds__(256) void bias_act_grad_kernel(const T* __restrict__ x, const T* __restrict__ b, const T* __restrict__ xref,
                                                             const T* __restrict__ yref, const T* __restrict__ dy, T* __restrict__ y, int64_t n,
-                                                            int sizeB, int64_t stepB, int G, float alpha, float gain, float clamp) {
+                                                            int sizeB, int64_t stepB, int G, float alpha_, float gain_, float clamp_) {
+    typedef typename Compute<T>::type S;
+    const S alpha = alpha_, gain = gain_, clamp = clamp_;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float xv = ld<T>(x, i);
-        float xr = xref ? ld<T>(xref, i) : 0.f;
-        float yr = yref ? ld<T>(yref, i) : 0.f;
-        const float dv = dy ? ld<T>(dy, i) : 1.f;
+        const S xv = ld<T>(x, i);
+        S xr = xref ? ld<T>(xref, i) : S(0);
+        S yr = yref ? ld<T>(yref, i) : S(0);
+        const S dv = dy ? ld<T>(dy, i) : S(1);
         if (b) xr = xr + ld<T>(b, (i / stepB) % sizeB);
-        const float yy = gain != 0.f ? yr / gain : 0.f;
-        float v = act_grad<ACT>(G, xv, xr, yy, alpha);
-        if (ACT == 9) yr = xr < -80.f ? 0.f : xr / (expf(-xr) + 1.f) * gain;        // swish saves x, not y: rebuild the forward output for the clamp
+        const S yy = gain != S(0) ? yr / gain : S(0);
+        S v = act_grad<ACT, S>(G, xv, xr, yy, alpha);
+        if (ACT == 9) yr = xr < S(-80) ? S(0) : xr / (m_exp(-xr) + S(1)) * gain;        // swish saves x, not y: rebuild the forward output for the clamp
         v = v * (gain * dv);
-        if (clamp >= 0.f) v = (yr > -clamp && yr < clamp) ? v : 0.f;
+        if (clamp >= S(0)) v = (yr > -clamp && yr < clamp) ? v : S(0);
         st<T>(y, i, v);
     }
 }
@@ -195,6 +219,9 @@ void launch_grad(const void* x, const void* b, const void* xref, const void* yre
     if (dtype == TDGP_F32)
         TDGP_LAUNCH("bias_act_grad_kernel", (bias_act_grad_kernel<ACT, float>), dim3(blocks), dim3(256), 0, s, (const float*)x, (const float*)b, (const float*)xref,
                     (const float*)yref, (const float*)dy, (float*)y, n, sizeB, stepB, G, alpha, gain, clamp);
+    else if (dtype == TDGP_F64)
+        TDGP_LAUNCH("bias_act_grad_kernel", (bias_act_grad_kernel<ACT, double>), dim3(blocks), dim3(256), 0, s, (const double*)x, (const double*)b, (const double*)xref,
+                    (const double*)yref, (const double*)dy, (double*)y, n, sizeB, stepB, G, alpha, gain, clamp);
     else if (dtype == TDGP_F16)
         TDGP_LAUNCH("bias_act_grad_kernel", (bias_act_grad_kernel<ACT, __half>), dim3(blocks), dim3(256), 0, s, (const __half*)x, (const __half*)b, (const __half*)xref,
                     (const __half*)yref, (const __half*)dy, (__half*)y, n, sizeB, stepB, G, alpha, gain, clamp);
@@ -210,7 +237,7 @@ TDGP_API int tdgp_bias_act_grad(const void* x, const void* b, const void* xref, 
     TDGP_CHECK(x && y, TDGP_EINVAL, "bias_act_grad: x and y must be device pointers");
     TDGP_CHECK(grad == 1 || grad == 2, TDGP_EINVAL, "bias_act_grad: grad must be 1 or 2 (0 is tdgp_bias_act)");
     TDGP_CHECK(n >= 0 && n <= INT32_MAX, TDGP_EINVAL, "bias_act_grad: x is too large");
-    TDGP_CHECK(dtype >= TDGP_F32 && dtype <= TDGP_BF16, TDGP_EINVAL, "bias_act_grad: unsupported dtype %d", dtype);
+    TDGP_CHECK(dtype >= TDGP_F32 && dtype <= TDGP_F64, TDGP_EINVAL, "bias_act_grad: unsupported dtype %d", dtype);
     TDGP_CHECK(act >= 1 && act <= 9, TDGP_EUNSUPPORTED, "bias_act_grad: no kernel found for the specified activation func (%d)", act);
     TDGP_CHECK(!b || (sizeB >= 1 && stepB >= 1), TDGP_EINVAL, "bias_act_grad: b has wrong number of elements / stride");
     if (n == 0) return TDGP_OK;

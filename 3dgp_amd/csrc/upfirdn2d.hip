@@ -28,8 +28,15 @@ template <> __device__ __forceinline__ void stx<float>(void* p, int64_t i, float
 template <> __device__ __forceinline__ void stx<__half>(void* p, int64_t i, float v) { ((__half*)p)[i] = __float2half(v); }
 template <> __device__ __forceinline__ void stx<hip_bfloat16>(void* p, int64_t i, float v) { ((hip_bfloat16*)p)[i] = hip_bfloat16(v); }
 
+// fp64 (upfirdn2d.cpp:63 dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF; the CUDA kernel's scalar_t is double for double tensors,
+// upfirdn2d.cu:21-27: accumulation and the gain in double).  Off the hot path: generic kernel only.
+template <> __device__ __forceinline__ float ldx<double>(const void* p, int64_t i) { return (float)((const double*)p)[i]; }
+template <typename T> struct UpAcc { typedef float type; };
+template <> struct UpAcc<double> { typedef double type; };
+
 template <typename T>
 __global__ __launch_bounds__(256) void upfirdn2d_generic(UpfirdnParams p) {
+    typedef typename UpAcc<T>::type S;
     const int64_t total = (int64_t)p.N * p.C * p.outH * p.outW;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int ox = (int)(i % p.outW);
@@ -38,7 +45,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic(UpfirdnParams p) {
         int c = (int)(r % p.C);
         int n = (int)(r / p.C);
         const int64_t xb = n * p.xs[0] + c * p.xs[1];
-        float acc = 0.f;
+        S acc = 0;
         for (int ky = 0; ky < p.fH; ky++) {
             int uy = oy * p.downy + ky - p.pady0;
             if (uy < 0 || uy >= p.inH * p.upy || (uy % p.upy) != 0) continue;
@@ -48,10 +55,14 @@ __global__ __launch_bounds__(256) void upfirdn2d_generic(UpfirdnParams p) {
                 if (ux < 0 || ux >= p.inW * p.upx || (ux % p.upx) != 0) continue;
                 int ix = ux / p.upx;
                 float fv = p.flip ? p.f[ky * p.fW + kx] : p.f[(p.fH - 1 - ky) * p.fW + (p.fW - 1 - kx)];
-                acc = fmaf_(fv, ldx<T>(p.x, xb + iy * p.xs[2] + ix * p.xs[3]), acc);
+                const int64_t xi = xb + iy * p.xs[2] + ix * p.xs[3];
+                if constexpr (sizeof(S) == 8) acc = __builtin_fma((double)fv, ((const double*)p.x)[xi], acc);
+                else acc = fmaf_(fv, ldx<T>(p.x, xi), acc);
             }
         }
-        stx<T>(p.y, n * p.ys[0] + c * p.ys[1] + oy * p.ys[2] + ox * p.ys[3], acc * p.gain);
+        const int64_t yi = n * p.ys[0] + c * p.ys[1] + oy * p.ys[2] + ox * p.ys[3];
+        if constexpr (sizeof(S) == 8) ((double*)p.y)[yi] = acc * (double)p.gain;
+        else stx<T>(p.y, yi, acc * p.gain);
     }
 }
 
@@ -220,7 +231,7 @@ TDGP_API int tdgp_upfirdn2d(const void* x, const float* f, void* y, int N, int C
     TDGP_CHECK(fH >= 1 && fW >= 1, TDGP_EINVAL, "upfirdn2d: f must be at least 1x1");
     TDGP_CHECK(upx >= 1 && upy >= 1, TDGP_EINVAL, "upfirdn2d: upsampling factor must be at least 1");
     TDGP_CHECK(downx >= 1 && downy >= 1, TDGP_EINVAL, "upfirdn2d: downsampling factor must be at least 1");
-    TDGP_CHECK(dtype >= TDGP_F32 && dtype <= TDGP_BF16, TDGP_EINVAL, "upfirdn2d: unsupported dtype %d", dtype);
+    TDGP_CHECK(dtype >= TDGP_F32 && dtype <= TDGP_F64, TDGP_EINVAL, "upfirdn2d: unsupported dtype %d", dtype);
     const int ow = (inW * upx + padx0 + padx1 - fW + downx) / downx;
     const int oh = (inH * upy + pady0 + pady1 - fH + downy) / downy;
     TDGP_CHECK(ow >= 1 && oh >= 1, TDGP_EINVAL, "upfirdn2d: output must be at least 1x1");
@@ -250,6 +261,7 @@ TDGP_API int tdgp_upfirdn2d(const void* x, const float* f, void* y, int N, int C
         const int blocks = (int)min((int64_t)(256 * 16), cdiv64(total, 256));
         if (dtype == TDGP_F32) TDGP_LAUNCH("upfirdn2d_generic", (upfirdn2d_generic<float>), dim3(blocks), dim3(256), 0, s, p);
         else if (dtype == TDGP_F16) TDGP_LAUNCH("upfirdn2d_generic", (upfirdn2d_generic<__half>), dim3(blocks), dim3(256), 0, s, p);
+        else if (dtype == TDGP_F64) TDGP_LAUNCH("upfirdn2d_generic", (upfirdn2d_generic<double>), dim3(blocks), dim3(256), 0, s, p);
         else TDGP_LAUNCH("upfirdn2d_generic", (upfirdn2d_generic<hip_bfloat16>), dim3(blocks), dim3(256), 0, s, p);
     }
     TDGP_LAUNCH_CHECK();

@@ -38,7 +38,7 @@ def _table():
 # same keys / fields as the reference's table (bias_act.py:21-31); cuda_idx is the kernel's activation id
 activation_funcs = _table()
 
-_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}      # include/tdgp.h TDGP_F32 / F16 / BF16 / F64
 
 
 def _init():
@@ -144,7 +144,7 @@ def _bias_act_ref(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=N
 def _bias_act_hip(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None):
     spec, alpha, gain, clamp = _resolve(act, alpha, gain, clamp)
     if x.dtype not in _DTYPES:
-        raise RuntimeError(f'bias_act: dtype {x.dtype} has no HIP kernel (float32 / float16 / bfloat16)')
+        raise RuntimeError(f'bias_act: dtype {x.dtype} has no HIP kernel (float32 / float64 / float16 / bfloat16)')
     # layout handling of BiasActCuda.forward (bias_act.py:144-150)
     memory_format = torch.channels_last if x.ndim > 2 and x.stride(1) == 1 else torch.contiguous_format
     x = x.contiguous(memory_format=memory_format)

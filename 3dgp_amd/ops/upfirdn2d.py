@@ -13,7 +13,7 @@ import torch
 
 from .. import _lib
 
-_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}      # include/tdgp.h TDGP_F32 / F16 / BF16 / F64
 
 
 def _init():
@@ -134,7 +134,7 @@ def _launch(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain
     if x.numel() == 0:
         raise RuntimeError('x has zero size')
     if x.dtype not in _DTYPES:
-        raise RuntimeError(f'upfirdn2d: dtype {x.dtype} has no HIP kernel (float32 / float16 / bfloat16)')
+        raise RuntimeError(f'upfirdn2d: dtype {x.dtype} has no HIP kernel (float32 / float64 / float16 / bfloat16)')
     f = f.contiguous()
     n, c, h, w = x.shape
     fh, fw = f.shape

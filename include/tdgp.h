@@ -7,7 +7,7 @@
  *     workspaces are caller-allocated) and passes the HIP stream to launch on;
  *   - every function returns 0 on success or a negative TDGP_E* code; tdgp_last_error() returns a
  *     thread-local message.  Nothing throws across the ABI;
- *   - fp32 unless a `dtype` argument says otherwise (TDGP_F32 / TDGP_F16 / TDGP_BF16);
+ *   - fp32 unless a `dtype` argument says otherwise (TDGP_F32 / TDGP_F16 / TDGP_BF16; TDGP_F64 for the two plugin ops);
  *   - re-entrant.  Process-wide state is limited to: the init-once kernel tables, the two switches tdgp_set_conv_arith (algorithm of
  *     the large 3x3 layers; default 0 = fp32 MFMA) and tdgp_profile_enable (per-kernel event timing; default off), and the launch
  *     geometry cached per kernel instantiation and device (resident blocks per CU, CU count, raised LDS caps), and the device-fault
@@ -36,6 +36,7 @@ extern "C" {
 #define TDGP_F32  0
 #define TDGP_F16  1
 #define TDGP_BF16 2
+#define TDGP_F64  3   /* tdgp_bias_act / tdgp_bias_act_grad / tdgp_upfirdn2d only (bias_act.cpp:77, upfirdn2d.cpp:63: ..._FLOATING_TYPES_AND_HALF); compute type double */
 
 typedef void* tdgp_stream_t;   /* hipStream_t */
 
