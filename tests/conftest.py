@@ -105,13 +105,13 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
 
       1. range-normalised error  max|d| / max|ref|  <= RANGE_TOL (1e-5) -- well-conditioned, the binding one;
       2. per-pixel max-rel (|d| / max(|ref|, 1e-3 max|ref|)) against the REFERENCE image
-         <= max(RGB_TOL, 4 x reference self-noise, 2 x reference-vs-exact)   (self-noise is ONE draw of the reference's own
-         run-to-run difference; the maximum over the pixels of a second, independent draw scatters by that much);
+         <= max(RGB_TOL, 1.5 x max(reference self-noise, reference-vs-exact)) when `exact` is given (every HIP test), 4 x self-noise
+         otherwise (self-noise is ONE draw of the reference's own run-to-run difference);
       3. when the exactly rounded image is available (`exact` = the fp64-accumulating oracle on the same inputs): the HIP
          image is no further from it, per pixel, than max(RGB_TOL, 1.5 x the reference's own distance from it);
       4. when the golden holds `<key>_f64` -- the REFERENCE ITSELF run in float64 on the same ws / rays / draws
          (tools/gen_goldens.py:gen_e2e; the pin that does not lean on this repo's oracle) -- the image is measured against it next
-         to the reference's own fp32 image: per-pixel max-rel <= max(RGB_TOL, 3 x the reference-fp32-vs-f64 figure) (a maximum
+         to the reference's own fp32 image: per-pixel max-rel <= max(RGB_TOL, 1.5 x the reference-fp32-vs-f64 figure) (a maximum
          over pixels of ulp-level noise amplified 1000x on near-zero pixels scatters by that much between two fp32 evaluations;
          the reference's fp32 run is 1.7e-4 / 3.0e-4 / 2.9e-4 from its own float64 run on the three goldens, i.e. it does not
          meet a flat 1e-4 against itself), and the robust statistic, mean |d| / max|ref|, <= 1.25 x the reference's + 6e-8 (half an fp32 ulp of the range).
@@ -133,7 +133,11 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
         figs['reference_vs_exact_sym'] = max_rel(ref, exact)
     report_parity(what, **figs)
     assert rng <= RANGE_TOL, f'{what}: range-normalised error {rng:.3e} > {RANGE_TOL:.0e}'
-    bound = max(pix_tol, 4 * self_noise, 2 * exact_noise)
+    # Round 4: with the exactly rounded image at hand the head-room is 1.5 x the LARGER of the reference's two own
+    # figures (its run-to-run difference and its distance from the exact image; measured r03: HIP sits at 0.44-1.3 x that), not 4 x / 2 x.
+    # Without `exact` (the oracle's own CPU tests: the image under test IS the exactly rounded one, so `pix` is the reference's rounding
+    # error -- one draw, held against `_alt`'s one draw) the 4 x stays.
+    bound = max(pix_tol, 1.5 * max(self_noise, exact_noise)) if exact is not None else max(pix_tol, 4 * self_noise)
     assert pix <= bound, f'{what}: max-rel {pix:.3e} > {bound:.3e} (reference self-noise {self_noise:.3e}, reference vs exact {exact_noise:.3e})'
     if exact is not None:
         b3 = max(pix_tol, 1.5 * figs['reference_vs_exact_sym'])
@@ -146,7 +150,9 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
         refs_mean = float(np.abs(np.asarray(ref, np.float64) - f64).mean() / scale)
         report_parity(what + ' vs the reference run in float64', pix_vs_reference_f64=ours, reference_fp32_vs_reference_f64=refs,
                       mean_err_vs_f64=ours_mean, reference_fp32_mean_err_vs_f64=refs_mean)
-        b4 = max(pix_tol, 3 * refs)
+        # HIP (exact given): 1.5 x the reference's own figure (measured r03: 0.6-1.0 x on the three goldens); the oracle's own tests keep 3 x
+        # (its e2e_tiny_mip image is 2.5 x: elementwise fp32 with double reductions is one more fp32 evaluation, not the float64 one)
+        b4 = max(pix_tol, (1.5 if exact is not None else 3.0) * refs)
         assert ours <= b4, f'{what}: max-rel vs the float64 reference {ours:.3e} > {b4:.3e} (the reference\'s fp32 run: {refs:.3e})'
         # + half an fp32 ulp of the range: depth maps sit at that floor on both sides
         assert ours_mean <= 1.25 * refs_mean + 6e-8, f'{what}: mean error vs the float64 reference {ours_mean:.3e} vs the reference\'s own {refs_mean:.3e}'

@@ -6,6 +6,8 @@ Bars (stated per test):
   * reductions (conv / FIR / dot products / compositing): relative to the tensor scale, <= 2e-6 .. 1e-5;
   * end-to-end RGB: the north-star 1e-4 max-rel (see conftest.assert_image_parity for the exact definition).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1036,6 +1038,173 @@ def test_config_c4_backbone_vs_oracle(tdgp, oracle):
     for _ in range(5):                                       # and it is deterministic (the race showed as ~1 bad run in 10)
         again = G.synthesis.tri_plane_decoder(ws, noise_mode='const', hwc=True)
         assert torch.equal(again.t, planes.t)
+
+
+def _wino_launches(tdgp, fn):
+    """Per-kernel launch counts of one call of `fn`, through the library's own profiler (tdgp_profile_enable / tdgp_profile_report)."""
+    tdgp._lib.profile_enable(True)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        rep = tdgp._lib.profile_report()
+    finally:
+        tdgp._lib.profile_enable(False)
+    return out, {k: v['launches'] for k, v in rep.items()}
+
+
+@pytest.mark.parametrize('B', [16, 4])
+def test_full_size_c3_at_bench_batches(tdgp, oracle, B):
+    """the configuration bench.py TIMES (C3, per-GPU batch 16 and 4, bench.py's own weights and inputs)
+    against the oracle.  Launch geometry depends on the batch -- the 32^2 x 512 layer is a Winograd launch only at B >= 8, split-K slice
+    counts and the tail model follow the launch size, the field kernel's persistent grid wraps 64 x instead of 8 x -- and every other
+    full-size test runs B = 2.  Here, at the timed batch:
+      * planes of sample 0 vs the CPU oracle (<= 1e-5 of the range);
+      * every image vs the SAME item rendered in a B = 2 launch (the oracle-checked geometry), <= 1e-5 of the range;
+      * a strip of rays of two samples through the whole renderer vs the oracle run on the same planes: stratified samples bit-exact,
+        the importance samples (= the searchsorted indices pushed through the inverse cdf) bit-exact per ray up to draws within an ulp
+        of a cdf knot (<= 2 rays per strip, the bound of test_e2e_tiny; measured 0), RGB and depth <= 1e-5;
+      * three repeats bit-identical;
+      * the library's profiler confirms which kernels ran: conv_wino_kernel takes 5 layers at B = 16 (incl. 32^2) and 4 at B = 4."""
+    cfg = tdgp.config.config_c3()
+    sd = tdgp.weights.random_state_dict(cfg, seed=0)                       # bench.py: random_state_dict(cfg, seed=0), synthetic_inputs(seed = rank_seed(0, 0, 1) = 0)
+    G = tdgp.generator.Generator(cfg)
+    G.load_numpy_state_dict(sd)
+    G = G.to(DEV)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=B, seed=tdgp.distributed.rank_seed(0, 0, 1))
+    z, c = T(inp['z']), T(inp['c'])
+    cam = {k: T(v) for k, v in inp['camera'].items()}
+    uc, uf = T(inp['u_coarse']), T(inp['u_fine'])
+    R, S = cfg.img_resolution ** 2, cfg.num_ray_steps
+    ws = G.mapping(z, c)
+    dec = G.synthesis.tri_plane_decoder
+    planes, launches = _wino_launches(tdgp, lambda: dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True))
+    assert launches.get('conv_wino_kernel', 0) == (5 if B == 16 else 4), launches           # bench.winograd_takes / wino_ok (modconv.hip)
+    import bench
+    assert sum(bench.winograd_takes(B, cfg.channels[r], cfg.channels[r], r) for r in cfg.block_resolutions) == launches['conv_wino_kernel']
+    # (1) planes of sample 0 vs the oracle
+    oracle.set_threads(min(64, os.cpu_count() or 1))
+    ows = oracle.mapping_forward(sd, cfg.to_dict(), inp['z'][:1], inp['c'][:1])
+    assert_close(N(ws[:1]), ows, 1e-5, f'B={B} ws', 1.0)
+    ref = oracle.synthesis_backbone(sd, cfg.to_dict(), N(ws[:1]), 'const')
+    planes_nchw0 = N(planes.t[:1].permute(0, 1, 4, 2, 3).reshape(1, 96, 512, 512))
+    e_pl = float(np.abs(planes_nchw0 - ref).max() / np.abs(ref).max())
+    assert e_pl <= 1e-5, e_pl
+    # (2) the timed forward itself: three repeats bit-identical, every image vs its B = 2 rendering
+    run = lambda sl=slice(None): G(z[sl], c[sl], {k: v[sl] for k, v in cam.items()}, noise_mode='const', u_coarse=uc[sl],   # noqa: E731
+                                   u_fine=uf.reshape(B, R, S)[sl].reshape(-1, S))
+    img = run()
+    assert img.shape == (B, 3, 256, 256) and torch.isfinite(img).all()
+    for _ in range(2):
+        assert torch.equal(run(), img)
+    worst = 0.0
+    for b0 in range(0, B, 2):
+        pair = run(slice(b0, b0 + 2))
+        scale = float(img[b0:b0 + 2].abs().max())
+        worst = max(worst, float((pair - img[b0:b0 + 2]).abs().max()) / scale)
+    assert worst <= 1e-5, worst
+    # (3) a ray strip of samples 0 and B - 1 through the renderer at the timed batch vs the oracle on the same planes
+    from oracle.pipeline import render_options
+    syn = G.synthesis
+    c2w = tdgp.renderer.compute_cam2world_matrix(cam)
+    ray_o, ray_d = tdgp.renderer.sample_rays(c2w, fov=cam['fov'], resolution=(256, 256), device=DEV)
+    opts = syn.rendering_options(syn._default_render_options)
+    opts.update(u_coarse=uc, u_fine=uf, ray_grid_w=256)
+    (rgb, dep, _, _), inter = syn.renderer(planes, syn.tri_plane_mlp, ray_o, ray_d, opts, return_intermediates=True)
+    assert_close(N(rgb).reshape(B, R, 3), N(img).reshape(B, 3, R).transpose(0, 2, 1), 0, 'renderer call == forward')
+    mlp = tuple(sd[f'synthesis.tri_plane_mlp.model.{i}.{n}'] for i in (0, 1) for n in ('weight', 'bias'))
+    oc2w = oracle.cam2world(inp['camera']['angles'], inp['camera']['radius'], inp['camera']['look_at'])
+    oro, ord_ = oracle.sample_rays(oc2w, inp['camera']['fov'], 256, 256)
+    np.testing.assert_array_equal(N(ray_o), oro)
+    np.testing.assert_array_equal(N(ray_d), ord_)
+    sel = np.concatenate([np.arange(r * 256, (r + 1) * 256) for r in (3, 128, 250)])
+    ni_tot = np_tot = 0
+    for b in (0, B - 1):
+        pl = N(planes.t[b:b + 1].permute(0, 1, 4, 2, 3).reshape(1, 96, 512, 512))
+        u1 = inp['u_coarse'].reshape(B, R, S)[b:b + 1, sel]
+        u2 = inp['u_fine'].reshape(B, R, S)[b, sel]
+        (orgb, odep, _, _), ointer = oracle.importance_render(pl, mlp, oro[b:b + 1, sel], ord_[b:b + 1, sel], render_options(cfg.to_dict()), u1, u2,
+                                                              return_intermediates=True)
+        np.testing.assert_array_equal(N(inter['sdist_coarse']).reshape(B, R, S)[b, sel], ointer['sdist_coarse'].reshape(len(sel), S))
+        # the importance samples are values of an inverse cdf evaluated at integer search results (searchsorted index -> interval):
+        # bit-equal fine samples <=> equal indices.  The kernel hands them out sorted, the oracle in draw order: compare per ray as sets.
+        hf = np.sort(N(inter['sdist_fine']).reshape(B, R, -1)[b, sel], axis=1)
+        of = np.sort(ointer['sdist_fine'].reshape(len(sel), -1), axis=1)
+        bad_rays = int((hf != of).any(axis=1).sum())
+        assert bad_rays <= 2, (b, bad_rays)                   # a draw within an ulp of a cdf knot (test_e2e_tiny's bound; measured 0)
+        ni_tot += bad_rays
+        np_tot += int((hf != of).sum())
+        got = N(rgb).reshape(B, R, 3)[b, sel]
+        e_rgb = float(np.abs(got - orgb[0]).max() / np.abs(orgb).max())
+        e_dep = float(np.abs(N(dep).reshape(B, R)[b, sel] - odep[0, :, 0]).max())
+        assert e_rgb <= 1e-5 and e_dep <= 1e-5, (b, e_rgb, e_dep)
+    report_parity(f'C3 at the timed batch B = {B} (bench.py inputs)', planes_range_err=e_pl, image_vs_b2_launch_range_err=worst,
+                  strip_rays_with_a_moved_fine_sample=ni_tot, strip_fine_samples_differing=np_tot, wino_launches=launches['conv_wino_kernel'])
+
+
+def test_c4_backbone_at_bench_batch(tdgp, oracle):
+    """C4 (cmax 1024) at the batch its FID loop and `bench.py --config c4` time next to 16: B = 4 -- planes of sample 0 vs the oracle, three
+    repeats bit-identical, every sample's planes vs a B = 1 launch of the same item (<= 1e-5 of the range)."""
+    cfg = tdgp.config.config_c4()
+    sd = tdgp.weights.random_state_dict(cfg, seed=0)
+    G = tdgp.generator.Generator(cfg)
+    G.load_numpy_state_dict(sd)
+    G = G.to(DEV)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=4, seed=0)
+    ws = G.mapping(T(inp['z']), T(inp['c']))
+    dec = G.synthesis.tri_plane_decoder
+    planes, launches = _wino_launches(tdgp, lambda: dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True))
+    import bench
+    assert launches.get('conv_wino_kernel', 0) == sum(bench.winograd_takes(4, cfg.channels[r], cfg.channels[r], r) for r in cfg.block_resolutions), launches
+    for _ in range(2):
+        assert torch.equal(dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True).t, planes.t)
+    oracle.set_threads(min(64, os.cpu_count() or 1))
+    ref = oracle.synthesis_backbone(sd, cfg.to_dict(), N(ws[:1]), 'const')
+    got = N(planes.t[:1].permute(0, 1, 4, 2, 3).reshape(1, 96, 512, 512))
+    e_pl = float(np.abs(got - ref).max() / np.abs(ref).max())
+    worst = 0.0
+    for b in range(4):
+        one = dec(ws[b:b + 1, :dec.num_ws], noise_mode='const', hwc=True).t
+        worst = max(worst, float((one - planes.t[b:b + 1]).abs().max() / planes.t[b:b + 1].abs().max()))
+    report_parity('C4 backbone at the timed batch B = 4', planes_range_err=e_pl, planes_vs_b1_launch_range_err=worst, wino_launches=launches.get('conv_wino_kernel', 0))
+    assert e_pl <= 1e-5 and worst <= 1e-5, (e_pl, worst)
+
+
+def test_torgb_overlap_on_and_off_produce_identical_bits(tdgp, full_c3):
+    """DESIGN claims 'same bits' for the ToRGB layers on a second stream (SynthesisBlocksSequence.overlap_torgb): asserted, at full size."""
+    G, ws = full_c3['G'], full_c3['ws']
+    dec = G.synthesis.tri_plane_decoder
+    assert dec.overlap_torgb
+    a = dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True).t.clone()
+    dec.overlap_torgb = False
+    try:
+        b = dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True).t.clone()
+    finally:
+        dec.overlap_torgb = True
+    assert torch.equal(a, b)
+    assert torch.equal(a, full_c3['planes'].t)
+
+
+def test_generator_survives_deepcopy_and_pickle_after_a_forward(tdgp):
+    """the reference deep-copies G on every snapshot and metric run (training_loop.py:459, metric_utils.py:293,328).  The
+    side stream of the ToRGB overlap must not live in the module: after an inference forward `copy.deepcopy(G)` and `pickle.dumps(G)` work,
+    and the copy renders the same bits."""
+    import copy
+    import io
+    cfg = tdgp.config.config_tiny()
+    g = load_golden('e2e_tiny')
+    G = _gen(tdgp, cfg, 21)
+    kw = dict(noise_mode='const', u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
+    img = G(T(g['z']), T(g['c']), _cam(g), **kw)
+    assert G.synthesis.tri_plane_decoder.overlap_torgb
+    assert not any(isinstance(v, torch.cuda.Stream) for m in G.modules() for v in vars(m).values())
+    G2 = copy.deepcopy(G)
+    assert torch.equal(G2(T(g['z']), T(g['c']), _cam(g), **kw), img)
+    buf = io.BytesIO()
+    torch.save(G, buf)
+    buf.seek(0)
+    G3 = torch.load(buf, weights_only=False)
+    assert torch.equal(G3(T(g['z']), T(g['c']), _cam(g), **kw), img)
+    assert tdgp.generator.side_stream_of(DEV) is tdgp.generator.side_stream_of(torch.device('cuda', torch.cuda.current_device()))
 
 
 def test_full_size_properties(tdgp, full_c3):
