@@ -19,7 +19,7 @@ from .ops import bias_act as _bias_act
 from .ops import conv2d_resample as _conv2d_resample
 from .ops import upfirdn2d as _upfirdn2d
 
-_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}       # include/tdgp.h TDGP_F32 / F16 / BF16 / F64
 
 
 class BiasActPlugin:

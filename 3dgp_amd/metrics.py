@@ -236,13 +236,22 @@ def _generator_batches(G, batch_gen, camera_cfg, c_sampler, dataset, device, fro
         yield z, c, camera_params
 
 
-def compute_feature_stats_for_generator(G, detector, max_items, batch_size=64, batch_gen=4, camera_cfg=None, c_sampler=None, num_gpus=1, rank=0,
+def resolve_batch_gen(batch_size, batch_gen=None):
+    """metric_utils.py:289-290 / :324-325: `min(batch_size, 4) if opts.batch_gen is None else opts.batch_gen`, which must divide batch_size."""
+    batch_gen = min(batch_size, 4) if batch_gen is None else int(batch_gen)
+    assert batch_gen >= 1 and batch_size % batch_gen == 0
+    return batch_gen
+
+
+def compute_feature_stats_for_generator(G, detector, max_items, batch_size=64, batch_gen=None, camera_cfg=None, c_sampler=None, num_gpus=1, rank=0,
                                         device='cuda', gatherer=None, G_kwargs=None, dataset=None, **stats_kwargs):
     """metric_utils.py:288-320: generate `batch_size` images per iteration in chunks of `batch_gen`, run the detector, gather the
     feature block across ranks, accumulate.  Conditioning comes from `iterate_random_conditioning` (labels / custom angles from
     `dataset`) or, when given, from `c_sampler(batch) -> c [batch, c_dim]`; cameras come from the prior (`camera_cfg`, default
-    camera/base.yaml) and pass through G's camera adaptor when it has one."""
-    assert batch_size % batch_gen == 0
+    camera/base.yaml) and pass through G's camera adaptor when it has one.
+    `batch_gen` is the caller's option it is in the reference (MetricOptions.batch_gen, metric_utils.py:26,36): None = the reference's default
+    min(batch_size, 4) (:289); 16 generates the same images 8-9 % faster on one MI355X (bench.py --fid-loop prints both)."""
+    batch_gen = resolve_batch_gen(batch_size, batch_gen)
     G_kwargs = {} if G_kwargs is None else G_kwargs
     stats = FeatureStats(max_items=max_items, **stats_kwargs)
     batches = _generator_batches(G, batch_gen, camera_cfg, c_sampler, dataset, device)
@@ -259,11 +268,11 @@ def compute_feature_stats_for_generator(G, detector, max_items, batch_size=64, b
     return stats
 
 
-def compute_flattened_depth_maps(G, max_items, batch_size=64, batch_gen=4, camera_cfg=None, c_sampler=None, num_gpus=1, rank=0, device='cuda',
+def compute_flattened_depth_maps(G, max_items, batch_size=64, batch_gen=None, camera_cfg=None, c_sampler=None, num_gpus=1, rank=0, device='cuda',
                                  gatherer=None, G_kwargs=None, dataset=None, cut_quantile=0.0):
     """metric_utils.py:324-349: frontal-camera depth maps of `max_items` generated samples, flattened to [max_items, h*w]
     (input of the reference's non-flatness score)."""
-    assert batch_size % batch_gen == 0
+    batch_gen = resolve_batch_gen(batch_size, batch_gen)
     G_kwargs = {} if G_kwargs is None else G_kwargs
     stats = FeatureStats(max_items=max_items, capture_all=True)
     batches = _generator_batches(G, batch_gen, camera_cfg, c_sampler, dataset, device, frontal_camera=True)

@@ -86,8 +86,13 @@ def test_plugin_ops_fp64(tdgp, oracle):
     ba = tdgp.ops.bias_act.bias_act
     g = load_golden('bias_act')
     x64, b64 = g['x'].astype(np.float64), g['b'].astype(np.float64)
+    specs = tdgp.ops.bias_act.activation_funcs
     for act in ACTS:
-        for kw in (dict(), dict(gain=0.7, clamp=0.4)):
+        # alpha / gain / clamp cross the plugin boundary as C floats (bias_act.cpp:32 `float alpha, float gain, float clamp`; the CUDA kernel
+        # widens them to scalar_t): the double computation uses the fp32-rounded scalars, so the comparison passes those to both sides
+        f32 = lambda v: float(np.float32(v))             # noqa: E731
+        base = dict(alpha=f32(specs[act].def_alpha), gain=f32(specs[act].def_gain))
+        for kw in (base, dict(base, gain=0.75, clamp=0.5)):
             xd = torch.tensor(x64, device=DEV, requires_grad=True)
             bd = torch.tensor(b64, device=DEV, requires_grad=True)
             y = ba(xd, bd, act=act, **kw)
@@ -95,8 +100,10 @@ def test_plugin_ops_fp64(tdgp, oracle):
             xc, bc = torch.tensor(x64, requires_grad=True), torch.tensor(b64, requires_grad=True)
             yc = ba(xc, bc, act=act, impl='ref', **kw)
             assert float((y.detach().cpu() - yc.detach()).abs().max()) <= 1e-13 * max(1.0, float(yc.abs().max())), act
-            if not kw:
+            if kw is base:
                 assert_close(N(y.detach()).astype(np.float32), g[f'y_{act}'], 2e-6, act + ' f64 vs the fp32 golden')
+            if act == 'linear' and 'clamp' in kw:
+                continue      # bias_act.py:28 `ref=''` for linear: the plugin's backward has no saved output to mask the clamp with (the reference's CUDA path alike)
             w = torch.tensor(np.random.RandomState(3).randn(*x64.shape))
             (gx, gb) = torch.autograd.grad((y * w.to(DEV)).sum(), [xd, bd], create_graph=True)
             (cx, cb) = torch.autograd.grad((yc * w).sum(), [xc, bc], create_graph=True)
@@ -1061,8 +1068,8 @@ def test_full_size_c3_at_bench_batches(tdgp, oracle, B):
       * planes of sample 0 vs the CPU oracle (<= 1e-5 of the range);
       * every image vs the SAME item rendered in a B = 2 launch (the oracle-checked geometry), <= 1e-5 of the range;
       * a strip of rays of two samples through the whole renderer vs the oracle run on the same planes: stratified samples bit-exact,
-        the importance samples (= the searchsorted indices pushed through the inverse cdf) bit-exact per ray up to draws within an ulp
-        of a cdf knot (<= 2 rays per strip, the bound of test_e2e_tiny; measured 0), RGB and depth <= 1e-5;
+        the searchsorted indices of the importance draws exact up to draws within an ulp of a cdf knot (<= 2 per strip, each to the
+        neighbouring interval: the bound of test_e2e_tiny), fine samples 99.9 % <= 2e-6, RGB and depth <= 1e-5;
       * three repeats bit-identical;
       * the library's profiler confirms which kernels ran: conv_wino_kernel takes 5 layers at B = 16 (incl. 32^2) and 4 at B = 4."""
     cfg = tdgp.config.config_c3()
@@ -1117,7 +1124,7 @@ def test_full_size_c3_at_bench_batches(tdgp, oracle, B):
     np.testing.assert_array_equal(N(ray_o), oro)
     np.testing.assert_array_equal(N(ray_d), ord_)
     sel = np.concatenate([np.arange(r * 256, (r + 1) * 256) for r in (3, 128, 250)])
-    ni_tot = np_tot = 0
+    ni_tot, np_tot = 0, 0.0
     for b in (0, B - 1):
         pl = N(planes.t[b:b + 1].permute(0, 1, 4, 2, 3).reshape(1, 96, 512, 512))
         u1 = inp['u_coarse'].reshape(B, R, S)[b:b + 1, sel]
@@ -1125,20 +1132,28 @@ def test_full_size_c3_at_bench_batches(tdgp, oracle, B):
         (orgb, odep, _, _), ointer = oracle.importance_render(pl, mlp, oro[b:b + 1, sel], ord_[b:b + 1, sel], render_options(cfg.to_dict()), u1, u2,
                                                               return_intermediates=True)
         np.testing.assert_array_equal(N(inter['sdist_coarse']).reshape(B, R, S)[b, sel], ointer['sdist_coarse'].reshape(len(sel), S))
-        # the importance samples are values of an inverse cdf evaluated at integer search results (searchsorted index -> interval):
-        # bit-equal fine samples <=> equal indices.  The kernel hands them out sorted, the oracle in draw order: compare per ray as sets.
+        # INT row: the searchsorted indices of the inverse-cdf draws, oracle stage on the oracle's own coarse weights vs the kernel's on its
+        # own (the chain: an fp32 MLP whose summation order differs feeds the cdf, so a draw within an ulp of a knot may move to the
+        # neighbouring interval -- bounded as in test_e2e_tiny, measured 0); the samples themselves agree to an ulp of the depth range.
+        _, oaux = oracle.sample_importance(ointer['sdist_coarse'].reshape(1, len(sel), S, 1), ointer['weights_coarse'], u2, cfg.ray_marcher_type, return_aux=True)
+        hi = inter['inds'].cpu().numpy().reshape(B, R, -1)[b, sel].astype(np.int64)
+        oi = oaux['inds'].reshape(len(sel), -1)
+        ni = int((hi != oi).sum())
+        assert ni <= 2 and (ni == 0 or np.abs(hi - oi).max() <= 1), (b, ni)
+        ni_tot += ni
         hf = np.sort(N(inter['sdist_fine']).reshape(B, R, -1)[b, sel], axis=1)
         of = np.sort(ointer['sdist_fine'].reshape(len(sel), -1), axis=1)
-        bad_rays = int((hf != of).any(axis=1).sum())
-        assert bad_rays <= 2, (b, bad_rays)                   # a draw within an ulp of a cdf knot (test_e2e_tiny's bound; measured 0)
-        ni_tot += bad_rays
-        np_tot += int((hf != of).sum())
+        np_tot = max(np_tot, float(np.abs(hf - of).max()))
+        # the samples are (u - cdf_lo) / (cdf_hi - cdf_lo) pushed through the bins: on a flat stretch of the cdf an ulp of the weights moves
+        # the value by 1e-5 of the depth range (measured max 3.0e-5, 99.9 % below 1e-6) -- bounded robustly, the integers above are the pin
+        d = np.abs(hf - of)
+        assert np.quantile(d, 0.999) <= 2e-6 and d.max() <= (1e-3 if ni == 0 else 1e-2), (b, float(np.quantile(d, 0.999)), float(d.max()))
         got = N(rgb).reshape(B, R, 3)[b, sel]
         e_rgb = float(np.abs(got - orgb[0]).max() / np.abs(orgb).max())
         e_dep = float(np.abs(N(dep).reshape(B, R)[b, sel] - odep[0, :, 0]).max())
         assert e_rgb <= 1e-5 and e_dep <= 1e-5, (b, e_rgb, e_dep)
     report_parity(f'C3 at the timed batch B = {B} (bench.py inputs)', planes_range_err=e_pl, image_vs_b2_launch_range_err=worst,
-                  strip_rays_with_a_moved_fine_sample=ni_tot, strip_fine_samples_differing=np_tot, wino_launches=launches['conv_wino_kernel'])
+                  strip_inds_mismatches=ni_tot, strip_fine_sample_max_abs_diff=np_tot, wino_launches=launches['conv_wino_kernel'])
 
 
 def test_c4_backbone_at_bench_batch(tdgp, oracle):
