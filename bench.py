@@ -119,8 +119,10 @@ def cpu_baseline(tdgp, cfg, n_img=8, budget_s=14.0):
                        f'samples) in {t_total:.1f} s; OpenMP C oracle (oracle/tdgp_oracle.c), {cores} threads')
 
 
-def timed_steps(step, barrier, steps, warmup, world, dev, finish=None):
-    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+def timed_steps(step, barrier, steps, warmup, world, dev, finish=None, per_rank=None):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.  `per_rank` (a list) receives
+    every rank's OWN time for the K steps -- stop-watch read after its own synchronize, BEFORE the closing barrier -- so that a straggler
+    shows in the line instead of hiding behind the maximum."""
     for _ in range(warmup):
         step()
     barrier()
@@ -129,14 +131,29 @@ def timed_steps(step, barrier, steps, warmup, world, dev, finish=None):
         img = step()
     if finish is not None:
         finish()
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+        if per_rank is not None:
+            mine = torch.tensor([own], dtype=torch.float64, device=dev)
+            every = torch.empty([world], dtype=torch.float64, device=dev)
+            torch.distributed.all_gather_into_tensor(every, mine)
+            per_rank[:] = [float(v) for v in every.tolist()]
+    elif per_rank is not None:
+        per_rank[:] = [own]
     assert torch.isfinite(img).all()
     return elapsed
+
+
+def straggler_figures(per_rank_s, steps):
+    """-> (per-rank ms per step, slowest / fastest)."""
+    ms = [round(v / steps * 1e3, 3) for v in per_rank_s]
+    return ms, (round(max(ms) / min(ms), 4) if ms and min(ms) > 0 else None)
 
 
 def spawn_ranks(n, script=None, argv=None):
@@ -149,9 +166,17 @@ def spawn_ranks(n, script=None, argv=None):
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
     procs = []
+    # Host threads: N Python ranks each defaulting to every host core (input synthesis, ATen micro-kernels, the OpenMP pools) oversubscribe the
+    # box N-fold; torchrun pins OMP_NUM_THREADS to 1, here each rank gets its share of the cores (and pins itself to the cores of its GPU's
+    # NUMA node once it knows its device: distributed.pin_rank).  A caller's own OMP_NUM_THREADS wins.
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    omp = os.environ.get('OMP_NUM_THREADS') or str(max(1, cores // n))
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+                   OMP_NUM_THREADS=omp, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rcs = [None] * n
@@ -190,6 +215,9 @@ def main():
                                                           'agree to 0.3 % at B = 16 and B = 4 -- the forward is not launch-bound')
     ap.add_argument('--fid-lanes', type=int, default=1, help='--fid-loop: run the 16 sub-batch forwards of a 64-image block as this many concurrent graph replays (one '
                     'captured graph and one stream per lane); 1 = one after the other, the order the reference issues them in')
+    ap.add_argument('--no-fid-loop', action='store_true', help='N > 1 times the FID-loop shape by default (it is the multi-GPU workload: one all-gather per 64 images per rank); this switches it off')
+    ap.add_argument('--batch-gen', default='4,16', help='--fid-loop: comma list of generator sub-batch sizes (MetricOptions.batch_gen, metric_utils.py:26,289: a caller option, '
+                                                         'default min(batch_size, 4)); the first one is `fid_loop`, the others are listed under `fid_loop.other_batch_gen`')
     ap.add_argument('--fid-loop', action='store_true', help="also time the reference's FID generation loop shape (metric_utils.py:288-319): 64 images per rank as 16 "
                                                              'sub-batches of 4 with device-side draws, one feature block (and, N > 1, one RCCL all-gather) per 64')
     ap.add_argument('--arith', default='f32', choices=['f32', 'direct', 'split'],
@@ -210,6 +238,9 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    host = D.pin_rank(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world))) if world > 1 else None      # cores of this GPU's NUMA node
+    if world > 1 and not args.no_fid_loop:
+        args.fid_loop = True
     tdgp._lib.load()                       # the HIP library must be there: no fallback
     if args.arith == 'split':
         tdgp._lib.set_conv_arith(1)
@@ -272,7 +303,8 @@ def main():
             gather.wait()
 
     x = inputs(args.batch)
-    elapsed = timed_steps(make_step(x), barrier, args.steps, args.warmup, world, dev, finish)
+    per_rank_s = []
+    elapsed = timed_steps(make_step(x), barrier, args.steps, args.warmup, world, dev, finish, per_rank=per_rank_s)
     # the other launch mode next to the headline (eager when the headline replays a graph, and the other way round)
     alt_elapsed = timed_steps(make_step(x, use_graph=args.no_graph), barrier, args.steps, args.warmup, world, dev, finish)
 
@@ -337,6 +369,9 @@ def main():
             v['tflops'] = round(flops[k][0] * args.batch / v['launches_per_step'] / (v['avg_ms'] * 1e-3) / 1e12, 2)
             if k in EXECUTED_FRACTION:
                 v['tflops_executed'] = round(v['tflops'] * EXECUTED_FRACTION[k], 2)
+            # against the kernel's OWN matrix peak (fp32 157.3 / bf16 2500 TFLOP/s), on the FLOP it executes
+            v['peak_tflops'] = flops[k][2]
+            v['frac_of_own_peak'] = round(v.get('tflops_executed', v['tflops']) / flops[k][2], 4)
     total_flop_img = sum(f for f, _, _ in flops.values())
     # what the matrix pipe EXECUTES: the Winograd layers multiply 16/36 of their algorithmic (direct-sum) FLOP.  `frac` (algorithmic) is
     # the metric's figure; `frac_executed` is the one an MFMA roofline bounds -- both are printed, neither alone.
@@ -353,6 +388,12 @@ def main():
                  mfma_busy_pct_time_weighted=round(sum(t * b for t, b in busy_w) / t_all, 1) if busy_w and t_all > 0 else None,
                  kernel_ms_sum=round(sum(v['ms_per_step'] for v in kernels.values()), 3), profiled_step_ms=round(profiled_step_ms, 3))
 
+    if cfg.fp16_resolution:
+        # BASELINE configs[4]: bf16 and fp32 FLOP divided by the fp32 peak is not a roofline -- the per-kernel
+        # `frac_of_own_peak` figures are the meaningful ones; the aggregate keeps the achieved rate only
+        for k_ in ('frac', 'frac_executed', 'peak'):
+            whole[k_] = None
+        whole['note'] = 'mixed bf16 / fp32 matrix work: no single peak; see kernels[*].frac_of_own_peak'
     others = {}
     for b in [int(t) for t in args.other_batches.split(',') if t.strip()]:
         if b == args.batch:
@@ -361,7 +402,7 @@ def main():
         eb = timed_steps(make_step(xb), barrier, args.steps, args.warmup, world, dev, finish)
         eb_alt = timed_steps(make_step(xb, use_graph=args.no_graph), barrier, args.steps, args.warmup, world, dev, finish)
         others[str(b)] = dict(value=round(b * world * args.steps / eb, 3), ms_per_step=round(eb / args.steps * 1e3, 3), batch_per_gpu=b, steps=args.steps,
-                              frac_of_fp32_mfma_ceiling=round(total_flop_img * b / (eb / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                              frac_of_fp32_mfma_ceiling=None if cfg.fp16_resolution else round(total_flop_img * b / (eb / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                               launch='eager' if args.no_graph else 'hip graph replay',
                               **{('graph_value' if args.no_graph else 'eager_value'): round(b * world * args.steps / eb_alt, 3)})
         del xb
@@ -369,47 +410,57 @@ def main():
     fid_loop = None
     if args.fid_loop:
         # metric_utils.py:288-319 (compute_feature_stats_for_generator): batch_size 64 per rank, generated as 64 // batch_gen forwards of
-        # batch_gen = 4 with noise_mode='random' and the renderer's own draws, concatenated, passed through the detector (stand-in: a fixed
+        # batch_gen images with noise_mode='random' and the renderer's own draws, concatenated, passed through the detector (stand-in: a fixed
         # pooling to [64, 2048], the Inception pickle is a URL download) and appended -- one all-gather of the [64, 2048] block per 64 images.
-        gen, per = 4, 64
+        # batch_gen is MetricOptions.batch_gen (a caller option; the reference's default is min(batch_size, 4)): both 4 and 16 are timed.
+        per = 64
         lanes = max(1, args.fid_lanes) if not args.no_graph else 1
-        ggs = [tdgp.graphs.GraphedGenerator(G, gen, noise_mode='random', explicit_draws=False) for _ in range(lanes)] if not args.no_graph else []
-        gg = ggs[0] if ggs else None
-        lane_streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)] if lanes > 1 else []
-        zs = [inputs(gen) for _ in range(2)]
 
-        def fid_step():
-            imgs = []
-            if lanes > 1:
-                # the block's 16 forwards are independent: `lanes` of them are in flight at a time, each a replay of its lane's own graph on its
-                # lane's stream -- the low-resolution layers of a 4-image forward fill a fraction of the chip, the lanes fill the rest
-                main = torch.cuda.current_stream(dev)
-                for st in lane_streams:
-                    st.wait_stream(main)
-                for i in range(per // gen):
-                    xi = zs[i & 1]
-                    with torch.cuda.stream(lane_streams[i % lanes]):
-                        imgs.append(ggs[i % lanes](xi['z'], xi['c'], xi['cam']).clone())
-                for st in lane_streams:
-                    main.wait_stream(st)
-            else:
-                for i in range(per // gen):
-                    xi = zs[i & 1]
-                    if gg is not None:
-                        imgs.append(gg(xi['z'], xi['c'], xi['cam']).clone())
-                    else:
-                        imgs.append(G(xi['z'], xi['c'], xi['cam'], noise_mode='random'))
-            feats = D.stand_in_features(torch.cat(imgs))
-            if gather is not None:
-                if gather._pending is not None:
-                    gather.wait()
-                gather.gather_async(feats)
-            return imgs[-1]
-        nfid = max(args.steps // 8, 3)
-        ef = timed_steps(fid_step, barrier, nfid, 1, world, dev, finish)
-        fid_loop = dict(value=round(per * world * nfid / ef, 3), unit='img/s', images_per_rank_per_step=per, sub_batch=gen, steps=nfid,
+        def time_fid(gen):
+            gen = tdgp.metrics.resolve_batch_gen(per, gen)
+            ggs = [tdgp.graphs.GraphedGenerator(G, gen, noise_mode='random', explicit_draws=False) for _ in range(lanes)] if not args.no_graph else []
+            gg = ggs[0] if ggs else None
+            lane_streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)] if lanes > 1 else []
+            zs = [inputs(gen) for _ in range(2)]
+
+            def fid_step():
+                imgs = []
+                if lanes > 1:
+                    # the block's forwards are independent: `lanes` of them are in flight at a time, each a replay of its lane's own graph on its
+                    # lane's stream -- the low-resolution layers of a 4-image forward fill a fraction of the chip, the lanes fill the rest
+                    main = torch.cuda.current_stream(dev)
+                    for st in lane_streams:
+                        st.wait_stream(main)
+                    for i in range(per // gen):
+                        xi = zs[i & 1]
+                        with torch.cuda.stream(lane_streams[i % lanes]):
+                            imgs.append(ggs[i % lanes](xi['z'], xi['c'], xi['cam']).clone())
+                    for st in lane_streams:
+                        main.wait_stream(st)
+                else:
+                    for i in range(per // gen):
+                        xi = zs[i & 1]
+                        if gg is not None:
+                            imgs.append(gg(xi['z'], xi['c'], xi['cam']).clone())
+                        else:
+                            imgs.append(G(xi['z'], xi['c'], xi['cam'], noise_mode='random'))
+                feats = D.stand_in_features(torch.cat(imgs))
+                if gather is not None:
+                    if gather._pending is not None:
+                        gather.wait()
+                    gather.gather_async(feats)
+                return imgs[-1]
+            nfid = max(args.steps // 8, 3)
+            pr = []
+            ef = timed_steps(fid_step, barrier, nfid, 1, world, dev, finish, per_rank=pr)
+            ms, strag = straggler_figures(pr, nfid)
+            return dict(value=round(per * world * nfid / ef, 3), unit='img/s', images_per_rank_per_step=per, batch_gen=gen, sub_batch=gen, steps=nfid,
                         ms_per_64=round(ef / nfid * 1e3, 3), noise_mode='random', draws='device (inside the graph)' if gg is not None else 'device',
-                        launch='hip graph replay' if gg is not None else 'eager', lanes=lanes, reference='metric_utils.py:288-319')
+                        launch='hip graph replay' if gg is not None else 'eager', lanes=lanes, per_rank_ms_per_64=ms, straggler_ratio=strag,
+                        reference='metric_utils.py:288-319; batch_gen = MetricOptions.batch_gen (:26,289), reference default min(batch_size, 4) = 4')
+        gens = [int(t) for t in args.batch_gen.split(',') if t.strip()] or [4]
+        fid_loop = time_fid(gens[0])
+        fid_loop['other_batch_gen'] = {str(g_): time_fid(g_) for g_ in gens[1:]}
 
     if rank == 0:
         total_imgs = args.batch * world * args.steps
@@ -429,7 +480,8 @@ def main():
                        'schedule': dict(chunk=G.synthesis.chunk, chunk_from=G.synthesis.chunk_from, torgb_on_second_stream=bool(overlap_was))},
             'launch': 'eager' if args.no_graph else 'hip graph replay (3dgp_amd/graphs.py: every kernel of the forward, one submission per step)',
             ('graph_value' if args.no_graph else 'eager_value'): round(total_imgs / alt_elapsed, 3), 'fid_loop': fid_loop,
-            'rccl_ranks_seen': ranks_seen, 'roofline': roofline, 'whole_forward': whole, 'other_batches': others, 'kernels': kernels,
+            'rccl_ranks_seen': ranks_seen, 'per_rank_ms': straggler_figures(per_rank_s, args.steps)[0], 'straggler_ratio': straggler_figures(per_rank_s, args.steps)[1],
+            'host': None if host is None else dict(rank0=host, omp_num_threads=os.environ.get('OMP_NUM_THREADS')), 'roofline': roofline, 'whole_forward': whole, 'other_batches': others, 'kernels': kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(tdgp, cfg)

@@ -3,6 +3,7 @@ FID-style feature all-gather, whose interleaved order must equal the reference's
 `torch.stack(ys, dim=1).flatten(0, 1)` (metric_utils.py:145-155)."""
 import os
 import socket
+import sys
 
 import pytest
 import numpy as np
@@ -192,8 +193,12 @@ dist.all_reduce(t)
 if sys.argv[1:] == ["--die"] and rank == 1:
     os._exit(3)
 dist.barrier()
+omp = torch.tensor([float(os.environ.get("OMP_NUM_THREADS", "-1"))])
+lo, hi = omp.clone(), omp.clone()
+dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+dist.all_reduce(hi, op=dist.ReduceOp.MAX)
 if rank == 0:
-    print(json.dumps(dict(ranks_seen=int(t.item()), argv=sys.argv[1:])))
+    print(json.dumps(dict(ranks_seen=int(t.item()), argv=sys.argv[1:], omp=[int(lo.item()), int(hi.item())])))
 '''
 
 
@@ -206,10 +211,72 @@ def test_bench_spawn_ranks_plumbing(tmp_path):
     child = tmp_path / 'child.py'
     child.write_text(_SPAWNED_CHILD)
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    drive = 'import sys; sys.path.insert(0, %r); import bench; bench.spawn_ranks(2, script=%r, argv=sys.argv[1:])' % (REPO, str(child))
-    out = subprocess.run([sys.executable, '-c', drive, '--x', '1'], capture_output=True, text=True, timeout=300, env=env)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
-    assert line == dict(ranks_seen=2, argv=['--x', '1'])
-    out = subprocess.run([sys.executable, '-c', drive, '--die'], capture_output=True, text=True, timeout=300, env=env)
+    env.pop('OMP_NUM_THREADS', None)
+    cores = len(os.sched_getaffinity(0))
+    for n in (2, 8):                       # 8 = the node the driver's scaling run uses: every rank gets its share of the host cores
+        drive = 'import sys; sys.path.insert(0, %r); import bench; bench.spawn_ranks(%d, script=%r, argv=sys.argv[1:])' % (REPO, n, str(child))
+        out = subprocess.run([sys.executable, '-c', drive, '--x', '1'], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+        assert line == dict(ranks_seen=n, argv=['--x', '1'], omp=[max(1, cores // n)] * 2)
+    out = subprocess.run([sys.executable, '-c', drive, '--x', '1'], capture_output=True, text=True, timeout=600, env=dict(env, OMP_NUM_THREADS='3'))
+    assert json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])['omp'] == [3, 3]          # a caller's own setting wins
+    out = subprocess.run([sys.executable, '-c', drive, '--die'], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode != 0 and 'rank(s) failed' in out.stderr
+
+
+def test_rank_cpus_follow_the_gpu_numa_node(tdgp):
+    """distributed.rank_cpus: ranks whose GPUs share a NUMA node split that node's cores; without NUMA information an even split of the
+    allowed set; never an empty set, never a core outside what the process may use."""
+    D = tdgp.distributed
+    node_cpus = {0: list(range(0, 64)), 1: list(range(64, 128))}
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    got = [D.rank_cpus(r, 8, nodes, allowed=range(128), node_cpus=node_cpus) for r in range(8)]
+    assert got[0] == list(range(0, 16)) and got[3] == list(range(48, 64)) and got[4] == list(range(64, 80)) and got[7] == list(range(112, 128))
+    assert sorted(c for g in got for c in g) == list(range(128))
+    flat = [D.rank_cpus(r, 4, [-1] * 4, allowed=range(10)) for r in range(4)]
+    assert flat == [[0, 1], [2, 3], [4, 5], [6, 7]]
+    assert D.rank_cpus(1, 2, [5, 5], allowed=range(8), node_cpus={}) == [4, 5, 6, 7]           # node without a cpulist -> even split
+    assert D.rank_cpus(0, 2, [0, 1], allowed=[3], node_cpus={0: [0, 1], 1: [2, 3]}) == [3]       # nothing of node 0 allowed -> what is allowed
+    assert D._parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    info = D.pin_rank(0, 1, set_threads=False)               # on this box: must not raise, affinity stays a subset of what it was
+    assert info['cpus'] is None or info['cpus'] >= 1
+
+
+def _timed_steps_rank(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import time
+    import torch.distributed as dist
+    sys.path.insert(0, REPO)
+    import bench
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.synchronize = lambda *a, **k: None             # CPU plumbing test of bench.timed_steps
+    per = []
+
+    def step():
+        time.sleep(0.02 * (1 + 2 * rank))                     # rank 1 is the straggler
+        return torch.ones(1)
+    el = bench.timed_steps(step, dist.barrier, 3, 1, world, 'cpu', per_rank=per)
+    q.put((rank, el, per))
+    dist.destroy_process_group()
+
+
+def test_bench_reports_every_rank(tdgp):
+    """bench.timed_steps hands back each rank's OWN time next to the max-over-ranks figure (a straggler is visible in the line)."""
+    import socket
+    sys.path.insert(0, REPO)
+    import bench
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_timed_steps_rank, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(60) for p in ps]
+    (_, el0, per0), (_, el1, per1) = res
+    assert per0 == per1 and len(per0) == 2 and per0[1] > 2.0 * per0[0] > 0
+    assert abs(el0 - el1) < 1e-9 and el0 >= max(per0) - 1e-3
+    ms, ratio = bench.straggler_figures(per0, 3)
+    assert ratio > 2.0 and ms[1] > ms[0]
