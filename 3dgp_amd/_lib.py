@@ -154,7 +154,7 @@ def device_fault(clear=False):
 
 
 def set_conv_arith(mode):
-    """0 (default): fp32 MFMA; 1: split-bf16 (3 x bf16 pieces per operand, 6 piece products, fp32 accumulation) for the 3x3 stride-1
+    """0 (default): fp32 MFMA, Winograd F(4x4,3x3) / F(2x2,3x3) on the layers where they pay; 2: direct sums only; 3: as 0 without F(4x4); 1: split-bf16 (3 x bf16 pieces per operand, 6 piece products, fp32 accumulation) for the 3x3 stride-1
     convolutions with W % 32 == 0 and >= 256 output tiles.  Process-wide; returns the previous mode."""
     lib = load()
     prev = int(lib.tdgp_set_conv_arith(int(mode)))

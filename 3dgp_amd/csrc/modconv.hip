@@ -2267,6 +2267,7 @@ __global__ __launch_bounds__(256) void z_gather_kernel(const float* __restrict__
 
 #include "modconv_bf16.inc"
 #include "modconv_wino.inc"
+#include "modconv_wino4.inc"
 
 // d[b,o] = rsqrt(sum_c s[b,c]^2 * wsq[c][o] + 1e-8)      (networks_stylegan2.py:62)
 // block (64 out-channels x 16 channel slices): coalesced wsq rows, 16-way split of the Cin loop, LDS tree at the end.
@@ -2362,7 +2363,7 @@ __global__ __launch_bounds__(256) void style_affine_kernel(const float* __restri
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
-struct PackInfo { int T, KC, CoutP, nchunks, niter16, nch32, nch8; int64_t wp_floats, wsq_floats, wsplit_floats, wbf_floats, wino_floats; };
+struct PackInfo { int T, KC, CoutP, nchunks, niter16, nch32, nch8, nch4, nsl64; int64_t wp_floats, wsq_floats, wsplit_floats, wbf_floats, wino_floats, wino4_floats; };
 inline PackInfo pack_info(int Cout, int Cin, int k) {
     PackInfo pi;
     pi.T = k * k;
@@ -2377,6 +2378,8 @@ inline PackInfo pack_info(int Cout, int Cin, int k) {
     pi.wbf_floats = k == 3 ? (int64_t)pi.nch32 * 9 * 2 * pi.CoutP * 8 : 0;          // bf16 copy of the 3x3 weights (reduced-precision blocks)
     pi.nch8 = (Cin + 7) / 8;
     pi.wino_floats = k == 3 ? (int64_t)pi.nch8 * 16 * 2 * pi.CoutP * 4 : 0;          // Winograd-domain weights G g G^T (modconv_wino.inc)
+    pi.nch4 = (Cin + 3) / 4; pi.nsl64 = (Cout + 63) / 64;
+    pi.wino4_floats = (k == 3 && Cin >= 128 && Cout >= 128) ? (int64_t)pi.nsl64 * pi.nch4 * (18 * 4 * 64 * 2) : 0;      // F(4x4,3x3)-domain weights (modconv_wino4.inc)
     return pi;
 }
 
@@ -2522,8 +2525,20 @@ inline int pick_tw_log2(int gridW) {
     return lg;
 }
 
-// Workspace layout: [demod coefficients B*Cout] [transposed-conv intermediate, up=2 only] [split-K partial sums]
-struct WsLayout { int64_t dco, z, partial, partial_floats, total; };
+// F(4x4,3x3) Winograd (modconv_wino4.inc): which stride-1 3x3 layers take it -- by shape only (the workspace is sized from the same test).
+// W % 64 / H % 8: whole 8 x 64-pixel tile groups; Cin, Cout >= 128: below, the separate input-transform pass (2.25 x the input, written and
+// read back) costs more than it saves; at least one item per CU; V addressed through a 4 GiB buffer descriptor.
+#ifndef TDGP_WINO4_MIN_C
+#define TDGP_WINO4_MIN_C 128
+#endif
+inline int64_t wino4_v_bytes(int B, int Cin, int H, int W) { return (int64_t)B * (H >> 3) * (W >> 6) * ((Cin + 3) / 4) * (18 * 4 * 32 * 2) * 4; }
+inline bool wino4_shape_ok(int B, int Cin, int Cout, int H, int W, int k, int up) {
+    return k == 3 && up == 1 && (W & 63) == 0 && (H & 7) == 0 && (Cin & 3) == 0 && Cin >= TDGP_WINO4_MIN_C && Cout >= TDGP_WINO4_MIN_C &&
+           (int64_t)B * (H >> 3) * (W >> 6) * cdiv(Cout, 64) >= 256 && wino4_v_bytes(B, Cin, H, W) < ((int64_t)1 << 32) - 65536;
+}
+
+// Workspace layout: [demod coefficients B*Cout] [transposed-conv intermediate, up=2 only] [split-K partial sums] [Winograd-domain input V]
+struct WsLayout { int64_t dco, z, partial, partial_floats, wino_v, total; };
 WsLayout ws_layout(int B, int Cin, int Cout, int H, int W, int k, int up) {
     WsLayout w;
     auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
@@ -2534,7 +2549,7 @@ WsLayout ws_layout(int B, int Cin, int Cout, int H, int W, int k, int up) {
         const UpPlan u = up_plan(B, Cin, Cout, H, W);
         w.partial = w.z + al(u.zslice * u.ksplit * (int64_t)sizeof(float));
         w.partial_floats = 0;
-        w.total = w.partial;
+        w.wino_v = w.total = w.partial;
         return w;
     }
     const int64_t out_elems = (int64_t)B * Cout * H * W;
@@ -2544,7 +2559,8 @@ WsLayout ws_layout(int B, int Cin, int Cout, int H, int W, int k, int up) {
     const int64_t cap = ((int64_t)64 << 20) / 4;
     if (pf > cap) pf = (cap / out_elems) * out_elems;
     w.partial_floats = pf;
-    w.total = w.partial + al(pf * (int64_t)sizeof(float));
+    w.wino_v = w.partial + al(pf * (int64_t)sizeof(float));
+    w.total = w.wino_v + (wino4_shape_ok(B, Cin, Cout, H, W, k, up) ? al(wino4_v_bytes(B, Cin, H, W)) : 0);
     return w;
 }
 
@@ -2553,7 +2569,7 @@ WsLayout ws_layout(int B, int Cin, int Cout, int H, int W, int k, int up) {
 TDGP_API int64_t tdgp_modconv_pack_bytes(int Cout, int Cin, int k) {
     if (Cout < 1 || Cin < 1 || (k != 1 && k != 3 && k != 5)) return -1;
     const PackInfo pi = pack_info(Cout, Cin, k);
-    return (pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats + pi.wino_floats) * (int64_t)sizeof(float);
+    return (pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats + pi.wino_floats + pi.wino4_floats) * (int64_t)sizeof(float);
 }
 
 TDGP_API int tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int Cin, int k, tdgp_stream_t stream) {
@@ -2573,13 +2589,16 @@ TDGP_API int tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int C
     if (pi.wino_floats > 0)
         TDGP_LAUNCH("pack_kernel", pack_wino_kernel, dim3((int)min((int64_t)4096, cdiv64(pi.wino_floats, 256))), dim3(256), 0, (hipStream_t)stream, weight,
                     wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats, Cout, Cin, pi.CoutP, pi.nch8);
+    if (pi.wino4_floats > 0)
+        TDGP_LAUNCH("pack_kernel", pack_wino4_kernel, dim3((int)min((int64_t)4096, cdiv64(pi.wino4_floats, 256))), dim3(256), 0, (hipStream_t)stream, weight,
+                    wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats + pi.wino_floats, Cout, Cin, pi.nsl64, pi.nch4);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }
 
 static int g_conv_arith = 0;
 TDGP_API int tdgp_set_conv_arith(int mode) {
-    TDGP_CHECK(mode >= 0 && mode <= 2, TDGP_EINVAL, "set_conv_arith: mode %d (0 = fp32 MFMA, Winograd F(2x2,3x3) where it pays; 1 = split-bf16 MFMA with fp32 accumulation; 2 = fp32 MFMA, direct sums only)", mode);
+    TDGP_CHECK(mode >= 0 && mode <= 3, TDGP_EINVAL, "set_conv_arith: mode %d (0 = fp32 MFMA, Winograd F(4x4,3x3) / F(2x2,3x3) where they pay; 1 = split-bf16 MFMA with fp32 accumulation; 2 = fp32 MFMA, direct sums only; 3 = as 0 without F(4x4))", mode);
     const int old = g_conv_arith;
     g_conv_arith = mode;
     return old;
@@ -2670,7 +2689,26 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 const size_t lds = (size_t)(2 * 3 * 3 * 64 * 32 + 3 * 10 * 34 * 32 + 5 * 64 * 4 + 2 * Cin * 4);
                 TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds - 2 * Cin * 4 + 2 * 2048 * 4)););
                 TDGP_LAUNCH("conv_mfma_kernel", conv3s_mfma_kernel, dim3((W >> 5) * cdiv(B * (H + 1), 8), cdiv(Cout, 64)), dim3(256), lds, s, q);
-            } else if (k == 3 && g_conv_arith == 0 && wino_ok(B, Cin, Cout, H, W) && out_layout == 0 && !skip && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 &&
+            } else if (g_conv_arith == 0 && wino4_shape_ok(B, Cin, Cout, H, W, k, up) && pi.wino4_floats > 0 && out_layout == 0 && !skip && ((uintptr_t)x & 15) == 0 &&
+                       ((uintptr_t)y & 15) == 0 && (!noise || (((uintptr_t)noise & 15) == 0 && (noise_bstride & 3) == 0))) {
+                Wino4Params q;
+                float* vbuf = (float*)((char*)workspace + wl.wino_v);
+                q.v = vbuf; q.u = wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats + pi.wino_floats; q.e = e;
+                q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W;
+                q.v_bytes = (uint32_t)wino4_v_bytes(B, Cin, H, W); q.u_bytes = (uint32_t)(pi.wino4_floats * 4);
+                q.gxn = W >> 6; q.gyn = H >> 3;
+                const int ntg = q.gxn * q.gyn * B;
+                TDGP_LAUNCH("wino4_input_kernel", wino4_input_kernel, dim3((unsigned)(ntg * pi.nch4)), dim3(128), 0, s, x, styles, vbuf, B, Cin, H, W, q.gxn, q.gyn, pi.nch4);
+                // persistent grid, one block per CU; the CUs of an XCD (blocks b, b + 8, ...) take a rectangle of rs slices x rt tile groups per pass:
+                // per pass an XCD's L2 then fetches rs U slices + rt V tile groups (a V tile group = half a U slice) instead of one of each per CU
+                const int cus = tdgp_cu_count(), nxcd = (cus % 8 == 0 && cus >= 64) ? 8 : 1, per = cus / nxcd;
+                int rs = 1;
+                while (rs * 2 <= pi.nsl64 && rs * 2 <= per && (per % (rs * 2)) == 0 && 2 * (rs * 2) + per / (rs * 2) < 2 * rs + per / rs) rs *= 2;
+                q.rs = rs; q.rt = per / rs; q.nxcd = nxcd;
+                const size_t lds = (size_t)(2 * W4_STAGE + 128) * 4;
+                TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
+                TDGP_LAUNCH("conv_wino4_kernel", conv3_wino4_kernel, dim3((unsigned)(nxcd * per)), dim3(512), lds, s, q);
+            } else if (k == 3 && (g_conv_arith == 0 || g_conv_arith == 3) && wino_ok(B, Cin, Cout, H, W) && out_layout == 0 && !skip && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 &&
                        (!noise || (((uintptr_t)noise & 7) == 0 && (noise_bstride & 1) == 0))) {        // 16-byte activation loads, 8-byte noise loads / stores
                 WinoParams q;
                 q.x = x; q.u = wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats; q.styles = styles; q.e = e;

@@ -48,12 +48,18 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf1
 # Fraction of the algorithmic (direct-sum) FLOP a kernel actually executes on the matrix pipe: Winograd F(2x2,3x3) multiplies 16 times
 # per 2x2 outputs where the direct sum multiplies 36 times.  `tflops` stays the algorithmic rate; `tflops_executed` is what
 # the MFMA roofline bounds.
-EXECUTED_FRACTION = {'conv_wino_kernel': 16.0 / 36.0}
+EXECUTED_FRACTION = {'conv_wino_kernel': 16.0 / 36.0, 'conv_wino4_kernel': 36.0 / 144.0}        # F(2x2): 16 per 4 outputs; F(4x4): 36 per 16 (direct: 9 per output)
 
 
 def winograd_takes(batch, cin, cout, r):
     """Mirror of wino_ok() in 3dgp_amd/csrc/modconv.hip: which stride-1 3x3 layers the default arithmetic runs as Winograd."""
     return batch is not None and r % 32 == 0 and cin % 8 == 0 and cin >= 64 and (r // 32) * (r // 8) * batch * ((cout + 63) // 64) >= 256
+
+
+def winograd4_takes(batch, cin, cout, r):
+    """Mirror of wino4_shape_ok() in 3dgp_amd/csrc/modconv.hip: the stride-1 3x3 layers the default arithmetic runs as F(4x4,3x3)."""
+    return (batch is not None and r % 64 == 0 and cin % 4 == 0 and cin >= 128 and cout >= 128 and batch * (r // 8) * (r // 64) * ((cout + 63) // 64) >= 256 and
+            batch * (r // 8) * (r // 64) * ((cin + 3) // 4) * 18432 < 2 ** 32 - 65536)
 
 
 def algorithmic_flops(cfg, batch=None):
@@ -64,7 +70,7 @@ def algorithmic_flops(cfg, batch=None):
     the bf16 MFMA peak.  -> {kernel label: (flop per image, launches per image batch, peak TFLOP/s)}"""
     ch = cfg.channels
     r16 = cfg.fp16_resolution
-    acc = dict(conv_mfma_kernel=[0, 0], conv_wino_kernel=[0, 0], upconv_mfma_kernel=[0, 0], torgb_mfma_kernel=[0, 0], conv_bf16_kernel=[0, 0],
+    acc = dict(conv_mfma_kernel=[0, 0], conv_wino_kernel=[0, 0], conv_wino4_kernel=[0, 0], upconv_mfma_kernel=[0, 0], torgb_mfma_kernel=[0, 0], conv_bf16_kernel=[0, 0],
                upconv_bf16_kernel=[0, 0])
     for i, r in enumerate(cfg.block_resolutions):
         c = ch[r]
@@ -73,7 +79,8 @@ def algorithmic_flops(cfg, batch=None):
             k = 'upconv_bf16_kernel' if bf else 'upconv_mfma_kernel'
             acc[k][0] += 2 * ch[r // 2] * c * 9 * (r // 2) ** 2   # stride-2 transposed conv: 9 taps per INPUT pixel
             acc[k][1] += 1
-        k = 'conv_bf16_kernel' if bf else ('conv_wino_kernel' if winograd_takes(batch, c, c, r) else 'conv_mfma_kernel')
+        k = 'conv_bf16_kernel' if bf else ('conv_wino4_kernel' if winograd4_takes(batch, c, c, r) else
+                                             ('conv_wino_kernel' if winograd_takes(batch, c, c, r) else 'conv_mfma_kernel'))
         acc[k][0] += 2 * c * c * 9 * r * r                         # conv1
         acc[k][1] += 1
         acc['torgb_mfma_kernel'][0] += 2 * c * cfg.plane_channels * r * r        # ToRGB 1x1

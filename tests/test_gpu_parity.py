@@ -282,6 +282,61 @@ def test_modconv_winograd_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
     assert e_w <= 1e-5, e_w            # F(2x2,3x3) in fp32: a few ulp more than the direct sum (transforms add roundings), same order
 
 
+@pytest.mark.parametrize('B,cin,cout,H,W,kw', [
+    (16, 128, 128, 64, 64, {}),                                          # the smallest shape that takes the F(4x4) kernels: exactly 256 items, 2 slices
+    (16, 132, 200, 64, 64, dict(clamp=0.7, noise='per_sample')),         # 33 chunks (odd), Cout tail inside a 64-channel slice, clamp, per-sample noise
+    (8, 256, 128, 64, 128, dict(noise=False)),                           # two tile groups per row, H != W, no noise
+    (16, 128, 128, 64, 64, dict(styles=False)),                          # unmodulated (Conv2dLayer form)
+    (4, 512, 512, 64, 64, {}),                                           # the 64^2 x 512 layer of C3: the longest reduction the default run sums in F(4x4)
+])
+def test_modconv_winograd4_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
+    """Winograd F(4x4,3x3) (modconv_wino4.inc: input-transform pass + 36-GEMM kernel, points 0, +-1, 1/2, -2, inf) against the double-accumulating
+    oracle, next to F(2x2) (`set_conv_arith(3)`) and the direct sum (`set_conv_arith(2)`) on the same call; the profiler names which ran.
+    Bound: 1e-5 of the un-clamped output range, the bound of every reduction row (measured per layer in the parity report)."""
+    rs = np.random.RandomState(cin * 7 + cout + 1)
+    x = rs.randn(B, cin, H, W).astype(np.float32)
+    x = np.where(x > 0, x, 0.2 * x).astype(np.float32) * np.float32(np.sqrt(2))          # the layers' real input: a leaky-ReLU output (non-zero mean)
+    w = rs.randn(cout, cin, 3, 3).astype(np.float32)
+    styles = kw.get('styles', True)
+    s = (1 + 0.5 * rs.randn(B, cin)).astype(np.float32) if styles else None
+    noise = (0.3 * rs.randn(H, W)).astype(np.float32) if kw.get('noise', True) else None
+    if kw.get('noise') == 'per_sample':
+        noise = (0.3 * rs.randn(B, 1, H, W)).astype(np.float32)
+    bias = (0.2 * rs.randn(cout)).astype(np.float32)
+    clamp = kw.get('clamp')
+    oracle.set_threads(min(64, os.cpu_count() or 1))
+    ref = oracle.modulated_conv2d(x, w, s if styles else np.ones([B, cin], np.float32), noise=noise, up=1, demodulate=styles,
+                                  resample_filter=oracle.setup_filter([1, 3, 3, 1]))
+    scale = np.abs(oracle.bias_act(ref, bias, act='lrelu')).max()
+    ref = oracle.bias_act(ref, bias, act='lrelu', clamp=clamp)
+    M = tdgp.ops.modconv
+    pk = M._packed(T(w))
+    out = {}
+    for mode in (0, 3, 2):
+        prev = tdgp._lib.set_conv_arith(mode)
+        tdgp._lib.profile_enable(True)
+        try:
+            y = M.modconv_forward(T(x), pk, None if s is None else T(s), noise=None if noise is None else T(noise), bias=T(bias), demodulate=styles,
+                                  act='lrelu', clamp=clamp)
+            torch.cuda.synchronize()
+            names = set(tdgp._lib.profile_report())
+            y2 = M.modconv_forward(T(x), pk, None if s is None else T(s), noise=None if noise is None else T(noise), bias=T(bias), demodulate=styles,
+                                   act='lrelu', clamp=clamp)
+            assert torch.equal(y, y2)                                  # deterministic
+        finally:
+            tdgp._lib.profile_enable(False)
+            tdgp._lib.set_conv_arith(prev)
+        out[mode] = (N(y), names)
+    assert {'conv_wino4_kernel', 'wino4_input_kernel'} <= out[0][1] and 'conv_wino_kernel' not in out[0][1], out[0][1]
+    assert ('conv_wino_kernel' in out[3][1] or cin % 8 != 0) and 'conv_wino4_kernel' not in out[3][1], out[3][1]        # (F(2x2) needs Cin % 8 == 0)
+    assert not ({'conv_wino_kernel', 'conv_wino4_kernel'} & out[2][1]), out[2][1]
+    e4, e2, ed = (float(np.abs(out[m][0] - ref).max() / scale) for m in (0, 3, 2))
+    rms4 = float(np.sqrt(np.mean((out[0][0] - ref).astype(np.float64) ** 2)) / scale)
+    report_parity(f'winograd F(4x4) 3x3 {cin}->{cout} @{H}x{W}', f4x4_vs_oracle=e4, f4x4_rms=rms4, f2x2_vs_oracle=e2, direct_vs_oracle=ed)
+    assert ed <= 5e-6 and e2 <= 1e-5, (ed, e2)
+    assert e4 <= 1e-5, e4
+
+
 def test_fused_layers_oracle(tdgp, oracle):
     """SynthesisLayer / ToRGB+skip as single fused calls (bias, lrelu*sqrt2, x2 FIR skip, channel-last output)."""
     rs = np.random.RandomState(5)
@@ -1071,7 +1126,7 @@ def test_full_size_c3_at_bench_batches(tdgp, oracle, B):
         the searchsorted indices of the importance draws exact up to draws within an ulp of a cdf knot (<= 2 per strip, each to the
         neighbouring interval: the bound of test_e2e_tiny), fine samples 99.9 % <= 2e-6, RGB and depth <= 1e-5;
       * three repeats bit-identical;
-      * the library's profiler confirms which kernels ran: conv_wino_kernel takes 5 layers at B = 16 (incl. 32^2) and 4 at B = 4."""
+      * the library's profiler confirms which kernels ran: F(4x4) takes the 64^2 ... 256^2 layers, F(2x2) the 512^2 layer and -- at B = 16 only -- 32^2."""
     cfg = tdgp.config.config_c3()
     sd = tdgp.weights.random_state_dict(cfg, seed=0)                       # bench.py: random_state_dict(cfg, seed=0), synthetic_inputs(seed = rank_seed(0, 0, 1) = 0)
     G = tdgp.generator.Generator(cfg)
@@ -1085,9 +1140,10 @@ def test_full_size_c3_at_bench_batches(tdgp, oracle, B):
     ws = G.mapping(z, c)
     dec = G.synthesis.tri_plane_decoder
     planes, launches = _wino_launches(tdgp, lambda: dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True))
-    assert launches.get('conv_wino_kernel', 0) == (5 if B == 16 else 4), launches           # bench.winograd_takes / wino_ok (modconv.hip)
     import bench
-    assert sum(bench.winograd_takes(B, cfg.channels[r], cfg.channels[r], r) for r in cfg.block_resolutions) == launches['conv_wino_kernel']
+    w4 = [bench.winograd4_takes(B, cfg.channels[r], cfg.channels[r], r) for r in cfg.block_resolutions]            # mirrors of wino4_shape_ok / wino_ok (modconv.hip)
+    w2 = [bench.winograd_takes(B, cfg.channels[r], cfg.channels[r], r) and not f for r, f in zip(cfg.block_resolutions, w4)]
+    assert (launches.get('conv_wino4_kernel', 0), launches.get('conv_wino_kernel', 0)) == (sum(w4), sum(w2)) == ((3, 2) if B == 16 else (3, 1)), launches
     # (1) planes of sample 0 vs the oracle
     oracle.set_threads(min(64, os.cpu_count() or 1))
     ows = oracle.mapping_forward(sd, cfg.to_dict(), inp['z'][:1], inp['c'][:1])
@@ -1153,7 +1209,7 @@ def test_full_size_c3_at_bench_batches(tdgp, oracle, B):
         e_dep = float(np.abs(N(dep).reshape(B, R)[b, sel] - odep[0, :, 0]).max())
         assert e_rgb <= 1e-5 and e_dep <= 1e-5, (b, e_rgb, e_dep)
     report_parity(f'C3 at the timed batch B = {B} (bench.py inputs)', planes_range_err=e_pl, image_vs_b2_launch_range_err=worst,
-                  strip_inds_mismatches=ni_tot, strip_fine_sample_max_abs_diff=np_tot, wino_launches=launches['conv_wino_kernel'])
+                  strip_inds_mismatches=ni_tot, strip_fine_sample_max_abs_diff=np_tot, wino4_launches=launches.get('conv_wino4_kernel', 0), wino2_launches=launches.get('conv_wino_kernel', 0))
 
 
 def test_c4_backbone_at_bench_batch(tdgp, oracle):
@@ -1169,7 +1225,9 @@ def test_c4_backbone_at_bench_batch(tdgp, oracle):
     dec = G.synthesis.tri_plane_decoder
     planes, launches = _wino_launches(tdgp, lambda: dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True))
     import bench
-    assert launches.get('conv_wino_kernel', 0) == sum(bench.winograd_takes(4, cfg.channels[r], cfg.channels[r], r) for r in cfg.block_resolutions), launches
+    w4 = [bench.winograd4_takes(4, cfg.channels[r], cfg.channels[r], r) for r in cfg.block_resolutions]
+    w2 = [bench.winograd_takes(4, cfg.channels[r], cfg.channels[r], r) and not f for r, f in zip(cfg.block_resolutions, w4)]
+    assert (launches.get('conv_wino4_kernel', 0), launches.get('conv_wino_kernel', 0)) == (sum(w4), sum(w2)), launches
     for _ in range(2):
         assert torch.equal(dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True).t, planes.t)
     oracle.set_threads(min(64, os.cpu_count() or 1))
@@ -1180,7 +1238,7 @@ def test_c4_backbone_at_bench_batch(tdgp, oracle):
     for b in range(4):
         one = dec(ws[b:b + 1, :dec.num_ws], noise_mode='const', hwc=True).t
         worst = max(worst, float((one - planes.t[b:b + 1]).abs().max() / planes.t[b:b + 1].abs().max()))
-    report_parity('C4 backbone at the timed batch B = 4', planes_range_err=e_pl, planes_vs_b1_launch_range_err=worst, wino_launches=launches.get('conv_wino_kernel', 0))
+    report_parity('C4 backbone at the timed batch B = 4', planes_range_err=e_pl, planes_vs_b1_launch_range_err=worst, wino4_launches=launches.get('conv_wino4_kernel', 0), wino2_launches=launches.get('conv_wino_kernel', 0))
     assert e_pl <= 1e-5 and worst <= 1e-5, (e_pl, worst)
 
 
