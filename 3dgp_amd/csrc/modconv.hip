@@ -2379,7 +2379,7 @@ inline PackInfo pack_info(int Cout, int Cin, int k) {
     pi.nch8 = (Cin + 7) / 8;
     pi.wino_floats = k == 3 ? (int64_t)pi.nch8 * 16 * 2 * pi.CoutP * 4 : 0;          // Winograd-domain weights G g G^T (modconv_wino.inc)
     pi.nch4 = (Cin + 3) / 4; pi.nsl64 = (Cout + 63) / 64;
-    pi.wino4_floats = (k == 3 && Cin >= 128 && Cout >= 128) ? (int64_t)pi.nsl64 * pi.nch4 * (18 * 4 * 64 * 2) : 0;      // F(4x4,3x3)-domain weights (modconv_wino4.inc)
+    pi.wino4_floats = (k == 3 && Cin >= 128 && Cout >= 128) ? (int64_t)cdiv(Cout, W4_BM) * pi.nch4 * W4_UCH : 0;      // F(4x4,3x3)-domain weights (modconv_wino4.inc)
     return pi;
 }
 
@@ -2531,7 +2531,7 @@ inline int pick_tw_log2(int gridW) {
 #ifndef TDGP_WINO4_MIN_C
 #define TDGP_WINO4_MIN_C 128
 #endif
-inline int64_t wino4_v_bytes(int B, int Cin, int H, int W) { return (int64_t)B * (H >> 3) * (W >> 6) * ((Cin + 3) / 4) * (18 * 4 * 32 * 2) * 4; }
+inline int64_t wino4_v_bytes(int B, int Cin, int H, int W) { return (int64_t)B * (H >> 3) * (W >> 6) * ((Cin + 3) / 4) * (9 * 4 * 32 * 4) * 4; }
 inline bool wino4_shape_ok(int B, int Cin, int Cout, int H, int W, int k, int up) {
     return k == 3 && up == 1 && (W & 63) == 0 && (H & 7) == 0 && (Cin & 3) == 0 && Cin >= TDGP_WINO4_MIN_C && Cout >= TDGP_WINO4_MIN_C &&
            (int64_t)B * (H >> 3) * (W >> 6) * cdiv(Cout, 64) >= 256 && wino4_v_bytes(B, Cin, H, W) < ((int64_t)1 << 32) - 65536;
@@ -2591,7 +2591,7 @@ TDGP_API int tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int C
                     wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats, Cout, Cin, pi.CoutP, pi.nch8);
     if (pi.wino4_floats > 0)
         TDGP_LAUNCH("pack_kernel", pack_wino4_kernel, dim3((int)min((int64_t)4096, cdiv64(pi.wino4_floats, 256))), dim3(256), 0, (hipStream_t)stream, weight,
-                    wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats + pi.wino_floats, Cout, Cin, pi.nsl64, pi.nch4);
+                    wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats + pi.wino_floats, Cout, Cin, cdiv(Cout, W4_BM), pi.nch4);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }
@@ -2701,13 +2701,15 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 TDGP_LAUNCH("wino4_input_kernel", wino4_input_kernel, dim3((unsigned)(ntg * pi.nch4)), dim3(128), 0, s, x, styles, vbuf, B, Cin, H, W, q.gxn, q.gyn, pi.nch4);
                 // persistent grid, one block per CU; the CUs of an XCD (blocks b, b + 8, ...) take a rectangle of rs slices x rt tile groups per pass:
                 // per pass an XCD's L2 then fetches rs U slices + rt V tile groups (a V tile group = half a U slice) instead of one of each per CU
-                const int cus = tdgp_cu_count(), nxcd = (cus % 8 == 0 && cus >= 64) ? 8 : 1, per = cus / nxcd;
+                const int bpc = W4_BM == 64 ? 1 : 2;                            // resident blocks per CU
+                const int cus = tdgp_cu_count(), nxcd = (cus % 8 == 0 && cus >= 64) ? 8 : 1, per = cus / nxcd * bpc, nsl = cdiv(Cout, W4_BM);
+                // rs slices x rt tile groups per XCD and pass: bytes into the XCD's L2 per pass ~ rs * BM + rt * 32 (a slice's U chunk : a tile group's V chunk)
                 int rs = 1;
-                while (rs * 2 <= pi.nsl64 && rs * 2 <= per && (per % (rs * 2)) == 0 && 2 * (rs * 2) + per / (rs * 2) < 2 * rs + per / rs) rs *= 2;
+                while (rs * 2 <= nsl && (per % (rs * 2)) == 0 && (rs * 2) * W4_BM + per / (rs * 2) * 32 < rs * W4_BM + per / rs * 32) rs *= 2;
                 q.rs = rs; q.rt = per / rs; q.nxcd = nxcd;
-                const size_t lds = (size_t)(2 * W4_STAGE + 128) * 4;
+                const size_t lds = (size_t)(2 * W4_STAGE + 2 * W4_BM) * 4;
                 TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
-                TDGP_LAUNCH("conv_wino4_kernel", conv3_wino4_kernel, dim3((unsigned)(nxcd * per)), dim3(512), lds, s, q);
+                TDGP_LAUNCH("conv_wino4_kernel", conv3_wino4_kernel, dim3((unsigned)(nxcd * per)), dim3(W4_NW * 64), lds, s, q);
             } else if (k == 3 && (g_conv_arith == 0 || g_conv_arith == 3) && wino_ok(B, Cin, Cout, H, W) && out_layout == 0 && !skip && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 &&
                        (!noise || (((uintptr_t)noise & 7) == 0 && (noise_bstride & 1) == 0))) {        // 16-byte activation loads, 8-byte noise loads / stores
                 WinoParams q;
