@@ -2526,15 +2526,26 @@ inline int pick_tw_log2(int gridW) {
 }
 
 // F(4x4,3x3) Winograd (modconv_wino4.inc): which stride-1 3x3 layers take it -- by shape only (the workspace is sized from the same test).
-// W % 64 / H % 8: whole 8 x 64-pixel tile groups; Cin, Cout >= 128: below, the separate input-transform pass (2.25 x the input, written and
+// whole tile groups of 512 pixels (64 x 8, or 32 x 16 for the 32-pixel-wide layers); Cin, Cout >= 128: below, the separate input-transform pass (2.25 x the input, written and
 // read back) costs more than it saves; at least one item per CU; V addressed through a 4 GiB buffer descriptor.
 #ifndef TDGP_WINO4_MIN_C
 #define TDGP_WINO4_MIN_C 128
 #endif
-inline int64_t wino4_v_bytes(int B, int Cin, int H, int W) { return (int64_t)B * (H >> 3) * (W >> 6) * ((Cin + 3) / 4) * (9 * 4 * 32 * 4) * 4; }
+inline int64_t wino4_v_bytes(int B, int Cin, int H, int W) { return (int64_t)B * ((H * W) >> 9) * ((Cin + 3) / 4) * (9 * 4 * 32 * 4) * 4; }       // 512 pixels per tile group
+inline int wino4_txl(int H, int W) { return (W & 63) == 0 && (H & 7) == 0 ? 4 : ((W & 31) == 0 && (H & 15) == 0 ? 3 : 0); }
+// The batch goes through the two kernels in sub-batches whose V fits one buffer descriptor (< 4 GiB; TDGP_WINO4_VCAP_MB lowers the cap for
+// experiments): C4's 512^2 x 128 layer at B = 16 has 4.8 GB of V.  The sub-batches share one V buffer (stream order).
+#ifndef TDGP_WINO4_VCAP_MB
+#define TDGP_WINO4_VCAP_MB 4095
+#endif
+inline int wino4_sub_batch(int B, int Cin, int H, int W) {
+    const int64_t per = wino4_v_bytes(1, Cin, H, W), cap = (int64_t)TDGP_WINO4_VCAP_MB << 20;
+    return (int)std::min<int64_t>(B, cap / per);
+}
 inline bool wino4_shape_ok(int B, int Cin, int Cout, int H, int W, int k, int up) {
-    return k == 3 && up == 1 && (W & 63) == 0 && (H & 7) == 0 && (Cin & 3) == 0 && Cin >= TDGP_WINO4_MIN_C && Cout >= TDGP_WINO4_MIN_C &&
-           (int64_t)B * (H >> 3) * (W >> 6) * cdiv(Cout, 64) >= 256 && wino4_v_bytes(B, Cin, H, W) < ((int64_t)1 << 32) - 65536;
+    if (!(k == 3 && up == 1 && wino4_txl(H, W) != 0 && (Cin & 3) == 0 && Cin >= TDGP_WINO4_MIN_C && Cout >= TDGP_WINO4_MIN_C)) return false;
+    const int bs = wino4_sub_batch(B, Cin, H, W);
+    return bs >= 1 && (int64_t)bs * ((H * W) >> 9) * cdiv(Cout, 64) >= 256;
 }
 
 // Workspace layout: [demod coefficients B*Cout] [transposed-conv intermediate, up=2 only] [split-K partial sums] [Winograd-domain input V]
@@ -2560,7 +2571,7 @@ WsLayout ws_layout(int B, int Cin, int Cout, int H, int W, int k, int up) {
     if (pf > cap) pf = (cap / out_elems) * out_elems;
     w.partial_floats = pf;
     w.wino_v = w.partial + al(pf * (int64_t)sizeof(float));
-    w.total = w.wino_v + (wino4_shape_ok(B, Cin, Cout, H, W, k, up) ? al(wino4_v_bytes(B, Cin, H, W)) : 0);
+    w.total = w.wino_v + (wino4_shape_ok(B, Cin, Cout, H, W, k, up) ? al(wino4_v_bytes(wino4_sub_batch(B, Cin, H, W), Cin, H, W)) : 0);
     return w;
 }
 
@@ -2691,25 +2702,33 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 TDGP_LAUNCH("conv_mfma_kernel", conv3s_mfma_kernel, dim3((W >> 5) * cdiv(B * (H + 1), 8), cdiv(Cout, 64)), dim3(256), lds, s, q);
             } else if (g_conv_arith == 0 && wino4_shape_ok(B, Cin, Cout, H, W, k, up) && pi.wino4_floats > 0 && out_layout == 0 && !skip && ((uintptr_t)x & 15) == 0 &&
                        ((uintptr_t)y & 15) == 0 && (!noise || (((uintptr_t)noise & 15) == 0 && (noise_bstride & 3) == 0))) {
-                Wino4Params q;
                 float* vbuf = (float*)((char*)workspace + wl.wino_v);
-                q.v = vbuf; q.u = wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats + pi.wino_floats; q.e = e;
-                q.B = B; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W;
-                q.v_bytes = (uint32_t)wino4_v_bytes(B, Cin, H, W); q.u_bytes = (uint32_t)(pi.wino4_floats * 4);
-                q.gxn = W >> 6; q.gyn = H >> 3;
-                const int ntg = q.gxn * q.gyn * B;
-                TDGP_LAUNCH("wino4_input_kernel", wino4_input_kernel, dim3((unsigned)(ntg * pi.nch4)), dim3(128), 0, s, x, styles, vbuf, B, Cin, H, W, q.gxn, q.gyn, pi.nch4);
-                // persistent grid, one block per CU; the CUs of an XCD (blocks b, b + 8, ...) take a rectangle of rs slices x rt tile groups per pass:
-                // per pass an XCD's L2 then fetches rs U slices + rt V tile groups (a V tile group = half a U slice) instead of one of each per CU
+                // persistent grid; the blocks of an XCD (b, b + 8, ...) take a rectangle of rs slices x rt tile groups per pass: per pass an XCD's L2 then
+                // fetches rs U slices + rt V tile groups instead of one of each per block (bytes ~ rs * BM + rt * 32: a slice's U chunk : a tile group's V chunk)
                 const int bpc = W4_BM == 64 ? 1 : 2;                            // resident blocks per CU
                 const int cus = tdgp_cu_count(), nxcd = (cus % 8 == 0 && cus >= 64) ? 8 : 1, per = cus / nxcd * bpc, nsl = cdiv(Cout, W4_BM);
-                // rs slices x rt tile groups per XCD and pass: bytes into the XCD's L2 per pass ~ rs * BM + rt * 32 (a slice's U chunk : a tile group's V chunk)
                 int rs = 1;
                 while (rs * 2 <= nsl && (per % (rs * 2)) == 0 && (rs * 2) * W4_BM + per / (rs * 2) * 32 < rs * W4_BM + per / rs * 32) rs *= 2;
-                q.rs = rs; q.rt = per / rs; q.nxcd = nxcd;
                 const size_t lds = (size_t)(2 * W4_STAGE + 2 * W4_BM) * 4;
                 TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
-                TDGP_LAUNCH("conv_wino4_kernel", conv3_wino4_kernel, dim3((unsigned)(nxcd * per)), dim3(W4_NW * 64), lds, s, q);
+                const int bsub = wino4_sub_batch(B, Cin, H, W);
+                for (int b0 = 0; b0 < B; b0 += bsub) {
+                    const int bn = std::min(bsub, B - b0);
+                    Wino4Params q;
+                    q.v = vbuf; q.u = wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats + pi.wino_floats; q.e = e;
+                    q.e.y = y + (int64_t)b0 * Cout * H * W;
+                    if (e.dcoef) q.e.dcoef = e.dcoef + (int64_t)b0 * Cout;
+                    if (e.noise) q.e.noise = e.noise + (int64_t)b0 * noise_bstride;
+                    q.e.B = bn;
+                    q.B = bn; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W;
+                    q.v_bytes = (uint32_t)wino4_v_bytes(bn, Cin, H, W); q.u_bytes = (uint32_t)(pi.wino4_floats * 4);
+                    q.txl = wino4_txl(H, W); q.gxn = W / (4 << q.txl); q.gyn = H / (128 >> q.txl);
+                    q.rs = rs; q.rt = per / rs; q.nxcd = nxcd;
+                    const int ntg = q.gxn * q.gyn * bn;
+                    TDGP_LAUNCH("wino4_input_kernel", wino4_input_kernel, dim3((unsigned)(ntg * pi.nch4)), dim3(128), 0, s, x + (int64_t)b0 * Cin * H * W,
+                                styles ? styles + (int64_t)b0 * Cin : nullptr, vbuf, bn, Cin, H, W, q.gxn, q.gyn, pi.nch4, q.txl);
+                    TDGP_LAUNCH("conv_wino4_kernel", conv3_wino4_kernel, dim3((unsigned)(nxcd * per)), dim3(W4_NW * 64), lds, s, q);
+                }
             } else if (k == 3 && (g_conv_arith == 0 || g_conv_arith == 3) && wino_ok(B, Cin, Cout, H, W) && out_layout == 0 && !skip && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 &&
                        (!noise || (((uintptr_t)noise & 7) == 0 && (noise_bstride & 1) == 0))) {        // 16-byte activation loads, 8-byte noise loads / stores
                 WinoParams q;

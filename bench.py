@@ -58,8 +58,11 @@ def winograd_takes(batch, cin, cout, r):
 
 def winograd4_takes(batch, cin, cout, r):
     """Mirror of wino4_shape_ok() in 3dgp_amd/csrc/modconv.hip: the stride-1 3x3 layers the default arithmetic runs as F(4x4,3x3)."""
-    return (batch is not None and r % 64 == 0 and cin % 4 == 0 and cin >= 128 and cout >= 128 and batch * (r // 8) * (r // 64) * ((cout + 63) // 64) >= 256 and
-            batch * (r // 8) * (r // 64) * ((cin + 3) // 4) * 18432 < 2 ** 32 - 65536)
+    if batch is None or not (r % 32 == 0 and cin % 4 == 0 and cin >= 128 and cout >= 128):
+        return False
+    per_sample = (r * r // 512) * ((cin + 3) // 4) * 18432           # bytes of Winograd-domain input per sample
+    sub = min(batch, (4095 << 20) // per_sample)                     # sub-batch whose V fits one buffer descriptor
+    return sub >= 1 and sub * (r * r // 512) * ((cout + 63) // 64) >= 256
 
 
 def algorithmic_flops(cfg, batch=None):
