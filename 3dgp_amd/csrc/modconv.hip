@@ -2379,7 +2379,7 @@ inline PackInfo pack_info(int Cout, int Cin, int k) {
     pi.nch8 = (Cin + 7) / 8;
     pi.wino_floats = k == 3 ? (int64_t)pi.nch8 * 16 * 2 * pi.CoutP * 4 : 0;          // Winograd-domain weights G g G^T (modconv_wino.inc)
     pi.nch4 = (Cin + 3) / 4; pi.nsl64 = (Cout + 63) / 64;
-    pi.wino4_floats = (k == 3 && Cin >= 128 && Cout >= 128) ? (int64_t)cdiv(Cout, W4_BM) * pi.nch4 * W4_UCH : 0;      // F(4x4,3x3)-domain weights (modconv_wino4.inc)
+    pi.wino4_floats = (k == 3 && Cin >= TDGP_WINO4_MIN_C && Cout >= TDGP_WINO4_MIN_C) ? (int64_t)cdiv(Cout, W4_BM) * pi.nch4 * W4_UCH : 0;      // F(4x4,3x3)-domain weights (modconv_wino4.inc)
     return pi;
 }
 
@@ -2528,9 +2528,6 @@ inline int pick_tw_log2(int gridW) {
 // F(4x4,3x3) Winograd (modconv_wino4.inc): which stride-1 3x3 layers take it -- by shape only (the workspace is sized from the same test).
 // whole tile groups of 512 pixels (64 x 8, or 32 x 16 for the 32-pixel-wide layers); Cin, Cout >= 128: below, the separate input-transform pass (2.25 x the input, written and
 // read back) costs more than it saves; at least one item per CU; V addressed through a 4 GiB buffer descriptor.
-#ifndef TDGP_WINO4_MIN_C
-#define TDGP_WINO4_MIN_C 128
-#endif
 inline int64_t wino4_v_bytes(int B, int Cin, int H, int W) { return (int64_t)B * ((H * W) >> 9) * ((Cin + 3) / 4) * (9 * 4 * 32 * 4) * 4; }       // 512 pixels per tile group
 inline int wino4_txl(int H, int W) { return (W & 63) == 0 && (H & 7) == 0 ? 4 : ((W & 31) == 0 && (H & 15) == 0 ? 3 : 0); }
 // The batch goes through the two kernels in sub-batches whose V fits one buffer descriptor (< 4 GiB; TDGP_WINO4_VCAP_MB lowers the cap for
@@ -2538,14 +2535,25 @@ inline int wino4_txl(int H, int W) { return (W & 63) == 0 && (H & 7) == 0 ? 4 : 
 #ifndef TDGP_WINO4_VCAP_MB
 #define TDGP_WINO4_VCAP_MB 4095
 #endif
-inline int wino4_sub_batch(int B, int Cin, int H, int W) {
-    const int64_t per = wino4_v_bytes(1, Cin, H, W), cap = (int64_t)TDGP_WINO4_VCAP_MB << 20;
-    return (int)std::min<int64_t>(B, cap / per);
+// Layers with few channels move 2.25 x their input through V for little arithmetic: there a sub-batch whose V stays inside the 256 MB
+// Infinity Cache between the two kernels (TDGP_WINO4_VSMALL_MB) beats one big launch (measured B = 16: 512^2 x 64 1.75 -> 1.63 ms,
+// 256^2 x 128 1.18 -> 1.12 ms; 128^2 x 256 0.93 -> 1.03 ms -- hence Cin <= 128 only).
+#ifndef TDGP_WINO4_VSMALL_MB
+#define TDGP_WINO4_VSMALL_MB 192
+#endif
+inline int64_t wino4_items(int bs, int Cout, int H, int W) { return (int64_t)bs * ((H * W) >> 9) * cdiv(Cout, 64); }
+inline int wino4_sub_batch(int B, int Cin, int Cout, int H, int W) {
+    const int64_t per = wino4_v_bytes(1, Cin, H, W);
+    if (Cin <= 128 && TDGP_WINO4_VSMALL_MB > 0) {
+        const int bs = (int)std::min<int64_t>(B, ((int64_t)TDGP_WINO4_VSMALL_MB << 20) / per);
+        if (bs >= 1 && wino4_items(bs, Cout, H, W) >= 256) return bs;
+    }
+    return (int)std::min<int64_t>(B, ((int64_t)TDGP_WINO4_VCAP_MB << 20) / per);
 }
 inline bool wino4_shape_ok(int B, int Cin, int Cout, int H, int W, int k, int up) {
     if (!(k == 3 && up == 1 && wino4_txl(H, W) != 0 && (Cin & 3) == 0 && Cin >= TDGP_WINO4_MIN_C && Cout >= TDGP_WINO4_MIN_C)) return false;
-    const int bs = wino4_sub_batch(B, Cin, H, W);
-    return bs >= 1 && (int64_t)bs * ((H * W) >> 9) * cdiv(Cout, 64) >= 256;
+    const int bs = wino4_sub_batch(B, Cin, Cout, H, W);
+    return bs >= 1 && wino4_items(bs, Cout, H, W) >= 256;
 }
 
 // Workspace layout: [demod coefficients B*Cout] [transposed-conv intermediate, up=2 only] [split-K partial sums] [Winograd-domain input V]
@@ -2571,7 +2579,7 @@ WsLayout ws_layout(int B, int Cin, int Cout, int H, int W, int k, int up) {
     if (pf > cap) pf = (cap / out_elems) * out_elems;
     w.partial_floats = pf;
     w.wino_v = w.partial + al(pf * (int64_t)sizeof(float));
-    w.total = w.wino_v + (wino4_shape_ok(B, Cin, Cout, H, W, k, up) ? al(wino4_v_bytes(wino4_sub_batch(B, Cin, H, W), Cin, H, W)) : 0);
+    w.total = w.wino_v + (wino4_shape_ok(B, Cin, Cout, H, W, k, up) ? al(wino4_v_bytes(wino4_sub_batch(B, Cin, Cout, H, W), Cin, H, W)) : 0);
     return w;
 }
 
@@ -2711,7 +2719,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 while (rs * 2 <= nsl && (per % (rs * 2)) == 0 && (rs * 2) * W4_BM + per / (rs * 2) * 32 < rs * W4_BM + per / rs * 32) rs *= 2;
                 const size_t lds = (size_t)(2 * W4_STAGE + 2 * W4_BM) * 4;
                 TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
-                const int bsub = wino4_sub_batch(B, Cin, H, W);
+                const int bsub = wino4_sub_batch(B, Cin, Cout, H, W);
                 for (int b0 = 0; b0 < B; b0 += bsub) {
                     const int bn = std::min(bsub, B - b0);
                     Wino4Params q;

@@ -58,11 +58,16 @@ def winograd_takes(batch, cin, cout, r):
 
 def winograd4_takes(batch, cin, cout, r):
     """Mirror of wino4_shape_ok() in 3dgp_amd/csrc/modconv.hip: the stride-1 3x3 layers the default arithmetic runs as F(4x4,3x3)."""
-    if batch is None or not (r % 32 == 0 and cin % 4 == 0 and cin >= 128 and cout >= 128):
+    if batch is None or not (r % 32 == 0 and cin % 4 == 0 and cin >= 64 and cout >= 64):
         return False
     per_sample = (r * r // 512) * ((cin + 3) // 4) * 18432           # bytes of Winograd-domain input per sample
+    items = lambda bs: bs * (r * r // 512) * ((cout + 63) // 64)     # noqa: E731
+    if cin <= 128:                                                   # few channels: sub-batches whose V stays inside the Infinity Cache
+        sub = min(batch, (192 << 20) // per_sample)
+        if sub >= 1 and items(sub) >= 256:
+            return True
     sub = min(batch, (4095 << 20) // per_sample)                     # sub-batch whose V fits one buffer descriptor
-    return sub >= 1 and sub * (r * r // 512) * ((cout + 63) // 64) >= 256
+    return sub >= 1 and items(sub) >= 256
 
 
 def algorithmic_flops(cfg, batch=None):

@@ -262,7 +262,7 @@ def test_modconv_winograd_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
     M = tdgp.ops.modconv
     pk = M._packed(T(w))
     out = {}
-    for mode in (0, 2):
+    for mode in (3, 2):                 # 3: the default arithmetic without F(4x4) (which takes the larger layers since round 4)
         prev = tdgp._lib.set_conv_arith(mode)
         tdgp._lib.profile_enable(True)
         try:
@@ -274,10 +274,10 @@ def test_modconv_winograd_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
             tdgp._lib.profile_enable(False)
             tdgp._lib.set_conv_arith(prev)
         out[mode] = (N(y), names)
-    assert 'conv_wino_kernel' in out[0][1] and 'conv_wino_kernel' not in out[2][1], (out[0][1], out[2][1])
-    e_w, e_d = np.abs(out[0][0] - ref).max() / scale, np.abs(out[2][0] - ref).max() / scale
+    assert 'conv_wino_kernel' in out[3][1] and 'conv_wino_kernel' not in out[2][1], (out[3][1], out[2][1])
+    e_w, e_d = np.abs(out[3][0] - ref).max() / scale, np.abs(out[2][0] - ref).max() / scale
     report_parity(f'winograd 3x3 {cin}->{cout} @{H}x{W}', winograd_vs_oracle=e_w, direct_vs_oracle=e_d,
-                  winograd_vs_direct=np.abs(out[0][0] - out[2][0]).max() / scale)
+                  winograd_vs_direct=np.abs(out[3][0] - out[2][0]).max() / scale)
     assert e_d <= 5e-6, e_d
     assert e_w <= 1e-5, e_w            # F(2x2,3x3) in fp32: a few ulp more than the direct sum (transforms add roundings), same order
 
@@ -288,6 +288,7 @@ def test_modconv_winograd_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
     (8, 256, 128, 64, 128, dict(noise=False)),                           # two tile groups per row, H != W, no noise
     (16, 128, 128, 64, 64, dict(styles=False)),                          # unmodulated (Conv2dLayer form)
     (4, 512, 512, 64, 64, {}),                                           # the 64^2 x 512 layer of C3: the longest reduction the default run sums in F(4x4)
+    (4, 64, 64, 256, 256, dict(clamp=0.8)),                              # the fewest channels F(4x4) takes (C3's 512^2 x 64 layer shape at a quarter of the area)
     (16, 256, 512, 32, 32, dict(noise='per_sample')),                    # 32-pixel-wide layers: tile groups of 8 x 4 tiles (32 x 16 pixels); 256 items
     (32, 128, 192, 48, 32, {}),                                          # ... with H a multiple of 16 only, three 64-channel slices
 ])
@@ -1159,7 +1160,7 @@ def test_full_size_c3_at_bench_batches(tdgp, oracle, B):
         the searchsorted indices of the importance draws exact up to draws within an ulp of a cdf knot (<= 8 of 49 152 per strip, each to the
         neighbouring interval; measured 0-3), fine samples 99.9 % <= 2e-6, RGB and depth <= 1e-5;
       * three repeats bit-identical;
-      * the library's profiler confirms which kernels ran: F(4x4) takes the 64^2 ... 256^2 layers (and 32^2 at B = 16), F(2x2) the 512^2 layer."""
+      * the library's profiler confirms which kernels ran: F(4x4) takes the 64^2 ... 512^2 layers (and 32^2 at B = 16)."""
     cfg = tdgp.config.config_c3()
     sd = tdgp.weights.random_state_dict(cfg, seed=0)                       # bench.py: random_state_dict(cfg, seed=0), synthetic_inputs(seed = rank_seed(0, 0, 1) = 0)
     G = tdgp.generator.Generator(cfg)
@@ -1176,7 +1177,9 @@ def test_full_size_c3_at_bench_batches(tdgp, oracle, B):
     import bench
     w4 = [bench.winograd4_takes(B, cfg.channels[r], cfg.channels[r], r) for r in cfg.block_resolutions]            # mirrors of wino4_shape_ok / wino_ok (modconv.hip)
     w2 = [bench.winograd_takes(B, cfg.channels[r], cfg.channels[r], r) and not f for r, f in zip(cfg.block_resolutions, w4)]
-    assert (launches.get('conv_wino4_kernel', 0), launches.get('conv_wino_kernel', 0)) == (sum(w4), sum(w2)) == ((4, 1) if B == 16 else (3, 1)), launches
+    # (a layer with few channels goes through the F(4x4) kernels in sub-batches: at least one launch per layer)
+    assert launches.get('conv_wino4_kernel', 0) >= sum(w4) == (5 if B == 16 else 4) and launches.get('conv_wino_kernel', 0) == sum(w2) == 0, launches
+    assert launches.get('conv_mfma_kernel', 0) == len(cfg.block_resolutions) - sum(w4), launches                    # the remaining stride-1 3x3 layers: direct sums
     # (1) planes of sample 0 vs the oracle
     oracle.set_threads(min(64, os.cpu_count() or 1))
     ows = oracle.mapping_forward(sd, cfg.to_dict(), inp['z'][:1], inp['c'][:1])
@@ -1262,7 +1265,7 @@ def test_c4_backbone_at_bench_batch(tdgp, oracle):
     import bench
     w4 = [bench.winograd4_takes(4, cfg.channels[r], cfg.channels[r], r) for r in cfg.block_resolutions]
     w2 = [bench.winograd_takes(4, cfg.channels[r], cfg.channels[r], r) and not f for r, f in zip(cfg.block_resolutions, w4)]
-    assert (launches.get('conv_wino4_kernel', 0), launches.get('conv_wino_kernel', 0)) == (sum(w4), sum(w2)), launches
+    assert launches.get('conv_wino4_kernel', 0) >= sum(w4) and launches.get('conv_wino_kernel', 0) == sum(w2), launches
     for _ in range(2):
         assert torch.equal(dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True).t, planes.t)
     oracle.set_threads(min(64, os.cpu_count() or 1))
