@@ -9,3 +9,5 @@ for c in c5 c4 c1 c2; do
   timeout 400 python bench.py --config $c --no-cpu-baseline --steps 10 --warmup 3 2>/dev/null | tail -1 > gpurun_out/$TAG/${c}_bench.json
   python -c "import json; d=json.load(open('gpurun_out/$TAG/${c}_bench.json')); print('$c', d['value'], d['ms_per_step'], d['config'].get('batch_per_gpu'))"
 done
+timeout 600 python bench.py --fid-loop --no-cpu-baseline --steps 24 --warmup 3 --other-batches "" 2>/dev/null | tail -1 > gpurun_out/$TAG/fid_bench.json
+python -c "import json; d=json.load(open('gpurun_out/$TAG/fid_bench.json')); f=d['fid_loop']; print('fid', d['value'], f['value'], f['batch_gen'], {k: v['value'] for k, v in f['other_batch_gen'].items()})"
