@@ -2652,8 +2652,15 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
     TDGP_CHECK(!skip || (up == 1 && k == 1 && fir4x4 && (H % 2) == 0 && (W % 2) == 0), TDGP_EINVAL, "modconv2d: skip needs k=1, up=1, even H/W and the filter");
     TDGP_CHECK(!demodulate || styles, TDGP_EINVAL, "modconv2d: demodulate needs styles");
     TDGP_CHECK(act >= 1 && act <= 9, TDGP_EUNSUPPORTED, "modconv2d: unknown activation %d", act);
-    TDGP_CHECK(out_layout == 0 || (out_layout == 1 && out_feat >= 4 && (out_feat % 4) == 0 && (Cout % out_feat) == 0 && up == 1 && k == 1), TDGP_EINVAL,
+    TDGP_CHECK(out_layout == 0 || out_layout == 2 || (out_layout == 1 && out_feat >= 4 && (out_feat % 4) == 0 && (Cout % out_feat) == 0 && up == 1 && k == 1), TDGP_EINVAL,
                "modconv2d: the channel-last plane layout is a ToRGB (k=1, up=1) output");
+    // out_layout 2: the x2 layers with the FIR folded into four 3x3 parity kernels (Cout = 4 x the real channels, channel 4 o + 2 py + px;
+    // y is [B, Cout / 4, 2H, 2W], noise a 2H x 2W map, bias / dcoef_in replicated per parity by the caller).  Only the F(4x4) kernels write it.
+    TDGP_CHECK(out_layout != 2 || (k == 3 && up == 1 && (Cout & 3) == 0 && !skip && (!demodulate || dcoef_in)), TDGP_EINVAL,
+               "modconv2d: out_layout 2 (folded x2 layer) needs k=3, up=1, Cout %% 4 == 0, no skip and precomputed demodulation coefficients");
+    TDGP_CHECK(out_layout != 2 || (g_conv_arith == 0 && wino4_shape_ok(B, Cin, Cout, H, W, k, up) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+                                   (!noise || (((uintptr_t)noise & 15) == 0 && (noise_bstride & 3) == 0))), TDGP_EUNSUPPORTED,
+               "modconv2d: out_layout 2 is written by the Winograd F(4x4) kernels only (shape %dx%d, %d -> %d channels, batch %d does not take them)", H, W, Cin, Cout, B);
     TDGP_CHECK((int64_t)B * Cin * H * W < ((int64_t)1 << 30) && (int64_t)B * Cout * (H * up + 1) * (W * up + 1) <= INT32_MAX, TDGP_EINVAL,
                "modconv2d: tensor too large (activations are addressed through 4 GiB buffer descriptors)");
     const WsLayout wl = ws_layout(B, Cin, Cout, H, W, k, up);
@@ -2708,7 +2715,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 const size_t lds = (size_t)(2 * 3 * 3 * 64 * 32 + 3 * 10 * 34 * 32 + 5 * 64 * 4 + 2 * Cin * 4);
                 TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds - 2 * Cin * 4 + 2 * 2048 * 4)););
                 TDGP_LAUNCH("conv_mfma_kernel", conv3s_mfma_kernel, dim3((W >> 5) * cdiv(B * (H + 1), 8), cdiv(Cout, 64)), dim3(256), lds, s, q);
-            } else if (g_conv_arith == 0 && wino4_shape_ok(B, Cin, Cout, H, W, k, up) && pi.wino4_floats > 0 && out_layout == 0 && !skip && ((uintptr_t)x & 15) == 0 &&
+            } else if (g_conv_arith == 0 && wino4_shape_ok(B, Cin, Cout, H, W, k, up) && pi.wino4_floats > 0 && (out_layout == 0 || out_layout == 2) && !skip && ((uintptr_t)x & 15) == 0 &&
                        ((uintptr_t)y & 15) == 0 && (!noise || (((uintptr_t)noise & 15) == 0 && (noise_bstride & 3) == 0))) {
                 float* vbuf = (float*)((char*)workspace + wl.wino_v);
                 // persistent grid; the blocks of an XCD (b, b + 8, ...) take a rectangle of rs slices x rt tile groups per pass: per pass an XCD's L2 then
@@ -2718,13 +2725,14 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 int rs = 1;
                 while (rs * 2 <= nsl && (per % (rs * 2)) == 0 && (rs * 2) * W4_BM + per / (rs * 2) * 32 < rs * W4_BM + per / rs * 32) rs *= 2;
                 const size_t lds = (size_t)(2 * W4_STAGE + 2 * W4_BM) * 4;
-                TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3_wino4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
+                TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3_wino4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipFuncSetAttribute((const void*)conv3_wino4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
                 const int bsub = wino4_sub_batch(B, Cin, Cout, H, W);
                 for (int b0 = 0; b0 < B; b0 += bsub) {
                     const int bn = std::min(bsub, B - b0);
                     Wino4Params q;
                     q.v = vbuf; q.u = wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats + pi.wino_floats; q.e = e;
-                    q.e.y = y + (int64_t)b0 * Cout * H * W;
+                    q.e.y = y + (int64_t)b0 * Cout * H * W;                        // (out_layout 2: Cout / 4 channels of 4 H W pixels -- the same count)
+                    q.ups = out_layout == 2 ? 1 : 0;
                     if (e.dcoef) q.e.dcoef = e.dcoef + (int64_t)b0 * Cout;
                     if (e.noise) q.e.noise = e.noise + (int64_t)b0 * noise_bstride;
                     q.e.B = bn;
@@ -2735,7 +2743,8 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                     const int ntg = q.gxn * q.gyn * bn;
                     TDGP_LAUNCH("wino4_input_kernel", wino4_input_kernel, dim3((unsigned)(ntg * pi.nch4)), dim3(128), 0, s, x + (int64_t)b0 * Cin * H * W,
                                 styles ? styles + (int64_t)b0 * Cin : nullptr, vbuf, bn, Cin, H, W, q.gxn, q.gyn, pi.nch4, q.txl);
-                    TDGP_LAUNCH("conv_wino4_kernel", conv3_wino4_kernel, dim3((unsigned)(nxcd * per)), dim3(W4_NW * 64), lds, s, q);
+                    if (q.ups) TDGP_LAUNCH("upconv_wino4_kernel", conv3_wino4_kernel<true>, dim3((unsigned)(nxcd * per)), dim3(W4_NW * 64), lds, s, q);
+                    else TDGP_LAUNCH("conv_wino4_kernel", conv3_wino4_kernel<false>, dim3((unsigned)(nxcd * per)), dim3(W4_NW * 64), lds, s, q);
                 }
             } else if (k == 3 && (g_conv_arith == 0 || g_conv_arith == 3) && wino_ok(B, Cin, Cout, H, W) && out_layout == 0 && !skip && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 &&
                        (!noise || (((uintptr_t)noise & 7) == 0 && (noise_bstride & 1) == 0))) {        // 16-byte activation loads, 8-byte noise loads / stores

@@ -431,7 +431,10 @@ class SynthesisBlocksSequence(torch.nn.Module):
                          dcoefs=[cut(t) for t in dcoefs[d_idx:d_idx + blk.num_conv]], hwc_feat=feat, side_stream=self._side(ws), **block_kwargs)
         return x, img
 
-    overlap_torgb = True         # ToRGB layers on a second stream beside the next block's x2 layer (measured r03: B = 16 +0.5 %, B = 4 +2.8 %; same bits)
+    # ToRGB layers on a second stream beside the next block's x2 layer: r03 +0.5 % (B = 16) / +2.8 % (B = 4) next to the transposed-convolution
+    # kernels; since the x2 layers run on the persistent F(4x4) grid (round 4) a concurrent kernel takes resident-block slots from a grid whose
+    # work is dealt statically -- measured -6 % -- so the default is off (TDGP_OVERLAP_TORGB=1 / the attribute switch it on; same bits either way)
+    overlap_torgb = __import__('os').environ.get('TDGP_OVERLAP_TORGB', '0') != '0'
 
     def _side(self, t):
         """The stream the ToRGB layers run on, per DEVICE and outside the module: a `torch.cuda.Stream` in `__dict__` would make the

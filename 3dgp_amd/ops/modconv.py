@@ -49,11 +49,33 @@ def fir_host_array(resample_filter):
     return (ctypes.c_float * 16)(*f.reshape(-1).tolist())
 
 
+def fold_up2_table(fir4x4):
+    """P[py, px, i, j, a, e] with  y[2A + py, 2B + px] = sum_{i,j in {-1,0,1}} x[A + i, B + j] * sum_{a,e} P[py,px,i+1,j+1,a,e] * w[a,e]
+    for the x2 layer of conv2d_resample.py:108-125 with flip_weight=False (networks_stylegan2.py:138): z[2m + a, 2n + e] += x[m,n] w[a,e]
+    (conv_transpose2d, stride 2, no padding), then y[Y,X] = 4 sum_{ky,kx} F[ky,kx] z[Y + ky - 1, X + kx - 1] with F = the flipped filter
+    (upfirdn2d, padding 1, gain up^2).  With Y = 2A + py, m = A + i:  a = py + ky - 1 - 2i, i.e. ky = a + 1 + 2i - py (and the same along x).
+    Every output parity is a 3x3 'same' correlation of x -- four stride-1 layers sharing one input, which is what the F(4x4) kernels run."""
+    f = np.asarray(fir4x4, np.float64).reshape(4, 4)[::-1, ::-1]          # upfirdn2d without flip_filter convolves: taps = flipped f
+    P = np.zeros((2, 2, 3, 3, 3, 3))
+    for py in range(2):
+        for px in range(2):
+            for i in (-1, 0, 1):
+                for j in (-1, 0, 1):
+                    for a in range(3):
+                        for e in range(3):
+                            ky, kx = a + 1 + 2 * i - py, e + 1 + 2 * j - px
+                            if 0 <= ky < 4 and 0 <= kx < 4:
+                                P[py, px, i + 1, j + 1, a, e] = 4.0 * f[ky, kx]
+    return P
+
+
 class PackedConv:
     """Weights of one conv layer packed for the MFMA kernel (done once; weights are static at inference)."""
 
-    def __init__(self, weight):
+    def __init__(self, weight, wsq_from=None):
         _lib.require_cuda(weight, 'weight')
+        self.weight = weight                  # the tensor this pack was made from (folded x2 form below; kept alive by the cache entry anyway)
+        self._folded = {}
         cout, cin, kh, kw = weight.shape
         if kh != kw or kh not in (1, 3, 5):
             raise NotImplementedError(f'modulated_conv2d: {kh}x{kw} kernels are not on the generator path (1x1 / 3x3 / 5x5)')
@@ -63,6 +85,38 @@ class PackedConv:
         w = _lib.f32c(weight.detach())
         with torch.cuda.device(weight.device):
             _lib.call('tdgp_modconv_pack', w.data_ptr(), self.buf.data_ptr(), self.cout, self.cin, self.k, _lib.stream_of(w))
+        if wsq_from is not None:
+            # folded x2 weights: the demodulation sums are those of the ORIGINAL 3x3 weights (networks_stylegan2.py:62), one copy per parity
+            off = int(_lib.load().tdgp_modconv_wsq_offset(self.cout, self.cin, self.k)) // 4          # bytes -> floats
+            coutp = (self.cout + 3) // 4 * 4
+            src_off = int(_lib.load().tdgp_modconv_wsq_offset(wsq_from.cout, wsq_from.cin, wsq_from.k)) // 4
+            src_p = (wsq_from.cout + 3) // 4 * 4
+            src = wsq_from.buf[src_off:src_off + self.cin * src_p].view(self.cin, src_p)[:, :wsq_from.cout]
+            self.buf[off:off + self.cin * coutp].view(self.cin, coutp)[:, :self.cout] = src.repeat_interleave(4, dim=1)
+
+    def folded_up2(self, fir4x4_host):
+        """The x2 form of this 3x3 layer as four parity kernels (fold_up2_table): PackedConv of [4 Cout, Cin, 3, 3], channel 4 o + 2 py + px."""
+        key = bytes(fir4x4_host)
+        hit = self._folded.get(key)
+        if hit is None:
+            P = torch.as_tensor(fold_up2_table(np.frombuffer(key, np.float32)), device=self.weight.device)
+            w64 = self.weight.detach().double()
+            weff = torch.einsum('pqijab,ocab->opqcij', P, w64).reshape(4 * self.cout, self.cin, 3, 3).float().contiguous()
+            hit = self._folded[key] = PackedConv(weff, wsq_from=self)
+        return hit
+
+
+import os as _os
+FOLD_UP2 = _os.environ.get('TDGP_FOLD_UP2', '1') != '0'       # module switch for A/B runs and tests: False keeps every x2 layer on the transposed-convolution + FIR kernels
+
+
+def demod_coefficients(packed, styles):
+    """d[b,o] = rsqrt(sum_c s[b,c]^2 wsq[c,o] + 1e-8) (networks_stylegan2.py:62) from the pack's own sums, through the library's kernel."""
+    B = styles.shape[0]
+    lib = _lib.load()
+    coutp = (packed.cout + 3) // 4 * 4
+    meta = torch.tensor([[wsq_address(packed), 0, packed.cin, packed.cout, coutp, 0]], dtype=torch.int64, device=styles.device)
+    return demod_batch(_lib.f32c(styles).reshape(-1), meta, B * packed.cout, B, packed.cout).view(B, packed.cout)
 
 
 def _packed(weight):
@@ -104,6 +158,25 @@ def modconv_forward(x, packed, styles, noise=None, bias=None, up=1, demodulate=T
         skip = _lib.f32c(skip)
     cout = packed.cout
     lib = _lib.load()
+    if up == 2 and packed.k == 3 and not bf16 and fir is not None and skip is None and out_layout == 0 and FOLD_UP2 and cin >= 64 and H * W >= 512:
+        # x2 layer: FIR folded into four parity kernels on the Winograd F(4x4) path (csrc/modconv_wino4.inc) when the C side takes the shape;
+        # otherwise (TDGP_EUNSUPPORTED, nothing launched) the transposed-convolution + FIR kernels below
+        pk2 = packed.folded_up2(fir)
+        rep = lambda t: None if t is None else t.repeat_interleave(4, dim=-1).contiguous()      # noqa: E731   per-parity copies of [.., Cout] vectors
+        if demodulate and dcoef is None:
+            dcoef = demod_coefficients(packed, styles)
+        ws2 = lib.tdgp_modconv2d_workspace_bytes(B, cin, 4 * cout, H, W, 3, 1)
+        wsb = torch.empty(max(ws2, 4) // 4, dtype=torch.float32, device=x.device)
+        y = torch.empty([B, cout, 2 * H, 2 * W], dtype=torch.float32, device=x.device)
+        d4, b4 = (rep(dcoef) if demodulate else None), rep(bias)      # named: a temporary inside the argument list is freed (and its block re-used) before the call
+        try:
+            with torch.cuda.device(x.device):
+                _lib.call('tdgp_modconv2d', x.data_ptr(), pk2.buf.data_ptr(), _lib.ptr(styles), _lib.ptr(d4), _lib.ptr(noise), nbs,
+                          _lib.ptr(b4), None, None, y.data_ptr(), B, cin, 4 * cout, H, W, 3, 1, int(bool(demodulate)), spec.cuda_idx, alpha, gain, clamp,
+                          2, 0, wsb.data_ptr(), ws2, _lib.stream_of(x))
+            return y
+        except _lib.Unsupported:
+            del y, wsb
     ws_bytes = lib.tdgp_modconv2d_workspace_bytes(B, cin, cout, H, W, packed.k, up)
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=x.device)
     if bf16:

@@ -78,13 +78,16 @@ def algorithmic_flops(cfg, batch=None):
     the bf16 MFMA peak.  -> {kernel label: (flop per image, launches per image batch, peak TFLOP/s)}"""
     ch = cfg.channels
     r16 = cfg.fp16_resolution
-    acc = dict(conv_mfma_kernel=[0, 0], conv_wino_kernel=[0, 0], conv_wino4_kernel=[0, 0], upconv_mfma_kernel=[0, 0], torgb_mfma_kernel=[0, 0], conv_bf16_kernel=[0, 0],
+    acc = dict(conv_mfma_kernel=[0, 0], conv_wino_kernel=[0, 0], conv_wino4_kernel=[0, 0], upconv_wino4_kernel=[0, 0], upconv_mfma_kernel=[0, 0], torgb_mfma_kernel=[0, 0], conv_bf16_kernel=[0, 0],
                upconv_bf16_kernel=[0, 0])
     for i, r in enumerate(cfg.block_resolutions):
         c = ch[r]
         bf = r16 is not None and r >= r16
         if i > 0:
-            k = 'upconv_bf16_kernel' if bf else 'upconv_mfma_kernel'
+            # fp32 x2 layers: FIR folded into four parity kernels on the F(4x4) path where the library takes the shape (ops/modconv.py); the four
+            # 3x3 parity convolutions execute 4 x 36/16 = 9 multiplies per input pixel -- exactly the algorithmic count of the transposed convolution
+            folded = (not bf) and ch[r // 2] >= 64 and (r // 2) ** 2 >= 512 and winograd4_takes(batch, ch[r // 2], 4 * c, r // 2)
+            k = 'upconv_bf16_kernel' if bf else ('upconv_wino4_kernel' if folded else 'upconv_mfma_kernel')
             acc[k][0] += 2 * ch[r // 2] * c * 9 * (r // 2) ** 2   # stride-2 transposed conv: 9 taps per INPUT pixel
             acc[k][1] += 1
         k = 'conv_bf16_kernel' if bf else ('conv_wino4_kernel' if winograd4_takes(batch, c, c, r) else

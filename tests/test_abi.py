@@ -137,3 +137,22 @@ def test_walk2_isa_check_runs_in_the_build(tdgp):
 def test_device_fault_word_is_exported_and_quiet(tdgp):
     """include/tdgp.h tdgp_device_fault: readable without a GPU (no fault word can be allocated -> 0), never raises."""
     assert tdgp._lib.device_fault() == 0 and tdgp._lib.device_fault(clear=True) == 0
+
+
+def test_fold_up2_table_is_the_x2_layer(tdgp):
+    """ops/modconv.fold_up2_table: the stride-2 transposed 3x3 convolution + 4x4 FIR of conv2d_resample.py:108-125 (flip_weight=False) as four
+    3x3 'same' correlations of x, one per output parity -- against the op's own reference path (torch CPU ops, float64), image borders
+    included, for the generator's symmetric filter and for an asymmetric one (the flip convention)."""
+    import numpy as np
+    import torch
+    M, CR = tdgp.ops.modconv, tdgp.ops.conv2d_resample
+    rs = np.random.RandomState(0)
+    x = torch.tensor(rs.randn(2, 3, 7, 9))
+    w = torch.tensor(rs.randn(4, 3, 3, 3))
+    for f in (tdgp.ops.upfirdn2d.setup_filter([1, 3, 3, 1]), torch.tensor(rs.rand(4, 4), dtype=torch.float32)):
+        ref = CR.conv2d_resample(x, w, f=f, up=2, padding=1, flip_weight=False)
+        P = torch.tensor(M.fold_up2_table(f.numpy()))
+        weff = torch.einsum('pqijab,ocab->opqcij', P, w).reshape(16, 3, 3, 3)
+        ph = torch.nn.functional.conv2d(x, weff, padding=1)                                   # channel 4 o + 2 py + px
+        got = ph.reshape(2, 4, 2, 2, 7, 9).permute(0, 1, 4, 2, 5, 3).reshape(2, 4, 14, 18)
+        assert float((got - ref).abs().max()) <= 1e-12 * float(ref.abs().max())

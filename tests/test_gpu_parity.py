@@ -371,6 +371,61 @@ def test_modconv_winograd4_sub_batches(tdgp, oracle):
     assert_close(N(y[:1, :, :16]), ref, 1e-5, 'sub-batched F(4x4) layer vs the oracle (rows 0-15 of sample 0)', 1.0)
 
 
+@pytest.mark.parametrize('B,cin,cout,H,kw', [
+    (16, 128, 64, 64, {}),                                   # C3's 128^2 -> 256^2 shape at a quarter of the area: 512 items
+    (16, 64, 64, 64, dict(clamp=0.9, noise='per_sample')),   # the fewest channels; clamp; one noise map per sample
+    (4, 512, 256, 64, {}),                                   # the longest reduction (C3's 64^2 -> 128^2 layer, C4's at half the channels)
+    (32, 132, 70, 32, dict(noise=False)),                    # 33 chunks, Cout' = 280 (a ragged last slice), 32-pixel-wide tile groups, no noise; 320 items
+])
+def test_modconv_up2_folded_vs_oracle(tdgp, oracle, B, cin, cout, H, kw):
+    """The x2 layers with the FIR folded into four 3x3 parity kernels on the Winograd F(4x4) path (ops/modconv.py: fold_up2_table,
+    csrc/modconv_wino4.inc out_layout 2) against the double-accumulating oracle of conv2d_resample.py:108-125, next to the transposed-
+    convolution + FIR kernels on the same call.  Bound: 1e-5 of the un-clamped output range, as for every reduction row."""
+    rs = np.random.RandomState(cin * 5 + cout)
+    mc = tdgp.ops.modconv
+    x = rs.randn(B, cin, H, H).astype(np.float32)
+    x = np.where(x > 0, x, 0.2 * x).astype(np.float32) * np.float32(np.sqrt(2))
+    w = rs.randn(cout, cin, 3, 3).astype(np.float32)
+    s = (1 + 0.5 * rs.randn(B, cin)).astype(np.float32)
+    bias = (0.2 * rs.randn(cout)).astype(np.float32)
+    noise = (0.3 * rs.randn(2 * H, 2 * H)).astype(np.float32) if kw.get('noise', True) else None
+    if kw.get('noise') == 'per_sample':
+        noise = (0.3 * rs.randn(B, 1, 2 * H, 2 * H)).astype(np.float32)
+    clamp = kw.get('clamp')
+    f = oracle.setup_filter([1, 3, 3, 1])
+    oracle.set_threads(min(64, os.cpu_count() or 1))
+    ref = oracle.modulated_conv2d(x, w, s, noise=noise, up=2, resample_filter=f)
+    scale = np.abs(oracle.bias_act(ref, bias, act='lrelu')).max()
+    ref = oracle.bias_act(ref, bias, act='lrelu', clamp=clamp)
+    pk = mc.PackedConv(T(w))
+    call = lambda: mc.modconv_forward(T(x), pk, T(s), noise=None if noise is None else T(noise), bias=T(bias), demodulate=True, act='lrelu', clamp=clamp,   # noqa: E731
+                                      up=2, fir=mc.fir_host_array(f))
+    out = {}
+    for fold in (True, False):
+        was, mc.FOLD_UP2 = mc.FOLD_UP2, fold
+        tdgp._lib.profile_enable(True)
+        try:
+            y = call()
+            torch.cuda.synchronize()
+            names = set(tdgp._lib.profile_report())
+            assert torch.equal(call(), y)
+        finally:
+            tdgp._lib.profile_enable(False)
+            mc.FOLD_UP2 = was
+        out[fold] = (N(y), names)
+    assert {'upconv_wino4_kernel', 'wino4_input_kernel'} <= out[True][1] and not ({'upconv_mfma_kernel', 'fir_act_kernel'} & out[True][1]), out[True][1]
+    assert {'upconv_mfma_kernel', 'fir_act_kernel'} <= out[False][1] and 'upconv_wino4_kernel' not in out[False][1], out[False][1]
+    ef, ed = (float(np.abs(out[k_][0] - ref).max() / scale) for k_ in (True, False))
+    report_parity(f'x2 layer {cin}->{cout} @{H}^2 -> {2 * H}^2', folded_f4x4_vs_oracle=ef, transposed_conv_fir_vs_oracle=ed)
+    assert ed <= 5e-6 and ef <= 1e-5, (ed, ef)
+    # with F(4x4) switched off the library refuses the folded form before launching anything and the op falls back
+    prev = tdgp._lib.set_conv_arith(3)
+    try:
+        assert torch.equal(call(), torch.as_tensor(out[False][0]).to(DEV))
+    finally:
+        tdgp._lib.set_conv_arith(prev)
+
+
 def test_fused_layers_oracle(tdgp, oracle):
     """SynthesisLayer / ToRGB+skip as single fused calls (bias, lrelu*sqrt2, x2 FIR skip, channel-last output)."""
     rs = np.random.RandomState(5)
@@ -1285,13 +1340,14 @@ def test_torgb_overlap_on_and_off_produce_identical_bits(tdgp, full_c3):
     """DESIGN claims 'same bits' for the ToRGB layers on a second stream (SynthesisBlocksSequence.overlap_torgb): asserted, at full size."""
     G, ws = full_c3['G'], full_c3['ws']
     dec = G.synthesis.tri_plane_decoder
-    assert dec.overlap_torgb
-    a = dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True).t.clone()
-    dec.overlap_torgb = False
+    was = dec.overlap_torgb                                   # (off by default since the x2 layers run on the persistent F(4x4) grid, round 4)
     try:
+        dec.overlap_torgb = True
+        a = dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True).t.clone()
+        dec.overlap_torgb = False
         b = dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True).t.clone()
     finally:
-        dec.overlap_torgb = True
+        dec.overlap_torgb = was
     assert torch.equal(a, b)
     assert torch.equal(a, full_c3['planes'].t)
 
@@ -1306,8 +1362,8 @@ def test_generator_survives_deepcopy_and_pickle_after_a_forward(tdgp):
     g = load_golden('e2e_tiny')
     G = _gen(tdgp, cfg, 21)
     kw = dict(noise_mode='const', u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
+    G.synthesis.tri_plane_decoder.overlap_torgb = True             # the configuration that used to put a stream into the module
     img = G(T(g['z']), T(g['c']), _cam(g), **kw)
-    assert G.synthesis.tri_plane_decoder.overlap_torgb
     assert not any(isinstance(v, torch.cuda.Stream) for m in G.modules() for v in vars(m).values())
     G2 = copy.deepcopy(G)
     assert torch.equal(G2(T(g['z']), T(g['c']), _cam(g), **kw), img)
@@ -2268,14 +2324,17 @@ def test_upconv_split_arith(tdgp, oracle, B, cin, cout, H):
     ref = oracle.bias_act(oracle.modulated_conv2d(x, w, s, noise=noise, up=2, resample_filter=f), bias, act='lrelu')
     pk = mc.PackedConv(T(w))
     kw = dict(noise=T(noise), bias=T(bias), demodulate=True, act='lrelu', up=2, fir=mc.fir_host_array(f))
-    y32 = mc.modconv_forward(T(x), pk, T(s), **kw)
-    prev = tdgp._lib.set_conv_arith(1)
+    fold_was, mc.FOLD_UP2 = mc.FOLD_UP2, False             # this test is about the transposed-convolution kernels (fp32 and split), not the folded F(4x4) form
+    prev = 0
     try:
+        y32 = mc.modconv_forward(T(x), pk, T(s), **kw)
+        prev = tdgp._lib.set_conv_arith(1)
         ysp = mc.modconv_forward(T(x), pk, T(s), **kw)
         for _ in range(5):
             assert torch.equal(mc.modconv_forward(T(x), pk, T(s), **kw), ysp)
     finally:
         tdgp._lib.set_conv_arith(prev)
+        mc.FOLD_UP2 = fold_was
     scale = np.abs(ref).max()
     e32, esp = np.abs(N(y32) - ref).max() / scale, np.abs(N(ysp) - ref).max() / scale
     assert e32 < 2e-6 and esp < 4e-6, (e32, esp)

@@ -9,6 +9,6 @@ for rep in 1 2; do
 import sys, json
 d = json.loads(sys.stdin.read())
 k = d['kernels']
-print('$v', d['value'], d['ms_per_step'], ' '.join(f\"{n.replace('_kernel','')}={k[n]['ms_per_step']:.3f}\" for n in ('conv_wino4_kernel','wino4_input_kernel','conv_wino_kernel','conv_mfma_kernel','upconv_mfma_kernel','torgb_mfma_kernel','fir_act_kernel','triplane_field_kernel') if n in k))"
+print('$v', d['value'], d['ms_per_step'], ' '.join(f\"{n.replace('_kernel','')}={k[n]['ms_per_step']:.3f}\" for n in ('conv_wino4_kernel','upconv_wino4_kernel','wino4_input_kernel','conv_wino_kernel','conv_mfma_kernel','upconv_mfma_kernel','torgb_mfma_kernel','fir_act_kernel','triplane_field_kernel') if n in k))"
   done
 done
