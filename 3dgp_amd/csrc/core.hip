@@ -66,6 +66,7 @@ namespace {
 struct ProfEvent { const char* name; hipEvent_t a, b; };
 std::mutex g_mu;
 std::vector<ProfEvent> g_events;
+std::vector<hipEvent_t> g_pool;         // events created ahead of the profiled launches (hipEventCreate per dispatch starved the GPU: ~190 launches per forward)
 std::atomic<int> g_on{0};
 }  // namespace
 
@@ -75,21 +76,30 @@ bool tdgp_prof_on() { return g_on.load(std::memory_order_relaxed) != 0; }
 void tdgp_prof_events(const char* name, hipEvent_t* a, hipEvent_t* b) {
     ProfEvent e;
     e.name = name;
-    (void)hipEventCreate(&e.a);
-    (void)hipEventCreate(&e.b);
-    *a = e.a; *b = e.b;
     std::lock_guard<std::mutex> lk(g_mu);
+    auto take = [&]() {
+        hipEvent_t ev = nullptr;
+        if (!g_pool.empty()) { ev = g_pool.back(); g_pool.pop_back(); }
+        else (void)hipEventCreate(&ev);
+        return ev;
+    };
+    e.a = take(); e.b = take();
+    *a = e.a; *b = e.b;
     g_events.push_back(e);
 }
 
 static void prof_clear() {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (auto& e : g_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : g_events) { g_pool.push_back(e.a); g_pool.push_back(e.b); }        // recycled, not destroyed
     g_events.clear();
 }
 
 TDGP_API int tdgp_profile_enable(int on) {
     prof_clear();
+    if (on) {                               // a pool for ~2 forwards' worth of launches, created before anything is timed
+        std::lock_guard<std::mutex> lk(g_mu);
+        while (g_pool.size() < 1024) { hipEvent_t ev = nullptr; if (hipEventCreate(&ev) != hipSuccess) break; g_pool.push_back(ev); }
+    }
     g_on.store(on ? 1 : 0);
     return TDGP_OK;
 }

@@ -2579,7 +2579,7 @@ WsLayout ws_layout(int B, int Cin, int Cout, int H, int W, int k, int up) {
     if (pf > cap) pf = (cap / out_elems) * out_elems;
     w.partial_floats = pf;
     w.wino_v = w.partial + al(pf * (int64_t)sizeof(float));
-    w.total = w.wino_v + (wino4_shape_ok(B, Cin, Cout, H, W, k, up) ? al(wino4_v_bytes(wino4_sub_batch(B, Cin, Cout, H, W), Cin, H, W)) : 0);
+    w.total = w.wino_v + (wino4_shape_ok(B, Cin, Cout, H, W, k, up) ? al(wino4_v_bytes(wino4_sub_batch(B, Cin, Cout, H, W), Cin, H, W)) + 256 : 0);      // + the item counters
     return w;
 }
 
@@ -2724,9 +2724,10 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 const int cus = tdgp_cu_count(), nxcd = (cus % 8 == 0 && cus >= 64) ? 8 : 1, per = cus / nxcd * bpc, nsl = cdiv(Cout, W4_BM);
                 int rs = 1;
                 while (rs * 2 <= nsl && (per % (rs * 2)) == 0 && (rs * 2) * W4_BM + per / (rs * 2) * 32 < rs * W4_BM + per / rs * 32) rs *= 2;
-                const size_t lds = (size_t)(2 * W4_STAGE + 2 * W4_BM) * 4;
+                const size_t lds = (size_t)(2 * W4_STAGE + 2 * W4_BM + 4) * 4;          // two stages, bias + demodulation of the slice, the ticket
                 TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3_wino4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipFuncSetAttribute((const void*)conv3_wino4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
                 const int bsub = wino4_sub_batch(B, Cin, Cout, H, W);
+                int* ticket = (int*)((char*)vbuf + ((wino4_v_bytes(bsub, Cin, H, W) + 255) / 256 * 256));
                 for (int b0 = 0; b0 < B; b0 += bsub) {
                     const int bn = std::min(bsub, B - b0);
                     Wino4Params q;
@@ -2739,10 +2740,10 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                     q.B = bn; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W;
                     q.v_bytes = (uint32_t)wino4_v_bytes(bn, Cin, H, W); q.u_bytes = (uint32_t)(pi.wino4_floats * 4);
                     q.txl = wino4_txl(H, W); q.gxn = W / (4 << q.txl); q.gyn = H / (128 >> q.txl);
-                    q.rs = rs; q.rt = per / rs; q.nxcd = nxcd;
+                    q.rs = rs; q.rt = per / rs; q.nxcd = nxcd; q.ticket = ticket;
                     const int ntg = q.gxn * q.gyn * bn;
                     TDGP_LAUNCH("wino4_input_kernel", wino4_input_kernel, dim3((unsigned)(ntg * pi.nch4)), dim3(128), 0, s, x + (int64_t)b0 * Cin * H * W,
-                                styles ? styles + (int64_t)b0 * Cin : nullptr, vbuf, bn, Cin, H, W, q.gxn, q.gyn, pi.nch4, q.txl);
+                                styles ? styles + (int64_t)b0 * Cin : nullptr, vbuf, bn, Cin, H, W, q.gxn, q.gyn, pi.nch4, q.txl, ticket);
                     if (q.ups) TDGP_LAUNCH("upconv_wino4_kernel", conv3_wino4_kernel<true>, dim3((unsigned)(nxcd * per)), dim3(W4_NW * 64), lds, s, q);
                     else TDGP_LAUNCH("conv_wino4_kernel", conv3_wino4_kernel<false>, dim3((unsigned)(nxcd * per)), dim3(W4_NW * 64), lds, s, q);
                 }

@@ -289,6 +289,7 @@ def test_modconv_winograd_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
     (16, 128, 128, 64, 64, dict(styles=False)),                          # unmodulated (Conv2dLayer form)
     (4, 512, 512, 64, 64, {}),                                           # the 64^2 x 512 layer of C3: the longest reduction the default run sums in F(4x4)
     (4, 64, 64, 256, 256, dict(clamp=0.8)),                              # the fewest channels F(4x4) takes (C3's 512^2 x 64 layer shape at a quarter of the area)
+    (4, 128, 640, 64, 64, dict(noise=False)),                            # 20 slices of 32 channels = 3 rectangles of 8 per XCD pass, the last one ragged: empty slots are skipped, not the end
     (16, 256, 512, 32, 32, dict(noise='per_sample')),                    # 32-pixel-wide layers: tile groups of 8 x 4 tiles (32 x 16 pixels); 256 items
     (32, 128, 192, 48, 32, {}),                                          # ... with H a multiple of 16 only, three 64-channel slices
 ])
