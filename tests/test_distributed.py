@@ -276,7 +276,7 @@ def test_bench_reports_every_rank(tdgp):
     res = sorted(q.get(timeout=120) for _ in ps)
     [p.join(60) for p in ps]
     (_, el0, per0), (_, el1, per1) = res
-    assert per0 == per1 and len(per0) == 2 and per0[1] > 2.0 * per0[0] > 0
+    assert per0 == per1 and len(per0) == 2 and per0[1] > 1.5 * per0[0] > 0
     assert abs(el0 - el1) < 1e-9 and el0 >= max(per0) - 1e-3
     ms, ratio = bench.straggler_figures(per0, 3)
-    assert ratio > 2.0 and ms[1] > ms[0]
+    assert ratio > 1.5 and ms[1] > ms[0]
