@@ -60,27 +60,32 @@ def main():
                 re.search(r'configs\[\d\]', bj['config']['workload']).group(0), 'c3')
         except Exception as e:        # noqa: BLE001
             print('bench.json not parsed:', e)
+    def family(name):
+        # the two instances of the F(4x4) kernel are different layers (x2 folded vs plain 3x3): keep them apart
+        if name.startswith('conv3_wino4_kernel<true>'):
+            return 'upconv_wino4_kernel'
+        base = name.split('<')[0].strip()
+        return ALIAS.get(base, base)
+
     fam = collections.defaultdict(lambda: dict(launches=0, fetch=0.0, write=0.0, mfma=0.0, active=0.0, mlaunches=0, hit=0.0, miss=0.0, req=0.0, rdreq=0.0, rlaunches=0))
     for key, fn, counter in (('fetch', 'pmc_FETCH_SIZE.md', 'FETCH_SIZE'), ('write', 'pmc_WRITE_SIZE.md', 'WRITE_SIZE')):
         for name, (calls, _, cs) in table(os.path.join(a.indir, fn)).items():
-            base = name.split('<')[0].strip()
-            f = fam[ALIAS.get(base, base)]
+            f = fam[family(name)]
             f[key] += calls * cs[counter] * 1024.0 * (FETCH_FACTOR if key == 'fetch' else 1.0)
             if key == 'fetch':
                 f['launches'] += calls
     for name, (calls, _, cs) in table(os.path.join(a.indir, 'pmc_SQ_VALU_MFMA_BUSY_CYCLES.md')).items():
-        base = name.split('<')[0].strip()
-        f = fam[ALIAS.get(base, base)]
+        f = fam[family(name)]
         f['mfma'] += calls * cs['SQ_VALU_MFMA_BUSY_CYCLES']
         f['active'] += calls * cs['GRBM_GUI_ACTIVE']
         f['mlaunches'] += calls
     for name, (calls, _, cs) in table(os.path.join(a.indir, 'pmc_TCC_HIT_sum.md')).items():
-        f = fam[ALIAS.get(name.split('<')[0].strip(), name.split('<')[0].strip())]
+        f = fam[family(name)]
         f['hit'] += calls * cs['TCC_HIT_sum']
         f['miss'] += calls * cs['TCC_MISS_sum']
         f['req'] += calls * cs.get('TCC_REQ_sum', 0.0)
     for name, (calls, _, cs) in table(os.path.join(a.indir, 'pmc_TCC_EA0_RDREQ_sum.md')).items():
-        f = fam[ALIAS.get(name.split('<')[0].strip(), name.split('<')[0].strip())]
+        f = fam[family(name)]
         f['rdreq'] += calls * cs['TCC_EA0_RDREQ_sum']
         f['rlaunches'] += calls
     try:
