@@ -122,6 +122,152 @@ __global__ __launch_bounds__(64) void ray_march_grad_kernel(MarchGradParams p) {
     }
 }
 
+
+// The same gradients with one WAVE per ray (round 4; the thread-per-ray kernel above walks S samples with a stride of S floats between
+// lanes and keeps two S-long arrays in scratch: 5.6 ms for 262 k rays x 128 samples, 0.6 GB of traffic).  lane l owns the EPL consecutive
+// intervals i = l EPL + e.  T_i is an exclusive prefix product (in-lane, then a 6-step wave scan of the lane totals); the backward
+// recurrence U_{i-1} = G_i a_i + q_i U_i is a suffix composition of affine maps u -> B + A u (in-lane, then a 6-step wave scan of (A, B)
+// pairs: (A1, B1) o (A2, B2) = (A1 A2, B1 + A1 B2)); the half-and-half deposits of the mip marcher take the left neighbour's interval from
+// the previous element / lane.  Same formulas as above; only the association of the products / sums differs (tests: the reference's
+// autograd goldens and the double-precision oracle, same bounds as before).  Loads and stores are EPL (x C) consecutive floats per lane.
+template <int C, int EPL>
+__global__ __launch_bounds__(256) void ray_march_grad_wave_kernel(MarchGradParams p) {
+    const int l = lane_id();
+    const int S = p.S;
+    const bool mip = p.marcher == 1, inf = p.flags & 1, last_back = (p.flags & 2) && !mip, white = (p.flags & 4) && mip, relu = p.flags & 8;
+    const int M = mip ? (inf ? S : S - 1) : S;              // intervals
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = wave; r < p.rays; r += nwaves) {
+        const float* col = p.colors + r * S * C;
+        const float* den = p.dens + r * S;
+        const float* dep = p.depths + r * S;
+        float drgb[C], drgb_sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++) { drgb[c] = p.d_rgb[r * C + c] * (mip ? 2.0f : 1.0f); drgb_sum += drgb[c]; }
+        const float ddep = p.d_depth ? p.d_depth[r] : 0.f;
+        // samples base .. base + EPL of this lane (the extra one closes its last interval), clamped to the ray
+        const int base = l * EPL;
+        float dn[EPL + 1], dp[EPL + 1], cl[EPL + 1][C];
+#pragma unroll
+        for (int e = 0; e <= EPL; e++) {
+            const int j = min(base + e, S - 1);
+            dn[e] = den[j]; dp[e] = dep[j];
+#pragma unroll
+            for (int c = 0; c < C; c++) cl[e][c] = col[j * C + c];
+        }
+        auto g_at = [&](const float (&c0)[C], const float (&c1)[C], float z0, float z1, bool tail, float dw) {
+            float g = 0.f;
+            if (mip) {
+#pragma unroll
+                for (int c = 0; c < C; c++) g += drgb[c] * (tail ? c0[c] : (c0[c] + c1[c]) * 0.5f);
+                g += ddep * (tail ? z0 : (z0 + z1) * 0.5f);
+                if (white) g -= drgb_sum;
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; c++) g += drgb[c] * c0[c];
+                g += ddep * z0;
+            }
+            return g + dw;
+        };
+        float g_last = 0.f;
+        if (last_back) {
+            float cs[C];
+#pragma unroll
+            for (int c = 0; c < C; c++) cs[c] = col[(S - 1) * C + c];
+            g_last = g_at(cs, cs, dep[S - 1], dep[S - 1], true, p.d_weights ? p.d_weights[r * M + S - 1] : 0.f);
+        }
+        // ---- per interval: a, q, G, s ---------------------------------------------------------------------------------------------
+        float a[EPL], q[EPL], G[EPL], sv[EPL], dl[EPL];
+        bool ok[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int i = base + e;
+            ok[e] = i < M;
+            const bool tail = i == S - 1;
+            const float delta = tail ? (inf ? 1e10f : 1e-3f) : dp[e + 1] - dp[e];
+            const float s_ = mip ? (tail ? dn[e] : (dn[e] + dn[e + 1]) * 0.5f) + p.density_bias : dn[e];
+            const float sigma = relu ? fmaxf(s_, 0.f) : softplus20(s_);
+            const float ai = ok[e] ? 1.0f - expf(-delta * sigma) : 0.f;
+            a[e] = ai; q[e] = ok[e] ? (1.0f - ai) + 1e-10f : 1.0f; sv[e] = s_; dl[e] = delta;
+            float g = ok[e] ? g_at(cl[e], cl[e + 1], dp[e], dp[e + 1], tail, p.d_weights ? p.d_weights[r * M + min(i, M - 1)] : 0.f) : 0.f;
+            if (last_back) g = (tail || !ok[e]) ? 0.f : g - g_last;
+            G[e] = g;
+        }
+        // ---- T_i: exclusive prefix product ------------------------------------------------------------------------------------------
+        float T[EPL], run = 1.f;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) { T[e] = run; run *= q[e]; }
+        float inc = run;                                     // inclusive scan of the lane totals
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(inc, d, 64); if (l >= d) inc *= o; }
+        float exc = __shfl_up(inc, 1, 64);
+        if (l == 0) exc = 1.f;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) T[e] *= exc;
+        float w_extra = 0.f;
+        if (last_back) {
+            float ws = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; e++) ws += a[e] * T[e];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) ws += __shfl_xor(ws, d, 64);
+            w_extra = 1.0f - ws;
+        }
+        // ---- U_i: suffix composition of u -> G a + q u ------------------------------------------------------------------------------
+        float A = 1.f, Bc = 0.f;                             // this lane's intervals, first applied last: f_first o ... o f_last
+#pragma unroll
+        for (int e = EPL - 1; e >= 0; e--) { Bc = G[e] * a[e] + q[e] * Bc; A *= q[e]; }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float oA = __shfl_down(A, d, 64), oB = __shfl_down(Bc, d, 64);
+            if (l + d < 64) { Bc = Bc + A * oB; A *= oA; }
+        }
+        float U = __shfl_down(Bc, 1, 64);                    // value behind this lane's last interval: the lanes to the right, applied to 0
+        if (l == 63) U = 0.f;
+        // ---- gradients per interval, last element first ------------------------------------------------------------------------------
+        float wv[EPL], ds[EPL];
+#pragma unroll
+        for (int e = EPL - 1; e >= 0; e--) {
+            const int i = base + e;
+            const bool tail = i == S - 1;
+            wv[e] = ok[e] ? a[e] * T[e] + ((last_back && tail) ? w_extra : 0.f) : 0.f;
+            const float da = T[e] * (G[e] - U);
+            const float dsigma = da * dl[e] * (1.0f - a[e]);
+            const float d_ = relu ? (sv[e] > 0.f ? dsigma : 0.f) : (sv[e] > 20.f ? dsigma : dsigma * sigmoidf_(sv[e]));
+            ds[e] = ok[e] ? d_ : 0.f;
+            U = G[e] * a[e] + q[e] * U;
+        }
+        // ---- deposits per SAMPLE j = base + e: classical: its own interval; mip: half of interval j (all of it for the far one) + half of j - 1
+        float wl = __shfl_up(wv[EPL - 1], 1, 64), dsl = __shfl_up(ds[EPL - 1], 1, 64);     // the left neighbour's last interval (never the far one)
+        if (l == 0) { wl = 0.f; dsl = 0.f; }
+        float od[EPL], oc[EPL][C];
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int j = base + e;
+            const bool tail = j == S - 1;
+            float wj, dj;
+            if (mip) {
+                const float wp = e == 0 ? wl : wv[e - 1], dpv = e == 0 ? dsl : ds[e - 1];
+                wj = (tail ? wv[e] : 0.5f * wv[e]) + 0.5f * wp;
+                dj = (tail ? ds[e] : 0.5f * ds[e]) + 0.5f * dpv;
+            } else { wj = wv[e]; dj = ds[e]; }
+            od[e] = dj;
+#pragma unroll
+            for (int c = 0; c < C; c++) oc[e][c] = mip ? ((tail ? wv[e] : 0.5f * wv[e]) * drgb[c]) + (0.5f * (e == 0 ? wl : wv[e - 1])) * drgb[c] : wj * drgb[c];
+            (void)wj;
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int j = base + e;
+            if (j < S) {
+                p.d_dens[r * S + j] = od[e];
+#pragma unroll
+                for (int c = 0; c < C; c++) p.d_colors[(r * S + j) * C + c] = oc[e][c];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 TDGP_API int tdgp_ray_march_grad(const float* colors, const float* densities, const float* depths, const float* d_rgb, const float* d_depth,
@@ -134,12 +280,25 @@ TDGP_API int tdgp_ray_march_grad(const float* colors, const float* densities, co
     MarchGradParams p;
     p.colors = colors; p.dens = densities; p.depths = depths; p.d_rgb = d_rgb; p.d_depth = d_depth; p.d_weights = d_weights;
     p.d_colors = d_colors; p.d_dens = d_densities; p.rays = rays; p.S = S; p.C = C; p.marcher = marcher; p.flags = flags; p.density_bias = density_bias;
-    const dim3 grid((unsigned)cdiv64(rays, 64)), block(64);
     hipStream_t s = (hipStream_t)stream;
-    if (C == 3) TDGP_LAUNCH("ray_march_grad_kernel", ray_march_grad_kernel<3>, grid, block, 0, s, p);
-    else if (C == 1) TDGP_LAUNCH("ray_march_grad_kernel", ray_march_grad_kernel<1>, grid, block, 0, s, p);
-    else if (C == 4) TDGP_LAUNCH("ray_march_grad_kernel", ray_march_grad_kernel<4>, grid, block, 0, s, p);
-    else TDGP_CHECK(false, TDGP_EUNSUPPORTED, "ray_march_grad: C=%d (1, 3 or 4 colour channels)", C);
+    TDGP_CHECK(C == 1 || C == 3 || C == 4, TDGP_EUNSUPPORTED, "ray_march_grad: C=%d (1, 3 or 4 colour channels)", C);
+#ifndef TDGP_MARCH_GRAD_WAVE
+#define TDGP_MARCH_GRAD_WAVE 1      // 0: the thread-per-ray kernel (A/B builds)
+#endif
+    if (TDGP_MARCH_GRAD_WAVE) {
+        // a wave per ray, 4 waves per block, persistent over the rays (a few blocks per CU's worth of waves cover the load latencies)
+        const dim3 grid((unsigned)std::min<int64_t>(cdiv64(rays, 4), (int64_t)tdgp_cu_count() * 8)), block(256);
+#define TDGP_MG(CC, EE) TDGP_LAUNCH("ray_march_grad_kernel", (ray_march_grad_wave_kernel<CC, EE>), grid, block, 0, s, p)
+#define TDGP_MG_C(EE) do { if (C == 3) TDGP_MG(3, EE); else if (C == 1) TDGP_MG(1, EE); else TDGP_MG(4, EE); } while (0)
+        if (S <= 64) TDGP_MG_C(1); else if (S <= 128) TDGP_MG_C(2); else TDGP_MG_C(4);
+#undef TDGP_MG_C
+#undef TDGP_MG
+    } else {
+        const dim3 grid((unsigned)cdiv64(rays, 64)), block(64);
+        if (C == 3) TDGP_LAUNCH("ray_march_grad_kernel", ray_march_grad_kernel<3>, grid, block, 0, s, p);
+        else if (C == 1) TDGP_LAUNCH("ray_march_grad_kernel", ray_march_grad_kernel<1>, grid, block, 0, s, p);
+        else TDGP_LAUNCH("ray_march_grad_kernel", ray_march_grad_kernel<4>, grid, block, 0, s, p);
+    }
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }
@@ -352,7 +511,11 @@ __global__ __launch_bounds__(64 * NW) void triplane_field_grad_kernel(FieldGradP
         // ---- 6. scatter: d_plane[tap] += w_tap * dg / 3 ------------------------------------------------------------------------
         // Transposed through LDS so that ONE atomic instruction adds the 32 channels of one tap (a 128-B line) per half-wave:
         // issued from the accumulator layout (lane = point) every instruction touched 64 different lines and the kernel ran at
-        // the L2's atomic line rate (82 ms for 8.4 M points).
+        // the L2's atomic line rate (82 ms for 8.4 M points).  What bounds it now (round 4, tools/dev/ubench_atomics.hip): the chip
+        // retires 10.3 G such lines per second = 0.6 lane-atomics per clock and CU -- the same for a 24-MiB and a 1.6-GiB target, with
+        // or without sc1 / nt, and with every XCD kept inside its own eighth of the target -- so 12 lines per point are 1.17 ms per
+        // million points whatever the access pattern; only fewer lines (an LDS window that merges the taps of neighbouring rays before
+        // they leave the CU) can lower it.
         if (p.d_planes || p.d_coords) {
 #pragma unroll
             for (int r = 0; r < 16; r++) gl[l32 * FG_PITCH + (r & 3) + 8 * (r >> 2) + 4 * half] = dg[r];

@@ -1892,6 +1892,27 @@ def test_ray_march_grad(tdgp, oracle, tag):
     assert_close(N(dd), rd, 5e-5, 'd_densities (S=128)', 1.0)
 
 
+@pytest.mark.parametrize('S', [2, 5, 63, 64, 65, 129, 200, 256])
+@pytest.mark.parametrize('tag', ['cl_inf', 'cl_noinf_lastback', 'mip_inf', 'mip_noinf_white_bias'])
+def test_ray_march_grad_sample_counts(tdgp, oracle, tag, S):
+    """The wave-per-ray gradient kernel at every lane layout (1, 2 and 4 intervals per lane), with ragged last lanes, the shortest rays and
+    the longest the entry point accepts, with all three incoming gradients: vs the double-precision oracle."""
+    from conftest import MARCH_GRAD_CASES
+    kw = dict(MARCH_GRAD_CASES[tag])
+    mode = kw.pop('mode')
+    rs = np.random.RandomState(S)
+    B, R = 2, 37
+    M = S if mode == 'classical' else (S if kw.get('use_inf_depth', True) else S - 1)
+    colors = rs.rand(B, R, S, 3).astype(np.float32)
+    dens = (rs.randn(B, R, S, 1) * 2).astype(np.float32)
+    depths = np.sort(0.75 + 0.5 * rs.rand(B, R, S, 1).astype(np.float32), axis=2)
+    d_rgb, d_depth, d_w = rs.randn(B, R, 3).astype(np.float32), rs.randn(B, R, 1).astype(np.float32), rs.randn(B, R, M, 1).astype(np.float32)
+    rc, rd = oracle.ray_march_grad(colors, dens, depths, d_rgb, d_depth, d_w, mode=mode, **kw)
+    dc, dd = tdgp.renderer.ray_march_backward(T(colors), T(dens), T(depths), kw, mode, T(d_rgb), T(d_depth), T(d_w))
+    assert_close(N(dc), rc, 1e-5, f'd_colors (S={S})', 1.0)
+    assert_close(N(dd), rd, 5e-5, f'd_densities (S={S})', 1.0)
+
+
 @pytest.mark.parametrize('tag', ['small', 'hot'])
 @pytest.mark.parametrize('marcher', ['classical', 'mip'])
 def test_field_grad(tdgp, oracle, tag, marcher):
