@@ -267,7 +267,7 @@ class SynthesisBlock(torch.nn.Module):
         return x, img
 
     def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, styles=None, dcoefs=None, hwc_feat=0, side_stream=None,
-                **layer_kwargs):
+                overlap=True, **layer_kwargs):
         """-> (x, img).  `styles` (optional) = pre-computed [conv0?, conv1, torgb] style tensors; `hwc_feat` > 0 keeps the
         running image in the channel-last plane layout [B, C/feat, H, W, feat]."""
         assert ws.shape[1] == self.num_conv + self.num_torgb and ws.shape[2] == self.w_dim, f'Wrong shape: ws {tuple(ws.shape)}'
@@ -281,7 +281,7 @@ class SynthesisBlock(torch.nn.Module):
             x = self.conv0(_to_dtype(x, dtype), next(w_iter), styles=next(s_iter), dcoef=next(d_iter), **layer_kwargs)      # x.to(dtype), :250
         x = self.conv1(x, next(w_iter), styles=next(s_iter), dcoef=next(d_iter), **layer_kwargs)
         fir = _modconv.fir_host_array(self.resample_filter) if img is not None else None
-        if side_stream is not None and not self.is_last:
+        if side_stream is not None and overlap and not self.is_last:
             # ToRGB of this block (reads x, the running image; HBM / instruction-bound, matrix pipe a third busy) on a second stream, next
             # to the next block's MFMA-bound x2 layer, which only needs x.  The running image lives on the side stream from block to block.
             main = torch.cuda.current_stream(x.device)
@@ -427,20 +427,23 @@ class SynthesisBlocksSequence(torch.nn.Module):
             blk = getattr(self, f'b{res}')
             w_idx, s_idx, d_idx = self._block_index[res]
             n = blk.num_conv + blk.num_torgb
+            ov = self.overlap_torgb is True or res <= int(self.overlap_torgb)
             x, img = blk(x, img, cut(ws).narrow(1, w_idx, n), styles=[cut(t) for t in styles[s_idx:s_idx + n]],
-                         dcoefs=[cut(t) for t in dcoefs[d_idx:d_idx + blk.num_conv]], hwc_feat=feat, side_stream=self._side(ws), **block_kwargs)
+                         dcoefs=[cut(t) for t in dcoefs[d_idx:d_idx + blk.num_conv]], hwc_feat=feat, side_stream=self._side(ws), overlap=ov, **block_kwargs)
         return x, img
 
     # ToRGB layers on a second stream beside the next block's x2 layer: r03 +0.5 % (B = 16) / +2.8 % (B = 4) next to the transposed-convolution
-    # kernels; since the x2 layers run on the persistent F(4x4) grid (round 4) a concurrent kernel takes resident-block slots from a grid whose
-    # work is dealt statically -- measured -6 % -- so the default is off (TDGP_OVERLAP_TORGB=1 / the attribute switch it on; same bits either way)
-    overlap_torgb = __import__('os').environ.get('TDGP_OVERLAP_TORGB', '0') != '0'
+    # kernels; since the x2 layers from 32^2 -> 64^2 up run on the persistent F(4x4) grid (round 4) a concurrent kernel there takes
+    # resident-block slots from a grid that owns every CU -- measured -6 % -- so by default only the blocks up to 16^2 overlap: their ToRGB
+    # layers are single-digit-block launches that take ~35 us whatever the batch (a serial K loop), next to x2 layers of the same kind.
+    # overlap_torgb: False = never, True = every block, an int = blocks up to that resolution (TDGP_OVERLAP_TORGB=0 / 1 / <res>); same bits always.
+    overlap_torgb = (lambda v: False if v == '0' else True if v == '1' else int(v))(__import__('os').environ.get('TDGP_OVERLAP_TORGB', '16'))
 
     def _side(self, t):
         """The stream the ToRGB layers run on, per DEVICE and outside the module: a `torch.cuda.Stream` in `__dict__` would make the
         generator un-picklable / un-deep-copyable after its first forward (training_loop.py:459 and metric_utils.py:293,328 deep-copy G)
         and would pin the overlap to the first device the module ran on."""
-        if not self.overlap_torgb:
+        if self.overlap_torgb is False or self.overlap_torgb == 0:
             return None
         return side_stream_of(t.device)
 

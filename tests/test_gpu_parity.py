@@ -1341,16 +1341,16 @@ def test_torgb_overlap_on_and_off_produce_identical_bits(tdgp, full_c3):
     """DESIGN claims 'same bits' for the ToRGB layers on a second stream (SynthesisBlocksSequence.overlap_torgb): asserted, at full size."""
     G, ws = full_c3['G'], full_c3['ws']
     dec = G.synthesis.tri_plane_decoder
-    was = dec.overlap_torgb                                   # (off by default since the x2 layers run on the persistent F(4x4) grid, round 4)
+    was = dec.overlap_torgb                                   # (default: the blocks up to 16^2 -- beside the persistent F(4x4) grids it costs time, round 4)
+    outs = {}
     try:
-        dec.overlap_torgb = True
-        a = dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True).t.clone()
-        dec.overlap_torgb = False
-        b = dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True).t.clone()
+        for mode in (True, False, 16, 64):                    # every block, none, the default threshold, a threshold inside the F(4x4) range
+            dec.overlap_torgb = mode
+            outs[mode] = dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True).t.clone()
     finally:
         dec.overlap_torgb = was
-    assert torch.equal(a, b)
-    assert torch.equal(a, full_c3['planes'].t)
+    for mode, t in outs.items():
+        assert torch.equal(t, full_c3['planes'].t), mode
 
 
 def test_generator_survives_deepcopy_and_pickle_after_a_forward(tdgp):

@@ -13,7 +13,7 @@ for B in (16, 4):
     x = dict(z=T(inp['z']), c=T(inp['c']), cam={k: T(v) for k, v in inp['camera'].items()}, uc=T(inp['u_coarse']), uf=T(inp['u_fine']))
     ref = None
     for rep in range(2):
-        for ov in (False, True):
+        for ov in (False, 16, 32, True):
             G.synthesis.tri_plane_decoder.overlap_torgb = ov
             for _ in range(3):
                 img = G(x['z'], x['c'], x['cam'], noise_mode='const', u_coarse=x['uc'], u_fine=x['uf'])
