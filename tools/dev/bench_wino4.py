@@ -10,7 +10,7 @@ tdgp = importlib.import_module('3dgp_amd')
 M = importlib.import_module('3dgp_amd.ops.modconv')
 L = tdgp._lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-shapes = dict(c3=[(512, 32), (512, 64), (256, 128), (128, 256), (64, 512)], c4=[(1024, 32), (1024, 64), (512, 128), (256, 256), (128, 512)])[sys.argv[2] if len(sys.argv) > 2 else 'c3']
+shapes = dict(c3=[(512, 32), (512, 64), (256, 128), (128, 256), (64, 512)], c4=[(1024, 32), (1024, 64), (512, 128), (256, 256), (128, 512)], low=[(512, 4), (512, 8), (512, 16), (512, 32)])[sys.argv[2] if len(sys.argv) > 2 else 'c3']
 dev = torch.device('cuda')
 torch.manual_seed(0)
 out = []
