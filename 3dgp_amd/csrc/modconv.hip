@@ -2550,10 +2550,25 @@ inline int wino4_sub_batch(int B, int Cin, int Cout, int H, int W) {
     }
     return (int)std::min<int64_t>(B, ((int64_t)TDGP_WINO4_VCAP_MB << 20) / per);
 }
-inline bool wino4_shape_ok(int B, int Cin, int Cout, int H, int W, int k, int up) {
+// Launches with too few items for the chip (the 32^2 layers at batch 4 .. 8) split the input channels of every item 2 or 4 ways (plain layers
+// only; >= 16 chunks per split; the whole batch in one launch); the splits' raw sums go through the split-K buffer of the direct kernels.
+// 0 = not a split-K shape.  B = 4, 32^2 x 512: direct sums 0.235 ms -> 4 splits (measured).
+#ifndef TDGP_WINO4_SPLITK
+#define TDGP_WINO4_SPLITK 1
+#endif
+inline int wino4_ksplit_log2(int B, int Cin, int Cout, int H, int W) {
+    if (!TDGP_WINO4_SPLITK || wino4_v_bytes(B, Cin, H, W) > ((int64_t)TDGP_WINO4_VSMALL_MB << 20)) return 0;
+    const int64_t base = wino4_items(B, Cout, H, W);
+    const int nch = Cin >> 2;
+    for (int l = 1; l <= 2; l++)
+        if ((base << l) >= 256 && (nch & ((1 << l) - 1)) == 0 && (nch >> l) >= 16) return l;
+    return 0;
+}
+inline bool wino4_shape_ok(int B, int Cin, int Cout, int H, int W, int k, int up, bool plain = false) {
     if (!(k == 3 && up == 1 && wino4_txl(H, W) != 0 && (Cin & 3) == 0 && Cin >= TDGP_WINO4_MIN_C && Cout >= TDGP_WINO4_MIN_C)) return false;
     const int bs = wino4_sub_batch(B, Cin, Cout, H, W);
-    return bs >= 1 && wino4_items(bs, Cout, H, W) >= 256;
+    if (bs >= 1 && wino4_items(bs, Cout, H, W) >= 256) return true;
+    return plain && wino4_items(B, Cout, H, W) < 256 && wino4_ksplit_log2(B, Cin, Cout, H, W) > 0;
 }
 
 // Workspace layout: [demod coefficients B*Cout] [transposed-conv intermediate, up=2 only] [split-K partial sums] [Winograd-domain input V]
@@ -2579,7 +2594,7 @@ WsLayout ws_layout(int B, int Cin, int Cout, int H, int W, int k, int up) {
     if (pf > cap) pf = (cap / out_elems) * out_elems;
     w.partial_floats = pf;
     w.wino_v = w.partial + al(pf * (int64_t)sizeof(float));
-    w.total = w.wino_v + (wino4_shape_ok(B, Cin, Cout, H, W, k, up) ? al(wino4_v_bytes(wino4_sub_batch(B, Cin, Cout, H, W), Cin, H, W)) + 256 : 0);      // + the item counters
+    w.total = w.wino_v + (wino4_shape_ok(B, Cin, Cout, H, W, k, up, true) ? al(wino4_v_bytes(wino4_sub_batch(B, Cin, Cout, H, W), Cin, H, W)) + 256 : 0);      // + the item counters
     return w;
 }
 
@@ -2715,19 +2730,23 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 const size_t lds = (size_t)(2 * 3 * 3 * 64 * 32 + 3 * 10 * 34 * 32 + 5 * 64 * 4 + 2 * Cin * 4);
                 TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds - 2 * Cin * 4 + 2 * 2048 * 4)););
                 TDGP_LAUNCH("conv_mfma_kernel", conv3s_mfma_kernel, dim3((W >> 5) * cdiv(B * (H + 1), 8), cdiv(Cout, 64)), dim3(256), lds, s, q);
-            } else if (g_conv_arith == 0 && wino4_shape_ok(B, Cin, Cout, H, W, k, up) && pi.wino4_floats > 0 && (out_layout == 0 || out_layout == 2) && !skip && ((uintptr_t)x & 15) == 0 &&
+            } else if (g_conv_arith == 0 && wino4_shape_ok(B, Cin, Cout, H, W, k, up, out_layout == 0) && pi.wino4_floats > 0 && (out_layout == 0 || out_layout == 2) && !skip && ((uintptr_t)x & 15) == 0 &&
                        ((uintptr_t)y & 15) == 0 && (!noise || (((uintptr_t)noise & 15) == 0 && (noise_bstride & 3) == 0))) {
                 float* vbuf = (float*)((char*)workspace + wl.wino_v);
                 // persistent grid; the blocks of an XCD (b, b + 8, ...) take a rectangle of rs slices x rt tile groups per pass: per pass an XCD's L2 then
                 // fetches rs U slices + rt V tile groups instead of one of each per block (bytes ~ rs * BM + rt * 32: a slice's U chunk : a tile group's V chunk)
                 const int bpc = W4_BM == 64 ? 1 : 2;                            // resident blocks per CU
-                const int cus = tdgp_cu_count(), nxcd = (cus % 8 == 0 && cus >= 64) ? 8 : 1, per = cus / nxcd * bpc, nsl = cdiv(Cout, W4_BM);
+                // K split (too few items for the chip): only when the unsplit shape does not qualify, the split-K buffer holds the slices, plain layers
+                int ksl = (out_layout == 0 && !wino4_shape_ok(B, Cin, Cout, H, W, k, up)) ? wino4_ksplit_log2(B, Cin, Cout, H, W) : 0;
+                const int64_t kslice = (int64_t)B * Cout * H * W;
+                TDGP_CHECK(ksl == 0 || (kslice << ksl) <= wl.partial_floats, TDGP_EINVAL, "modconv2d: split-K buffer too small for the F(4x4) splits");
+                const int cus = tdgp_cu_count(), nxcd = (cus % 8 == 0 && cus >= 64) ? 8 : 1, per = cus / nxcd * bpc, nsl = cdiv(Cout, W4_BM) << ksl;
                 int rs = 1;
                 while (rs * 2 <= nsl && (per % (rs * 2)) == 0 && (rs * 2) * W4_BM + per / (rs * 2) * 32 < rs * W4_BM + per / rs * 32) rs *= 2;
                 const size_t lds = (size_t)(2 * W4_STAGE + 2 * W4_BM + 4) * 4;          // two stages, bias + demodulation of the slice, the ticket
                 TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3_wino4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipFuncSetAttribute((const void*)conv3_wino4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
-                const int bsub = wino4_sub_batch(B, Cin, Cout, H, W);
-                int* ticket = (int*)((char*)vbuf + ((wino4_v_bytes(bsub, Cin, H, W) + 255) / 256 * 256));
+                const int bsub = ksl ? B : wino4_sub_batch(B, Cin, Cout, H, W);
+                int* ticket = (int*)((char*)vbuf + ((wino4_v_bytes(wino4_sub_batch(B, Cin, Cout, H, W), Cin, H, W) + 255) / 256 * 256));
                 for (int b0 = 0; b0 < B; b0 += bsub) {
                     const int bn = std::min(bsub, B - b0);
                     Wino4Params q;
@@ -2740,12 +2759,13 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                     q.B = bn; q.Cin = Cin; q.Cout = Cout; q.CoutP = pi.CoutP; q.H = H; q.W = W;
                     q.v_bytes = (uint32_t)wino4_v_bytes(bn, Cin, H, W); q.u_bytes = (uint32_t)(pi.wino4_floats * 4);
                     q.txl = wino4_txl(H, W); q.gxn = W / (4 << q.txl); q.gyn = H / (128 >> q.txl);
-                    q.rs = rs; q.rt = per / rs; q.nxcd = nxcd; q.ticket = ticket;
+                    q.rs = rs; q.rt = per / rs; q.nxcd = nxcd; q.ticket = ticket; q.ksl = ksl; q.partial = partial;
                     const int ntg = q.gxn * q.gyn * bn;
                     TDGP_LAUNCH("wino4_input_kernel", wino4_input_kernel, dim3((unsigned)(ntg * pi.nch4)), dim3(128), 0, s, x + (int64_t)b0 * Cin * H * W,
                                 styles ? styles + (int64_t)b0 * Cin : nullptr, vbuf, bn, Cin, H, W, q.gxn, q.gyn, pi.nch4, q.txl, ticket);
                     if (q.ups) TDGP_LAUNCH("upconv_wino4_kernel", conv3_wino4_kernel<true>, dim3((unsigned)(nxcd * per)), dim3(W4_NW * 64), lds, s, q);
                     else TDGP_LAUNCH("conv_wino4_kernel", conv3_wino4_kernel<false>, dim3((unsigned)(nxcd * per)), dim3(W4_NW * 64), lds, s, q);
+                    if (ksl) TDGP_LAUNCH("splitk_reduce_kernel", splitk_reduce_kernel, dim3((int)min((int64_t)2048, cdiv64(kslice, 256))), dim3(256), 0, s, partial, 1 << ksl, e);
                 }
             } else if (k == 3 && (g_conv_arith == 0 || g_conv_arith == 3) && wino_ok(B, Cin, Cout, H, W) && out_layout == 0 && !skip && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 &&
                        (!noise || (((uintptr_t)noise & 7) == 0 && (noise_bstride & 1) == 0))) {        // 16-byte activation loads, 8-byte noise loads / stores

@@ -56,8 +56,9 @@ def winograd_takes(batch, cin, cout, r):
     return batch is not None and r % 32 == 0 and cin % 8 == 0 and cin >= 64 and (r // 32) * (r // 8) * batch * ((cout + 63) // 64) >= 256
 
 
-def winograd4_takes(batch, cin, cout, r):
-    """Mirror of wino4_shape_ok() in 3dgp_amd/csrc/modconv.hip: the stride-1 3x3 layers the default arithmetic runs as F(4x4,3x3)."""
+def winograd4_takes(batch, cin, cout, r, plain=True):
+    """Mirror of wino4_shape_ok() in 3dgp_amd/csrc/modconv.hip: the stride-1 3x3 layers the default arithmetic runs as F(4x4,3x3);
+    `plain` (not a folded x2 layer): launches with too few items may split the input channels 2 or 4 ways (wino4_ksplit_log2)."""
     if batch is None or not (r % 32 == 0 and cin % 4 == 0 and cin >= 64 and cout >= 64):
         return False
     per_sample = (r * r // 512) * ((cin + 3) // 4) * 18432           # bytes of Winograd-domain input per sample
@@ -67,7 +68,10 @@ def winograd4_takes(batch, cin, cout, r):
         if sub >= 1 and items(sub) >= 256:
             return True
     sub = min(batch, (4095 << 20) // per_sample)                     # sub-batch whose V fits one buffer descriptor
-    return sub >= 1 and items(sub) >= 256
+    if sub >= 1 and items(sub) >= 256:
+        return True
+    nch = cin // 4                                                   # K split: >= 16 chunks per split, V of the whole batch inside the Infinity Cache
+    return plain and batch * per_sample <= (192 << 20) and any((items(batch) << l) >= 256 and nch % (1 << l) == 0 and (nch >> l) >= 16 for l in (1, 2))
 
 
 def algorithmic_flops(cfg, batch=None):
@@ -86,7 +90,7 @@ def algorithmic_flops(cfg, batch=None):
         if i > 0:
             # fp32 x2 layers: FIR folded into four parity kernels on the F(4x4) path where the library takes the shape (ops/modconv.py); the four
             # 3x3 parity convolutions execute 4 x 36/16 = 9 multiplies per input pixel -- exactly the algorithmic count of the transposed convolution
-            folded = (not bf) and ch[r // 2] >= 64 and (r // 2) ** 2 >= 512 and winograd4_takes(batch, ch[r // 2], 4 * c, r // 2)
+            folded = (not bf) and ch[r // 2] >= 64 and (r // 2) ** 2 >= 512 and winograd4_takes(batch, ch[r // 2], 4 * c, r // 2, plain=False)
             k = 'upconv_bf16_kernel' if bf else ('upconv_wino4_kernel' if folded else 'upconv_mfma_kernel')
             acc[k][0] += 2 * ch[r // 2] * c * 9 * (r // 2) ** 2   # stride-2 transposed conv: 9 taps per INPUT pixel
             acc[k][1] += 1

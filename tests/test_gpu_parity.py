@@ -292,6 +292,9 @@ def test_modconv_winograd_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
     (4, 128, 640, 64, 64, dict(noise=False)),                            # 20 slices of 32 channels = 3 rectangles of 8 per XCD pass, the last one ragged: empty slots are skipped, not the end
     (16, 256, 512, 32, 32, dict(noise='per_sample')),                    # 32-pixel-wide layers: tile groups of 8 x 4 tiles (32 x 16 pixels); 256 items
     (32, 128, 192, 48, 32, {}),                                          # ... with H a multiple of 16 only, three 64-channel slices
+    (4, 512, 512, 32, 32, dict(splitk=True)),                            # K split 4 ways: C3's 32^2 layer at batch 4 (64 items unsplit) -- raw sums through the split-K buffer
+    (8, 512, 512, 32, 32, dict(splitk=True, noise='per_sample', clamp=0.9)),   # K split 2 ways (batch 8), per-sample noise and clamp applied by the reduction pass
+    (8, 256, 200, 32, 32, dict(splitk=True, noise=False)),               # 4 splits of exactly 16 chunks, a ragged last slice
 ])
 def test_modconv_winograd4_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
     """Winograd F(4x4,3x3) (modconv_wino4.inc: input-transform pass + 36-GEMM kernel, points 0, +-1, 1/2, -2, inf) against the double-accumulating
@@ -332,6 +335,7 @@ def test_modconv_winograd4_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
             tdgp._lib.set_conv_arith(prev)
         out[mode] = (N(y), names)
     assert {'conv_wino4_kernel', 'wino4_input_kernel'} <= out[0][1] and 'conv_wino_kernel' not in out[0][1], out[0][1]
+    assert ('splitk_reduce_kernel' in out[0][1]) == bool(kw.get('splitk')), out[0][1]
     assert 'conv_wino4_kernel' not in out[3][1] and ('conv_wino_kernel' in out[3][1] or cin % 8 != 0 or W < 64), out[3][1]   # (F(2x2): Cin % 8 == 0, >= 256 of its own blocks)
     assert not ({'conv_wino_kernel', 'conv_wino4_kernel'} & out[2][1]), out[2][1]
     e4, e2, ed = (float(np.abs(out[m][0] - ref).max() / scale) for m in (0, 3, 2))
@@ -1234,7 +1238,7 @@ def test_full_size_c3_at_bench_batches(tdgp, oracle, B):
     w4 = [bench.winograd4_takes(B, cfg.channels[r], cfg.channels[r], r) for r in cfg.block_resolutions]            # mirrors of wino4_shape_ok / wino_ok (modconv.hip)
     w2 = [bench.winograd_takes(B, cfg.channels[r], cfg.channels[r], r) and not f for r, f in zip(cfg.block_resolutions, w4)]
     # (a layer with few channels goes through the F(4x4) kernels in sub-batches: at least one launch per layer)
-    assert launches.get('conv_wino4_kernel', 0) >= sum(w4) == (5 if B == 16 else 4) and launches.get('conv_wino_kernel', 0) == sum(w2) == 0, launches
+    assert launches.get('conv_wino4_kernel', 0) >= sum(w4) == 5 and launches.get('conv_wino_kernel', 0) == sum(w2) == 0, launches
     assert launches.get('conv_mfma_kernel', 0) == len(cfg.block_resolutions) - sum(w4), launches                    # the remaining stride-1 3x3 layers: direct sums
     # (1) planes of sample 0 vs the oracle
     oracle.set_threads(min(64, os.cpu_count() or 1))

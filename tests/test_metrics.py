@@ -272,7 +272,8 @@ def test_bench_flop_model_matches_survey(tdgp):
     assert abs((f16['upconv_wino4_kernel'][0] + f16['upconv_mfma_kernel'][0]) / 1e9 - 35.4) < 0.1
     assert abs(sum(v[0] for v in f16.values()) / 1e9 - 170.4) < 0.3
     f4b = bench.algorithmic_flops(tdgp.config.config_c3(), batch=4)
-    assert f4b['conv_wino4_kernel'][1] == 4 and f4b['conv_mfma_kernel'][1] == 4        # 32^2 at B = 4: too few items for the persistent grid
+    assert f4b['conv_wino4_kernel'][1] == 5 and f4b['conv_mfma_kernel'][1] == 3        # 32^2 at B = 4: too few items for the persistent grid -> its input channels split 4 ways
+    assert bench.winograd4_takes(8, 512, 512, 32) and not bench.winograd4_takes(2, 512, 512, 32) and not bench.winograd4_takes(4, 512, 512, 16)
     assert bench.EXECUTED_FRACTION['conv_wino4_kernel'] == 0.25 and 'upconv_wino4_kernel' not in bench.EXECUTED_FRACTION    # 36/16 of 9; 4 x 36/16 = the transposed conv's 9
     f4 = bench.algorithmic_flops(tdgp.config.config_c4())
     back4 = sum(f4[k][0] for k in ('conv_mfma_kernel', 'upconv_mfma_kernel', 'torgb_mfma_kernel')) / 1e9
