@@ -1562,7 +1562,7 @@ def _recorded_randn(fn):
 def test_full_size_backbone_random_noise_vs_oracle(tdgp, oracle, full_c3):
     """noise_mode='random' -- the default of the FID loop (metric_utils.py:310) -- at the real C3 shapes with non-zero noise strengths:
     every layer gets its own [B,1,res,res] map (networks_stylegan2.py:133-134), i.e. the per-sample noise path (noise_bstride != 0) of the
-    Winograd kernel, the direct kernel and the x2 FIR pass.  The draws are recorded and handed to the oracle as explicit maps."""
+    Winograd kernels, the split-K reduction, the direct kernel and the x2 FIR pass.  The draws are recorded and handed to the oracle as explicit maps."""
     cfg, sd, G = full_c3['cfg'], full_c3['sd'], full_c3['G']
     dec = G.synthesis.tri_plane_decoder
     ws = full_c3['ws'][:2]
@@ -1585,7 +1585,9 @@ def test_full_size_backbone_random_noise_vs_oracle(tdgp, oracle, full_c3):
     assert_close(got, ref, 1e-5, 'tri-planes 512^2, per-sample random noise', 1.0)
     const = N(full_c3['planes'].t[:1].permute(0, 1, 4, 2, 3).reshape(1, 96, 512, 512))
     assert np.abs(got - const).max() > 1e-2 * np.abs(const).max()          # the noise maps matter
-    assert 'conv_wino_kernel' in names and 'fir_act_kernel' in names, names     # B = 2: the 64^2 ... 512^2 stride-1 layers run as Winograd
+    # B = 2: the 64^2 ... 512^2 stride-1 layers run as F(4x4) -- the 64^2 one with its input channels split, i.e. the per-sample noise is applied by the
+    # reduction pass --, the low-resolution x2 layers through the FIR pass (F(2x2) with per-sample noise: test_modconv_winograd4_vs_oracle, mode 3)
+    assert {'conv_wino4_kernel', 'splitk_reduce_kernel', 'fir_act_kernel'} <= names, names
 
 
 def test_config_c5_vs_oracle(tdgp, oracle):
