@@ -2536,17 +2536,20 @@ inline int wino4_txl(int H, int W) { return (W & 63) == 0 && (H & 7) == 0 ? 4 : 
 #define TDGP_WINO4_VCAP_MB 4095
 #endif
 // Layers with few channels move 2.25 x their input through V for little arithmetic: there a sub-batch whose V stays inside the 256 MB
-// Infinity Cache between the two kernels (TDGP_WINO4_VSMALL_MB) beats one big launch (measured B = 16: 512^2 x 64 1.75 -> 1.63 ms,
-// 256^2 x 128 1.18 -> 1.12 ms; 128^2 x 256 0.93 -> 1.03 ms -- hence Cin <= 128 only).
+// Infinity Cache between the two kernels (TDGP_WINO4_VSMALL_MB) beats one big launch (measured B = 16: 256^2 x 128 1.38 (one sample per launch) /
+// 1.22 (two) / 1.25 (three) ms; 128^2 x 256 0.93 -> 1.03 ms -- hence Cin <= 128 only, and at least two samples per launch).
 #ifndef TDGP_WINO4_VSMALL_MB
 #define TDGP_WINO4_VSMALL_MB 192
+#endif
+#ifndef TDGP_WINO4_VSMALL_MINB
+#define TDGP_WINO4_VSMALL_MINB 2          // fewest samples per launch on that path (1: A/B builds)
 #endif
 inline int64_t wino4_items(int bs, int Cout, int H, int W) { return (int64_t)bs * ((H * W) >> 9) * cdiv(Cout, 64); }
 inline int wino4_sub_batch(int B, int Cin, int Cout, int H, int W) {
     const int64_t per = wino4_v_bytes(1, Cin, H, W);
     if (Cin <= 128 && TDGP_WINO4_VSMALL_MB > 0) {
         const int bs = (int)std::min<int64_t>(B, ((int64_t)TDGP_WINO4_VSMALL_MB << 20) / per);
-        if (bs >= 1 && wino4_items(bs, Cout, H, W) >= 256) return bs;
+        if (bs >= TDGP_WINO4_VSMALL_MINB && wino4_items(bs, Cout, H, W) >= 256) return bs;      // (one sample per launch -- 512^2 x 64: 151 MB of V next to 134 MB of x and y -- does not stay in the cache anyway: 1.84 vs 1.77 ms for the whole batch at once)
     }
     return (int)std::min<int64_t>(B, ((int64_t)TDGP_WINO4_VCAP_MB << 20) / per);
 }

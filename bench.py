@@ -65,7 +65,7 @@ def winograd4_takes(batch, cin, cout, r, plain=True):
     items = lambda bs: bs * (r * r // 512) * ((cout + 63) // 64)     # noqa: E731
     if cin <= 128:                                                   # few channels: sub-batches whose V stays inside the Infinity Cache
         sub = min(batch, (192 << 20) // per_sample)
-        if sub >= 1 and items(sub) >= 256:
+        if sub >= 2 and items(sub) >= 256:
             return True
     sub = min(batch, (4095 << 20) // per_sample)                     # sub-batch whose V fits one buffer descriptor
     if sub >= 1 and items(sub) >= 256:
