@@ -23,19 +23,27 @@ __global__ __launch_bounds__(512) void k(const float* src, uint32_t src_bytes, i
     float av = (float)l, bv = 1.0f;
     for (int i = 0; i < iters; i++) {
         const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(((blockIdx.x * 8 + wv) * 64 + (i & 63)) * 9216u) % (src_bytes - 16384u)));
+        float4 fab[3], fbb[3];
+        auto frag = [&](int g, int q) {
+            fab[q] = *(const float4*)(smem + wv * 2304 + ((g * 64 + l) & 511) * 4);
+            fbb[q] = *(const float4*)(smem + wv * 2304 + 1024 + ((g * 64 + l) & 255) * 4);
+        };
+        if (FR == 2) { frag(0, 0); frag(1, 1); }
 #pragma unroll
         for (int g = 0; g < 9; g++) {
             float4 fa = make_float4(av, av, av, av), fb = make_float4(bv, bv, bv, bv);
-            if (FR) { fa = *(const float4*)(smem + wv * 2304 + ((g * 64 + l) & 511) * 4); fb = *(const float4*)(smem + wv * 2304 + 1024 + ((g * 64 + l) & 255) * 4); }
+            if (FR == 1) { fa = *(const float4*)(smem + wv * 2304 + ((g * 64 + l) & 511) * 4); fb = *(const float4*)(smem + wv * 2304 + 1024 + ((g * 64 + l) & 255) * 4); }
+            if (FR == 2) { if (g + 2 < 9) frag(g + 2, (g + 2) % 3); __builtin_amdgcn_sched_barrier(0); fa = fab[g % 3]; fb = fbb[g % 3]; }
             __builtin_amdgcn_sched_barrier(0);
             acc[4 * g + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.x, fb.x, acc[4 * g + 0], 0, 0, 0);
             acc[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.y, fb.y, acc[4 * g + 1], 0, 0, 0);
             {
-                constexpr int per = PL == 0 ? 1 : (PL == 1 ? 2 : 9);
+                constexpr int per = PL == 0 ? 1 : (PL == 2 ? 9 : 2);
+                constexpr int g0 = PL == 3 ? 1 : (PL == 4 ? 2 : (PL == 5 ? 3 : 0));
 #pragma unroll
                 for (int q = 0; q < per; q++) {
-                    const int pi = g * per + q;
-                    if (pi < N && (PL != 2 || g == 0)) {
+                    const int pi = (g - g0) * per + q;
+                    if (g >= g0 && pi < N && (PL != 2 || g == 0)) {
                         const uint32_t dst = lds_base + pi * 1024, sop = so + pi * 1024u;
                         __builtin_amdgcn_sched_barrier(0);
                         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(dst), "v"(voff), "s"(d), "s"(sop) : "memory");
@@ -76,14 +84,13 @@ int main() {
     const uint32_t bytes = 8u << 20;
     float *src, *sink;
     hipMalloc(&src, bytes); hipMemset(src, 0, bytes); hipMalloc(&sink, 64);
-    const uint32_t big = 1u << 30;                  // 1 GiB source: beyond L2 and the Infinity Cache
-    float* srcb; hipMalloc(&srcb, big); hipMemset(srcb, 0, big);
-    run<9, 1, 1>("1 per group, frags, barrier", 8, src, bytes, sink);
-    run<9, 1, 1>("1 per group, frags, barrier", 4, src, bytes, sink, 2);
-    run<9, 1, 1, -1, 1>("2 per group, frags, barrier", 8, src, bytes, sink);
-    run<9, 1, 1, -1, 1>("2 per group, frags, barrier", 4, src, bytes, sink, 2);
-    run<9, 1, 1>("1 per group, frags, barrier, 1 GiB source", 4, srcb, big, sink, 2);
-    run<9, 1, 1, -1, 1>("2 per group, frags, barrier, 1 GiB source", 4, srcb, big, sink, 2);
-    run<0, 1, 1>("no loads, frags, barrier", 4, src, bytes, sink, 2);
+    run<0, 1, 2>("no loads, prefetched frags, barrier", 4, src, bytes, sink, 2);
+    run<9, 1, 2, -1, 0>("1/group g0-8, prefetched frags, barrier", 4, src, bytes, sink, 2);
+    run<9, 1, 2, -1, 1>("2/group g0-4, prefetched frags, barrier", 4, src, bytes, sink, 2);
+    run<9, 1, 2, -1, 3>("2/group g1-5, prefetched frags, barrier", 4, src, bytes, sink, 2);
+    run<9, 1, 2, -1, 4>("2/group g2-6, prefetched frags, barrier", 4, src, bytes, sink, 2);
+    run<9, 1, 2, -1, 5>("2/group g3-7, prefetched frags, barrier", 4, src, bytes, sink, 2);
+    run<9, 1, 2, -1, 2>("burst g0, prefetched frags, barrier", 4, src, bytes, sink, 2);
+    run<9, 0, 2, -1, 1>("2/group g0-4, prefetched frags, NO barrier", 4, src, bytes, sink, 2);
     return 0;
 }
