@@ -38,7 +38,7 @@ __global__ __launch_bounds__(512) void k(const float* src, uint32_t src_bytes, i
             acc[4 * g + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.x, fb.x, acc[4 * g + 0], 0, 0, 0);
             acc[4 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.y, fb.y, acc[4 * g + 1], 0, 0, 0);
             {
-                constexpr int per = PL == 0 ? 1 : (PL == 2 ? 9 : 2);
+                constexpr int per = (PL == 0 || PL == 6) ? 1 : (PL == 2 ? 9 : 2);
                 constexpr int g0 = PL == 3 ? 1 : (PL == 4 ? 2 : (PL == 5 ? 3 : 0));
 #pragma unroll
                 for (int q = 0; q < per; q++) {
@@ -52,10 +52,12 @@ __global__ __launch_bounds__(512) void k(const float* src, uint32_t src_bytes, i
                 }
             }
             if (MID >= 0 && g == 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(MID >= 0 ? MID : 0) : "memory");
+            if (PL == 6 && g == 4) { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); if (BAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
             acc[4 * g + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.z, fb.z, acc[4 * g + 2], 0, 0, 0);
             acc[4 * g + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.w, fb.w, acc[4 * g + 3], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (PL == 6) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (BAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
@@ -85,12 +87,14 @@ int main() {
     float *src, *sink;
     hipMalloc(&src, bytes); hipMemset(src, 0, bytes); hipMalloc(&sink, 64);
     run<0, 1, 2>("no loads, prefetched frags, barrier", 4, src, bytes, sink, 2);
-    run<9, 1, 2, -1, 0>("1/group g0-8, prefetched frags, barrier", 4, src, bytes, sink, 2);
-    run<9, 1, 2, -1, 1>("2/group g0-4, prefetched frags, barrier", 4, src, bytes, sink, 2);
-    run<9, 1, 2, -1, 3>("2/group g1-5, prefetched frags, barrier", 4, src, bytes, sink, 2);
-    run<9, 1, 2, -1, 4>("2/group g2-6, prefetched frags, barrier", 4, src, bytes, sink, 2);
-    run<9, 1, 2, -1, 5>("2/group g3-7, prefetched frags, barrier", 4, src, bytes, sink, 2);
-    run<9, 1, 2, -1, 2>("burst g0, prefetched frags, barrier", 4, src, bytes, sink, 2);
-    run<9, 0, 2, -1, 1>("2/group g0-4, prefetched frags, NO barrier", 4, src, bytes, sink, 2);
+    run<9, 1, 2, -1, 0>("1/group, wait at chunk end", 4, src, bytes, sink, 2);
+    run<9, 1, 2, -1, 1>("2/group g0-4, wait at chunk end", 4, src, bytes, sink, 2);
+    run<9, 1, 2, -1, 6>("1/group, SKEWED half-chunk waits", 4, src, bytes, sink, 2);
+    run<9, 1, 2, -1, 6>("1/group, SKEWED, 8 waves 1 block", 8, src, bytes, sink, 1);
+    run<9, 1, 2, -1, 0>("1/group, chunk end, 8 waves 1 block", 8, src, bytes, sink, 1);
+    const uint32_t mid = 192u << 20;                // beyond the L2s, inside the Infinity Cache
+    float* srcm; hipMalloc(&srcm, mid); hipMemset(srcm, 0, mid);
+    run<9, 1, 2, -1, 0>("1/group, chunk end, 192 MiB source", 4, srcm, mid, sink, 2);
+    run<9, 1, 2, -1, 6>("1/group, SKEWED, 192 MiB source", 4, srcm, mid, sink, 2);
     return 0;
 }
