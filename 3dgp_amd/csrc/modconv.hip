@@ -2738,16 +2738,21 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 float* vbuf = (float*)((char*)workspace + wl.wino_v);
                 // persistent grid; the blocks of an XCD (b, b + 8, ...) take a rectangle of rs slices x rt tile groups per pass: per pass an XCD's L2 then
                 // fetches rs U slices + rt V tile groups instead of one of each per block (bytes ~ rs * BM + rt * 32: a slice's U chunk : a tile group's V chunk)
-                const int bpc = W4_BM == 64 ? 1 : 2;                            // resident blocks per CU
+#ifndef TDGP_WINO4_PAIR
+#define TDGP_WINO4_PAIR 1          // 1: the 8-wave form (a slice x a pair of tile groups per block, three V stages; modconv_wino4.inc)
+#endif
+                constexpr bool pairk = TDGP_WINO4_PAIR && W4_BM == 32;
+                const int bpc = (W4_BM == 64 || pairk) ? 1 : 2;                 // resident blocks per CU
                 // K split (too few items for the chip): only when the unsplit shape does not qualify, the split-K buffer holds the slices, plain layers
                 int ksl = (out_layout == 0 && !wino4_shape_ok(B, Cin, Cout, H, W, k, up)) ? wino4_ksplit_log2(B, Cin, Cout, H, W) : 0;
                 const int64_t kslice = (int64_t)B * Cout * H * W;
                 if ((kslice << ksl) > wl.partial_floats) ksl = 0;               // (cannot happen for shapes under 256 items: 4 splits x 255 items x 32768 floats < the 64 MiB buffer; unsplit is still correct)
                 const int cus = tdgp_cu_count(), nxcd = (cus % 8 == 0 && cus >= 64) ? 8 : 1, per = cus / nxcd * bpc, nsl = cdiv(Cout, W4_BM) << ksl;
                 int rs = 1;
-                while (rs * 2 <= nsl && (per % (rs * 2)) == 0 && (rs * 2) * W4_BM + per / (rs * 2) * 32 < rs * W4_BM + per / rs * 32) rs *= 2;
-                const size_t lds = (size_t)(2 * W4_STAGE + 2 * W4_BM + 4) * 4;          // two stages, bias + demodulation of the slice, the ticket
-                TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3_wino4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipFuncSetAttribute((const void*)conv3_wino4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
+                const int tpi = pairk ? 64 : 32;                                // tiles per item
+                while (rs * 2 <= nsl && (per % (rs * 2)) == 0 && (rs * 2) * W4_BM + per / (rs * 2) * tpi < rs * W4_BM + per / rs * tpi) rs *= 2;
+                const size_t lds = pairk ? (size_t)(8 * W4_UCH + 3 * W4_BM + 4) * 4 : (size_t)(2 * W4_STAGE + 2 * W4_BM + 4) * 4;          // the stages, bias + demodulation of the slice, the ticket
+                TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3_wino4_kernel<false, pairk>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); (void)hipFuncSetAttribute((const void*)conv3_wino4_kernel<true, pairk>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
                 const int bsub = ksl ? B : wino4_sub_batch(B, Cin, Cout, H, W);
                 int* ticket = (int*)((char*)vbuf + ((wino4_v_bytes(wino4_sub_batch(B, Cin, Cout, H, W), Cin, H, W) + 255) / 256 * 256));
                 for (int b0 = 0; b0 < B; b0 += bsub) {
@@ -2766,8 +2771,8 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                     const int ntg = q.gxn * q.gyn * bn;
                     TDGP_LAUNCH("wino4_input_kernel", wino4_input_kernel, dim3((unsigned)(ntg * pi.nch4)), dim3(128), 0, s, x + (int64_t)b0 * Cin * H * W,
                                 styles ? styles + (int64_t)b0 * Cin : nullptr, vbuf, bn, Cin, H, W, q.gxn, q.gyn, pi.nch4, q.txl, ticket);
-                    if (q.ups) TDGP_LAUNCH("upconv_wino4_kernel", conv3_wino4_kernel<true>, dim3((unsigned)(nxcd * per)), dim3(W4_NW * 64), lds, s, q);
-                    else TDGP_LAUNCH("conv_wino4_kernel", conv3_wino4_kernel<false>, dim3((unsigned)(nxcd * per)), dim3(W4_NW * 64), lds, s, q);
+                    if (q.ups) TDGP_LAUNCH("upconv_wino4_kernel", (conv3_wino4_kernel<true, pairk>), dim3((unsigned)(nxcd * per)), dim3(pairk ? 512 : W4_NW * 64), lds, s, q);
+                    else TDGP_LAUNCH("conv_wino4_kernel", (conv3_wino4_kernel<false, pairk>), dim3((unsigned)(nxcd * per)), dim3(pairk ? 512 : W4_NW * 64), lds, s, q);
                     if (ksl) TDGP_LAUNCH("splitk_reduce_kernel", splitk_reduce_kernel, dim3((int)min((int64_t)2048, cdiv64(kslice, 256))), dim3(256), 0, s, partial, 1 << ksl, e);
                 }
             } else if (k == 3 && (g_conv_arith == 0 || g_conv_arith == 3) && wino_ok(B, Cin, Cout, H, W) && out_layout == 0 && !skip && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 &&
