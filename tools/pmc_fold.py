@@ -62,7 +62,7 @@ def main():
             print('bench.json not parsed:', e)
     def family(name):
         # the two instances of the F(4x4) kernel are different layers (x2 folded vs plain 3x3): keep them apart
-        if name.startswith('conv3_wino4_kernel<true>'):
+        if name.startswith('conv3_wino4_kernel<true'):
             return 'upconv_wino4_kernel'
         base = name.split('<')[0].strip()
         return ALIAS.get(base, base)
