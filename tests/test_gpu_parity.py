@@ -292,6 +292,7 @@ def test_modconv_winograd_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
     (4, 128, 640, 64, 64, dict(noise=False)),                            # 20 slices of 32 channels = 3 rectangles of 8 per XCD pass, the last one ragged: empty slots are skipped, not the end
     (16, 256, 512, 32, 32, dict(noise='per_sample')),                    # 32-pixel-wide layers: tile groups of 8 x 4 tiles (32 x 16 pixels); 256 items
     (32, 128, 192, 48, 32, {}),                                          # ... with H a multiple of 16 only, three 64-channel slices
+    (43, 64, 128, 24, 64, dict(noise='per_sample')),                     # 129 tile groups: the last PAIR of the 8-wave form has one group only (its second half multiplies the first group's data and stores nothing)
     (4, 512, 512, 32, 32, dict(splitk=True)),                            # K split 4 ways: C3's 32^2 layer at batch 4 (64 items unsplit) -- raw sums through the split-K buffer
     (8, 512, 512, 32, 32, dict(splitk=True, noise='per_sample', clamp=0.9)),   # K split 2 ways (batch 8), per-sample noise and clamp applied by the reduction pass
     (8, 256, 200, 32, 32, dict(splitk=True, noise=False)),               # 4 splits of exactly 16 chunks, a ragged last slice
