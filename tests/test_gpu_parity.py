@@ -346,6 +346,29 @@ def test_modconv_winograd4_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
     assert e4 <= 1e-5, e4
 
 
+def test_modconv_winograd4_repeats_are_bit_identical(tdgp):
+    """The 8-wave form of the F(4x4) kernel lets the V pieces of chunk c + 2 fly past the wait that ends chunk c (`vmcnt(4)`): that counts on
+    LDS-direct loads completing in issue order.  A violation would be a race, i.e. run-to-run differences: 80 repeats of a layer whose V comes
+    from beyond the L2 (and of a folded x2 layer), with other traffic in between, every output compared with the first bit for bit
+    (tools/dev/stress_w4.py: 2100 repeats over seven shapes, none differing)."""
+    M, U = tdgp.ops.modconv, tdgp.ops.upfirdn2d
+    torch.manual_seed(5)
+    fir = M.fir_host_array(U.setup_filter([1, 3, 3, 1]))
+    churn = torch.randn(32 << 20, device=DEV)
+    for (B, ci, co, R, up) in ((16, 128, 128, 256, 1), (16, 256, 128, 128, 2)):
+        x = torch.randn(B, ci, R, R, device=DEV)
+        pk = M._packed(torch.randn(co, ci, 3, 3, device=DEV))
+        s = torch.randn(B, ci, device=DEV) * 0.5 + 1.0
+        bias = torch.randn(co, device=DEV) * 0.1
+        f = (lambda: M.modconv_forward(x, pk, s, bias=bias, act='lrelu')) if up == 1 else (lambda: M.modconv_forward(x, pk, s, bias=bias, up=2, fir=fir, act='lrelu'))
+        ref = f().clone()
+        for i in range(80):
+            if i % 5 == 0:
+                churn.mul_(1.0001)
+            assert torch.equal(f(), ref), (B, ci, co, R, up, i)
+        del x, pk, ref
+
+
 def test_modconv_winograd4_sub_batches(tdgp, oracle):
     """A layer whose Winograd-domain input exceeds one 4 GiB buffer descriptor goes through the F(4x4) kernels in sub-batches sharing one V
     buffer -- exactly C4's 512^2 x 128 layer at B = 16: 302 MB of V per sample, 4.8 GB in all -> 13 + 3 samples.  Every sample equals the same
