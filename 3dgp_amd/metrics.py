@@ -99,44 +99,81 @@ def sample_camera_params(cfg, batch_size, device='cpu', origin_angles=None):
 # ----------------------------------------------------------------------------------------------------------------------
 # feature statistics + Frechet distance
 # ----------------------------------------------------------------------------------------------------------------------
+class _RawMoments:
+    """fp64 first and second raw moments (sum of rows, sum of row outer products) of fp32 feature rows.  One block = one
+    `rows.sum(0)` and one Gram matrix `rows^T rows` in fp64, added to the running totals: the accumulation order the golden
+    `metrics.npz` pins bit for bit (what `metric_utils.py:128-161` computes)."""
+    __slots__ = ('s1', 's2')
+
+    def __init__(self, width):
+        self.s1 = np.zeros(width, np.float64)
+        self.s2 = np.zeros((width, width), np.float64)
+
+    def add_block(self, rows32):
+        r = rows32.astype(np.float64)
+        self.s1 += r.sum(axis=0)
+        self.s2 += r.T @ r
+
+    def central(self, count):
+        mu = self.s1 / count
+        return mu, self.s2 / count - np.outer(mu, mu)
+
+
 class FeatureStats:
-    """metric_utils.py:104-169: running fp64 sum / outer-product sum of feature rows (and, optionally, the rows themselves)."""
+    """Feature accumulator of the FID loop; public surface of `metric_utils.py:104-169` (`append`, `append_torch`, `is_full`,
+    `get_all`, `get_mean_cov`, `num_items`, `num_features`, `max_items`), written from its behaviour:
+
+    * rows arrive in blocks `[n, F]` and are taken as fp32; F is fixed by the first block;
+    * with `max_items` set, a block that would overshoot is cut to the remaining room and later blocks are dropped whole;
+    * `capture_all` keeps the accepted rows (in arrival order), `capture_mean_cov` keeps fp64 raw moments (`_RawMoments`);
+    * multi-rank: one all-gather per block, rows interleaved rank-major (`distributed.FeatureGatherer`), so that every rank
+      accumulates the same sequence and row i of the gathered block came from rank i % world (`metric_utils.py:145-155`).
+    """
 
     def __init__(self, capture_all=False, capture_mean_cov=False, max_items=None):
-        self.capture_all, self.capture_mean_cov, self.max_items = capture_all, capture_mean_cov, max_items
+        self.capture_all = bool(capture_all)
+        self.capture_mean_cov = bool(capture_mean_cov)
+        self.max_items = None if max_items is None else int(max_items)
         self.num_items = 0
         self.num_features = None
-        self.all_features = None
-        self.raw_mean = None
-        self.raw_cov = None
+        self._kept = []                  # accepted fp32 blocks (capture_all)
+        self._moments = None             # _RawMoments (capture_mean_cov), made when F is known
 
+    # -- bookkeeping --------------------------------------------------------------------------------------------------
     def set_num_features(self, num_features):
-        if self.num_features is not None:
-            assert num_features == self.num_features
-        else:
+        """Fix the feature width F (idempotent; a different F later is an error)."""
+        num_features = int(num_features)
+        if self.num_features is None:
             self.num_features = num_features
-            self.all_features = []
-            self.raw_mean = np.zeros([num_features], dtype=np.float64)
-            self.raw_cov = np.zeros([num_features, num_features], dtype=np.float64)
+            self._moments = _RawMoments(num_features)
+        elif self.num_features != num_features:
+            raise AssertionError(f'feature width changed: {self.num_features} -> {num_features}')
+
+    def _room(self):
+        return None if self.max_items is None else max(self.max_items - self.num_items, 0)
 
     def is_full(self):
-        return (self.max_items is not None) and (self.num_items >= self.max_items)
+        return self._room() == 0
 
+    raw_mean = property(lambda self: None if self._moments is None else self._moments.s1)
+    raw_cov = property(lambda self: None if self._moments is None else self._moments.s2)
+
+    # -- accumulation -------------------------------------------------------------------------------------------------
     def append(self, x):
-        x = np.asarray(x, dtype=np.float32)
-        assert x.ndim == 2
-        if (self.max_items is not None) and (self.num_items + x.shape[0] > self.max_items):
-            if self.num_items >= self.max_items:
-                return
-            x = x[:self.max_items - self.num_items]
-        self.set_num_features(x.shape[1])
-        self.num_items += x.shape[0]
+        rows = np.asarray(x, dtype=np.float32)
+        if rows.ndim != 2:
+            raise AssertionError(f'expected [n, F] feature rows, got shape {rows.shape}')
+        room = self._room()
+        if room is not None and rows.shape[0] > room:
+            if room == 0:
+                return                    # already full: the block is dropped before it can fix F
+            rows = rows[:room]
+        self.set_num_features(rows.shape[1])
+        self.num_items += rows.shape[0]
         if self.capture_all:
-            self.all_features.append(x)
+            self._kept.append(rows)
         if self.capture_mean_cov:
-            x64 = x.astype(np.float64)
-            self.raw_mean += x64.sum(axis=0)
-            self.raw_cov += x64.T @ x64
+            self._moments.add_block(rows)
 
     def append_torch(self, x, num_gpus=1, rank=0, gatherer=None):
         """Rows of every rank, interleaved (item i of the gathered block came from rank i % world, :154).  `gatherer`: a
@@ -150,32 +187,36 @@ class FeatureStats:
             x = gatherer.gather(x)
         self.append(x.cpu().numpy())
 
+    # -- results ------------------------------------------------------------------------------------------------------
     def get_all(self):
-        assert self.capture_all
-        return np.concatenate(self.all_features, axis=0)
+        if not self.capture_all:
+            raise AssertionError('constructed without capture_all')
+        return np.concatenate(self._kept, axis=0)
 
     def get_mean_cov(self):
-        assert self.capture_mean_cov
-        mean = self.raw_mean / self.num_items
-        cov = self.raw_cov / self.num_items
-        return mean, cov - np.outer(mean, mean)
+        if not self.capture_mean_cov:
+            raise AssertionError('constructed without capture_mean_cov')
+        return self._moments.central(self.num_items)
 
+    # -- persistence: a neutral container (npz) instead of the reference's pickle of __dict__ ---------------------------
     def save(self, path):
-        """Neutral container (npz) instead of the reference's pickle of __dict__."""
+        width = self.num_features or 0
         np.savez(path, capture_all=self.capture_all, capture_mean_cov=self.capture_mean_cov, max_items=-1 if self.max_items is None else self.max_items,
-                 num_items=self.num_items, raw_mean=self.raw_mean, raw_cov=self.raw_cov,
-                 all_features=self.get_all() if self.capture_all and self.all_features else np.zeros([0, self.num_features or 0], np.float32))
+                 num_items=self.num_items, raw_mean=self._moments.s1 if self._moments else np.zeros(width), raw_cov=self._moments.s2 if self._moments else np.zeros((width, width)),
+                 all_features=self.get_all() if self.capture_all and self._kept else np.zeros([0, width], np.float32))
 
     @staticmethod
     def load(path):
         d = np.load(path)
-        obj = FeatureStats(capture_all=bool(d['capture_all']), capture_mean_cov=bool(d['capture_mean_cov']), max_items=None if int(d['max_items']) < 0 else int(d['max_items']))
-        obj.set_num_features(int(d['raw_mean'].shape[0]))
-        obj.num_items = int(d['num_items'])
-        obj.raw_mean, obj.raw_cov = d['raw_mean'].astype(np.float64), d['raw_cov'].astype(np.float64)
-        if obj.capture_all and d['all_features'].size:
-            obj.all_features = [d['all_features']]
-        return obj
+        cap = int(d['max_items'])
+        st = FeatureStats(capture_all=bool(d['capture_all']), capture_mean_cov=bool(d['capture_mean_cov']), max_items=None if cap < 0 else cap)
+        st.set_num_features(d['raw_mean'].shape[0])
+        st.num_items = int(d['num_items'])
+        st._moments.s1[...] = d['raw_mean']
+        st._moments.s2[...] = d['raw_cov']
+        if st.capture_all and d['all_features'].size:
+            st._kept = [d['all_features']]
+        return st
 
 
 def frechet_distance(mu_gen, sigma_gen, mu_real, sigma_real):
