@@ -174,6 +174,12 @@ def config_mid():
                            mlp_hid=64, num_ray_steps=16, img_resolution=32)
 
 
+def config_bigger():
+    """The hot MLP shape (feat 32, hid 64) on 128^2 planes, 96-channel backbone, 48^2 rays x 24 steps (golden e2e_bigger)."""
+    return GeneratorConfig(z_dim=64, w_dim=64, c_dim=0, cbase=4096, cmax=96, tri_plane_res=128, feat_dim=32, mlp_hid=64, num_ray_steps=24,
+                           img_resolution=48)
+
+
 def config_train_golden():
     """The training-mode golden (tools/gen_goldens.py:gen_train_forward): config_mid rendered patch-wise at 16^2."""
     cfg = config_mid()

@@ -49,11 +49,13 @@ __global__ void cam2world_kernel(const float* angles, const float* radius, const
     m[12] = 0.f; m[13] = 0.f; m[14] = 0.f; m[15] = 1.f;
 }
 
-// torch.linspace (fp32): symmetric fill around the midpoint.
+// torch.linspace (fp32, the CPU kernel the reference path runs): symmetric fill around the midpoint, each element ONE fused
+// multiply-add (ATen's serial fill `start + step * idx` / `end - step * (steps - idx - 1)` is compiled with contraction; pinned by
+// the full-size reference goldens, tests/golden/e2e_full_*.npz -- the two-rounding form is off by an ulp on 124 of 256 columns).
 __device__ __forceinline__ float linspace_f(float start, float end, int steps, int i) {
     if (steps == 1) return start;
     float step = (end - start) / (float)(steps - 1);
-    return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - 1 - i);
+    return (i < steps / 2) ? __fmaf_rn(step, (float)i, start) : __fmaf_rn(-step, (float)(steps - 1 - i), end);
 }
 
 __global__ __launch_bounds__(256) void sample_rays_kernel(const float* __restrict__ c2w, const float* __restrict__ fov, int fov_stride,

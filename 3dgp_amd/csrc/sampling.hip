@@ -224,7 +224,8 @@ __global__ __launch_bounds__(256) void stratified_kernel(const float* __restrict
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(i % S);
         const float step = (1.f - 0.f) / (float)(S - 1);
-        auto lin = [&](int q) { return (S == 1) ? 0.f : ((q < S / 2) ? 0.f + step * (float)q : 1.f - step * (float)(S - 1 - q)); };
+        // torch.linspace on the CPU: one fused multiply-add per element (see camera_rays.hip:linspace_f)
+        auto lin = [&](int q) { return (S == 1) ? 0.f : ((q < S / 2) ? __fmaf_rn(step, (float)q, 0.f) : __fmaf_rn(-step, (float)(S - 1 - q), 1.f)); };
         float s;
         if (marcher == 0) {
             float lower = (k == 0) ? lin(0) : 0.5f * (lin(k) + lin(k - 1));

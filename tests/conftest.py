@@ -103,7 +103,11 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
     """End-to-end image parity against a golden captured from the reference.  Every figure is MEASURED and recorded
     (report_parity -> terminal summary + gpurun_out/parity_report.json); three bounds are asserted:
 
-      1. range-normalised error  max|d| / max|ref|  <= RANGE_TOL (1e-5) -- well-conditioned, the binding one;
+      1. range-normalised error  max|d| / max|ref|  <= RANGE_TOL (1e-5) -- well-conditioned, the binding one.  When the golden holds the
+         reference's float64 run and the reference's OWN fp32 image is r of the range from it, the bound is max(1e-5, 2 r): two fp32
+         evaluations that are each r from the exact image can be 2 r apart (triangle inequality).  r is 2e-7 ... 1e-6 on the small
+         goldens (1e-5 stays binding) and 5e-6 ... 7e-6 on the full-size ones (e2e_full_c1/c2/c3: 512-channel backbone, sharp
+         densities), where the exactly rounded image itself is 8.1e-6 ... 8.6e-6 from the reference's fp32 image;
       2. per-pixel max-rel (|d| / max(|ref|, 1e-3 max|ref|)) against the REFERENCE image
          <= max(RGB_TOL, 1.5 x max(reference self-noise, reference-vs-exact)) when `exact` is given (every HIP test), 4 x self-noise
          otherwise (self-noise is ONE draw of the reference's own run-to-run difference);
@@ -131,13 +135,22 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
     if exact is not None:
         figs['hip_vs_exact'] = max_rel(img, exact)
         figs['reference_vs_exact_sym'] = max_rel(ref, exact)
+    rng_bound = RANGE_TOL
+    if (key + '_f64') in g:
+        ref_rng = float(np.abs(np.asarray(ref, np.float64) - np.asarray(g[key + '_f64'], np.float64)).max() / np.abs(ref).max())
+        figs['reference_fp32_vs_f64_range_err'] = ref_rng
+        rng_bound = max(RANGE_TOL, 2 * ref_rng)
     report_parity(what, **figs)
-    assert rng <= RANGE_TOL, f'{what}: range-normalised error {rng:.3e} > {RANGE_TOL:.0e}'
+    assert rng <= rng_bound, f'{what}: range-normalised error {rng:.3e} > {rng_bound:.2e}'
     # Round 4: with the exactly rounded image at hand the head-room is 1.5 x the LARGER of the reference's two own
     # figures (its run-to-run difference and its distance from the exact image; measured r03: HIP sits at 0.44-1.3 x that), not 4 x / 2 x.
     # Without `exact` (the oracle's own CPU tests: the image under test IS the exactly rounded one, so `pix` is the reference's rounding
     # error -- one draw, held against `_alt`'s one draw) the 4 x stays.
-    bound = max(pix_tol, 1.5 * max(self_noise, exact_noise)) if exact is not None else max(pix_tol, 4 * self_noise)
+    # Round 5: the reference's float64 run, when the golden holds it, is the third (and least noisy) yardstick -- |x - ref| <= |x - f64| +
+    # |f64 - ref|, and an image as good as the reference's is as far from f64 as the reference is: 1.5 x max_rel(ref, f64) joins the bound
+    # (e2e_bigger: one `_alt` draw reads 2.9e-4 while the reference is 1.1e-3 per pixel from its own float64 image).
+    f64_noise = max_rel(ref, g[key + '_f64']) if (key + '_f64') in g else 0.0
+    bound = max(pix_tol, 1.5 * max(self_noise, exact_noise, f64_noise)) if exact is not None else max(pix_tol, 4 * self_noise, 1.5 * f64_noise)
     assert pix <= bound, f'{what}: max-rel {pix:.3e} > {bound:.3e} (reference self-noise {self_noise:.3e}, reference vs exact {exact_noise:.3e})'
     if exact is not None:
         b3 = max(pix_tol, 1.5 * figs['reference_vs_exact_sym'])
@@ -157,6 +170,72 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
         # + half an fp32 ulp of the range: depth maps sit at that floor on both sides
         assert ours_mean <= 1.25 * refs_mean + 6e-8, f'{what}: mean error vs the float64 reference {ours_mean:.3e} vs the reference\'s own {refs_mean:.3e}'
     return rng, pix, self_noise
+
+
+# ------------------------------------------------------------------------------------------------ full-size goldens (BASELINE configs[0..2])
+FULL_GOLDENS = dict(c1=('config_c1', 101), c2=('config_c2', 103), c3=('config_c3', 105))      # tools/gen_goldens.py:FULL_CONFIGS
+
+
+def load_full_golden(tag):
+    """`e2e_full_<tag>.npz` (tools/gen_goldens.py:gen_e2e_full): ONE image of a BASELINE configuration at its real size from the
+    reference itself.  The float64 run and the native-convolution re-run are stored as float16 differences from the fp32 image in units
+    of their own maximum (they differ from it by ~1e-7 of the range); they are unpacked here under the keys assert_image_parity reads
+    (`<key>_f64`, `<key>_alt`), exact to ~1e-3 of that difference = ~1e-10 of the range."""
+    g = load_golden('e2e_full_' + tag)
+    for key in ('img', 'depth'):
+        base = g[key].astype(np.float64)
+        g[key + '_f64'] = base + g[key + '_f64_d16'].astype(np.float64) * float(g[key + '_f64_scale'])
+        g[key + '_alt'] = (base + g[key + '_alt_d16'].astype(np.float64) * float(g[key + '_alt_scale'])).astype(np.float32)
+    return g
+
+
+def full_golden_case(tdgp, tag):
+    """(cfg, state dict, inputs) the full-size golden was generated from: everything regenerates from the seed."""
+    cfg_name, seed = FULL_GOLDENS[tag]
+    cfg = getattr(tdgp.config, cfg_name)()
+    return cfg, tdgp.weights.random_state_dict(cfg, seed=seed, exercise_all=True), tdgp.weights.synthetic_inputs(cfg, batch=1, seed=seed + 1)
+
+
+def _ulps_apart(a, b):
+    """Distance in fp32 units in the last place (of the larger magnitude)."""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)).astype(np.float64)
+
+
+def assert_inds_mismatches_in_window(inds_a, inds_b, u, cdf_b, cdf_a=None, what='inds', max_ulp=4.0, max_knot_ulp=64.0):
+    """SURVEY.md 9.2 protocol for the INT row `inds = searchsorted(cdf, u, right=True)` (tri_plane_renderer.py:282) compared THROUGH THE
+    CHAIN (each side ranks the draw against its own cdf, and the two cdfs carry independent fp32 rounding from the MLP sums upstream):
+    every draw whose index differs must be EXPLAINED, i.e. sit inside the ambiguity window of a knot.
+
+    inds = #{k : cdf[k] <= u}.  For a mismatching draw (row r, draw j) with a = inds_a, b = inds_b, the knots k in [min(a,b), max(a,b)) are
+    exactly those on which the two sides disagree about `cdf[k] <= u`.  Asserted for each such knot:
+      * with both cdfs (`cdf_a` given): u lies in the closed interval spanned by cdf_a[k] and cdf_b[k] -- the flip is CAUSED by the two
+        knot values straddling the draw -- and the two knot values are within `max_knot_ulp` fp32 ulps of each other (the tolerance the
+        cdf rows themselves are held to);
+      * with one cdf: |u - cdf_b[k]| <= `max_ulp` ulps of the knot.
+    Anything else (a draw far from every knot landing in another interval) fails.  Returns (mismatches, worst distance in ulps)."""
+    a, b = np.asarray(inds_a, np.int64), np.asarray(inds_b, np.int64)
+    u, cdf_b = np.asarray(u, np.float32), np.asarray(cdf_b, np.float32)
+    assert a.shape == b.shape == u.shape and cdf_b.shape[0] == a.shape[0], (a.shape, b.shape, u.shape, cdf_b.shape)
+    rows, cols = np.nonzero(a != b)
+    worst = 0.0
+    for r, j in zip(rows, cols):
+        lo, hi = sorted((int(a[r, j]), int(b[r, j])))
+        for k in range(lo, hi):
+            assert 0 <= k < cdf_b.shape[1], f'{what}: draw ({r},{j}) flips across knot {k} outside the cdf'
+            if cdf_a is not None:
+                ka, kb = np.float32(cdf_a[r, k]), np.float32(cdf_b[r, k])
+                assert min(ka, kb) <= u[r, j] <= max(ka, kb), \
+                    f'{what}: draw ({r},{j}) u={u[r, j]!r} has inds {a[r, j]} vs {b[r, j]} but does not lie between the two values of knot {k}: {ka!r}, {kb!r}'
+                d = float(_ulps_apart(ka, kb))
+                assert d <= max_knot_ulp, f'{what}: knot {k} of row {r} differs by {d:.1f} ulp between the two cdfs (> {max_knot_ulp})'
+            else:
+                d = float(_ulps_apart(u[r, j], cdf_b[r, k]))
+                assert d <= max_ulp, f'{what}: draw ({r},{j}) u={u[r, j]!r} has inds {a[r, j]} vs {b[r, j]} but is {d:.1f} ulp from knot {k} = {cdf_b[r, k]!r}'
+            worst = max(worst, d)
+    report_parity(what + ': INT row inds through the chain, every mismatch explained by a knot window', mismatches=int(rows.size), draws=int(a.size),
+                  worst_window_ulp=worst)
+    return int(rows.size), worst
 
 # ------------------------------------------------------------------------------------------------ SURVEY 8f rank 4: upfirdn2d backward
 UPFIRDN_GRAD_CASES = dict(up2=dict(up=(2, 2), down=(1, 1), padding=(2, 1, 2, 1), gain=4.0, flip=False, x_hw=(8, 6)),

@@ -12,7 +12,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_close, assert_close_up_to_threshold_flips, assert_image_parity, load_golden, report_parity
+from conftest import (RGB_TOL, assert_close, assert_close_up_to_threshold_flips, assert_image_parity, assert_inds_mismatches_in_window, load_golden,
+                      report_parity)
 
 pytestmark = pytest.mark.gpu
 
@@ -921,8 +922,17 @@ def test_e2e_tiny(tdgp, oracle):
                   perm_total=int(g['perm'].size))
     # measured: 0 / 4096 and 0 / 8192 (profiles/*_parity_report.json).  Bound = "a handful, each explained": a mismatching index may only
     # move to the neighbouring cdf interval (a draw within an ulp of a knot), a mismatching sort slot only swap with its neighbour.
-    hi, gi = inter['inds'].cpu().numpy().reshape(-1).astype(np.int64), g['inds'].reshape(-1).astype(np.int64)
-    assert ni <= 2 and (ni == 0 or np.abs(hi - gi).max() <= 1), (ni, np.abs(hi - gi).max())
+    # ... and explained: the reference's own cdf (the oracle's importance stage on the reference's coarse weights reproduces
+    # the reference's cdf bit for bit, test_importance_stage_of_e2e) vs the kernel's; every mismatching draw lies between the two values of
+    # the knot it flips across.
+    hi = inter['inds'].cpu().numpy().reshape(g['inds'].shape[0], -1).astype(np.int64)
+    _, raux = oracle.sample_importance(g['imp_sdist'], g['imp_weights'], g['u_fine'], cfg.ray_marcher_type, return_aux=True)
+    np.testing.assert_array_equal(raux['inds'].reshape(hi.shape), g['inds'].reshape(hi.shape))
+    Bt, Rt = inter['sdist_coarse'].shape[:2]
+    cdf_rows = [_hip_strip_cdf(tdgp, G, inter, b, np.arange(Rt), g['u_fine'].reshape(Bt, Rt, -1)[b])[0] for b in range(Bt)]
+    assert_inds_mismatches_in_window(hi, g['inds'].reshape(hi.shape).astype(np.int64), g['u_fine'].reshape(hi.shape), raux['cdf'].reshape(hi.shape[0], -1),
+                                     np.concatenate(cdf_rows), what='e2e_tiny vs the reference')
+    assert ni <= 4, ni
     assert npm <= 4, npm
 
 
@@ -1037,23 +1047,16 @@ def test_e2e_tiny_mip(tdgp, oracle):
 
 
 def test_e2e_vs_oracle_bigger(tdgp, oracle):
-    """A configuration with the hot MLP shape (feat 32, hid 64), 128^2 planes, 48^2 rays x 24 steps: HIP vs oracle."""
-    cfg = tdgp.GeneratorConfig(z_dim=64, w_dim=64, c_dim=0, cbase=4096, cmax=96, tri_plane_res=128, feat_dim=32, mlp_hid=64, num_ray_steps=24,
-                               img_resolution=48)
-    sd = tdgp.weights.random_state_dict(cfg, seed=5, exercise_all=True)
-    inp = tdgp.weights.synthetic_inputs(cfg, batch=2, seed=6)
-    G = tdgp.generator.Generator(cfg)
-    G.load_numpy_state_dict(sd)
-    G = G.to(DEV)
-    ws = oracle.mapping_forward(sd, cfg.to_dict(), inp['z'], inp['c'])
-    oimg, odepth = oracle.synthesis_forward(sd, cfg.to_dict(), ws, inp['camera'], inp['u_coarse'], inp['u_fine'], 'const')
-    out = G.synthesis(T(ws), camera_params={k: T(v) for k, v in inp['camera'].items()}, noise_mode='const', render_opts=dict(return_depth=True),
-                      u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']))
-    # Two fp32 evaluations (MFMA fp32 chains vs fp64-accumulated oracle) of a signed image: the range-normalised bound
-    # (1e-5) is the binding one; the per-pixel metric has no reference self-noise to calibrate against here, so it is
-    # bounded at 1e-3 (= abs error <= 1e-6 of the image range on near-zero pixels).
-    assert_image_parity(N(out.img), dict(img=oimg), 'e2e_bigger img vs oracle', pix_tol=1e-3)
-    assert_image_parity(N(out.depth), dict(depth=odepth), 'e2e_bigger depth vs oracle', 'depth', pix_tol=1e-3)
+    """A configuration with the hot MLP shape (feat 32, hid 64), 128^2 planes, 48^2 rays x 24 steps: HIP vs the reference's own image
+    (golden e2e_bigger, round 5 -- before, this case was held to the oracle only and to a per-pixel figure of 1e-3 for want of a
+    reference figure) through the same four bounds as the other end-to-end goldens, the oracle's image as the exactly rounded one."""
+    cfg = tdgp.config.config_bigger()
+    g = load_golden('e2e_bigger')
+    G = _gen(tdgp, cfg, 5)
+    ex_img, ex_depth = _exact(oracle, tdgp, cfg, 5, g)
+    out = G.synthesis(T(g['ws']), camera_params=_cam(g), noise_mode='const', render_opts=dict(return_depth=True), u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
+    assert_image_parity(N(out.img), g, 'e2e_bigger img', exact=ex_img)
+    assert_image_parity(N(out.depth), g, 'e2e_bigger depth', 'depth', exact=ex_depth)
 
 
 # ------------------------------------------------------------------------------------------------ full size (BASELINE configs[2])
@@ -1147,7 +1150,81 @@ def test_full_size_renderer_strip_vs_oracle(tdgp, oracle, full_c3):
     assert np.abs(depth.reshape(2, R)[:, sel] - odepth[..., 0]).max() < 1e-5
 
 
-def _config_vs_oracle(tdgp, oracle, cfg, rows, seed, tag):
+def _hip_strip_cdf(tdgp, G, inter, b, sel, u2):
+    """The cdf knots the HIP path ranked the importance draws of a ray strip against.  The fused kernel (tdgp_importance_from_coarse)
+    keeps its cdf in LDS; the op-level pair (ray marcher -> tdgp_sample_importance, the reference's own staging) run on the SAME coarse
+    field outputs reproduces it, which is checked on the spot: its `inds` must equal the fused kernel's on every draw of the strip."""
+    syn = G.synthesis
+    opts = syn.rendering_options(syn._default_render_options)
+    rend = syn.renderer
+    B, R, S = inter['sdist_coarse'].shape[:3]
+    idx = torch.as_tensor(sel, device=DEV)
+    rg = inter['rgbs_coarse'].reshape(B, R, S, 4)[b:b + 1, idx]
+    sd = inter['sdist_coarse'].reshape(B, R, S, 1)[b:b + 1, idx]
+    _, _, w, _ = rend.ray_marcher(rg[..., :3].contiguous(), rg[..., 3:4].contiguous(), sd.contiguous(), opts)
+    _, aux = rend.sample_importance(sd.contiguous(), w, u2.shape[-1], u=T(u2), return_aux=True)
+    fused = inter['inds'].reshape(B, R, -1)[b, idx]
+    assert torch.equal(aux['inds'].reshape(fused.shape), fused), 'op-level importance stage != fused kernel on the strip'
+    return N(aux['cdf']).reshape(len(sel), -1), fused.cpu().numpy().astype(np.int64)
+
+
+@pytest.mark.parametrize('tag', ['c1', 'c2', 'c3'])
+def test_full_size_vs_reference_golden(tdgp, oracle, tag):
+    """BASELINE configs[0..2] at their REAL size against the REFERENCE ITSELF (tests/golden/e2e_full_<tag>.npz,
+    generated by tools/gen_goldens.py:gen_e2e_full from the imported reference; weights and inputs regenerate from the seed):
+      * ws, 4096 sampled texels of the tri-planes;
+      * image and depth through assert_image_parity with the oracle's image as the exactly rounded one: range-normalised error vs the
+        reference; per-pixel max-rel vs the reference bounded by 1.5 x the reference's own two noise figures; per-pixel
+        max-rel vs the reference's FLOAT64 run bounded by max(1e-4, 1.5 x what the reference's own fp32 run achieves) -- at these sizes
+        the reference's fp32 image is 1.5e-3 ... 3.2e-3 per pixel (5e-6 ... 7e-6 of the range) from its own float64 image, so a flat
+        1e-4 is not a property of the reference path; the bound that IS asserted is "no further from the exact image than 1.5 x the
+        reference is", plus the mean error <= 1.25 x the reference's;
+      * INT rows on a strip of image rows: stratified samples bit-exact vs the reference; searchsorted indices vs the reference's with
+        EVERY mismatch explained by a knot window (conftest.assert_inds_mismatches_in_window: the draw lies between the two
+        implementations' values of the knot it flips across, and those are within 64 ulp); fine samples."""
+    from conftest import assert_inds_mismatches_in_window, full_golden_case, load_full_golden
+    g = load_full_golden(tag)
+    cfg, sd, inp = full_golden_case(tdgp, tag)
+    G = tdgp.generator.Generator(cfg)
+    G.load_numpy_state_dict(sd)
+    G = G.to(DEV)
+    ws = G.mapping(T(inp['z']), T(inp['c']))
+    assert_close(N(ws), g['ws'], 1e-5, tag + ' ws', 1.0)
+    cam = {k: T(v) for k, v in inp['camera'].items()}
+    h, S = cfg.img_resolution, cfg.num_ray_steps
+    R = h * h
+    uc, uf = T(inp['u_coarse']), T(inp['u_fine'])
+    out = G.synthesis(T(g['ws']), camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True), u_coarse=uc, u_fine=uf)
+    oracle.set_threads(min(64, os.cpu_count() or 1))
+    ex_img, ex_depth = oracle.synthesis_forward(sd, cfg.to_dict(), g['ws'], inp['camera'], inp['u_coarse'], inp['u_fine'], 'const')
+    rng, pix, _ = assert_image_parity(N(out.img), g, f'{tag} full size img', exact=ex_img)
+    assert_image_parity(N(out.depth), g, f'{tag} full size depth', 'depth', exact=ex_depth)
+    dec = G.synthesis.tri_plane_decoder
+    planes = dec(T(g['ws'])[:, :dec.num_ws], noise_mode='const', hwc=True)
+    res, F3 = cfg.tri_plane_res, 3 * cfg.feat_dim
+    pl = N(planes.t.permute(0, 1, 4, 2, 3).reshape(1, F3, res, res)).reshape(-1)[g['planes_pick']]
+    e_pl = float(np.abs(pl - g['planes_vals']).max() / g['planes_absmax'])
+    report_parity(f'{tag} full size tri-planes (4096 sampled texels vs the reference)', range_err=e_pl)
+    assert e_pl <= 1e-5, e_pl
+    # the strip
+    syn = G.synthesis
+    c2w = tdgp.renderer.compute_cam2world_matrix(cam)
+    ray_o, ray_d = tdgp.renderer.sample_rays(c2w, fov=cam['fov'], resolution=(h, h), device=DEV)
+    opts = syn.rendering_options(syn._default_render_options)
+    opts.update(u_coarse=uc, u_fine=uf, ray_grid_w=h)
+    (rgb, _, _, _), inter = syn.renderer(planes, syn.tri_plane_mlp, ray_o, ray_d, opts, return_intermediates=True)
+    assert_close(N(rgb).reshape(1, R, 3), N(out.img).reshape(1, 3, R).transpose(0, 2, 1), 0, 'renderer call == forward')
+    sel = np.concatenate([np.arange(r * h, (r + 1) * h) for r in g['rows']])
+    np.testing.assert_array_equal(N(inter['sdist_coarse']).reshape(R, S)[sel], g['strip_sdist_coarse'])
+    u2 = inp['u_fine'].reshape(R, S)[sel]
+    cdf_h, inds_h = _hip_strip_cdf(tdgp, G, inter, 0, sel, u2)
+    n, worst = assert_inds_mismatches_in_window(inds_h, g['strip_inds'], u2, g['strip_cdf'], cdf_h, what=f'{tag} full size strip vs the reference')
+    assert n <= 16, n
+    d = np.abs(np.sort(N(inter['sdist_fine']).reshape(R, -1)[sel], axis=1) - np.sort(g['strip_sdist_fine'], axis=1))
+    assert np.quantile(d, 0.999) <= 2e-5 and d.max() <= (1e-3 if n == 0 else 1e-2), (float(np.quantile(d, 0.999)), float(d.max()))
+
+
+def _config_vs_oracle(tdgp, oracle, cfg, rows, seed, tag, ref_tag=None):
     """One BASELINE configuration at its REAL size, HIP against the CPU oracle: the whole backbone for one sample (every layer shape,
     tile configuration and split-K factor of that configuration) and a strip of image rows through the whole renderer from the same
     planes (rays are independent: a strip is a full-fidelity check of ray generation, both field passes, importance sampling, merge
@@ -1184,19 +1261,28 @@ def _config_vs_oracle(tdgp, oracle, cfg, rows, seed, tag):
     got = img.reshape(2, 3, R)[:, :, sel].transpose(0, 2, 1)
     e_rgb = float(np.abs(got - orgb).max() / np.abs(orgb).max())
     e_dep = float(np.abs(depth.reshape(2, R)[:, sel] - odepth[..., 0]).max())
+    pix = __import__('conftest').max_rel(got, orgb)
+    # SURVEY.md 9.9's per-pixel figure of the strip, ASSERTED: the oracle's strip is the exactly rounded one, and
+    # the yardstick is what the REFERENCE's own fp32 run achieves against its own float64 run on this configuration at this size
+    # (tests/golden/e2e_full_<ref_tag>.npz: 1.5e-3 / 3.2e-3 / 2.9e-3 for C1 / C2 / C3) -- the HIP strip may be no further from the exact
+    # one than 1.5 x that (measured r04: 5.5e-5 / 2.2e-4, i.e. 0.04 x / 0.07 x), and never further than a flat 1e-3.
+    from conftest import load_full_golden
+    fg = load_full_golden(ref_tag or 'c3')
+    ref_fig = __import__('conftest').max_rel(fg['img'], fg['img_f64'])
     report_parity(tag + f' renderer strip vs oracle ({len(rows)} rows x {h} rays x {S}+{S} samples)', rgb_range_err=e_rgb, depth_abs_err=e_dep,
-                  rgb_pix_max_rel=__import__('conftest').max_rel(got, orgb))
+                  rgb_pix_max_rel=pix, reference_fp32_vs_its_f64_at_this_size=ref_fig)
     assert e_rgb < 1e-5 and e_dep < 1e-5, (e_rgb, e_dep)
+    assert pix <= min(1e-3, max(RGB_TOL, 1.5 * ref_fig)), (pix, ref_fig)
 
 
 def test_config_c1_vs_oracle(tdgp, oracle):
     """BASELINE configs[0]: SDFood-like 64^2, 32(+32) ray steps, single class (c_dim 0), cmax 512."""
-    _config_vs_oracle(tdgp, oracle, tdgp.config.config_c1(), rows=[0, 17, 40, 63], seed=101, tag='C1 64^2/32')
+    _config_vs_oracle(tdgp, oracle, tdgp.config.config_c1(), rows=[0, 17, 40, 63], seed=101, tag='C1 64^2/32', ref_tag='c1')
 
 
 def test_config_c2_vs_oracle(tdgp, oracle):
     """BASELINE configs[1]: Dogs 128^2, 48(+48) ray steps (a pdf row of 46 elements, ray tiles of 3 x 16 samples)."""
-    _config_vs_oracle(tdgp, oracle, tdgp.config.config_c2(), rows=[0, 77, 127], seed=103, tag='C2 128^2/48')
+    _config_vs_oracle(tdgp, oracle, tdgp.config.config_c2(), rows=[0, 77, 127], seed=103, tag='C2 128^2/48', ref_tag='c2')
 
 
 def test_config_c4_backbone_vs_oracle(tdgp, oracle):
@@ -1299,7 +1385,9 @@ def test_full_size_c3_at_bench_batches(tdgp, oracle, B):
     oro, ord_ = oracle.sample_rays(oc2w, inp['camera']['fov'], 256, 256)
     np.testing.assert_array_equal(N(ray_o), oro)
     np.testing.assert_array_equal(N(ray_d), ord_)
-    sel = np.concatenate([np.arange(r * 256, (r + 1) * 256) for r in (3, 128, 250)])
+    # rows 3 / 128 / 250 of sample 0 and of sample B - 1: the last patches of the launch are the ones the persistent grid reaches after its
+    # last wrap, row 255 the last ray tile of all
+    sel = np.concatenate([np.arange(r * 256, (r + 1) * 256) for r in (3, 128, 250, 255)])
     ni_tot, np_tot = 0, 0.0
     for b in (0, B - 1):
         pl = N(planes.t[b:b + 1].permute(0, 1, 4, 2, 3).reshape(1, 96, 512, 512))
@@ -1312,12 +1400,13 @@ def test_full_size_c3_at_bench_batches(tdgp, oracle, B):
         # own (the chain: an fp32 MLP whose summation order differs feeds the cdf, so a draw within an ulp of a knot may move to the
         # neighbouring interval -- bounded as in test_e2e_tiny, measured 0); the samples themselves agree to an ulp of the depth range.
         _, oaux = oracle.sample_importance(ointer['sdist_coarse'].reshape(1, len(sel), S, 1), ointer['weights_coarse'], u2, cfg.ray_marcher_type, return_aux=True)
-        hi = inter['inds'].cpu().numpy().reshape(B, R, -1)[b, sel].astype(np.int64)
+        # every mismatching draw must be EXPLAINED -- it lies between the kernel's and the oracle's value of the knot it
+        # flips across, and those two values are within 64 ulp (conftest.assert_inds_mismatches_in_window); a draw away from every knot
+        # landing in another interval fails the test.  (Before round 5 the mismatches were counted, <= 8 per strip, and not explained.)
+        cdf_h, hi = _hip_strip_cdf(tdgp, G, inter, b, sel, u2)
         oi = oaux['inds'].reshape(len(sel), -1)
-        ni = int((hi != oi).sum())
-        # 49 152 draws against 63 cdf knots each, cdf values carrying ~1e-7 of fp32 noise from the two MLP evaluations: a handful of draws sit within
-        # that of a knot (measured 0-3 per strip depending on the planes); every one may only move to the neighbouring interval
-        assert ni <= 8 and (ni == 0 or np.abs(hi - oi).max() <= 1), (b, ni)
+        ni, _ = assert_inds_mismatches_in_window(hi, oi, u2, oaux['cdf'].reshape(len(sel), -1), cdf_h, what=f'C3 B={B} sample {b} strip vs the oracle')
+        assert ni <= 16, ni
         ni_tot += ni
         hf = np.sort(N(inter['sdist_fine']).reshape(B, R, -1)[b, sel], axis=1)
         of = np.sort(ointer['sdist_fine'].reshape(len(sel), -1), axis=1)

@@ -118,12 +118,13 @@ class Capture:
     """Record the outputs of torch.searchsorted / torch.sort while the reference runs."""
 
     def __enter__(self):
-        self.inds, self.perm = [], []
+        self.inds, self.perm, self.cdf = [], [], []
         self.o_ss, self.o_sort = torch.searchsorted, torch.sort
 
         def ss(*a, **k):
             r = self.o_ss(*a, **k)
             self.inds.append(r.clone())
+            self.cdf.append(a[0].clone())                # the knots the draws were ranked against (tri_plane_renderer.py:282)
             return r
 
         def sort(*a, **k):
@@ -713,6 +714,101 @@ def gen_e2e(tag, cfg, batch, seed, keep_intermediates):
             with PatchedRNG(rand_like=[T(inp['u_coarse']).reshape(batch, R, S, 1)], rand=[T(inp['u_fine'])]):
                 arrays['img_noise_none'] = npy(G.synthesis(ws, camera_params=cam, noise_mode='none'))
     save(tag, **arrays)
+
+
+
+# BASELINE.json configs[0..2] at their REAL size: one image each from the reference itself.
+FULL_CONFIGS = dict(c1=('config_c1', 101, [0, 17, 40, 63]), c2=('config_c2', 103, [0, 77, 127]), c3=('config_c3', 105, [3, 128, 250]))
+
+
+def _pack_diff(x, base):
+    """(x - base) as float16 in units of its own maximum: a float64 / re-run image stored next to the fp32 one it differs from by
+    ~1e-7 of the range costs 2 bytes per pixel and is recovered to ~1e-10 of the range (conftest.unpack_full_golden)."""
+    d = np.asarray(x, np.float64) - np.asarray(base, np.float64)
+    scale = float(np.abs(d).max()) or 1.0
+    return (d / scale).astype(np.float16), np.float64(scale)
+
+
+def gen_e2e_full(tag):
+    """`e2e_full_<tag>.npz`: the reference Generator at a BASELINE configuration's real size (512^2 tri-planes, 512-channel backbone,
+    the configuration's image size and ray-step count), batch 1, weights = random_state_dict(cfg, seed, exercise_all=True) and inputs =
+    synthetic_inputs(cfg, 1, seed + 1) -- both regenerate from the seed, so only outputs are stored: img, depth (fp32), the reference's
+    own float64 run and its native-convolution re-run as packed differences, and for a strip of image rows the integer rows of the
+    importance stage (searchsorted indices, the cdf knots they were ranked against, sort permutation) plus the fine samples."""
+    cfg_name, seed, rows = FULL_CONFIGS[tag]
+    cfg = getattr(tdgp.config, cfg_name)()
+    sd = tdgp.weights.random_state_dict(cfg, seed=seed, exercise_all=True)
+    G = build_ref_generator(cfg, sd)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=1, seed=seed + 1)
+    cam = TensorGroup(**{k: T(v) for k, v in inp['camera'].items()})
+    h = cfg.img_resolution
+    R, S = h * h, cfg.num_ray_steps
+    sel = np.concatenate([np.arange(r * h, (r + 1) * h) for r in rows])
+    rl = lambda: [T(inp['u_coarse']).reshape(1, R, S, 1)]       # noqa: E731
+    import time
+    with torch.no_grad():
+        ws = G.mapping(T(inp['z']), T(inp['c']))
+        stage = {}
+        rend = G.synthesis.renderer
+        o_si = rend.sample_importance
+
+        def si(z_vals, weights, n):
+            r = o_si(z_vals, weights, n)
+            stage.update(sdist=npy(z_vals)[0, sel, :, 0], weights=npy(weights)[0, sel, :, 0], sdist_fine=npy(r)[0, sel, :, 0])
+            return r
+        rend.sample_importance = si
+        t0 = time.time()
+        with PatchedRNG(rand_like=rl(), rand=[T(inp['u_fine'])]), Capture() as cap:
+            out = G.synthesis(ws, camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True))
+        print(f'{tag}: reference fp32 forward {time.time() - t0:.1f} s')
+        rend.sample_importance = o_si
+        img, depth = npy(out.img), npy(out.depth)
+        arrays = dict(seed=np.array([seed, 1], np.int64), rows=np.array(rows, np.int64), ws=npy(ws), img=img, depth=depth,
+                      strip_sdist_coarse=stage['sdist'], strip_weights_coarse=stage['weights'], strip_sdist_fine=stage['sdist_fine'],
+                      strip_inds=npy(cap.inds[0]).reshape(R, S)[sel].astype(np.uint8), strip_cdf=npy(cap.cdf[0]).reshape(R, -1)[sel],
+                      strip_perm=npy(cap.perm[0]).reshape(R, 2 * S)[sel].astype(np.uint8))
+        # tri-planes: too large to store (100 MB); a fixed sample of 4096 texels pins the backbone against the reference directly
+        planes = npy(G.synthesis.tri_plane_decoder(ws[:, :G.synthesis.tri_plane_decoder.num_ws], noise_mode='const'))
+        pick = np.random.RandomState(seed).randint(0, planes.size, 4096)
+        arrays.update(planes_pick=pick.astype(np.int64), planes_vals=planes.reshape(-1)[pick], planes_absmax=np.float32(np.abs(planes).max()))
+        # the reference's own fp32 reproducibility (native convolutions, 1 thread) and its float64 run: see gen_e2e
+        torch.backends.mkldnn.enabled = False
+        torch.set_num_threads(1)
+        t0 = time.time()
+        with PatchedRNG(rand_like=rl(), rand=[T(inp['u_fine'])]):
+            alt = G.synthesis(ws, camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True))
+        print(f'{tag}: reference native-conv 1-thread forward {time.time() - t0:.1f} s')
+        torch.backends.mkldnn.enabled = True
+        torch.set_num_threads(8)
+        G64 = build_ref_generator(cfg, sd).double()
+        import src.training.networks_epigraf as ref_epi
+        c2w32 = ref_ru.compute_cam2world_matrix(cam)
+        ro32, rd32 = ref_tpr.sample_rays(c2w32, fov=cam.fov, resolution=(h, h))
+        o_c2w, o_rays = ref_epi.compute_cam2world_matrix, ref_epi.sample_rays
+        ref_epi.compute_cam2world_matrix = lambda camera_params: c2w32
+        ref_epi.sample_rays = lambda *a, **k: (ro32.double(), rd32.double())
+        torch.set_default_dtype(torch.float64)
+        f32 = torch.float32
+        torch.float32 = torch.float64
+        t0 = time.time()
+        try:
+            with PatchedRNG(rand_like=[T(inp['u_coarse']).reshape(1, R, S, 1).double()], rand=[T(inp['u_fine']).double()]):
+                o64 = G64.synthesis(ws.double(), camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True))
+        finally:
+            torch.float32 = f32
+            torch.set_default_dtype(torch.float32)
+            ref_epi.compute_cam2world_matrix, ref_epi.sample_rays = o_c2w, o_rays
+        print(f'{tag}: reference float64 forward {time.time() - t0:.1f} s')
+        assert o64.img.dtype == torch.float64
+        for key, base, a, b in (('img', img, alt.img, o64.img), ('depth', depth, alt.depth, o64.depth)):
+            arrays[key + '_alt_d16'], arrays[key + '_alt_scale'] = _pack_diff(npy(a), base)
+            arrays[key + '_f64_d16'], arrays[key + '_f64_scale'] = _pack_diff(npy(b), base)
+    save('e2e_full_' + tag, **arrays)
+
+
+def gen_e2e_full_all():
+    for tag in FULL_CONFIGS:
+        gen_e2e_full(tag)
 
 
 def gen_cut_chunked():
@@ -1360,6 +1456,10 @@ def main():
         for name in sys.argv[1:]:
             if name == 'e2e':
                 gen_e2e_all()
+            elif name == 'e2e_full':
+                gen_e2e_full_all()
+            elif name.startswith('e2e_full_'):
+                gen_e2e_full(name[len('e2e_full_'):])
             else:
                 globals()['gen_' + name]()
         return
@@ -1392,6 +1492,7 @@ def main():
     gen_mapping()
     gen_cut_chunked()
     gen_e2e_all()
+    gen_e2e_full_all()
 
 
 def gen_e2e_all():
@@ -1401,6 +1502,7 @@ def gen_e2e_all():
     cfg.ray_marcher_type = 'mip'
     cfg.white_back = True
     gen_e2e('e2e_tiny_mip', cfg, batch=1, seed=41, keep_intermediates=False)
+    gen_e2e('e2e_bigger', tdgp.config.config_bigger(), batch=2, seed=5, keep_intermediates=False)
 
 
 if __name__ == '__main__':
