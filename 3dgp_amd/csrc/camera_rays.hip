@@ -17,15 +17,18 @@ __device__ __forceinline__ void sph2cart(float rot, float pitch, float radius, f
     o[1] = radius * cp;
     o[2] = radius * sp * cr;
 }
+// The fp32 chains below follow what the reference's CPU/PyTorch path executes (probed against torch 2.10; DESIGN.md (c), "fp32 chains restated"):
+// torch.norm over 3 components = x0*x0 -> fma -> fma -> sqrt; torch.cross = fma(a_i, b_j, -(a_j * b_i)); the K = 3 bmm = an in-order
+// fused chain.  With these the rays are bit-identical to the reference's whenever the cam2world matrix is (its sin / cos are Sleef's
+// 1-ulp routines there, correctly rounded here: ~5 % of angles differ in the last bit).
 __device__ __forceinline__ void norm3(float* v) {
-    double s = (double)(v[0] * v[0]) + (double)(v[1] * v[1]) + (double)(v[2] * v[2]);
-    float n = (float)sqrt(s);
-    v[0] = v[0] / n; v[1] = v[1] / n; v[2] = v[2] / n;
+    float n = __fsqrt_rn(__fmaf_rn(v[2], v[2], __fmaf_rn(v[1], v[1], v[0] * v[0])));
+    v[0] = __fdiv_rn(v[0], n); v[1] = __fdiv_rn(v[1], n); v[2] = __fdiv_rn(v[2], n);
 }
 __device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
-    o[0] = a[1] * b[2] - a[2] * b[1];
-    o[1] = a[2] * b[0] - a[0] * b[2];
-    o[2] = a[0] * b[1] - a[1] * b[0];
+    o[0] = __fmaf_rn(a[1], b[2], -(a[2] * b[1]));
+    o[1] = __fmaf_rn(a[2], b[0], -(a[0] * b[2]));
+    o[2] = __fmaf_rn(a[0], b[1], -(a[1] * b[0]));
 }
 
 __global__ void cam2world_kernel(const float* angles, const float* radius, const float* look_at, float* c2w, int B) {
@@ -80,8 +83,7 @@ __global__ __launch_bounds__(256) void sample_rays_kernel(const float* __restric
         norm3(d);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            double acc = (double)m[k * 4 + 0] * d[0] + (double)m[k * 4 + 1] * d[1] + (double)m[k * 4 + 2] * d[2];
-            ray_d[r * 3 + k] = (float)acc;
+            ray_d[r * 3 + k] = __fmaf_rn(m[k * 4 + 2], d[2], __fmaf_rn(m[k * 4 + 1], d[1], m[k * 4 + 0] * d[0]));
             ray_o[r * 3 + k] = m[k * 4 + 3];
         }
     }

@@ -1216,6 +1216,10 @@ def test_full_size_vs_reference_golden(tdgp, oracle, tag):
     assert_close(N(rgb).reshape(1, R, 3), N(out.img).reshape(1, 3, R).transpose(0, 2, 1), 0, 'renderer call == forward')
     sel = np.concatenate([np.arange(r * h, (r + 1) * h) for r in g['rows']])
     np.testing.assert_array_equal(N(inter['sdist_coarse']).reshape(R, S)[sel], g['strip_sdist_coarse'])
+    assert_close(N(c2w), g['c2w'], 2e-7, 'c2w', 1.0)                          # sin / cos: 1-ulp routines in torch, correctly rounded here
+    if np.array_equal(N(c2w), g['c2w']):                                     # ... and given the same matrix the rays are the reference's bits
+        np.testing.assert_array_equal(N(ray_d)[0, sel], g['strip_ray_d'])
+    np.testing.assert_array_equal(N(ray_o)[0, sel], g['strip_ray_o'])
     u2 = inp['u_fine'].reshape(R, S)[sel]
     cdf_h, inds_h = _hip_strip_cdf(tdgp, G, inter, 0, sel, u2)
     n, worst = assert_inds_mismatches_in_window(inds_h, g['strip_inds'], u2, g['strip_cdf'], cdf_h, what=f'{tag} full size strip vs the reference')

@@ -767,6 +767,9 @@ def gen_e2e_full(tag):
                       strip_sdist_coarse=stage['sdist'], strip_weights_coarse=stage['weights'], strip_sdist_fine=stage['sdist_fine'],
                       strip_inds=npy(cap.inds[0]).reshape(R, S)[sel].astype(np.uint8), strip_cdf=npy(cap.cdf[0]).reshape(R, -1)[sel],
                       strip_perm=npy(cap.perm[0]).reshape(R, 2 * S)[sel].astype(np.uint8))
+        c2w = ref_ru.compute_cam2world_matrix(cam)
+        ro, rd = ref_tpr.sample_rays(c2w, fov=cam.fov, resolution=(h, h))
+        arrays.update(c2w=npy(c2w), strip_ray_o=npy(ro)[0, sel], strip_ray_d=npy(rd)[0, sel])
         # tri-planes: too large to store (100 MB); a fixed sample of 4096 texels pins the backbone against the reference directly
         planes = npy(G.synthesis.tri_plane_decoder(ws[:, :G.synthesis.tri_plane_decoder.num_ws], noise_mode='const'))
         pick = np.random.RandomState(seed).randint(0, planes.size, 4096)
