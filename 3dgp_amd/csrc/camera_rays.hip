@@ -22,8 +22,9 @@ __device__ __forceinline__ void sph2cart(float rot, float pitch, float radius, f
 // fused chain.  With these the rays are bit-identical to the reference's whenever the cam2world matrix is (its sin / cos are Sleef's
 // 1-ulp routines there, correctly rounded here: ~5 % of angles differ in the last bit).
 __device__ __forceinline__ void norm3(float* v) {
-    float n = __fsqrt_rn(__fmaf_rn(v[2], v[2], __fmaf_rn(v[1], v[1], v[0] * v[0])));
-    v[0] = __fdiv_rn(v[0], n); v[1] = __fdiv_rn(v[1], n); v[2] = __fdiv_rn(v[2], n);
+    // sqrtf and `/` are the correctly rounded fp32 forms in this build (hipcc's default; `__fsqrt_rn` is NOT -- it maps to the native sqrt)
+    float n = sqrtf(__fmaf_rn(v[2], v[2], __fmaf_rn(v[1], v[1], v[0] * v[0])));
+    v[0] = v[0] / n; v[1] = v[1] / n; v[2] = v[2] / n;
 }
 __device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
     o[0] = __fmaf_rn(a[1], b[2], -(a[2] * b[1]));

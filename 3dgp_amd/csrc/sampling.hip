@@ -53,7 +53,8 @@ __device__ __forceinline__ float s2t(float s, float t_near, float t_far) { retur
 // ------------------------------------------------------------------------------------------------
 __device__ void march_classical_lds(const float* z, const float* sig, float* w, int S, int flags, float cut_thr, float& final_T, float& wagg) {
     const int l = lane_id();
-    float carry = 1.0f, wsum = 0.0f;
+    double carry = 1.0;
+    float wsum = 0.0f;
     for (int base = 0; base < S; base += 64) {
         const int i = base + l;
         float alpha = 0.f, fac = 1.0f;
@@ -64,14 +65,19 @@ __device__ void march_classical_lds(const float* z, const float* sig, float* w, 
             alpha = 1.0f - expf(-(delta * sp));
             fac = (1.0f - alpha) + 1e-10f;
         }
-        const float incl = wave_scan_f32<true>(fac) * carry;
-        const float excl = wave_shr1_f32(incl, carry);
+        // transmittance = torch.cumprod on the CPU: prefixes accumulated in fp64, each rounded to fp32.  The fp64 DPP
+        // scan (6 steps of 2 moves + 1 v_mul_f64) rounds to the same fp32 prefix as the sequential fp64 product except with probability
+        // ~2^-29 per element.  Round 5: the fp32 scan used since round 2 left the composited depth 2.4e-7 (2 ulp) from the reference's
+        // float64 image on average where the reference's own fp32 run sits at 0.9e-7 (e2e_full_c3) -- with this it is level.
+        const double incl64 = wave_scan_f64<true>((double)fac) * carry;
+        const float incl = (float)incl64;
+        const float excl = wave_shr1_f32(incl, (float)carry);
         const float wi = alpha * excl;
         if (i < S) { w[i] = wi; wsum += wi; }
-        carry = wave_last_f32(incl);
+        carry = wave_last_f64(incl64);
     }
     wagg = wave_sum_f32(wsum);
-    final_T = carry;
+    final_T = (float)carry;
     wave_sync();
     if ((flags & 2) && l == 0) w[S - 1] += (1.0f - wagg);
     wave_sync();
@@ -83,7 +89,8 @@ __device__ void march_mip_lds(const float* z, const float* sig, float* w, int S,
                               float& wagg) {
     const int l = lane_id();
     const int M = (flags & 1) ? S : S - 1;
-    float carry = 1.0f, wsum = 0.0f;
+    double carry = 1.0;
+    float wsum = 0.0f;
     for (int base = 0; base < M; base += 64) {
         const int i = base + l;
         float alpha = 0.f, fac = 1.0f;
@@ -97,14 +104,15 @@ __device__ void march_mip_lds(const float* z, const float* sig, float* w, int S,
             alpha = 1.0f - expf(-dd);
             fac = (1.0f - alpha) + 1e-10f;
         }
-        const float incl = wave_scan_f32<true>(fac) * carry;
-        const float excl = wave_shr1_f32(incl, carry);
+        const double incl64 = wave_scan_f64<true>((double)fac) * carry;        // fp64 prefixes rounded to fp32: see march_classical_lds
+        const float incl = (float)incl64;
+        const float excl = wave_shr1_f32(incl, (float)carry);
         const float wi = alpha * excl;
         if (i < M) { w[i] = wi; wsum += wi; }
-        carry = wave_last_f32(incl);
+        carry = wave_last_f64(incl64);
     }
     wagg = wave_sum_f32(wsum);
-    final_T = carry;
+    final_T = (float)carry;
     wave_sync();
 }
 

@@ -153,7 +153,9 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
     bound = max(pix_tol, 1.5 * max(self_noise, exact_noise, f64_noise)) if exact is not None else max(pix_tol, 4 * self_noise, 1.5 * f64_noise)
     assert pix <= bound, f'{what}: max-rel {pix:.3e} > {bound:.3e} (reference self-noise {self_noise:.3e}, reference vs exact {exact_noise:.3e})'
     if exact is not None:
-        b3 = max(pix_tol, 1.5 * figs['reference_vs_exact_sym'])
+        # (the reference's distance from the exact image is ONE draw of a heavy-tailed maximum -- e2e_full_c1: 3.8e-4 from the oracle's image
+        # but 9.9e-4 from its own re-run and 1.5e-3 from its own float64 run -- so the yardstick is the largest of its three own figures)
+        b3 = max(pix_tol, 1.5 * max(figs['reference_vs_exact_sym'], self_noise, f64_noise))
         assert figs['hip_vs_exact'] <= b3, f"{what}: HIP vs exactly-rounded image {figs['hip_vs_exact']:.3e} > {b3:.3e}"
     if (key + '_f64') in g:
         f64 = np.asarray(g[key + '_f64'], np.float64)
