@@ -28,6 +28,7 @@ _PROTOTYPES = {
     'tdgp_modconv_pack_bytes': (c_int64, [c_int, c_int, c_int]),
     'tdgp_modconv_pack': (c_int, [P, P, c_int, c_int, c_int, P]),
     'tdgp_modconv2d_workspace_bytes': (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'tdgp_modconv2d_takes_folded_up2': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'tdgp_conv2d': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'tdgp_conv2d_weight_grad_workspace_bytes': (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     'tdgp_conv2d_weight_grad': (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
@@ -151,6 +152,16 @@ def profile_report():
 def device_fault(clear=False):
     """The library's device-fault word (include/tdgp.h: a bounded in-kernel wait that ran out); read it after synchronising."""
     return int(load().tdgp_device_fault(int(bool(clear))))
+
+
+def raise_on_device_fault(where=''):
+    """Call AFTER a synchronisation point (an image fetched to the host, the end of a training step, a graph replay whose outputs were read):
+    a launch whose bounded in-kernel wait ran out has set the fault word -- its results are invalid.  Reads, clears and raises; the C side
+    only notices at the entry of the NEXT field / per-ray call, which the last forward of a run never reaches."""
+    code = device_fault(clear=True)
+    if code:
+        raise RuntimeError(f'libtdgp_hip: device fault {code} reported{" in " + where if where else ""}: a bounded in-kernel wait ran out, '
+                           'the results of that launch are invalid (the fault word has been cleared)')
 
 
 def set_conv_arith(mode):

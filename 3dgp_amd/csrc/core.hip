@@ -35,8 +35,8 @@ int* tdgp_fault_word() {
     w = word.load(std::memory_order_acquire);
     if (!w) {
         void* hp = nullptr;
-        // 64 bytes of pinned, mapped, coherent host memory: the one allocation the library makes (not device memory; never freed)
-        if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || !hp) { (void)hipGetLastError(); return nullptr; }
+        // 64 bytes of pinned, mapped, coherent, PORTABLE (every device of the process sees it) host memory: the one allocation the library makes (not device memory; never freed)
+        if (hipHostMalloc(&hp, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || !hp) { (void)hipGetLastError(); return nullptr; }
         *(volatile int*)hp = 0;
         w = (int*)hp;
         word.store(w, std::memory_order_release);

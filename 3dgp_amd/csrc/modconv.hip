@@ -2642,6 +2642,13 @@ TDGP_API int tdgp_set_conv_arith(int mode) {
 }
 
 
+// Cheap shape query (no launch, no allocation): does tdgp_modconv2d take a FOLDED x2 layer (out_layout 2: four parity 3x3 kernels, Cout4 = 4 x the
+// layer's output channels) of this shape on the Winograd F(4x4) kernels under the current arithmetic mode?  The binding asks BEFORE it folds and
+// packs the [4 Cout, Cin, 3, 3] weights (small launches paid the fold, the pack and an exception to learn the answer).
+TDGP_API int tdgp_modconv2d_takes_folded_up2(int B, int Cin, int Cout4, int H, int W) {
+    return (g_conv_arith == 0 && B >= 1 && (Cout4 & 3) == 0 && wino4_shape_ok(B, Cin, Cout4, H, W, 3, 1)) ? 1 : 0;
+}
+
 TDGP_API int64_t tdgp_modconv2d_workspace_bytes(int B, int Cin, int Cout, int H, int W, int k, int up) {
     return ws_layout(B, Cin, Cout, H, W, k, up).total;
 }

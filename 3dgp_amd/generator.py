@@ -297,16 +297,19 @@ class SynthesisBlock(torch.nn.Module):
         return x, img
 
 
-_SIDE_STREAMS = {}           # (device type, index) -> torch.cuda.Stream; process-wide, never part of a module's state
+_SIDE_STREAMS = {}           # (device index, main stream handle) -> torch.cuda.Stream; process-wide, never part of a module's state
 
 
 def side_stream_of(device):
-    """One side stream per GPU for work that overlaps the main stream (ToRGB beside the next block's x2 layer)."""
+    """The side stream for work that overlaps the CURRENT stream of `device` (ToRGB beside the next block's x2 layer).  One per (GPU,
+    main stream): generators that run on different streams -- the lanes of bench.py's FID loop, a GraphedGenerator being captured next
+    to eager work -- do not serialise their ToRGB layers on one shared stream, and a capture never records another lane's work."""
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    st = _SIDE_STREAMS.get(idx)
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=torch.device('cuda', idx))
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=torch.device('cuda', idx))
     return st
 
 
@@ -437,7 +440,23 @@ class SynthesisBlocksSequence(torch.nn.Module):
     # resident-block slots from a grid that owns every CU -- measured -6 % -- so by default only the blocks up to 16^2 overlap: their ToRGB
     # layers are single-digit-block launches that take ~35 us whatever the batch (a serial K loop), next to x2 layers of the same kind.
     # overlap_torgb: False = never, True = every block, an int = blocks up to that resolution (TDGP_OVERLAP_TORGB=0 / 1 / <res>); same bits always.
-    overlap_torgb = (lambda v: False if v == '0' else True if v == '1' else int(v))(__import__('os').environ.get('TDGP_OVERLAP_TORGB', '16'))
+    @staticmethod
+    def _parse_overlap(v, default=16):
+        """'0' / 'false' / 'off' -> False, '1' / 'true' / 'on' / 'all' -> True, an integer -> that resolution; anything else -> the default, with a warning
+        (an unparsable environment variable must not make the package unimportable)."""
+        t = str(v).strip().lower()
+        if t in ('0', 'false', 'off', 'no'):
+            return False
+        if t in ('1', 'true', 'on', 'yes', 'all'):
+            return True
+        try:
+            return int(t)
+        except ValueError:
+            import warnings
+            warnings.warn(f'TDGP_OVERLAP_TORGB={v!r} is not 0 / 1 / a resolution: using {default}')
+            return default
+
+    overlap_torgb = _parse_overlap.__func__(__import__('os').environ.get('TDGP_OVERLAP_TORGB', '16'))
 
     def _side(self, t):
         """The stream the ToRGB layers run on, per DEVICE and outside the module: a `torch.cuda.Stream` in `__dict__` would make the

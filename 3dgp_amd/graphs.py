@@ -71,6 +71,14 @@ class GraphedGenerator:
         self.graph.replay()
         return self.out
 
+    def result(self):
+        """The static output AFTER the replay has finished: synchronises the device and raises if a launch of the replay reported a device
+        fault (a graph replay never passes through the C entry points that would notice one)."""
+        from . import _lib
+        torch.cuda.synchronize(self.out.device if isinstance(self.out, torch.Tensor) else None)
+        _lib.raise_on_device_fault('a graph replay')
+        return self.out
+
     def __call__(self, z, c, camera_params, u_coarse=None, u_fine=None):
         self.load(z, c, camera_params, u_coarse, u_fine)
         return self.replay()

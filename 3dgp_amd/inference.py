@@ -8,6 +8,7 @@ Reference: `src/training/inference_utils.py:88-215` -- `generate`, `generate_tra
 import numpy as np
 import torch
 
+from . import _lib
 from .generator import TensorGroup
 from .metrics import camera_base, sample_camera_params
 
@@ -27,7 +28,9 @@ def generate(G, ws, camera_params, batch_size=8, **synthesis_kwargs):
             depth_range = G.cfg.ray_end - G.cfg.ray_start
             depth_mid = (G.cfg.ray_start + G.cfg.ray_end) * 0.5
             frame.depth = (frame.depth - depth_mid) / depth_range * 2.0
-        frames.append(frame.clamp(-1, 1).cpu() * 0.5 + 0.5)
+        frames.append(frame.clamp(-1, 1).cpu() * 0.5 + 0.5)             # a synchronisation point
+        if ws.is_cuda:
+            _lib.raise_on_device_fault('generate()')
     return TensorGroup.cat(frames, dim=0) if isinstance(frames[0], TensorGroup) else torch.cat(frames, dim=0)
 
 

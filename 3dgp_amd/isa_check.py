@@ -9,6 +9,10 @@ window that crosses the back edge).
 import re
 
 
+class IsaListingError(RuntimeError):
+    """The assembly listing does not have the shape the checker parses (not a violation of the property it checks)."""
+
+
 def _regs(tok):
     out = set()
     for m in re.finditer(r'v\[(\d+):(\d+)\]', tok):
@@ -25,6 +29,9 @@ def _code(lines):
 def check_kernel(body, fq):
     """`body` = assembly lines of ONE walk2 instantiation.  -> (summary dict, [(why, instruction)])"""
     heads = [i for i, ln in enumerate(body) if 'Loop Header: Depth=1' in ln]
+    if not heads:
+        raise IsaListingError("no 'Loop Header: Depth=1' comment in the listing of triplane_walk2_kernel: this hipcc does not annotate loops "
+                              '(asm-verbose off, or a different compiler) -- the check cannot locate the producer loop')
     lo = heads[-1]                  # the producer loop: the kernel's last outermost loop
     ends = [i for i, ln in enumerate(body) if 's_endpgm' in ln and i > lo]
     hi = ends[0] if ends else len(body) - 1
@@ -61,6 +68,9 @@ def check_kernel(body, fq):
             touched = [t for d, t in inflight if _regs(ins) & d]
             if touched:
                 bad.append((f'touches the destination of `{touched[0]}`', ins))
+    if nloads == 0 and hand_waits == 0:
+        # the hand-issued path is compiled out (TDGP_WALK2_ASMLOAD=0 A/B builds): the compiler keeps its own wait counts, nothing to verify
+        return dict(loop_instructions=len(loop), tap_loads=0, hand_waits=0, compiler_vmcnt_waits=comp_waits, skipped='no hand-issued loads'), []
     if nloads != 6 * fq or hand_waits != 2:
         bad.append((f'expected {6 * fq} tap loads and 2 hand-written waits in the producer loop, found {nloads} / {hand_waits}', ''))
     return dict(loop_instructions=len(loop), tap_loads=nloads, hand_waits=hand_waits, compiler_vmcnt_waits=comp_waits), bad
@@ -76,4 +86,69 @@ def check_walk2_asm(asm_text):
             continue
         end = next((j for j in range(i, len(lines)) if lines[j].strip().startswith('.amdhsa_kernel')), len(lines))
         out[m.group(1)] = check_kernel(lines[i:end], int(m.group(2)))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# conv3_wino4_kernel (csrc/modconv_wino4.inc): hand-issued LDS-direct loads (`s_mov_b32 m0, ..; s_nop 0; buffer_load_dwordx4 .. lds`) and
+# the hand-counted `s_waitcnt vmcnt(4)` of the pair form's K loop.  Properties checked in the ISA of every instantiation:
+#   1. m0 is written only by `s_mov_b32 m0, <sgpr>` and each such write is followed by `s_nop 0` and an LDS-direct buffer load -- the
+#      compiler keeps nothing of its own in m0 (it cannot be told about the write: reserved registers are rejected on clobber lists);
+#   2. in the K loop that ends in `vmcnt(4)`: every vector-memory instruction is an LDS-direct `buffer_load_dwordx4`, there are exactly
+#      8 issue sites (3 of U, then 5 of V: the wait lets the <= 4 youngest -- V pieces of chunk c + 2 -- fly, LDS-direct loads complete
+#      in issue order among themselves), the U sites precede the V sites, and `vmcnt(4)` is the loop's only vector-memory wait.
+# ------------------------------------------------------------------------------------------------------------------------------------
+def check_wino4_kernel(body):
+    code = [(i, ln.split(';')[0].strip()) for i, ln in enumerate(body)]
+    code = [(i, c) for i, c in code if c and not c.startswith('.') or re.match(r'^\.LBB\d+_\d+:', c or '')]
+    bad = []
+    ins_only = [(i, c) for i, c in code if not c.endswith(':')]
+    # 1. m0
+    m0_writes = 0
+    for k, (i, c) in enumerate(ins_only):
+        if not re.search(r'\bm0\b', c):
+            continue
+        if not re.match(r'^s_mov_b32 m0, s\d+$', c):
+            bad.append(('m0 is touched by an instruction other than the hand-written `s_mov_b32 m0, <sgpr>`', c))
+            continue
+        m0_writes += 1
+        nxt = [x for _, x in ins_only[k + 1:k + 3]]
+        if len(nxt) < 2 or nxt[0] != 's_nop 0' or not (nxt[1].startswith('buffer_load_dwordx4') and nxt[1].endswith(' lds')):
+            bad.append(('`s_mov_b32 m0` is not followed by `s_nop 0` + an LDS-direct buffer load', c + ' | ' + ' | '.join(nxt)))
+    # 2. the pair form's K loop
+    waits = [k for k, (_, c) in enumerate(code) if re.match(r'^s_waitcnt vmcnt\(4\)$', c)]
+    summary = dict(m0_writes=m0_writes, pair_loops=len(waits))
+    for w in waits:
+        lab = next((code[k][1][:-1] for k in range(w, -1, -1) if code[k][1].endswith(':')), None)
+        back = [k for k in range(w, len(code)) if re.match(r'^s_c?branch\w* ' + re.escape(lab or '?') + '$', code[k][1])]
+        if lab is None or not back:
+            raise IsaListingError('conv3_wino4_kernel: the block of `s_waitcnt vmcnt(4)` is not the latch of a loop in this listing')
+        k0 = next(k for k in range(w, -1, -1) if code[k][1] == lab + ':')
+        loop = [c for _, c in code[k0:back[-1] + 1] if not c.endswith(':')]
+        vmem = [c for c in loop if re.match(r'^(buffer_|global_|flat_|scratch_)', c)]
+        notlds = [c for c in vmem if not (c.startswith('buffer_load_dwordx4') and c.endswith(' lds'))]
+        for c in notlds:
+            bad.append(('a vector-memory instruction other than an LDS-direct load inside the K loop (the hand-counted vmcnt(4) does not know it)', c))
+        if len(vmem) - len(notlds) != 8:
+            bad.append((f'expected 8 LDS-direct issue sites (3 U + 5 V) in the K loop, found {len(vmem) - len(notlds)}', ''))
+        descs = [re.search(r'(s\[\d+:\d+\])', c).group(1) for c in vmem if c not in notlds]
+        if len(set(descs)) != 2 or descs != [descs[0]] * descs.count(descs[0]) + [descs[-1]] * descs.count(descs[-1]) or descs.count(descs[0]) != 3:
+            bad.append(('the U loads (3 sites, one descriptor) must be issued before the V loads (5 sites, the other descriptor)', ' '.join(descs)))
+        vwaits = [c for c in loop if c.startswith('s_waitcnt') and 'vmcnt' in c]
+        if vwaits != ['s_waitcnt vmcnt(4)']:
+            bad.append(('the K loop must hold exactly one vector-memory wait, the hand-written vmcnt(4)', ' | '.join(vwaits)))
+        summary.update(loop_instructions=len(loop), lds_direct_sites=len(vmem) - len(notlds), mfma=sum(c.startswith('v_mfma') for c in loop))
+    return summary, bad
+
+
+def check_wino4_asm(asm_text):
+    """Every conv3_wino4_kernel instantiation in a modconv.hip assembly listing.  -> {mangled name: (summary, violations)}"""
+    lines = asm_text.splitlines()
+    out = {}
+    for i, ln in enumerate(lines):
+        m = re.match(r'^(_ZN\S*conv3_wino4_kernelILb([01])ELb([01])E\S*):', ln)
+        if not m:
+            continue
+        end = next((j for j in range(i, len(lines)) if lines[j].strip().startswith('.amdhsa_kernel')), len(lines))
+        out[m.group(1)] = check_wino4_kernel(lines[i:end])
     return out

@@ -185,7 +185,11 @@ class FeatureStats:
                 from .distributed import FeatureGatherer
                 gatherer = FeatureGatherer(side_stream=False)
             x = gatherer.gather(x)
-        self.append(x.cpu().numpy())
+        rows = x.cpu().numpy()                            # a synchronisation point: the features are on the host
+        if x.is_cuda:
+            from . import _lib
+            _lib.raise_on_device_fault('the generator forward behind this feature block')
+        self.append(rows)
 
     # -- results ------------------------------------------------------------------------------------------------------
     def get_all(self):

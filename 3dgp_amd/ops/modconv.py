@@ -158,9 +158,11 @@ def modconv_forward(x, packed, styles, noise=None, bias=None, up=1, demodulate=T
         skip = _lib.f32c(skip)
     cout = packed.cout
     lib = _lib.load()
-    if up == 2 and packed.k == 3 and not bf16 and fir is not None and skip is None and out_layout == 0 and FOLD_UP2 and cin >= 64 and H * W >= 512:
-        # x2 layer: FIR folded into four parity kernels on the Winograd F(4x4) path (csrc/modconv_wino4.inc) when the C side takes the shape;
-        # otherwise (TDGP_EUNSUPPORTED, nothing launched) the transposed-convolution + FIR kernels below
+    if (up == 2 and packed.k == 3 and not bf16 and fir is not None and skip is None and out_layout == 0 and FOLD_UP2 and cin >= 64 and H * W >= 512 and
+            lib.tdgp_modconv2d_takes_folded_up2(B, cin, 4 * cout, H, W) and (noise is None or (noise.data_ptr() % 16 == 0 and nbs % 4 == 0))):
+        # x2 layer: FIR folded into four parity kernels on the Winograd F(4x4) path (csrc/modconv_wino4.inc) -- the C side was ASKED first
+        # (tdgp_modconv2d_takes_folded_up2: no fold, no pack, no exception for launches it does not take); TDGP_EUNSUPPORTED stays handled
+        # for the conditions only the call itself can see
         pk2 = packed.folded_up2(fir)
         rep = lambda t: None if t is None else t.repeat_interleave(4, dim=-1).contiguous()      # noqa: E731   per-parity copies of [.., Cout] vectors
         if demodulate and dcoef is None:

@@ -125,6 +125,9 @@ int tdgp_upfirdn2d(const void* x, const float* f, void* y, int N, int C, int inH
 int64_t tdgp_modconv_pack_bytes(int Cout, int Cin, int k);
 int     tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int Cin, int k, tdgp_stream_t stream);
 int64_t tdgp_modconv2d_workspace_bytes(int B, int Cin, int Cout, int H, int W, int k, int up);
+/* 1 when tdgp_modconv2d would take a folded x2 layer (out_layout 2, Cout4 = 4 x Cout parity channels) of this shape on the F(4x4) kernels
+ * under the current arithmetic mode, else 0 -- a host-side query (no launch) the binding makes before folding and packing the weights. */
+int     tdgp_modconv2d_takes_folded_up2(int B, int Cin, int Cout4, int H, int W);
 int     tdgp_modconv2d(const float* x, const void* wpack, const float* styles, const float* dcoef, const float* noise,
                        int64_t noise_bstride, const float* bias, const float* fir4x4, const float* skip,
                        float* y, int B, int Cin, int Cout, int H, int W, int k, int up, int demodulate,

@@ -134,6 +134,42 @@ def test_walk2_isa_check_runs_in_the_build(tdgp):
     assert bad and 'touches the destination' in bad[0][0]
 
 
+def test_wino4_isa_check_runs_in_the_build(tdgp):
+    """conv3_wino4_kernel's LDS-direct loads are hand-issued (M0 written inside the asm statement, which hipcc will not let a clobber
+    list name) and its pair-form K loop ends in a hand-counted `vmcnt(4)`.  isa_check.check_wino4_asm verifies on the generated code that M0 is
+    written only by those statements, that the K loop holds nothing but the 8 expected LDS-direct issue sites (U before V) and that vmcnt(4) is
+    its only vector-memory wait; the build runs it whenever modconv.hip is recompiled.  Here: re-run on the kept listing, then three injected
+    violations must each be caught."""
+    import importlib
+    build = importlib.import_module('3dgp_amd.build')
+    isa = importlib.import_module('3dgp_amd.isa_check')
+    asm = os.path.join(build.CSRC, 'build', 'modconv.s')
+    if not os.path.exists(asm):
+        subprocess.check_call([build._hipcc()] + build.FLAGS + ['-S', '--cuda-device-only', '-o', asm, os.path.join(build.CSRC, 'modconv.hip')], stderr=subprocess.DEVNULL)
+    res = build.verify_modconv_isa(asm)
+    assert len(res) == 2 and all(not bad for _, bad in res.values())
+    assert all(s['lds_direct_sites'] == 8 and s['mfma'] == 36 and s['m0_writes'] > 0 for s, _ in res.values())
+    lines = open(asm).read().splitlines()
+    i0 = next(i for i, ln in enumerate(lines) if re.match(r'^_ZN\S*conv3_wino4_kernelILb1ELb1E\S*:', ln))
+    i1 = next(j for j in range(i0, len(lines)) if lines[j].strip().startswith('.amdhsa_kernel'))
+    body = lines[i0:i1]
+    w = next(i for i, ln in enumerate(body) if 's_waitcnt vmcnt(4)' in ln)
+    for inject, needle in (('\tglobal_load_dword v0, v[2:3], off', 'other than an LDS-direct load'), ('\ts_movrels_b32 s0, s1 ; uses m0', None),
+                           ('\tv_readlane_b32 s0, v1, m0', 'm0 is touched')):
+        if needle is None:
+            continue
+        b2 = list(body)
+        b2.insert(w + 8, inject)                                   # inside the K loop (its body follows the latch block in the listing)
+        _, bad = isa.check_wino4_kernel(b2)
+        assert bad and any(needle in why for why, _ in bad), (inject, bad[:2])
+    b3 = [ln for i, ln in enumerate(body) if not (i > w and ' lds' in ln and i < w + 120)]      # drop the first LDS-direct sites of the loop
+    _, bad = isa.check_wino4_kernel(b3)
+    assert bad
+    # a listing without loop annotations is reported as unreadable, not as an IndexError
+    with pytest.raises(isa.IsaListingError):
+        isa.check_kernel(['_Zfoo:', '\ts_endpgm'], 8)
+
+
 def test_device_fault_word_is_exported_and_quiet(tdgp):
     """include/tdgp.h tdgp_device_fault: readable without a GPU (no fault word can be allocated -> 0), never raises."""
     assert tdgp._lib.device_fault() == 0 and tdgp._lib.device_fault(clear=True) == 0
