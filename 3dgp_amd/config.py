@@ -141,11 +141,13 @@ def config_c4():
     return GeneratorConfig(c_dim=1000, img_resolution=256, num_ray_steps=64, cmax=1024, cbase=65536)
 
 
-def config_c5():
-    """BASELINE configs[4]: ImageNet 256x256, 96(+96) ray steps, the four highest-resolution backbone blocks (64^2 ... 512^2) in bfloat16
+def config_c5(cmax=512, cbase=32768):
+    """`config_c5(cmax=1024, cbase=65536)` is the sizing of BASELINE.md section 3, row 3 (bf16 at the 1024-channel backbone of configs[3],
+    ~559 GFLOP per image); the default keeps configs[2]'s 512-channel backbone (BASELINE.json's configs[4] names no cmax).
+    BASELINE configs[4]: ImageNet 256x256, 96(+96) ray steps, the four highest-resolution backbone blocks (64^2 ... 512^2) in bfloat16
     with fp32 accumulation and conv_clamp 256 -- the reference's `num_fp16_res = 4, conv_clamp = 256` defaults (networks_epigraf.py:82,
     networks_stylegan2.py:220) with bf16 in the place of fp16; skip image / tri-planes and the renderer stay fp32, as there."""
-    return GeneratorConfig(c_dim=1000, img_resolution=256, num_ray_steps=96, num_fp16_res=4, conv_clamp=256.0)
+    return GeneratorConfig(c_dim=1000, img_resolution=256, num_ray_steps=96, num_fp16_res=4, conv_clamp=256.0, cmax=cmax, cbase=cbase)
 
 
 def config_mid_bf16():

@@ -538,6 +538,7 @@ class SynthesisNetwork(torch.nn.Module):
         # samples at a time so that a sample's high-resolution activations and tri-planes are consumed out of the Infinity Cache
         # (SynthesisBlocksSequence.forward_chunks).  None = the whole batch through every kernel.
         self.chunk, self.chunk_from = None, 128
+        self.strict_nan_propagation = __import__('os').environ.get('TDGP_STRICT_NAN', '0') not in ('', '0')
 
     def progressive_update(self, cur_kimg):
         """networks_epigraf.py:191-194: density-noise std decays linearly to 0 over nerf_noise_kimg_growth; the depth adaptor anneals."""
@@ -673,11 +674,19 @@ class SynthesisNetwork(torch.nn.Module):
         depth = depth.reshape(B, 1, h, w)
         depth_adapted = None
         if self.depth_adaptor is not None:                                  # networks_epigraf.py:246-253
-            depth_adapted = self.depth_adaptor(depth, ws[:, 0])
-            if render_opts['concat_depth']:
-                img = torch.cat([img, depth_adapted], dim=1)
-            else:
-                img = img + 0.0 * depth_adapted.max()
+            needed = render_opts['concat_depth'] or render_opts['return_depth_adapted'] or self.strict_nan_propagation
+            if needed:
+                depth_adapted = self.depth_adaptor(depth, ws[:, 0])
+                if render_opts['concat_depth']:
+                    img = torch.cat([img, depth_adapted], dim=1)
+                else:
+                    img = img + 0.0 * depth_adapted.max()
+            # else: ELIDED.  The reference evaluates the adaptor (27 GFLOP per 256^2 image: three 5x5 convolutions at 64 channels) and then adds
+            # `0.0 * depth_adapted.max()` to the image (:253, "to avoid potential DataParallel issues") -- for finite values that is `img`, bit
+            # for bit (x + 0.0 == x for every finite and infinite x; only -0.0 pixels would become +0.0, and a raw MLP output is never -0.0
+            # after `+ b1`... either way equal under ==).  The adaptor draws no random numbers in eval mode, so skipping it leaves every RNG
+            # stream where the reference's is.  What IS lost: a NaN / Inf inside the adaptor (non-finite adaptor weights) no longer poisons the
+            # image; `strict_nan_propagation = True` (or TDGP_STRICT_NAN=1) restores the literal forward.  Training-mode forwards are never elided.
         if render_opts['return_depth'] or render_opts['return_depth_adapted']:
             out = TensorGroup(img=img)
             if render_opts['return_depth']:

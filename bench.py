@@ -141,6 +141,64 @@ def cpu_baseline(tdgp, cfg, n_img=8, budget_s=14.0):
                        f'samples) in {t_total:.1f} s; OpenMP C oracle (oracle/tdgp_oracle.c), {cores} threads')
 
 
+def host_launch_probe(step, steps=3):
+    """Host-side cost of ENQUEUEING one eager step (no synchronisation inside the stop-watch): wall and CPU milliseconds per step.  A few steps
+    only, so the launch queue never fills and the host is never blocked on the device.  SURVEY.md 8(e): with one Python process per GPU the
+    threat to 8-GPU scaling is this figure growing under contention, not xGMI."""
+    torch.cuda.synchronize()
+    t0, c0 = time.perf_counter(), time.process_time()
+    for _ in range(steps):
+        step()
+    t1, c1 = time.perf_counter(), time.process_time()
+    torch.cuda.synchronize()
+    return (t1 - t0) / steps * 1e3, (c1 - c0) / steps * 1e3
+
+
+def with_host_competitors(n, fn):
+    """Run fn() while `n` dummy processes spin on OTHER cores than this process's (each pinned to one core outside our affinity set when the box
+    has room, else unpinned): what the launch thread of one rank sees when 7 sibling ranks keep their own cores busy.  The children are
+    started and killed by PID here."""
+    import subprocess
+    try:
+        mine = sorted(os.sched_getaffinity(0))
+        every = list(range(os.cpu_count() or 1))
+    except AttributeError:
+        mine, every = [], []
+    others = [c for c in every if c not in mine] or every
+    code = ('import os,sys\n'
+            'c=int(sys.argv[1])\n'
+            'try:\n os.sched_setaffinity(0,{c}) if c>=0 else None\nexcept OSError:\n pass\n'
+            'import array\nb=array.array("d",[1.0])*(1<<20)\ni=0\n'
+            'while True:\n i=(i+4099)&((1<<20)-1); b[i]+=1.0\n')            # a cache-unfriendly busy loop: ALU + LLC / memory pressure
+    procs = [subprocess.Popen([sys.executable, '-c', code, str(others[i % len(others)] if others else -1)]) for i in range(n)]
+    try:
+        time.sleep(0.3)
+        return fn()
+    finally:
+        for p_ in procs:
+            p_.kill()
+        for p_ in procs:
+            p_.wait()
+
+
+def parity_statement(config):
+    """What `-m gpu` asserts for this configuration and the figures the last committed GPU test run met (profiles/parity_latest.json =
+    gpurun_out/parity_report.json of that run; tests/conftest.py:assert_image_parity defines every figure)."""
+    st = dict(stated='<= 1e-4 max-rel RGB vs the reference CPU/PyTorch path (north_star); INT rows bit-exact on identical inputs',
+              asserted='tests/test_gpu_parity.py::test_full_size_vs_reference_golden[c1|c2|c3]: range-normalised error <= max(1e-5, 2 x the reference\'s own fp32-vs-float64 '
+                       'figure); per-pixel max-rel (SURVEY 9.9) <= max(1e-4, 1.5 x the largest of the reference\'s own three noise figures: re-run, vs exactly rounded, vs its float64 run); '
+                       'mean error vs the float64 reference <= 1.25 x the reference\'s own; every INT-row mismatch through the chain explained by a cdf-knot window',
+              why_not_flat_1e4='at 512-channel / 512^2 size the reference\'s OWN fp32 image is 1.5e-3 ... 3.2e-3 per pixel (5e-6 ... 7e-6 of the range) from its own float64 run '
+                               '(tests/golden/e2e_full_*.npz): a flat 1e-4 per-pixel figure is not a property of the reference path itself')
+    path = os.path.join(REPO, 'profiles', 'parity_latest.json')
+    tag = {'c1': 'c1', 'c2': 'c2', 'c3': 'c3'}.get(config, 'c3')
+    if os.path.exists(path):
+        rows = [r for r in json.load(open(path)) if r.get('what', '').startswith(f'{tag} full size')]
+        st['met'] = {r['what']: {k: v for k, v in r.items() if k != 'what'} for r in rows}
+        st['met_source'] = 'profiles/parity_latest.json (the -m gpu run committed with this tree)'
+    return st
+
+
 def timed_steps(step, barrier, steps, warmup, world, dev, finish=None, per_rank=None):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.  `per_rank` (a list) receives
     every rank's OWN time for the K steps -- stop-watch read after its own synchronize, BEFORE the closing barrier -- so that a straggler
@@ -218,7 +276,8 @@ def spawn_ranks(n, script=None, argv=None):
         sys.exit(f'bench.py: rank(s) failed: {bad}')
 
 
-def main():
+def parse_args(argv=None):
+    """The command line of bench.py (the driver's: `--gpus N --steps K --warmup W`)."""
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -227,6 +286,8 @@ def main():
     ap.add_argument('--other-batches', default='4', help='comma list of further per-GPU batch sizes measured in the same run (4 = training/base.yaml:5); "" = none')
     ap.add_argument('--config', default='c3', choices=['c1', 'c2', 'c3', 'c4', 'c5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cmax', type=int, default=0, help='override the backbone width (cbase = 64 x cmax): `--config c5 --cmax 1024` is the bf16 configuration as BASELINE.md section 3 sizes it')
+    ap.add_argument('--no-host-probe', action='store_true', help='skip the host-side launch-cost probe (host_launch_ms / launch_bound_margin)')
     ap.add_argument('--depth-adaptor', action='store_true', help='also run the DepthAdaptor inside G.forward (SURVEY 8f rank 1; off = the 8a hot path)')
     ap.add_argument('--profile-steps', type=int, default=3)
     ap.add_argument('--chunk', type=int, default=-1, help='samples per pass through the high-resolution blocks + renderer (Infinity-Cache-sized working set); '
@@ -245,9 +306,37 @@ def main():
     ap.add_argument('--arith', default='f32', choices=['f32', 'direct', 'split'],
                     help="arithmetic of the large 3x3 convolutions: f32 = fp32 MFMA (default, the reported metric); split = opt-in 3 x bf16 split operands, "
                          "6 piece products, fp32 accumulation (fp32-grade results; reported with dtype 'bf16x3->f32' and never mixed with the default line)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     args.no_graph = not args.graph
+    return args
 
+
+def setup_rank(args, tdgp, backend='nccl', need_gpu=True):
+    """One process per GPU: rank / world / local rank from the launcher's environment (torchrun's or spawn_ranks'), process group on `backend`
+    (nccl == RCCL on ROCm), device = cuda:LOCAL_RANK, host threads pinned to the cores of that GPU's NUMA node.  `backend='gloo',
+    need_gpu=False` is the CPU rehearsal of exactly this code (tests/test_distributed.py runs the driver's command shape through it)."""
+    D = tdgp.distributed
+    rank, world, local_rank = D.init_from_env(backend)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if need_gpu:
+        assert torch.cuda.is_available(), 'bench.py needs a GPU'
+        assert local_rank < torch.cuda.device_count(), f'LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible (HIP_VISIBLE_DEVICES={os.environ.get("HIP_VISIBLE_DEVICES")})'
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+    else:
+        dev = torch.device('cpu')
+    host = D.pin_rank(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world))) if world > 1 else None      # cores of this GPU's NUMA node
+    return rank, world, local_rank, dev, host
+
+
+def runs_cpu_baseline(args, world, rank):
+    """The CPU-baseline leg runs on rank 0 of a ONE-GPU job only (the contract: N = 1; at N > 1 eight copies of a 32-thread OpenMP run
+    would fight the launch threads for the host)."""
+    return world == 1 and rank == 0 and not args.no_cpu_baseline
+
+
+def main():
+    args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         assert torch.cuda.is_available() and torch.cuda.device_count() >= args.gpus, \
             f'--gpus {args.gpus} but {torch.cuda.device_count() if torch.cuda.is_available() else 0} GPU(s) visible'
@@ -255,14 +344,9 @@ def main():
 
     tdgp = importlib.import_module('3dgp_amd')
     D = tdgp.distributed
-    rank, world, local_rank = D.init_from_env('nccl')
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    host = D.pin_rank(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world))) if world > 1 else None      # cores of this GPU's NUMA node
-    if world > 1 and not args.no_fid_loop:
-        args.fid_loop = True
+    rank, world, local_rank, dev, host = setup_rank(args, tdgp)
+    if not args.no_fid_loop:
+        args.fid_loop = True                # N > 1: it IS the multi-GPU workload; N == 1: the FID forward with and without the adaptors
     tdgp._lib.load()                       # the HIP library must be there: no fallback
     if args.arith == 'split':
         tdgp._lib.set_conv_arith(1)
@@ -270,6 +354,8 @@ def main():
         tdgp._lib.set_conv_arith(2)
 
     cfg = getattr(tdgp.config, f'config_{args.config}')()
+    if args.cmax > 0:
+        cfg.cmax, cfg.cbase = args.cmax, 64 * args.cmax
     if args.depth_adaptor:
         cfg.depth_adaptor = tdgp.config.DepthAdaptorConfig()
     G = tdgp.generator.Generator(cfg)
@@ -325,6 +411,50 @@ def main():
             gather.wait()
 
     x = inputs(args.batch)
+    # ---- host-side launch cost: is the eager forward launch-bound, alone and beside 7 busy sibling processes? ----
+    host_probe = None
+    if not args.no_host_probe:
+        eager = make_step(x, use_graph=False)
+        for _ in range(3):
+            eager()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eager()
+        torch.cuda.synchronize()
+        gpu_ms = (time.perf_counter() - t0) / 3 * 1e3
+        wall_ms, cpu_ms = host_launch_probe(eager)
+        host_probe = dict(host_launch_ms=round(wall_ms, 3), host_cpu_ms=round(cpu_ms, 3), gpu_step_ms=round(gpu_ms, 3), launch_bound_margin=round(gpu_ms / max(wall_ms, 1e-6), 2),
+                          batch_per_gpu=args.batch, note='enqueue time of one eager forward (every kernel a host call, no sync inside the stop-watch) vs its GPU time; '
+                          'margin = gpu_step_ms / host_launch_ms: > 1 means the host stays ahead of the device')
+        if world == 1:
+            w8, c8 = with_host_competitors(7, lambda: host_launch_probe(eager))
+            host_probe.update(host_launch_ms_7_competitors=round(w8, 3), host_cpu_ms_7_competitors=round(c8, 3), launch_bound_margin_7_competitors=round(gpu_ms / max(w8, 1e-6), 2))
+            xb4 = inputs(4)
+            e4 = make_step(xb4, use_graph=False)
+            for _ in range(3):
+                e4()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                e4()
+            torch.cuda.synchronize()
+            g4 = (time.perf_counter() - t0) / 3 * 1e3
+            w4, _c4 = host_launch_probe(e4)
+            w48, _ = with_host_competitors(7, lambda: host_launch_probe(e4))
+            host_probe['batch_4'] = dict(host_launch_ms=round(w4, 3), gpu_step_ms=round(g4, 3), launch_bound_margin=round(g4 / max(w4, 1e-6), 2),
+                                         host_launch_ms_7_competitors=round(w48, 3), launch_bound_margin_7_competitors=round(g4 / max(w48, 1e-6), 2))
+            del xb4, e4
+        else:
+            # every rank must take the same launch mode: the smallest margin over the ranks decides
+            m = torch.tensor([host_probe['launch_bound_margin']], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MIN)
+            host_probe['launch_bound_margin_min_over_ranks'] = round(float(m.item()), 2)
+            if float(m.item()) < 2.0 and not args.graph:
+                args.graph, args.no_graph = True, False            # launch-bound within a factor 2: replay the captured forward instead
+                host_probe['decision'] = 'margin < 2 on some rank: headline switched to HIP graph replay'
+            else:
+                host_probe['decision'] = 'eager kept' if not args.graph else 'graph requested'
     per_rank_s = []
     elapsed = timed_steps(make_step(x), barrier, args.steps, args.warmup, world, dev, finish, per_rank=per_rank_s)
     # the other launch mode next to the headline (eager when the headline replays a graph, and the other way round)
@@ -440,9 +570,10 @@ def main():
         per = 64
         lanes = max(1, args.fid_lanes) if not args.no_graph else 1
 
-        def time_fid(gen):
+        def time_fid(gen, Gx=None, cam_adaptor=False):
+            Gx = G if Gx is None else Gx
             gen = tdgp.metrics.resolve_batch_gen(per, gen)
-            ggs = [tdgp.graphs.GraphedGenerator(G, gen, noise_mode='random', explicit_draws=False) for _ in range(lanes)] if not args.no_graph else []
+            ggs = [tdgp.graphs.GraphedGenerator(Gx, gen, noise_mode='random', explicit_draws=False) for _ in range(lanes)] if not args.no_graph else []
             gg = ggs[0] if ggs else None
             lane_streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)] if lanes > 1 else []
             zs = [inputs(gen) for _ in range(2)]
@@ -464,10 +595,13 @@ def main():
                 else:
                     for i in range(per // gen):
                         xi = zs[i & 1]
+                        cam_i = xi['cam']
+                        if cam_adaptor:                                   # metric_utils.py:305-307: the camera adaptor runs on the sampled cameras first
+                            cam_i = Gx.synthesis.camera_adaptor(cam_i, xi['z'], xi['c'])
                         if gg is not None:
-                            imgs.append(gg(xi['z'], xi['c'], xi['cam']).clone())
+                            imgs.append(gg(xi['z'], xi['c'], cam_i).clone())
                         else:
-                            imgs.append(G(xi['z'], xi['c'], xi['cam'], noise_mode='random'))
+                            imgs.append(Gx(xi['z'], xi['c'], cam_i, noise_mode='random'))
                 feats = D.stand_in_features(torch.cat(imgs))
                 if gather is not None:
                     if gather._pending is not None:
@@ -485,6 +619,25 @@ def main():
         gens = [int(t) for t in args.batch_gen.split(',') if t.strip()] or [4]
         fid_loop = time_fid(gens[0])
         fid_loop['other_batch_gen'] = {str(g_): time_fid(g_) for g_ in gens[1:]}
+        if cfg.depth_adaptor is None and lanes == 1:
+            # The FID forward AS THE REFERENCE RUNS IT (metric_utils.py:305-310): depth and camera adaptors are enabled in every 3dgp config
+            # (configs/training/base.yaml:7,9), so G.forward evaluates the DepthAdaptor (27 GFLOP per 256^2 image) and multiplies it by 0.0
+            # (networks_epigraf.py:253).  `elided` = this package's default (the adaptor is skipped when nothing consumes it; same bits, see
+            # SynthesisNetwork.forward), `literal` = strict_nan_propagation (the reference's exact op sequence).
+            import copy
+            cfg_ad = copy.deepcopy(cfg)
+            cfg_ad.depth_adaptor, cfg_ad.camera_adaptor = tdgp.config.DepthAdaptorConfig(), tdgp.config.CameraAdaptorConfig()
+            G_ad = tdgp.generator.Generator(cfg_ad)
+            G_ad.load_numpy_state_dict(tdgp.weights.random_state_dict(cfg_ad, seed=0))
+            G_ad = G_ad.to(dev)
+            ad = {}
+            for name, strict in (('elided', False), ('literal', True)):
+                G_ad.synthesis.strict_nan_propagation = strict
+                ad[name] = {str(g_): {k_: v_ for k_, v_ in time_fid(g_, G_ad, cam_adaptor=True).items() if k_ in ('value', 'ms_per_64', 'batch_gen', 'launch')} for g_ in gens}
+            base = {str(gens[0]): fid_loop['value'], **{k_: v_['value'] for k_, v_ in fid_loop['other_batch_gen'].items()}}
+            ad['vs_adaptor_off_pct'] = {k_: dict(elided=round(100.0 * (ad['elided'][k_]['value'] / base[k_] - 1.0), 2), literal=round(100.0 * (ad['literal'][k_]['value'] / base[k_] - 1.0), 2)) for k_ in base}
+            fid_loop['adaptors'] = ad
+            del G_ad
 
     if rank == 0:
         total_imgs = args.batch * world * args.steps
@@ -505,9 +658,10 @@ def main():
             'launch': 'eager' if args.no_graph else 'hip graph replay (3dgp_amd/graphs.py: every kernel of the forward, one submission per step)',
             ('graph_value' if args.no_graph else 'eager_value'): round(total_imgs / alt_elapsed, 3), 'fid_loop': fid_loop,
             'rccl_ranks_seen': ranks_seen, 'per_rank_ms': straggler_figures(per_rank_s, args.steps)[0], 'straggler_ratio': straggler_figures(per_rank_s, args.steps)[1],
-            'host': None if host is None else dict(rank0=host, omp_num_threads=os.environ.get('OMP_NUM_THREADS')), 'roofline': roofline, 'whole_forward': whole, 'other_batches': others, 'kernels': kernels,
+            'host': None if host is None else dict(rank0=host, omp_num_threads=os.environ.get('OMP_NUM_THREADS')), 'host_launch': host_probe,
+            'parity_tolerance': parity_statement(args.config), 'roofline': roofline, 'whole_forward': whole, 'other_batches': others, 'kernels': kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if runs_cpu_baseline(args, world, rank):
             out['cpu_baseline'] = cpu_baseline(tdgp, cfg)
             out['cpu_baseline_c1'] = out['cpu_baseline'] if args.config == 'c1' else cpu_baseline(tdgp, tdgp.config.config_c1(), n_img=16, budget_s=8.0)
         else:

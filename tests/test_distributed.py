@@ -199,7 +199,30 @@ dist.all_reduce(lo, op=dist.ReduceOp.MIN)
 dist.all_reduce(hi, op=dist.ReduceOp.MAX)
 if rank == 0:
     print(json.dumps(dict(ranks_seen=int(t.item()), argv=sys.argv[1:], omp=[int(lo.item()), int(hi.item())])))
+dist.destroy_process_group()          # (without it gloo's threads occasionally abort at interpreter exit: "terminate called without an active exception")
 '''
+
+# The driver's multi-GPU command, rehearsed on CPU: the child runs bench.py's OWN argument parser and rank set-up (bench.parse_args,
+# bench.setup_rank with backend gloo / no GPU) under the environment bench.spawn_ranks -- or torchrun -- gives it.
+_DRIVER_SHAPE_CHILD = '''
+import importlib, json, os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import bench
+args = bench.parse_args()
+tdgp = importlib.import_module("3dgp_amd")
+rank, world, local_rank, dev, host = bench.setup_rank(args, tdgp, backend="gloo", need_gpu=False)
+seen = torch.ones(1); dist.all_reduce(seen)
+lr = torch.zeros(world); lr[rank] = local_rank; dist.all_reduce(lr)
+base = torch.tensor([1.0 if bench.runs_cpu_baseline(args, world, rank) else 0.0]); dist.all_reduce(base)
+seeds = torch.zeros(world); seeds[rank] = tdgp.distributed.rank_seed(0, rank, world); dist.all_reduce(seeds)
+if rank == 0:
+    print(json.dumps(dict(gpus=args.gpus, steps=args.steps, warmup=args.warmup, batch=args.batch, fid_loop_default=not args.no_fid_loop, ranks_seen=int(seen.item()),
+                          local_ranks=[int(v) for v in lr.tolist()], cpu_baseline_ranks=int(base.item()), seeds=[int(v) for v in seeds.tolist()],
+                          master=[os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"])], pinned=host is not None,
+                          hsa_ipc=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))))
+dist.destroy_process_group()
+''' % REPO
 
 
 def test_bench_spawn_ranks_plumbing(tmp_path):
@@ -223,6 +246,43 @@ def test_bench_spawn_ranks_plumbing(tmp_path):
     assert json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])['omp'] == [3, 3]          # a caller's own setting wins
     out = subprocess.run([sys.executable, '-c', drive, '--die'], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode != 0 and 'rank(s) failed' in out.stderr
+
+
+def test_driver_command_shape_on_cpu(tmp_path):
+    """the driver's exact multi-GPU command shapes, rehearsed on CPU through bench.py's own parser and rank set-up:
+      (a) `python bench.py --gpus 8 --steps 20 --warmup 5`  -> bench.spawn_ranks: 8 children, free port on 127.0.0.1, LOCAL_RANK i <-> GPU i;
+      (b) `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`.
+    Checked: argument values, world size seen by a real collective, the LOCAL_RANK -> device mapping, per-rank seeds (seed * world + rank), the
+    cpu_baseline leg on NO rank at N > 1, the HSA IPC mode exported to every child."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    child = tmp_path / 'bench_child.py'
+    child.write_text(_DRIVER_SHAPE_CHILD)
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'LOCAL_WORLD_SIZE')}
+    argv = ['--gpus', '8', '--steps', '20', '--warmup', '5']
+    drive = 'import sys; sys.path.insert(0, %r); import bench; bench.spawn_ranks(8, script=%r, argv=sys.argv[1:])' % (REPO, str(child))
+    out = subprocess.run([sys.executable, '-c', drive] + argv, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert (line['gpus'], line['steps'], line['warmup'], line['batch']) == (8, 20, 5, 16) and line['fid_loop_default'] is True
+    assert line['ranks_seen'] == 8 and line['local_ranks'] == list(range(8)) and line['seeds'] == list(range(8))
+    assert line['cpu_baseline_ranks'] == 0 and line['master'][0] == '127.0.0.1' and line['pinned'] is True and line['hsa_ipc'] == '0'
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           str(child), '--gpus', '2', '--steps', '20', '--warmup', '5']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['gpus'] == 2 and line['ranks_seen'] == 2 and line['local_ranks'] == [0, 1] and line['cpu_baseline_ranks'] == 0 and line['master'] == ['127.0.0.1', port]
+    # N = 1: the parser's defaults finish within minutes and the baseline leg belongs to rank 0
+    sys.path.insert(0, REPO)
+    import bench
+    a = bench.parse_args([])
+    assert (a.gpus, a.steps, a.warmup) == (1, 50, 10) and bench.runs_cpu_baseline(a, 1, 0) and not bench.runs_cpu_baseline(a, 8, 0)
 
 
 def test_rank_cpus_follow_the_gpu_numa_node(tdgp):
