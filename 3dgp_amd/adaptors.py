@@ -167,32 +167,49 @@ class CameraAdaptor(torch.nn.Module):
 
     @staticmethod
     def roll_camera_params(cp):
-        return TensorGroup(angles=cp[:, [0, 1, 2]], fov=cp[:, 3], radius=cp[:, 4], look_at=cp[:, [5, 6, 7]])
+        # (slices, not `cp[:, [0, 1, 2]]`: indexing with a Python list builds an index tensor on the host and copies it to the device --
+        #  a synchronising transfer per call, and the adaptor runs once per generator sub-batch in the FID loop)
+        return TensorGroup(angles=cp[:, 0:3], fov=cp[:, 3], radius=cp[:, 4], look_at=cp[:, 5:8])
+
+    # Column order of the unrolled parameters: yaw, pitch, roll, fov, radius, look-at yaw, pitch, radius.  The per-column expressions of the
+    # reference (:74-97) are evaluated as ONE elementwise expression over the [N, 8] block with per-column constants -- the same fp32
+    # operations per element in the same order (x - lo, / (hi - lo + eps); sigmoid * scale, + lo, + 1e-5 for the pitch), so the results are the
+    # reference's bits; columns that pass through use lo = 0, range = 1 (x - 0 and x / 1 are exact).  Two dozen kernel launches become four.
+    _CONST_CACHE = {}
+
+    @classmethod
+    def _columns(cls, cam: CameraRanges, device, eps=1e-8):
+        key = (id(cam), tuple(map(tuple, (cam.yaw, cam.pitch, cam.fov, cam.look_at_yaw, cam.look_at_pitch, cam.look_at_radius))), str(device), eps)
+        hit = cls._CONST_CACHE.get(key)
+        if hit is None:
+            f = lambda v: torch.tensor(v, dtype=torch.float64).to(torch.float32).to(device)       # noqa: E731  python floats rounded to fp32 once, like a scalar operand
+            rng = lambda r: r[1] - r[0]                                                            # noqa: E731
+            n_lo = f([cam.yaw[0], cam.pitch[0], 0.0, cam.fov[0], 0.0, cam.look_at_yaw[0], cam.look_at_pitch[0], cam.look_at_radius[0]])
+            n_den = f([rng(cam.yaw) + eps, rng(cam.pitch) + eps, 1.0, rng(cam.fov) + eps, 1.0, rng(cam.look_at_yaw) + eps, rng(cam.look_at_pitch) + eps,
+                       rng(cam.look_at_radius) + eps])
+            # :86-97 incl. the reference's look-at radius expression (it mixes the radius max with the look-at PITCH min)
+            d_scale = f([rng(cam.yaw), rng(cam.pitch) - 2e-5, 0.0, rng(cam.fov), 0.0, rng(cam.look_at_yaw), rng(cam.look_at_pitch), cam.look_at_radius[1] - cam.look_at_pitch[0]])
+            d_lo = f([cam.yaw[0], cam.pitch[0], 0.0, cam.fov[0], 0.0, cam.look_at_yaw[0], cam.look_at_pitch[0], cam.look_at_pitch[0]])
+            d_add = f([0.0, 1e-5, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+            is_sig = torch.tensor([True, True, False, True, False, True, True, True], device=device)
+            passthrough = f([0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])                              # roll * 0.0, radius * 1.0
+            hit = cls._CONST_CACHE[key] = (n_lo, n_den, d_scale, d_lo, d_add, is_sig, passthrough)
+        return hit
 
     @staticmethod
     def normalize_camera_params(cam: CameraRanges, cp, eps=1e-8):
         """:74-84 -- yaw, pitch, fov and the look-at triple are mapped to [0, 1] by their prior ranges; roll and radius pass."""
-        yaw, pitch, roll, fov, radius, la_yaw, la_pitch, la_radius = CameraAdaptor.unroll_camera_params(cp).split(1, dim=1)
-        yaw = (yaw - cam.yaw[0]) / (cam.yaw[1] - cam.yaw[0] + eps)
-        pitch = (pitch - cam.pitch[0]) / (cam.pitch[1] - cam.pitch[0] + eps)
-        fov = (fov - cam.fov[0]) / (cam.fov[1] - cam.fov[0] + eps)
-        la_yaw = (la_yaw - cam.look_at_yaw[0]) / (cam.look_at_yaw[1] - cam.look_at_yaw[0] + eps)
-        la_pitch = (la_pitch - cam.look_at_pitch[0]) / (cam.look_at_pitch[1] - cam.look_at_pitch[0] + eps)
-        la_radius = (la_radius - cam.look_at_radius[0]) / (cam.look_at_radius[1] - cam.look_at_radius[0] + eps)
-        return CameraAdaptor.roll_camera_params(torch.cat([yaw, pitch, roll, fov, radius, la_yaw, la_pitch, la_radius], dim=1))
+        x = CameraAdaptor.unroll_camera_params(cp)
+        n_lo, n_den = CameraAdaptor._columns(cam, x.device, eps)[:2]
+        return CameraAdaptor.roll_camera_params((x - n_lo) / n_den)
 
     @staticmethod
     def denormalize_camera_params(cam: CameraRanges, cp):
-        """:86-97, including the reference's look-at radius expression (it mixes the radius max with the look-at PITCH min)."""
-        yaw, pitch, roll, fov, radius, la_yaw, la_pitch, la_radius = CameraAdaptor.unroll_camera_params(cp).split(1, dim=1)
-        yaw = yaw.sigmoid() * (cam.yaw[1] - cam.yaw[0]) + cam.yaw[0]
-        pitch = pitch.sigmoid() * (cam.pitch[1] - cam.pitch[0] - 2e-5) + cam.pitch[0] + 1e-5
-        roll = roll * 0.0
-        fov = fov.sigmoid() * (cam.fov[1] - cam.fov[0]) + cam.fov[0]
-        la_yaw = la_yaw.sigmoid() * (cam.look_at_yaw[1] - cam.look_at_yaw[0]) + cam.look_at_yaw[0]
-        la_pitch = la_pitch.sigmoid() * (cam.look_at_pitch[1] - cam.look_at_pitch[0]) + cam.look_at_pitch[0]
-        la_radius = la_radius.sigmoid() * (cam.look_at_radius[1] - cam.look_at_pitch[0]) + cam.look_at_pitch[0]
-        return CameraAdaptor.roll_camera_params(torch.cat([yaw, pitch, roll, fov, radius, la_yaw, la_pitch, la_radius], dim=1))
+        """:86-97: sigmoid onto the prior ranges (pitch kept 1e-5 inside its range), roll zeroed, radius passed."""
+        x = CameraAdaptor.unroll_camera_params(cp)
+        _, _, d_scale, d_lo, d_add, is_sig, passthrough = CameraAdaptor._columns(cam, x.device)
+        y = x.sigmoid() * d_scale + d_lo + d_add
+        return CameraAdaptor.roll_camera_params(torch.where(is_sig, y, x * passthrough))
 
     def adjust_for_prior(self, old, new):
         """:99-108: components that are not learned keep their prior value."""
@@ -210,9 +227,9 @@ class CameraAdaptor(torch.nn.Module):
         """:110-124."""
         origin_params = torch.cat([old_norm.angles, old_norm.radius.unsqueeze(1)], dim=1)
         origin_new = self.origin_adaptor(origin_params, c=c)
-        look_at_in = torch.cat([origin_new[:, :3], old_norm.fov.unsqueeze(1), origin_new[:, [3]], old_norm.look_at], dim=1)
+        look_at_in = torch.cat([origin_new[:, :3], old_norm.fov.unsqueeze(1), origin_new[:, 3:4], old_norm.look_at], dim=1)
         look_at_new = self.look_at_adaptor(look_at_in, z, c)
-        new_norm = self.roll_camera_params(torch.cat([origin_new[:, :3], look_at_new[:, [0]], origin_new[:, [3]], look_at_new[:, [1, 2, 3]]], dim=1))
+        new_norm = self.roll_camera_params(torch.cat([origin_new[:, :3], look_at_new[:, 0:1], origin_new[:, 3:4], look_at_new[:, 1:4]], dim=1))
         if self.cfg.residual:
             new_norm = TensorGroup(**{k: old_norm[k] + new_norm[k] for k in new_norm})
         return new_norm

@@ -624,7 +624,8 @@ void launch_field_t(const FieldParams& p, hipStream_t s) {
     const bool walk = FQ % 4 == 0 && p.ray_w > 0 && p.planes_bytes != 0;
     if constexpr (FQ % 4 == 0 && FQ <= 8 && TDGP_WALK2) {
         // producer / consumer walk (field_walk2.inc): whole groups of four samples, a ring that is shorter than a patch's march
-        if (walk && (p.S & 3) == 0 && p.S >= 16) {
+        // (the walk addresses ray_o / ray_d / t through scalar base + 32-bit byte offset)
+        if (walk && (p.S & 3) == 0 && p.S >= 16 && p.total * 4 < ((int64_t)1 << 32) && (p.total / p.S) * 12 < ((int64_t)1 << 32)) {
             using L = Walk2Lds<FQ, MT>;
             const int cus = tdgp_cu_count();
             TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)triplane_walk2_kernel<FQ, MT, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, L::total));

@@ -32,9 +32,20 @@ def check_kernel(body, fq):
     if not heads:
         raise IsaListingError("no 'Loop Header: Depth=1' comment in the listing of triplane_walk2_kernel: this hipcc does not annotate loops "
                               '(asm-verbose off, or a different compiler) -- the check cannot locate the producer loop')
-    lo = heads[-1]                  # the producer loop: the kernel's last outermost loop
-    ends = [i for i, ln in enumerate(body) if 's_endpgm' in ln and i > lo]
-    hi = ends[0] if ends else len(body) - 1
+    # the producer loop: the outermost loop that holds the hand-written tap-buffer waits (round 5: no longer "the last loop before s_endpgm" --
+    # the bounded waits now end the wave in place, so s_endpgm also appears inside the loops)
+    hand = [i for i, ln in enumerate(body) if re.search(r's_waitcnt vmcnt\((%d|%d)\)\s*$' % (3 * fq, 3 * fq + 3), ln.split(';')[0])]
+    cand = [h for h in heads if hand and h < hand[-1]]
+    lo = cand[-1] if cand else heads[-1]
+    m = re.match(r'^\.L(BB\d+_\d+):', body[lo])
+    label = m.group(1) if m else None
+    members = [i for i, ln in enumerate(body) if label and re.search(r'Header=%s\b' % re.escape(label), ln)]
+    if members:
+        hi = next((j - 1 for j in range(members[-1] + 1, len(body)) if re.match(r'^\.LBB\d+_\d+:', body[j]) and not re.search(r'Header=%s\b' % re.escape(label), body[j])),
+                  len(body) - 1)
+    else:
+        ends = [i for i, ln in enumerate(body) if 's_endpgm' in ln and i > lo]
+        hi = ends[0] if ends else len(body) - 1
     loop = _code(body[lo:hi + 1])
     pro0 = next((i for i, ln in enumerate(body[:lo]) if 'global_load_dwordx3' in ln), lo)
     prologue = _code(body[pro0:lo])
