@@ -57,6 +57,8 @@ _PROTOTYPES = {
     'tdgp_unify_samples': (c_int, [P, P, P, c_int, P, P, P, c_int, P, P, P, P, c_int64, c_int, P]),
     'tdgp_importance_from_coarse': (c_int, [P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P]),
     'tdgp_merge_composite': (c_int, [P, P, c_int, P, P, c_int, P, P, P, P, P, P, c_int64, c_int, c_int, c_float, c_float, P]),
+    'tdgp_render_fused_workspace_bytes': (c_int64, [c_int, c_int64, c_int, c_int]),
+    'tdgp_render_fused': (c_int, [P] * 13 + [c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_int, c_float, P, c_int64, P]),
     'tdgp_rays_to_image': (c_int, [P, P, c_int, c_int, P]),
 }
 EXPORTS = tuple(_PROTOTYPES)

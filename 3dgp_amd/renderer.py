@@ -345,6 +345,8 @@ class MipRayMarcher2(torch.nn.Module):
 # ------------------------------------------------------------------------------------------------ importance renderer
 
 class ImportanceRenderer(torch.nn.Module):
+    fused_entry = True        # forward() through the single C-ABI call tdgp_render_fused when no intermediates / cut_quantile / density noise are asked for
+
     def __init__(self, ray_marcher_type: str):
         super().__init__()
         assert ray_marcher_type in ['classical', 'mip']
@@ -500,6 +502,27 @@ class ImportanceRenderer(torch.nn.Module):
             side = int(round(R ** 0.5))
             ray_w = side if side * side == R else 0
         stream = _lib.stream_of(ray_o)
+        cut_on = float(opts.get('cut_quantile', 0.0)) > 0.0
+        if (self.fused_entry and N > 0 and not return_intermediates and not cut_on and dnoise == 0.0 and B * R > 0):
+            # the plain forward: ONE C-ABI call (tdgp_render_fused) -- the same five kernels the staged path below issues, same bits
+            u_fine = opts.get('u_fine')
+            u_fine = torch.rand([B * R, N], device=dev) if u_fine is None else _lib.f32c(u_fine.to(dev))
+            if u_fine.numel() != B * R * N:
+                raise RuntimeError(f'u_fine must have {B * R}x{N} elements')
+            p_ = planes.t
+            _, _, H, W, F = p_.shape
+            w0, b0, w1, b1, _ = mlp
+            rgb = torch.empty([B, R, 3], dtype=torch.float32, device=dev)
+            depth = torch.empty([B, R, 1], dtype=torch.float32, device=dev)
+            wsum = torch.empty([B, R, 1], dtype=torch.float32, device=dev)
+            final_T = torch.empty([B, R], dtype=torch.float32, device=dev)
+            nbytes = _lib.load().tdgp_render_fused_workspace_bytes(B, R, S, N)
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.call('tdgp_render_fused', p_.data_ptr(), w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(), ray_o.data_ptr(), ray_d.data_ptr(),
+                          u_coarse.data_ptr(), u_fine.data_ptr(), rgb.data_ptr(), depth.data_ptr(), wsum.data_ptr(), final_T.data_ptr(), B, R, int(ray_w), S, N,
+                          F, H, W, w0.shape[0], float(scale), t_near, t_far, mid, flags, dbias, ws.data_ptr(), nbytes, stream)
+            return rgb, depth, wsum, final_T
         with torch.cuda.device(dev):
             sdist = torch.empty([B, R, S], dtype=torch.float32, device=dev)
             tdist = torch.empty([B, R, S], dtype=torch.float32, device=dev)

@@ -339,6 +339,21 @@ int tdgp_merge_composite(const float* rgbs_coarse, const float* t_coarse, int S1
                          const int32_t* fine_perm, int64_t rays, int marcher, int flags, float density_bias,
                          float cut_threshold, tdgp_stream_t stream);
 
+/* ImportanceRenderer.forward (tri_plane_renderer.py:126-170) as ONE call: stratified samples -> field -> coarse march -> importance samples ->
+ * field -> merge + march.  planes_hwc [B,3,H,W,F]; w0 [hid,F], b0 [hid], w1 [4,hid], b1 [4] raw module parameters; ray_o / ray_d [B,R,3];
+ * u_coarse [B*R,S], u_fine [B*R,N] the two uniform draws (tri_plane_renderer.py:225,279) -> rgb [B*R,3], depth [B*R], wsum [B*R] (may be NULL),
+ * final_T [B*R] (may be NULL).  ray_w > 0: the R rays are a [R/ray_w, ray_w] image (4x4-pixel tiles, same results); scale = box_size / 2;
+ * flags as in tdgp_ray_march; no cut_quantile / density noise / intermediates (those go through the staged entry points above).
+ * Same kernels, same bits as tdgp_sample_stratified + tdgp_triplane_field + tdgp_importance_from_coarse + tdgp_triplane_field +
+ * tdgp_merge_composite.  workspace: tdgp_render_fused_workspace_bytes(B, R, S, N) bytes, 16-byte aligned, caller-owned. */
+int64_t tdgp_render_fused_workspace_bytes(int B, int64_t R, int S, int N);
+int     tdgp_render_fused(const float* planes_hwc, const float* w0, const float* b0, const float* w1, const float* b1,
+                          const float* ray_o, const float* ray_d, const float* u_coarse, const float* u_fine,
+                          float* rgb, float* depth, float* wsum, float* final_T,
+                          int B, int64_t R, int ray_w, int S, int N, int F, int H, int W, int hid, float scale,
+                          float t_near, float t_far, int marcher, int flags, float density_bias,
+                          void* workspace, int64_t workspace_bytes, tdgp_stream_t stream);
+
 /* [B, h*w, 3] ray colours -> [B,3,h,w] image (networks_epigraf.py:242). */
 int tdgp_rays_to_image(const float* rgb, float* img, int B, int hw, tdgp_stream_t stream);
 

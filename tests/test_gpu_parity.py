@@ -763,6 +763,44 @@ def test_fused_chain_equals_op_level_chain(tdgp, S):
         assert_close(N(wsum), N(w2.sum(2)), 1e-6, 'weights.sum', 1.0)
 
 
+@pytest.mark.parametrize('marcher', ['classical', 'mip'])
+def test_render_fused_equals_staged_calls(tdgp, marcher):
+    """tdgp_render_fused (ImportanceRenderer.forward as ONE C-ABI call, include/tdgp.h) against the staged entry points it stands for
+    (tdgp_sample_stratified -> tdgp_triplane_field -> tdgp_importance_from_coarse -> tdgp_triplane_field -> tdgp_merge_composite): rgb,
+    depth, weights.sum and final transmittance bit for bit, at an image-shaped and at a ragged ray count; plus its argument checks."""
+    rs = np.random.RandomState(11)
+    F, H, hid, S = 32, 64, 64, 16
+    for B, hw, ray_w in ((2, 24 * 16, 24), (1, 301, 0)):
+        planes = T(rs.randn(B, 3 * F, H, H))
+        mlp = _mlp(tdgp, rs.randn(hid, F), 0.3 * rs.randn(hid), rs.randn(4, hid), 0.3 * rs.randn(4), marcher)
+        cam = dict(angles=T([[0.3, 1.2, 0.0], [-0.6, 1.8, 0.0]][:B]), radius=T([1.0, 1.0][:B]), look_at=T(np.zeros((B, 3))))
+        side = 24
+        ro, rd = tdgp.renderer.sample_rays(tdgp.renderer.compute_cam2world_matrix(cam), T([25.0, 40.0][:B]), (side, side))
+        ro, rd = ro[:, :hw].contiguous(), rd[:, :hw].contiguous()
+        u1, u2 = T(rs.rand(B, hw, S, 1)), T(rs.rand(B * hw, S))
+        opts = dict(box_size=1.0, num_proposal_steps=S, num_fine_steps=S, clamp_mode='softplus', use_inf_depth=True, ray_start=0.75, ray_end=1.25,
+                    white_back=(marcher == 'mip'), density_bias=0.0, u_coarse=u1, u_fine=u2, ray_grid_w=ray_w)
+        rend = tdgp.renderer.ImportanceRenderer(marcher)
+        assert rend.fused_entry
+        _, launches = _wino_launches(tdgp, lambda: rend(planes, mlp, ro, rd, opts))
+        fused = rend(planes, mlp, ro, rd, opts)
+        rend.fused_entry = False
+        staged = rend(planes, mlp, ro, rd, opts)
+        for a, b, name in zip(fused, staged, ('rgb', 'depth', 'wsum', 'final_T')):
+            assert torch.equal(a, b), (marcher, B, hw, name)
+        assert launches.get('triplane_field_kernel') == 2 and launches.get('merge_composite_kernel') == 1 and launches.get('stratified_kernel') == 1, launches
+    L = tdgp._lib
+    assert L.load().tdgp_render_fused_workspace_bytes(2, 100, 16, 16) == L.load().tdgp_render_fused_workspace_bytes(2, 100, 16, 16) > 2 * 100 * 16 * 4 * 11
+    with pytest.raises(RuntimeError, match='workspace'):
+        ws = torch.empty(16, device=DEV)
+        p_ = tdgp.renderer.planes_to_hwc(planes).t
+        w0, b0, w1, b1, _ = tdgp.renderer._mlp_params(mlp)
+        out = [torch.empty(hw * B * 3, device=DEV) for _ in range(4)]
+        L.call('tdgp_render_fused', p_.data_ptr(), w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(), ro.data_ptr(), rd.data_ptr(), u1.data_ptr(), u2.data_ptr(),
+               out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), B, hw, 0, S, S, F, H, H, hid, 0.5, 0.75, 1.25, 0, 1, 0.0, ws.data_ptr(), 64,
+               L.stream_of(ws))
+
+
 def _merge_case(tdgp, rs, rays, S, sorted_lists, flags_kw, cut=0.0, with_perm2=False):
     """tdgp_merge_composite on explicit lists vs the op-level chain unify_samples -> ray marcher, everything bit for bit."""
     L = tdgp._lib
