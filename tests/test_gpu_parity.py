@@ -790,7 +790,7 @@ def test_render_fused_equals_staged_calls(tdgp, marcher):
             assert torch.equal(a, b), (marcher, B, hw, name)
         assert launches.get('triplane_field_kernel') == 2 and launches.get('merge_composite_kernel') == 1 and launches.get('stratified_kernel') == 1, launches
     L = tdgp._lib
-    assert L.load().tdgp_render_fused_workspace_bytes(2, 100, 16, 16) == L.load().tdgp_render_fused_workspace_bytes(2, 100, 16, 16) > 2 * 100 * 16 * 4 * 11
+    assert L.load().tdgp_render_fused_workspace_bytes(2, 100, 16, 16) == 200 * (2 * 16 * 4 + 16 * 16 + 16 * 4 + 16 * 16)      # sdist, tdist, rgbs_c, tfine, rgbs_f
     with pytest.raises(RuntimeError, match='workspace'):
         ws = torch.empty(16, device=DEV)
         p_ = tdgp.renderer.planes_to_hwc(planes).t
