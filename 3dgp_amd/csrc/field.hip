@@ -30,9 +30,6 @@
 
 // Compile-time ablations for timing experiments (tools/dev/build_variant.sh): 1 = no tap loads, 2 = no layer-1 MFMAs,
 // 4 = no stores, 32 = per-phase cycle counts of one wave (printed).  Always 0 in the shipped library.
-#ifndef TDGP_FIELD_ABL
-#define TDGP_FIELD_ABL 0
-#endif
 #ifndef TDGP_WALK_WAVES
 #define TDGP_WALK_WAVES 2      // waves per SIMD the table walk is compiled for (3: 168 registers, 24 spilled -- measured slower)
 #endif
@@ -225,18 +222,10 @@ __device__ __forceinline__ void field_body(const FieldParams& p) {
             const int xa = min(max(x0, 0), p.W - 1), xb = min(max(x0 + 1, 0), p.W - 1);
             const int ya = min(max(y0, 0), p.H - 1), yb = min(max(y0 + 1, 0), p.H - 1);
             const int ra = ya * p.W, rb = yb * p.W;         // 32-bit element offsets inside one plane (< 2^31)
-            if (TDGP_FIELD_ABL & 1) {
-#pragma unroll
-                for (int s = 0; s < FQ / 2; s++) {
-                    tap[pl][0][s] = (f32x2){(float)(ra + xa + s), 1.f}; tap[pl][1][s] = (f32x2){(float)(ra + xb), 2.f};
-                    tap[pl][2][s] = (f32x2){(float)(rb + xa), 3.f}; tap[pl][3][s] = (f32x2){(float)(rb + xb), 4.f};
-                }
-            } else {
             load_texel<FQ>(base + (ra + xa) * F, gc4, tap[pl][0]);
             load_texel<FQ>(base + (ra + xb) * F, gc4, tap[pl][1]);
             load_texel<FQ>(base + (rb + xa) * F, gc4, tap[pl][2]);
             load_texel<FQ>(base + (rb + xb) * F, gc4, tap[pl][3]);
-            }
         }
     };
     // ---- the arithmetic of one 16-point tile, cut into PASSES of 16 channels (4 per gathering lane = one 16-B piece of every texel):
@@ -271,7 +260,6 @@ __device__ __forceinline__ void field_body(const FieldParams& p) {
                                                                                              // one 16-B LDS read, not 4*MT resident registers) is the initial accumulator
     };
     auto mlp_pass = [&](f32x4* acc, int ps, const float* gp) {     // layer 1 on the matrix cores: h^T[hid x 16 pts] += W0s[:, pass] * g^T[pass]
-        if (!(TDGP_FIELD_ABL & 2))
 #pragma unroll
         for (int i = 0; i < 2 * PP; i++)
 #pragma unroll
@@ -326,7 +314,7 @@ __device__ __forceinline__ void field_body(const FieldParams& p) {
     auto eval_tile = [&](float cx, float cy, float cz, const float* __restrict__ bplanes, int64_t ggp, bool gvalid, int64_t gp, bool valid) {
         issue_taps(cx, cy, cz, bplanes, ggp, gvalid);
         const float4 o = tile_from_taps();
-        if (q == 0 && valid && (!(TDGP_FIELD_ABL & 4) || o.x == 123.f)) {
+        if (q == 0 && valid) {
             float4 on = o;
             if (p.snoise) on.w = __fadd_rn(on.w, __fmul_rn(p.snoise[gp], p.snoise_std));
             ((float4*)p.rgbs)[gp] = on;
@@ -457,8 +445,7 @@ __device__ __forceinline__ void field_body(const FieldParams& p) {
                         for (int t = 0; t < 4; t++)
 #pragma unroll
                             for (int jj = 0; jj < FQ / 4; jj++) {
-                                float4 v = make_float4((float)(ov[t] + jj), 1.f, 2.f, 3.f);
-                                if (!(TDGP_FIELD_ABL & 1)) v = buf_load4(rpl, ov[t] + 64u * jj, so);
+                                const float4 v = buf_load4(rpl, ov[t] + 64u * jj, so);
                                 tap[pl][t][2 * jj] = (f32x2){v.x, v.y}; tap[pl][t][2 * jj + 1] = (f32x2){v.z, v.w};
                             }
                     }
@@ -491,7 +478,7 @@ __device__ __forceinline__ void field_body(const FieldParams& p) {
                             if (j < nk) v0.w = __fadd_rn(v0.w, __fmul_rn(np[0], p.snoise_std));
                             if (j + 1 < nk) v1.w = __fadd_rn(v1.w, __fmul_rn(np[1], p.snoise_std));
                         }
-                        if (fok && !(TDGP_FIELD_ABL & 4)) {
+                        if (fok) {
                             if (j < nk) dst[0] = v0;
                             if (j + 1 < nk) dst[1] = v1;
                         }
@@ -549,7 +536,7 @@ __device__ __forceinline__ void field_body(const FieldParams& p) {
                         if (j < nk) v0.w = __fadd_rn(v0.w, __fmul_rn(np[0], p.snoise_std));
                         if (j + 1 < nk) v1.w = __fadd_rn(v1.w, __fmul_rn(np[1], p.snoise_std));
                     }
-                    if (fok && !(TDGP_FIELD_ABL & 4)) {
+                    if (fok) {
                         if (j < nk) dst[0] = v0;
                         if (j + 1 < nk) dst[1] = v1;
                     }

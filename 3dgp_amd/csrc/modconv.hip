@@ -1119,7 +1119,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN > 4 ? 1 : 2)) void upconv_mf
         int b = b0, vp0 = vpb + nn * 32;                 // GS is a multiple of 32: the 32 points of a sub-tile share their sample
         while (vp0 >= p.GS) { vp0 -= p.GS; b++; }
         const int obase = m0 + (wm * MTW + mm) * 32;
-        if (b < p.B && (!(TDGP_UP_ABL & 1) || acc[0][0][0][0] == 123.f)) {
+        if (b < p.B) {
             if (zbuf && obase + 32 <= p.Cout) {
                 const uint32_t zb = (uint32_t)(((b * p.Cout + obase) * 2 + py) * (2 * p.GS) + 2 * vp0) * 4u;
 #pragma unroll
