@@ -163,6 +163,19 @@ __device__ __forceinline__ float wave_scan_f32(float v) {
 #undef TDGP_SCAN_STEP
     return v;
 }
+// inclusive prefix maximum of non-negative ints over the 64 lanes (identity 0), the same DPP steps
+__device__ __forceinline__ int wave_scan_max_i32(int v) {
+#define TDGP_SCAN_STEP(CTRL, RMASK) { const int o = __builtin_amdgcn_update_dpp(0, v, CTRL, RMASK, 0xf, false); v = o > v ? o : v; }
+    TDGP_SCAN_STEP(0x111, 0xf)
+    TDGP_SCAN_STEP(0x112, 0xf)
+    TDGP_SCAN_STEP(0x114, 0xf)
+    TDGP_SCAN_STEP(0x118, 0xf)
+    TDGP_SCAN_STEP(0x142, 0xa)
+    TDGP_SCAN_STEP(0x143, 0xc)
+#undef TDGP_SCAN_STEP
+    return v;
+}
+__device__ __forceinline__ int wave_last_i32(int v) { return __builtin_amdgcn_readlane(v, 63); }
 __device__ __forceinline__ float wave_last_f32(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 __device__ __forceinline__ float wave_shr1_f32(float v, float first) { return dpp_f32<0x138, 0xf>(first, v); }
 __device__ __forceinline__ float wave_sum_f32(float v) { return wave_last_f32(wave_scan_f32<false>(v)); }

@@ -590,39 +590,61 @@ __global__ __launch_bounds__(256) void merge_composite_kernel(const float* __res
     if (__any(bad)) {
         stable_ranks(sc.cdf, M, rank);
     } else {
-        // the searches of a lane's slots advance together, a fixed number of branch-free steps: one chain of dependent LDS reads
-        // instead of one per slot (this phase was 40 % of the kernel's time when each slot ran its own while loop)
+        // Ranks of a stable merge of two ascending lists (coarse wins ties).
+        //   fine element j:    its own index + #coarse <= f_j  =: j + cnt_j     -- a binary search in the coarse list;
+        //   coarse element i:  its own index + #fine < c_i.  No second search: c_i <= f_j  <=>  cnt_j >= i + 1, so #fine < c_i = #{j : cnt_j <= i}, and
+        //                      cnt_j does not decrease with j, so that count is (the largest j with cnt_j <= i) + 1 = a PREFIX MAXIMUM over
+        //                      last[c] = max{j + 1 : cnt_j = c} -- one LDS max-scatter by the fine elements and one wave scan.
+        // (Round 5.  Before, every element searched the other list: 7 lock-step rounds of ~14 vector instructions on both slots of a lane, a third of
+        //  this kernel's instructions; now the slots that hold only coarse elements skip the search.)  The searches of a lane's slots still advance
+        //  together, a fixed number of branch-free steps: one chain of dependent LDS reads instead of one per slot.
         constexpr int NSL = MS / 64;
         float v[NSL];
-        int lo[NSL], hi[NSL], ob[NSL];
+        int lo[NSL], hi[NSL];
         bool fine[NSL];
+        int* const last = (int*)sc.bins;                 // [S1 + 1] (S1 + 1 <= MS: the list lengths are checked on the host)
+        for (int c = l; c <= S1 && c < MS; c += 64) last[c] = 0;        // (c == MS only when there is no fine list at all)
 #pragma unroll
         for (int cc = 0; cc < NSL; cc++) {
             const int i = l + 64 * cc;
             v[cc] = i < M ? sc.cdf[i] : 0.f;
-            fine[cc] = i >= S1;
-            ob[cc] = fine[cc] ? 0 : S1;                // first element of the OTHER list
+            fine[cc] = i >= S1 && i < M;
             lo[cc] = 0;
-            hi[cc] = i < M ? (fine[cc] ? S1 : S2) : 0;
+            hi[cc] = fine[cc] ? S1 : 0;                  // coarse elements (and slots past the end) never open a search
         }
-        const int steps = 32 - __clz(S1 > S2 ? S1 : S2);
+        const int steps = 32 - __clz(S1);
         for (int it = 0; it < steps; it++) {
 #pragma unroll
-            for (int cc = 0; cc < NSL; cc++) {         // fine: #coarse <= v (coarse wins ties);  coarse: #fine < v
+            for (int cc = 0; cc < NSL; cc++) {           // #coarse <= v (coarse wins ties)
+                if (64 * cc + 64 <= S1) continue;        // a slot of coarse elements only (wave-uniform)
                 const bool open = lo[cc] < hi[cc];
                 const int mid = (lo[cc] + hi[cc]) >> 1;
-                const float o = sc.cdf[ob[cc] + (open ? mid : 0)];
-                const bool right = fine[cc] ? (o <= v[cc]) : (o < v[cc]);
+                const float o = sc.cdf[open ? mid : 0];
+                const bool right = o <= v[cc];
                 lo[cc] = (open && right) ? mid + 1 : lo[cc];
                 hi[cc] = (open && !right) ? mid : hi[cc];
             }
         }
-#pragma unroll
-        for (int cc = 0; cc < MAXS / 64; cc++) rank[cc] = 0;
+        wave_sync();                                     // last[] is zeroed before the scatter below
 #pragma unroll
         for (int cc = 0; cc < NSL; cc++) {
             const int i = l + 64 * cc;
-            rank[cc] = (fine[cc] ? i - S1 : i) + lo[cc];
+            if (fine[cc]) atomicMax(&last[lo[cc]], i - S1 + 1);
+        }
+        wave_sync();
+#pragma unroll
+        for (int cc = 0; cc < MAXS / 64; cc++) rank[cc] = 0;
+        int carry = 0;
+#pragma unroll
+        for (int cc = 0; cc < NSL; cc++) {
+            const int i = l + 64 * cc;
+            if (64 * cc < S1) {                          // this slot holds coarse elements: F(i) = max over c <= i of last[c]
+                const int incl = max(wave_scan_max_i32((i <= S1 && i < MS) ? last[i] : 0), carry);
+                carry = wave_last_i32(incl);
+                rank[cc] = fine[cc] ? (i - S1) + lo[cc] : i + incl;
+            } else {
+                rank[cc] = (i - S1) + lo[cc];
+            }
         }
     }
     TPH(1)
