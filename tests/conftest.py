@@ -184,7 +184,7 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
 
 
 # ------------------------------------------------------------------------------------------------ full-size goldens (BASELINE configs[0..2])
-FULL_GOLDENS = dict(c1=('config_c1', 101), c2=('config_c2', 103), c3=('config_c3', 105))      # tools/gen_goldens.py:FULL_CONFIGS
+FULL_GOLDENS = dict(c1=('config_c1', 101), c2=('config_c2', 103), c3=('config_c3', 105), c4=('config_c4', 109))      # tools/gen_goldens.py:FULL_CONFIGS
 
 
 def load_full_golden(tag):

@@ -1206,9 +1206,9 @@ def _hip_strip_cdf(tdgp, G, inter, b, sel, u2):
     return N(aux['cdf']).reshape(len(sel), -1), fused.cpu().numpy().astype(np.int64)
 
 
-@pytest.mark.parametrize('tag', ['c1', 'c2', 'c3'])
+@pytest.mark.parametrize('tag', ['c1', 'c2', 'c3', 'c4'])
 def test_full_size_vs_reference_golden(tdgp, oracle, tag):
-    """BASELINE configs[0..2] at their REAL size against the REFERENCE ITSELF (tests/golden/e2e_full_<tag>.npz,
+    """BASELINE configs[0..3] at their REAL size (configs[3] = the cmax-1024 backbone) against the REFERENCE ITSELF (tests/golden/e2e_full_<tag>.npz,
     generated by tools/gen_goldens.py:gen_e2e_full from the imported reference; weights and inputs regenerate from the seed):
       * ws, 4096 sampled texels of the tri-planes;
       * image and depth through assert_image_parity with the oracle's image as the exactly rounded one: range-normalised error vs the
@@ -1255,9 +1255,12 @@ def test_full_size_vs_reference_golden(tdgp, oracle, tag):
     sel = np.concatenate([np.arange(r * h, (r + 1) * h) for r in g['rows']])
     np.testing.assert_array_equal(N(inter['sdist_coarse']).reshape(R, S)[sel], g['strip_sdist_coarse'])
     assert_close(N(c2w), g['c2w'], 2e-7, 'c2w', 1.0)                          # sin / cos: 1-ulp routines in torch, correctly rounded here
-    if np.array_equal(N(c2w), g['c2w']):                                     # ... and given the same matrix the rays are the reference's bits
+    if np.array_equal(N(c2w), g['c2w']):                                     # ... and given the same matrix the rays are the reference's bits (c1 / c2 / c3)
         np.testing.assert_array_equal(N(ray_d)[0, sel], g['strip_ray_d'])
-    np.testing.assert_array_equal(N(ray_o)[0, sel], g['strip_ray_o'])
+        np.testing.assert_array_equal(N(ray_o)[0, sel], g['strip_ray_o'])
+    else:                                                                    # c4's camera: one matrix entry an ulp off
+        assert_close(N(ray_d)[0, sel], g['strip_ray_d'], 2e-7, 'ray_d', 1.0)
+        assert_close(N(ray_o)[0, sel], g['strip_ray_o'], 2e-7, 'ray_o', 1.0)
     u2 = inp['u_fine'].reshape(R, S)[sel]
     cdf_h, inds_h = _hip_strip_cdf(tdgp, G, inter, 0, sel, u2)
     n, worst = assert_inds_mismatches_in_window(inds_h, g['strip_inds'], u2, g['strip_cdf'], cdf_h, what=f'{tag} full size strip vs the reference')

@@ -244,9 +244,9 @@ def test_e2e_mid(oracle, tdgp):
     assert_image_parity(depth, g, 'oracle e2e_mid depth', 'depth')
 
 
-@pytest.mark.parametrize('tag', ['c1', 'c2', 'c3'])
+@pytest.mark.parametrize('tag', ['c1', 'c2', 'c3', 'c4'])
 def test_e2e_full_size(oracle, tdgp, tag):
-    """BASELINE configs[0..2] at their REAL size (512^2 tri-planes, 512-channel backbone, 64^2/32 - 128^2/48 - 256^2/64 rays x steps):
+    """BASELINE configs[0..3] at their REAL size (512^2 tri-planes, 512-channel backbone -- 1024 for configs[3] --, 64^2/32 - 128^2/48 - 256^2/64 rays x steps):
     the oracle against ONE image from the reference itself (tools/gen_goldens.py:gen_e2e_full) -- this is what pins "oracle == reference"
     at the shapes the GPU tests then hold the HIP path to (VERDICT r04 missing #2).  Image and depth through assert_image_parity (range
     <= 1e-5, per-pixel bound against the reference's own float64 run); 4096 sampled texels of the 100 MB tri-planes; and the integer
@@ -271,9 +271,12 @@ def test_e2e_full_size(oracle, tdgp, tag):
     # rays: bit-identical to the reference's (norm / cross / bmm restated as the fused chains torch's CPU kernels execute; the cam2world
     # matrix is bit-identical for these cameras -- its sin / cos are 1-ulp routines in torch, so that part is held to 2e-7 in general)
     assert_close(inter['c2w'], g['c2w'], 2e-7, 'c2w', 1.0)
-    if np.array_equal(inter['c2w'], g['c2w']):
+    if np.array_equal(inter['c2w'], g['c2w']):                # (c1 / c2 / c3; c4's camera has one matrix entry an ulp off: torch's sin / cos are 1-ulp routines)
         np.testing.assert_array_equal(inter['ray_d'][0, sel], g['strip_ray_d'])
-    np.testing.assert_array_equal(inter['ray_o'][0, sel], g['strip_ray_o'])
+        np.testing.assert_array_equal(inter['ray_o'][0, sel], g['strip_ray_o'])
+    else:
+        assert_close(inter['ray_d'][0, sel], g['strip_ray_d'], 2e-7, 'ray_d', 1.0)
+        assert_close(inter['ray_o'][0, sel], g['strip_ray_o'], 2e-7, 'ray_o', 1.0)
     w_c = inter['weights_coarse'][0, sel]
     assert_close(w_c[..., 0], g['strip_weights_coarse'], 1e-5, 'coarse weights of the strip', 1.0)
     _, aux = oracle.sample_importance(inter['sdist_coarse'][:1, sel, :, None], w_c[None], inp['u_fine'].reshape(h * h, S)[sel], cfg.ray_marcher_type, return_aux=True)

@@ -718,7 +718,8 @@ def gen_e2e(tag, cfg, batch, seed, keep_intermediates):
 
 
 # BASELINE.json configs[0..2] at their REAL size: one image each from the reference itself.
-FULL_CONFIGS = dict(c1=('config_c1', 101, [0, 17, 40, 63]), c2=('config_c2', 103, [0, 77, 127]), c3=('config_c3', 105, [3, 128, 250]))
+FULL_CONFIGS = dict(c1=('config_c1', 101, [0, 17, 40, 63]), c2=('config_c2', 103, [0, 77, 127]), c3=('config_c3', 105, [3, 128, 250]),
+                    c4=('config_c4', 109, [7, 130, 251]))          # configs[3]: cmax 1024 / cbase 65536
 
 
 def _pack_diff(x, base):
