@@ -1680,6 +1680,27 @@ def test_bf16_generator_vs_reference_golden(tdgp, oracle):
     _assert_bf16_close(N(planes), oplanes, 'tri-planes vs the oracle')
 
 
+def test_bf16_full_size_vs_reference_golden(tdgp):
+    """BASELINE configs[4] at its REAL size against the REFERENCE's own reduced-precision run with bfloat16 (tests/golden/bf16_full_c5.npz):
+    16384 sampled texels of the tri-planes, the 256^2 image and the depth map (96 + 96 ray steps), at the bf16 tolerances of the mid-size golden."""
+    g = load_golden('bf16_full_c5')
+    cfg = tdgp.config.config_c5()
+    seed = int(g['seed'][0])
+    G = _gen(tdgp, cfg, seed)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=1, seed=seed + 1)
+    ws = T(g['ws'])
+    dec = G.synthesis.tri_plane_decoder
+    planes = dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True)
+    got = N(planes.t.permute(0, 1, 4, 2, 3).reshape(1, 96, 512, 512)).reshape(-1)[g['planes_pick']]
+    err = np.abs(got - g['planes_vals']) / g['planes_absmax']
+    report_parity('bf16 C5 full size tri-planes (16384 sampled texels vs the reference)', max_err=float(err.max()), mean_err=float(err.mean()))
+    assert err.max() <= BF16_MAX and err.mean() <= BF16_MEAN, (float(err.max()), float(err.mean()))
+    out = G.synthesis(ws, camera_params={k: T(v) for k, v in inp['camera'].items()}, noise_mode='const', render_opts=dict(return_depth=True),
+                      u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']))
+    _assert_bf16_close(N(out.img), g['img'], 'C5 full size image vs the reference', max_tol=3e-2, mean_tol=4e-3)
+    _assert_bf16_close(N(out.depth), g['depth'], 'C5 full size depth vs the reference', max_tol=2e-2, mean_tol=2e-3)
+
+
 def test_bf16_planes_nchw_equal_channel_last(tdgp):
     """with reduced-precision blocks the tri-plane image must stay fp32 in BOTH layouts (networks_stylegan2.py:268
     `y.to(float32); img.add_`): the public NCHW form (hwc=False) takes the widened ToRGB fallback and must neither round the accumulated

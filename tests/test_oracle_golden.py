@@ -561,6 +561,27 @@ def test_bf16_modconv(oracle, tag):
     np.testing.assert_array_equal(act, g[f'{tag}_act'])                             # elementwise chain on identical inputs: exact
 
 
+def test_bf16_full_size_backbone(oracle, tdgp):
+    """BASELINE configs[4] at its REAL size: the oracle's bf16 backbone (blocks 64^2 ... 512^2 in bfloat16, 512 channels) against 16384 texels of
+    the tri-planes the REFERENCE's own reduced-precision path produced with bfloat16 (tests/golden/bf16_full_c5.npz, tools/gen_goldens.py:
+    gen_bf16_full) -- the pin of "oracle == reference" for the bf16 arithmetic at the shapes the GPU test holds the HIP kernels to."""
+    g = load_golden('bf16_full_c5')
+    cfg = tdgp.config.config_c5()
+    seed = int(g['seed'][0])
+    sd = tdgp.weights.random_state_dict(cfg, seed=seed, exercise_all=True)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=1, seed=seed + 1)
+    from oracle import pipeline as P
+    oracle.set_threads(os.cpu_count() or 1)
+    ws = oracle.mapping_forward(sd, cfg.to_dict(), inp['z'], inp['c'])
+    assert_close(ws, g['ws'], 1e-5, 'ws', 1.0)
+    planes = P.synthesis_backbone(sd, cfg.to_dict(), g['ws'], 'const')
+    got = planes.reshape(-1)[g['planes_pick']]
+    err = np.abs(got - g['planes_vals']) / g['planes_absmax']
+    from conftest import report_parity
+    report_parity('oracle bf16 C5 full size tri-planes (16384 sampled texels vs the reference)', max_err=float(err.max()), mean_err=float(err.mean()))
+    assert err.max() <= 1.5e-2 and err.mean() <= 2e-3, (float(err.max()), float(err.mean()))
+
+
 def test_bf16_backbone_and_image(oracle, tdgp):
     """The generator with its two highest-resolution blocks in bf16 (config_mid_bf16), block by block against the reference's own run."""
     cfg = tdgp.config.config_mid_bf16()

@@ -922,6 +922,41 @@ def gen_bf16():
     save('bf16', **arrays)
 
 
+def gen_bf16_full():
+    """`bf16_full_c5.npz`: BASELINE configs[4] at its REAL size from the reference's own reduced-precision path run with bfloat16 (as gen_bf16):
+    512-channel backbone with the four highest-resolution blocks (64^2 ... 512^2) in bf16, 256^2 rays x 96 + 96 steps, batch 1.  Weights and inputs
+    regenerate from the seed; stored: ws, 16384 sampled texels of the fp32 tri-planes (+ their index and the tensor's max), img, depth."""
+    import time
+    cfg = tdgp.config.config_c5()
+    seed = 121
+    sd = tdgp.weights.random_state_dict(cfg, seed=seed, exercise_all=True)
+    G = Generator(ref_cfg(cfg), img_resolution=cfg.img_resolution, img_channels=3, mapping_kwargs={}, num_fp16_res=cfg.num_fp16_res,
+                  conv_clamp=cfg.conv_clamp, fused_modconv_default='inference_only').eval()
+    G.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    dec = G.synthesis.tri_plane_decoder
+    assert [getattr(dec, f'b{r}').use_fp16 for r in dec.block_resolutions] == [False] * 4 + [True] * 4
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=1, seed=seed + 1)
+    cam = TensorGroup(**{k: T(v) for k, v in inp['camera'].items()})
+    R, S = cfg.img_resolution ** 2, cfg.num_ray_steps
+    o_fwd = dec.forward
+    dec.forward = lambda ws, **kw: o_fwd(ws.as_subclass(_CudaFlag), **kw)
+    t0 = time.time()
+    with torch.no_grad(), _Bf16ForFp16():
+        ws = G.mapping(T(inp['z']), T(inp['c']))
+        planes = dec(ws, noise_mode='const')
+        print(f'c5: reference bf16 backbone {time.time() - t0:.1f} s')
+        with PatchedRNG(rand_like=[T(inp['u_coarse']).reshape(1, R, S, 1)], rand=[T(inp['u_fine'])]):
+            out = G.synthesis(ws, camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True))
+    dec.forward = o_fwd
+    print(f'c5: reference bf16 forward {time.time() - t0:.1f} s')
+    assert planes.dtype == torch.float32
+    pl = npy(planes)
+    pick = np.random.RandomState(seed).randint(0, pl.size, 16384)
+    save('bf16_full_c5', seed=np.array([seed, 1], np.int64), ws=npy(ws), planes_pick=pick.astype(np.int64), planes_vals=pl.reshape(-1)[pick],
+         planes_absmax=np.float32(np.abs(pl).max()), planes_absmean=np.float32(np.abs(pl).mean()), img=npy(out.img), depth=npy(out.depth))
+
+
+
 def ref_camera_cfg(r):
     mm = lambda t: EasyDict(min=t[0], max=t[1])   # noqa: E731
     return EasyDict(origin=EasyDict(angles=EasyDict(yaw=mm(r.yaw), pitch=mm(r.pitch))), fov=mm(r.fov),
@@ -1491,6 +1526,7 @@ def main():
     gen_sampling()
     gen_sampling_hot()
     gen_bf16()
+    gen_bf16_full()
     gen_marchers()
     gen_camera()
     gen_mapping()
