@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     i=$((i + 1))
-    timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$OUT/sq_$i" -o pmc -- python "$REPO/bench.py" --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --other-batches "" > "$OUT/sq_$i.log" 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$OUT/sq_$i" -o pmc -- python "$REPO/bench.py" --steps 2 --warmup 1 --profile-steps 1 --no-cpu-baseline --other-batches "" --no-fid-loop --no-host-probe > "$OUT/sq_$i.log" 2>&1
     echo "sq pass $i rc=$?"
     DB=$(find "$OUT/sq_$i" -name '*.db' | head -1)
     [ -n "$DB" ] && python "$REPO/tools/rocpd_pmc.py" "$DB" "$OUT/sq_$i.md" | head -3
