@@ -7,7 +7,11 @@ chains the primitives into the reference's call order.  Only ``tests/``,
 it; the product package (``3dgp_amd/``) never does.
 
 Pinned by ``tests/golden/*.npz`` -- vectors produced by importing the reference
-itself in the build container (``tools/gen_goldens.py``).  The reference ships
+itself in the build container (``tools/gen_goldens.py``): op level for every
+row of SURVEY.md section 8a, end to end at three small configurations, and
+(round 5) at the REAL size of BASELINE configs[0..4] (``e2e_full_c1..c4``,
+``bf16_full_c5``: image, depth, the reference's own float64 run, sampled
+tri-plane texels, rays and the integer rows of a strip of image rows).  The reference ships
 no tests/golden vectors of its own for this path and its
 native code is CUDA-only (not buildable here: no nvcc), so there is no
 ``oracle/_ref`` build.
