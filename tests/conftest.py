@@ -184,7 +184,7 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
 
 
 # ------------------------------------------------------------------------------------------------ full-size goldens (BASELINE configs[0..2])
-FULL_GOLDENS = dict(c1=('config_c1', 101), c2=('config_c2', 103), c3=('config_c3', 105), c4=('config_c4', 109))      # tools/gen_goldens.py:FULL_CONFIGS
+FULL_GOLDENS = dict(c1=('config_c1', 101), c2=('config_c2', 103), c3=('config_c3', 105), c4=('config_c4', 109), c2mip=('config_c2', 111))      # tools/gen_goldens.py:FULL_CONFIGS
 
 
 def load_full_golden(tag):
@@ -204,6 +204,8 @@ def full_golden_case(tdgp, tag):
     """(cfg, state dict, inputs) the full-size golden was generated from: everything regenerates from the seed."""
     cfg_name, seed = FULL_GOLDENS[tag]
     cfg = getattr(tdgp.config, cfg_name)()
+    if tag.endswith('mip'):                                   # configs[1]'s shape under MipRayMarcher2 with a white background
+        cfg.ray_marcher_type, cfg.white_back = 'mip', True
     return cfg, tdgp.weights.random_state_dict(cfg, seed=seed, exercise_all=True), tdgp.weights.synthetic_inputs(cfg, batch=1, seed=seed + 1)
 
 

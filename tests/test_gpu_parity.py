@@ -1206,7 +1206,7 @@ def _hip_strip_cdf(tdgp, G, inter, b, sel, u2):
     return N(aux['cdf']).reshape(len(sel), -1), fused.cpu().numpy().astype(np.int64)
 
 
-@pytest.mark.parametrize('tag', ['c1', 'c2', 'c3', 'c4'])
+@pytest.mark.parametrize('tag', ['c1', 'c2', 'c3', 'c4', 'c2mip'])
 def test_full_size_vs_reference_golden(tdgp, oracle, tag):
     """BASELINE configs[0..3] at their REAL size (configs[3] = the cmax-1024 backbone) against the REFERENCE ITSELF (tests/golden/e2e_full_<tag>.npz,
     generated by tools/gen_goldens.py:gen_e2e_full from the imported reference; weights and inputs regenerate from the seed):

@@ -244,7 +244,7 @@ def test_e2e_mid(oracle, tdgp):
     assert_image_parity(depth, g, 'oracle e2e_mid depth', 'depth')
 
 
-@pytest.mark.parametrize('tag', ['c1', 'c2', 'c3', 'c4'])
+@pytest.mark.parametrize('tag', ['c1', 'c2', 'c3', 'c4', 'c2mip'])
 def test_e2e_full_size(oracle, tdgp, tag):
     """BASELINE configs[0..3] at their REAL size (512^2 tri-planes, 512-channel backbone -- 1024 for configs[3] --, 64^2/32 - 128^2/48 - 256^2/64 rays x steps):
     the oracle against ONE image from the reference itself (tools/gen_goldens.py:gen_e2e_full) -- this is what pins "oracle == reference"

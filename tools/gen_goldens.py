@@ -719,7 +719,8 @@ def gen_e2e(tag, cfg, batch, seed, keep_intermediates):
 
 # BASELINE.json configs[0..2] at their REAL size: one image each from the reference itself.
 FULL_CONFIGS = dict(c1=('config_c1', 101, [0, 17, 40, 63]), c2=('config_c2', 103, [0, 77, 127]), c3=('config_c3', 105, [3, 128, 250]),
-                    c4=('config_c4', 109, [7, 130, 251]))          # configs[3]: cmax 1024 / cbase 65536
+                    c4=('config_c4', 109, [7, 130, 251]),          # configs[3]: cmax 1024 / cbase 65536
+                    c2mip=('config_c2', 111, [5, 64, 120]))        # configs[1]'s shape with the 'mip' ray marcher (MipRayMarcher2, white background)
 
 
 def _pack_diff(x, base):
@@ -738,6 +739,8 @@ def gen_e2e_full(tag):
     importance stage (searchsorted indices, the cdf knots they were ranked against, sort permutation) plus the fine samples."""
     cfg_name, seed, rows = FULL_CONFIGS[tag]
     cfg = getattr(tdgp.config, cfg_name)()
+    if tag.endswith('mip'):
+        cfg.ray_marcher_type, cfg.white_back = 'mip', True
     sd = tdgp.weights.random_state_dict(cfg, seed=seed, exercise_all=True)
     G = build_ref_generator(cfg, sd)
     inp = tdgp.weights.synthetic_inputs(cfg, batch=1, seed=seed + 1)
