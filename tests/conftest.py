@@ -215,7 +215,7 @@ def _ulps_apart(a, b):
     return np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)).astype(np.float64)
 
 
-def assert_inds_mismatches_in_window(inds_a, inds_b, u, cdf_b, cdf_a=None, what='inds', max_ulp=4.0, max_knot_ulp=64.0):
+def assert_inds_mismatches_in_window(inds_a, inds_b, u, cdf_b, cdf_a=None, what='inds', max_ulp=4.0, max_knot_ulp=64.0, samples_a=None, samples_b=None, sample_tol=5e-6):
     """SURVEY.md 9.2 protocol for the INT row `inds = searchsorted(cdf, u, right=True)` (tri_plane_renderer.py:282) compared THROUGH THE
     CHAIN (each side ranks the draw against its own cdf, and the two cdfs carry independent fp32 rounding from the MLP sums upstream):
     every draw whose index differs must be EXPLAINED, i.e. sit inside the ambiguity window of a knot.
@@ -226,7 +226,9 @@ def assert_inds_mismatches_in_window(inds_a, inds_b, u, cdf_b, cdf_a=None, what=
         knot values straddling the draw -- and the two knot values are within `max_knot_ulp` fp32 ulps of each other (the tolerance the
         cdf rows themselves are held to);
       * with one cdf: |u - cdf_b[k]| <= `max_ulp` ulps of the knot.
-    Anything else (a draw far from every knot landing in another interval) fails.  Returns (mismatches, worst distance in ulps)."""
+    Anything else (a draw far from every knot landing in another interval) fails.  With `samples_a` / `samples_b` (the fine samples of both sides in DRAW
+    order, s-space: depth range 1): the inverse cdf is continuous across a knot, so the two samples of a flipped draw must agree to `sample_tol` (measured <= 1.7e-6 at knot windows of up to 47 ulp; SURVEY 9.2:
+    "output continuity") -- asserted for every mismatching draw.  Returns (mismatches, worst distance in ulps)."""
     a, b = np.asarray(inds_a, np.int64), np.asarray(inds_b, np.int64)
     u, cdf_b = np.asarray(u, np.float32), np.asarray(cdf_b, np.float32)
     assert a.shape == b.shape == u.shape and cdf_b.shape[0] == a.shape[0], (a.shape, b.shape, u.shape, cdf_b.shape)
@@ -246,8 +248,14 @@ def assert_inds_mismatches_in_window(inds_a, inds_b, u, cdf_b, cdf_a=None, what=
                 d = float(_ulps_apart(u[r, j], cdf_b[r, k]))
                 assert d <= max_ulp, f'{what}: draw ({r},{j}) u={u[r, j]!r} has inds {a[r, j]} vs {b[r, j]} but is {d:.1f} ulp from knot {k} = {cdf_b[r, k]!r}'
             worst = max(worst, d)
+    worst_s = 0.0
+    if samples_a is not None and samples_b is not None and rows.size:
+        sa, sb = np.asarray(samples_a, np.float64).reshape(a.shape), np.asarray(samples_b, np.float64).reshape(a.shape)
+        ds = np.abs(sa[rows, cols] - sb[rows, cols])
+        worst_s = float(ds.max())
+        assert worst_s <= sample_tol, f'{what}: a flipped draw moved its fine sample by {worst_s:.3e} (> {sample_tol:.1e}): the inverse cdf is continuous across a knot'
     report_parity(what + ': INT row inds through the chain, every mismatch explained by a knot window', mismatches=int(rows.size), draws=int(a.size),
-                  worst_window_ulp=worst)
+                  worst_window_ulp=worst, worst_sample_move=worst_s)
     return int(rows.size), worst
 
 # ------------------------------------------------------------------------------------------------ upfirdn2d backward

@@ -1263,7 +1263,8 @@ def test_full_size_vs_reference_golden(tdgp, oracle, tag):
         assert_close(N(ray_o)[0, sel], g['strip_ray_o'], 2e-7, 'ray_o', 1.0)
     u2 = inp['u_fine'].reshape(R, S)[sel]
     cdf_h, inds_h = _hip_strip_cdf(tdgp, G, inter, 0, sel, u2)
-    n, worst = assert_inds_mismatches_in_window(inds_h, g['strip_inds'], u2, g['strip_cdf'], cdf_h, what=f'{tag} full size strip vs the reference')
+    n, worst = assert_inds_mismatches_in_window(inds_h, g['strip_inds'], u2, g['strip_cdf'], cdf_h, what=f'{tag} full size strip vs the reference',
+                                                samples_a=N(inter['sdist_fine']).reshape(R, -1)[sel], samples_b=g['strip_sdist_fine'])
     assert n <= 16, n
     d = np.abs(np.sort(N(inter['sdist_fine']).reshape(R, -1)[sel], axis=1) - np.sort(g['strip_sdist_fine'], axis=1))
     assert np.quantile(d, 0.999) <= 2e-5 and d.max() <= (1e-3 if n == 0 else 1e-2), (float(np.quantile(d, 0.999)), float(d.max()))
@@ -1450,7 +1451,8 @@ def test_full_size_c3_at_bench_batches(tdgp, oracle, B):
         # landing in another interval fails the test.  (Before round 5 the mismatches were counted, <= 8 per strip, and not explained.)
         cdf_h, hi = _hip_strip_cdf(tdgp, G, inter, b, sel, u2)
         oi = oaux['inds'].reshape(len(sel), -1)
-        ni, _ = assert_inds_mismatches_in_window(hi, oi, u2, oaux['cdf'].reshape(len(sel), -1), cdf_h, what=f'C3 B={B} sample {b} strip vs the oracle')
+        ni, _ = assert_inds_mismatches_in_window(hi, oi, u2, oaux['cdf'].reshape(len(sel), -1), cdf_h, what=f'C3 B={B} sample {b} strip vs the oracle',
+                                                 samples_a=N(inter['sdist_fine']).reshape(B, R, -1)[b, sel], samples_b=ointer['sdist_fine'].reshape(len(sel), -1))
         assert ni <= 16, ni
         ni_tot += ni
         hf = np.sort(N(inter['sdist_fine']).reshape(B, R, -1)[b, sel], axis=1)
