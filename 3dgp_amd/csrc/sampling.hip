@@ -55,6 +55,33 @@ __device__ void march_classical_lds(const float* z, const float* sig, float* w, 
     const int l = lane_id();
     double carry = 1.0;
     float wsum = 0.0f;
+    if (S > 64 && S <= 128) {
+        // Two chunks of 64 samples (the merged 64 + 64 list): both chunks' softplus / exp / prefix products are evaluated SIDE BY SIDE -- two independent
+        // dependency chains the scheduler interleaves -- and joined by the one multiplication that couples them.  The loop below runs them one after the
+        // other, and these kernels are bound by the length of a wave's dependent chain at the SIMD's 8-wave occupancy.  Same operations on
+        // the same values (the first chunk's `* carry` is `* 1.0`): same bits.
+        float alpha[2], fac[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int i = 64 * c + l;
+            alpha[c] = 0.f; fac[c] = 1.0f;
+            if (i < S) {
+                const float delta = (i < S - 1) ? (z[i + 1] - z[i]) : ((flags & 1) ? 1e10f : 1e-3f);
+                float sp = (flags & 8) ? (sig[i] > 0.f ? sig[i] : 0.f) : softplus20f(sig[i]);
+                if (sp < cut_thr) sp = 0.f;
+                alpha[c] = 1.0f - expf(-(delta * sp));
+                fac[c] = (1.0f - alpha[c]) + 1e-10f;
+            }
+        }
+        const double s0 = wave_scan_f64<true>((double)fac[0]), s1 = wave_scan_f64<true>((double)fac[1]);
+        const double c1 = wave_last_f64(s0);
+        const double i1 = s1 * c1;
+        const float incl0 = (float)s0, incl1 = (float)i1;
+        const float wi0 = alpha[0] * wave_shr1_f32(incl0, 1.0f), wi1 = alpha[1] * wave_shr1_f32(incl1, (float)c1);
+        w[l] = wi0; wsum += wi0;
+        if (64 + l < S) { w[64 + l] = wi1; wsum += wi1; }
+        carry = wave_last_f64(i1);
+    } else
     for (int base = 0; base < S; base += 64) {
         const int i = base + l;
         float alpha = 0.f, fac = 1.0f;
