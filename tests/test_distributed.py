@@ -285,6 +285,32 @@ def test_driver_command_shape_on_cpu(tmp_path):
     assert (a.gpus, a.steps, a.warmup) == (1, 50, 10) and bench.runs_cpu_baseline(a, 1, 0) and not bench.runs_cpu_baseline(a, 8, 0)
 
 
+def test_host_launch_probe_plumbing():
+    """bench.host_launch_probe / with_host_competitors on CPU (torch.cuda.synchronize stubbed): wall and CPU milliseconds per step come back,
+    the competitor processes really run while the probe does, and every one of them is gone afterwards (started and killed by PID)."""
+    import time
+    import psutil
+    sys.path.insert(0, REPO)
+    import bench
+    real = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        before = {p.pid for p in psutil.Process().children(recursive=True)}
+        seen = []
+
+        def probe():
+            seen.append(len({p.pid for p in psutil.Process().children(recursive=True)} - before))
+            return bench.host_launch_probe(lambda: time.sleep(0.002), steps=3)
+        wall, cpu = bench.with_host_competitors(3, probe)
+        assert seen == [3] and 1.5 <= wall <= 50.0 and 0.0 <= cpu <= wall + 5.0
+        deadline = time.time() + 10
+        while time.time() < deadline and ({p.pid for p in psutil.Process().children(recursive=True)} - before):
+            time.sleep(0.05)
+        assert not ({p.pid for p in psutil.Process().children(recursive=True)} - before)
+    finally:
+        torch.cuda.synchronize = real
+
+
 def test_rank_cpus_follow_the_gpu_numa_node(tdgp):
     """distributed.rank_cpus: ranks whose GPUs share a NUMA node split that node's cores; without NUMA information an even split of the
     allowed set; never an empty set, never a core outside what the process may use."""
