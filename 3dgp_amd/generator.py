@@ -297,7 +297,8 @@ class SynthesisBlock(torch.nn.Module):
         return x, img
 
 
-_SIDE_STREAMS = {}           # (device index, main stream handle) -> torch.cuda.Stream; process-wide, never part of a module's state
+_SIDE_STREAMS = {}           # (device index, main stream handle) -> side torch.cuda.Stream; process-wide LRU, never part of a module's state
+_SIDE_STREAMS_MAX = 16       # transient main streams (bench lanes, capture streams) must not accumulate side streams for the life of the process
 
 
 def side_stream_of(device):
@@ -306,10 +307,18 @@ def side_stream_of(device):
     to eager work -- do not serialise their ToRGB layers on one shared stream, and a capture never records another lane's work."""
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
-    st = _SIDE_STREAMS.get(key)
-    if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=torch.device('cuda', idx))
+    main = torch.cuda.current_stream(idx)
+    key = (idx, main.cuda_stream)
+    ent = _SIDE_STREAMS.get(key)
+    if ent is not None:
+        _SIDE_STREAMS[key] = _SIDE_STREAMS.pop(key)          # most recently used last
+        return ent
+    if len(_SIDE_STREAMS) >= _SIDE_STREAMS_MAX:
+        # Bounded: the least recently used entry goes (a handle whose stream was destroyed and re-issued would otherwise map a new main
+        # stream onto an old side stream for ever; with the bound it is at worst shared for a while, which is only a lost overlap --
+        # every use brackets the side stream with wait_stream / record_stream on both sides).
+        _SIDE_STREAMS.pop(next(iter(_SIDE_STREAMS)))
+    st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=torch.device('cuda', idx))
     return st
 
 
@@ -674,7 +683,9 @@ class SynthesisNetwork(torch.nn.Module):
         depth = depth.reshape(B, 1, h, w)
         depth_adapted = None
         if self.depth_adaptor is not None:                                  # networks_epigraf.py:246-253
-            needed = render_opts['concat_depth'] or render_opts['return_depth_adapted'] or self.strict_nan_propagation
+            # (self.training: DepthAdaptor.forward with out_strategy='random' draws np.random.choice in training mode -- the host RNG
+            #  stream must advance exactly as the reference's, which always evaluates the adaptor: networks_depth_adaptor.py:86-92)
+            needed = render_opts['concat_depth'] or render_opts['return_depth_adapted'] or self.strict_nan_propagation or self.training
             if needed:
                 depth_adapted = self.depth_adaptor(depth, ws[:, 0])
                 if render_opts['concat_depth']:

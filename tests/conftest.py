@@ -99,7 +99,7 @@ RGB_TOL = 1e-4        # north-star tolerance: max-rel RGB error vs the reference
 RANGE_TOL = 1e-5      # stricter, well-conditioned companion: max|delta| / max|ref|
 
 
-def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=None):
+def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=None, full_size=False):
     """End-to-end image parity against a golden captured from the reference.  Every figure is MEASURED and recorded
     (report_parity -> terminal summary + gpurun_out/parity_report.json); three bounds are asserted:
 
@@ -120,6 +120,12 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
          the reference's fp32 run is 1.7e-4 / 3.0e-4 / 2.9e-4 from its own float64 run on the three goldens, i.e. it does not
          meet a flat 1e-4 against itself), and the robust statistic, mean |d| / max|ref|, <= 1.25 x the reference's + 6e-8 (half an fp32 ulp of the range).
 
+    `full_size`: the head-room that the full-size goldens (e2e_full_*, e2e_bigger: 512-channel backbones, maxima over 12 k ... 197 k
+    heavy-tailed per-pixel ratios) needed in round 5 -- range bound max(1e-5, 2 r) instead of a flat 1e-5, the float64 run as a third yardstick in
+    (2) / (3), the maximum vs the float64 image at 2 x instead of 1.5 x the reference's own figure -- applies ONLY when the caller passes
+    full_size=True.  The small goldens keep the round-4 bounds (1e-5; 1.5 x) so that they keep their regression sensitivity.  The p99.9 and mean
+    assertions are the same for both.
+
     Why (2) is not a flat 1e-4: raw 'classical' RGB crosses zero, and with the 1e-3 floor an fp32 rounding error of 1e-7 of
     the image range already reads as 1e-4 on a near-zero pixel.  The floor any fp32 implementation hits is measured two
     ways: `<key>_alt` in the golden = the REFERENCE ITSELF re-run on identical inputs with native instead of oneDNN
@@ -139,7 +145,8 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
     if (key + '_f64') in g:
         ref_rng = float(np.abs(np.asarray(ref, np.float64) - np.asarray(g[key + '_f64'], np.float64)).max() / np.abs(ref).max())
         figs['reference_fp32_vs_f64_range_err'] = ref_rng
-        rng_bound = max(RANGE_TOL, 2 * ref_rng)
+        if full_size:
+            rng_bound = max(RANGE_TOL, 2 * ref_rng)
     report_parity(what, **figs)
     assert rng <= rng_bound, f'{what}: range-normalised error {rng:.3e} > {rng_bound:.2e}'
     # Round 4: with the exactly rounded image at hand the head-room is 1.5 x the LARGER of the reference's two own
@@ -149,7 +156,7 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
     # Round 5: the reference's float64 run, when the golden holds it, is the third (and least noisy) yardstick -- |x - ref| <= |x - f64| +
     # |f64 - ref|, and an image as good as the reference's is as far from f64 as the reference is: 1.5 x max_rel(ref, f64) joins the bound
     # (e2e_bigger: one `_alt` draw reads 2.9e-4 while the reference is 1.1e-3 per pixel from its own float64 image).
-    f64_noise = max_rel(ref, g[key + '_f64']) if (key + '_f64') in g else 0.0
+    f64_noise = max_rel(ref, g[key + '_f64']) if (full_size and (key + '_f64') in g) else 0.0
     bound = max(pix_tol, 1.5 * max(self_noise, exact_noise, f64_noise)) if exact is not None else max(pix_tol, 4 * self_noise, 1.5 * f64_noise)
     assert pix <= bound, f'{what}: max-rel {pix:.3e} > {bound:.3e} (reference self-noise {self_noise:.3e}, reference vs exact {exact_noise:.3e})'
     if exact is not None:
@@ -171,7 +178,7 @@ def assert_image_parity(img, g, what='img', key='img', pix_tol=RGB_TOL, exact=No
         # evaluations (measured HIP / reference: 1.66 on e2e_full_c1, 0.99 on c2, 1.13 on c3; the oracle's own image: 1.13 / 0.97 / 0.93), so
         # the maximum is held to 2 x and the body of the distribution -- the 99.9th percentile of the same ratio -- to 1.5 x the reference's own
         # (measured HIP / reference: 1.29 on c1, whose reference image happens to sit closest to the exact one; 0.9 - 1.1 on c2 / c3).
-        b4 = max(pix_tol, (2.0 if exact is not None else 3.0) * refs)
+        b4 = max(pix_tol, ((2.0 if full_size else 1.5) if exact is not None else 3.0) * refs)
         assert ours <= b4, f'{what}: max-rel vs the float64 reference {ours:.3e} > {b4:.3e} (the reference\'s fp32 run: {refs:.3e})'
         den = np.maximum(np.abs(f64), 1e-3 * max(scale, 1e-30))
         p_ours = float(np.quantile(np.abs(np.asarray(img, np.float64) - f64) / den, 0.999))

@@ -801,64 +801,76 @@ def test_render_fused_equals_staged_calls(tdgp, marcher):
                L.stream_of(ws))
 
 
-def _merge_case(tdgp, rs, rays, S, sorted_lists, flags_kw, cut=0.0, with_perm2=False):
-    """tdgp_merge_composite on explicit lists vs the op-level chain unify_samples -> ray marcher, everything bit for bit."""
+def _merge_case(tdgp, rs, rays, S, sorted_lists, flags_kw, cut=0.0, with_perm2=False, S2=None):
+    """tdgp_merge_composite on explicit lists (S coarse + S2 fine samples; S2 defaults to S) vs the op-level chain unify_samples -> ray
+    marcher, everything bit for bit."""
+    S2 = S if S2 is None else S2
     L = tdgp._lib
     t1 = rs.uniform(0.75, 1.25, (rays, S)).astype(np.float32)
-    t2 = rs.uniform(0.75, 1.25, (rays, S)).astype(np.float32)
+    t2 = rs.uniform(0.75, 1.25, (rays, S2)).astype(np.float32)
     if sorted_lists:
         t1.sort(axis=1)
         t2.sort(axis=1)
-        t2[:, ::5] = t1[:, ::5]                                       # ties between the lists: coarse first
+        nt = len(range(0, min(S, S2), 5))
+        t2[:, 0:5 * nt:5] = t1[:, 0:5 * nt:5]                         # ties between the lists: coarse first
         t2.sort(axis=1)
     else:
         t1[::3].sort(axis=1)                                          # a mix of ascending and arbitrary lists inside one tile
         t2[1::2].sort(axis=1)
-        if rays > 5:
+        if rays > 5 and S > 7:
             t1[5, 3] = t1[5, 7]                                       # ties inside a list
-    c1, c2 = rs.randn(rays, S, 4).astype(np.float32), rs.randn(rays, S, 4).astype(np.float32)
+    c1, c2 = rs.randn(rays, S, 4).astype(np.float32), rs.randn(rays, S2, 4).astype(np.float32)
     c1[..., 3] *= 4
     c2[..., 3] *= 4
-    perm2 = np.stack([rs.permutation(S) for _ in range(rays)]).astype(np.int32) if with_perm2 else None
+    perm2 = np.stack([rs.permutation(S2) for _ in range(rays)]).astype(np.int32) if with_perm2 else None
     flags = tdgp.renderer._marcher_flags(dict(flags_kw), 'classical')
     dt1, dt2, dc1, dc2 = T(t1), T(t2), T(c1), T(c2)
     rgb, dep, wsum, fT = (torch.empty(rays, n, device=DEV) for n in (3, 1, 1, 1))
-    perm = torch.empty(rays, 2 * S, dtype=torch.int32, device=DEV)
+    perm = torch.empty(rays, S + S2, dtype=torch.int32, device=DEV)
     dperm2 = torch.as_tensor(perm2).to(DEV) if with_perm2 else None
-    L.call('tdgp_merge_composite', dc1.data_ptr(), dt1.data_ptr(), S, dc2.data_ptr(), dt2.data_ptr(), S, rgb.data_ptr(), dep.data_ptr(), wsum.data_ptr(),
+    L.call('tdgp_merge_composite', dc1.data_ptr(), dt1.data_ptr(), S, dc2.data_ptr(), dt2.data_ptr(), S2, rgb.data_ptr(), dep.data_ptr(), wsum.data_ptr(),
            fT.data_ptr(), perm.data_ptr(), L.ptr(dperm2), rays, 0, flags, 0.0, float(cut), L.stream_of(dt1))
     rend = tdgp.renderer.ImportanceRenderer('classical')
-    sh = lambda a, c: a.reshape(1, rays, S, c)                        # noqa: E731
+    sh = lambda a, c: a.reshape(1, rays, -1, c)                       # noqa: E731
     d, c, sg, uperm = rend.unify_samples(sh(dt1, 1), sh(dc1[..., :3].contiguous(), 3), sh(dc1[..., 3].contiguous(), 1),
                                          sh(dt2, 1), sh(dc2[..., :3].contiguous(), 3), sh(dc2[..., 3].contiguous(), 1), return_perm=True)
     orgb = torch.empty(1, rays, 3, device=DEV)
-    odep, ow, ofT = torch.empty(1, rays, 1, device=DEV), torch.empty(1, rays, 2 * S, 1, device=DEV), torch.empty(1, rays, device=DEV)
-    L.call('tdgp_ray_march', c.data_ptr(), sg.data_ptr(), d.data_ptr(), orgb.data_ptr(), odep.data_ptr(), ow.data_ptr(), ofT.data_ptr(), rays, 2 * S, 3, 0,
+    odep, ow, ofT = torch.empty(1, rays, 1, device=DEV), torch.empty(1, rays, S + S2, 1, device=DEV), torch.empty(1, rays, device=DEV)
+    L.call('tdgp_ray_march', c.data_ptr(), sg.data_ptr(), d.data_ptr(), orgb.data_ptr(), odep.data_ptr(), ow.data_ptr(), ofT.data_ptr(), rays, S + S2, 3, 0,
            flags, 0.0, float(cut), L.stream_of(dt1))
-    tag = f'S={S} rays={rays} sorted={sorted_lists} {flags_kw} cut={cut}'
-    want_perm = uperm.reshape(rays, 2 * S).cpu().numpy().astype(np.int64)
+    tag = f'S={S}+{S2} rays={rays} sorted={sorted_lists} {flags_kw} cut={cut}'
+    want_perm = uperm.reshape(rays, S + S2).cpu().numpy().astype(np.int64)
     if with_perm2:
-        want_perm = np.where(want_perm < S, want_perm, S + np.take_along_axis(perm2.astype(np.int64), np.clip(want_perm - S, 0, S - 1), axis=1))
+        want_perm = np.where(want_perm < S, want_perm, S + np.take_along_axis(perm2.astype(np.int64), np.clip(want_perm - S, 0, S2 - 1), axis=1))
     np.testing.assert_array_equal(perm.cpu().numpy().astype(np.int64), want_perm, err_msg=tag)
     np.testing.assert_array_equal(N(rgb), N(orgb).reshape(rays, 3), err_msg=tag)
     np.testing.assert_array_equal(N(dep), N(odep).reshape(rays, 1), err_msg=tag)
     np.testing.assert_array_equal(N(fT).reshape(-1), N(ofT).reshape(-1), err_msg=tag)
-    assert_close(N(wsum).reshape(-1), N(ow).reshape(rays, 2 * S).astype(np.float64).sum(1), 2e-6, 'weights.sum ' + tag, 1.0)
+    assert_close(N(wsum).reshape(-1), N(ow).reshape(rays, S + S2).astype(np.float64).sum(1), 2e-6, 'weights.sum ' + tag, 1.0)
 
 
 @pytest.mark.parametrize('S', [16, 32, 48, 64, 96])
 def test_merge_composite_equals_unify_then_march(tdgp, S):
-    """The fused merge + march + composite against the op-level chain, bit for bit, at the shapes that take the ray-tile kernel
-    (sampling_tile.inc: S in 32 / 48 / 64 / 96, lane-per-ray merge, prefix product and sums walked in the wave trees' own order) and one
-    that stays on the wave-per-ray kernel (16): ascending lists with ties across them, lists that are NOT ascending (repair path; mixed
-    with ascending ones inside a tile), a tile that is not full, every marcher flag, a cut threshold, and the permutation with and
-    without the fine list's own draw permutation."""
+    """The fused merge + march + composite (merge_composite_kernel: one wave per ray, MS = 64 / 128 / 256 slots) against the op-level
+    chain, bit for bit: ascending lists with ties across them, lists that are NOT ascending (brute-force rank path; mixed with ascending
+    ones in one launch), every marcher flag, a cut threshold, and the permutation with and without the fine list's own draw permutation."""
     rs = np.random.RandomState(100 + S)
     _merge_case(tdgp, rs, 256, S, True, dict(use_inf_depth=True), with_perm2=True)
     _merge_case(tdgp, rs, 150, S, True, dict(use_inf_depth=False, last_back=True))
     _merge_case(tdgp, rs, 70, S, True, dict(use_inf_depth=True, clamp_mode='relu'), cut=0.3)
     _merge_case(tdgp, rs, 200, S, False, dict(use_inf_depth=True), with_perm2=True)
     _merge_case(tdgp, rs, 1, S, False, dict(use_inf_depth=True, last_back=True))
+
+
+@pytest.mark.parametrize('S1,S2', [(96, 32), (48, 80), (64, 1), (1, 64), (33, 31), (64, 96), (20, 100)])
+def test_merge_composite_with_lists_of_different_lengths(tdgp, S1, S2):
+    """the C ABI takes S1 != S2 (tdgp.h: tdgp_merge_composite) but every other case merges equal lists.  The rank computation
+    (fine elements binary-search the coarse list; coarse ranks = prefix maximum over an LDS max-scatter of the fine counts) and the two-chunk
+    march have paths that only unequal lists reach: `64 cc < S1` with partial 64-slot chunks, the MS = 128 form with S1 != S2, a list of one."""
+    rs = np.random.RandomState(1000 * S1 + S2)
+    _merge_case(tdgp, rs, 130, S1, True, dict(use_inf_depth=True), with_perm2=True, S2=S2)
+    _merge_case(tdgp, rs, 77, S1, True, dict(use_inf_depth=False, last_back=True), cut=0.3, S2=S2)
+    _merge_case(tdgp, rs, 40, S1, False, dict(use_inf_depth=True, clamp_mode='relu'), with_perm2=True, S2=S2)
 
 
 @pytest.mark.parametrize('S', [16, 48, 64, 96, 128])
@@ -1093,8 +1105,8 @@ def test_e2e_vs_oracle_bigger(tdgp, oracle):
     G = _gen(tdgp, cfg, 5)
     ex_img, ex_depth = _exact(oracle, tdgp, cfg, 5, g)
     out = G.synthesis(T(g['ws']), camera_params=_cam(g), noise_mode='const', render_opts=dict(return_depth=True), u_coarse=T(g['u_coarse']), u_fine=T(g['u_fine']))
-    assert_image_parity(N(out.img), g, 'e2e_bigger img', exact=ex_img)
-    assert_image_parity(N(out.depth), g, 'e2e_bigger depth', 'depth', exact=ex_depth)
+    assert_image_parity(N(out.img), g, 'e2e_bigger img', exact=ex_img, full_size=True)
+    assert_image_parity(N(out.depth), g, 'e2e_bigger depth', 'depth', exact=ex_depth, full_size=True)
 
 
 # ------------------------------------------------------------------------------------------------ full size (BASELINE configs[2])
@@ -1235,8 +1247,8 @@ def test_full_size_vs_reference_golden(tdgp, oracle, tag):
     out = G.synthesis(T(g['ws']), camera_params=cam, noise_mode='const', render_opts=dict(return_depth=True), u_coarse=uc, u_fine=uf)
     oracle.set_threads(min(64, os.cpu_count() or 1))
     ex_img, ex_depth = oracle.synthesis_forward(sd, cfg.to_dict(), g['ws'], inp['camera'], inp['u_coarse'], inp['u_fine'], 'const')
-    rng, pix, _ = assert_image_parity(N(out.img), g, f'{tag} full size img', exact=ex_img)
-    assert_image_parity(N(out.depth), g, f'{tag} full size depth', 'depth', exact=ex_depth)
+    rng, pix, _ = assert_image_parity(N(out.img), g, f'{tag} full size img', exact=ex_img, full_size=True)
+    assert_image_parity(N(out.depth), g, f'{tag} full size depth', 'depth', exact=ex_depth, full_size=True)
     dec = G.synthesis.tri_plane_decoder
     planes = dec(T(g['ws'])[:, :dec.num_ws], noise_mode='const', hwc=True)
     res, F3 = cfg.tri_plane_res, 3 * cfg.feat_dim
@@ -1912,6 +1924,32 @@ def test_depth_adaptor_is_elided_in_the_plain_eval_forward(tdgp):
     out = G(*args, **kw, render_opts=dict(return_depth_adapted=True))
     assert torch.isnan(out.depth_adapted).any()                               # (c) asked for -> evaluated
     assert G(*args, **kw, render_opts=dict(concat_depth=True)).shape[1] == 4
+    # (d) a training-mode forward is never elided: with out_strategy='random' (the 3dgp.yaml default) DepthAdaptor.forward draws
+    # np.random.choice per sample (networks_depth_adaptor.py:86-92) -- the host RNG stream must advance exactly as the reference's, which
+    # always evaluates the adaptor (networks_epigraf.py:246-253)
+    tag_a, cfg_a = tdgp.config.configs_adaptor_goldens()[0]
+    assert cfg_a.depth_adaptor.out_strategy == 'random'
+    Ga = _gen(tdgp, cfg_a, 51)
+    inp_a = tdgp.weights.synthetic_inputs(cfg_a, batch=2, seed=54)
+    args_a = (T(inp_a['z']), T(inp_a['c']), {k: T(v) for k, v in inp_a['camera'].items()})
+    kw_a = dict(noise_mode='const', u_coarse=T(inp_a['u_coarse']), u_fine=T(inp_a['u_fine']))
+    Ga(*args_a, **kw_a)                                                       # (weight packing launches)
+    _, n_eval = launches(lambda: Ga(*args_a, **kw_a))
+    np.random.seed(11)
+    untouched = np.random.get_state()[1].copy()
+    Ga(*args_a, **kw_a)
+    assert np.array_equal(np.random.get_state()[1], untouched)               # eval: elided, and the adaptor would not have drawn anyway
+    Ga.synthesis.train()
+    try:
+        Ga(*args_a, **kw_a)                                                   # (first training-mode forward: any first-use launches)
+        np.random.seed(11)
+        _, n_train = launches(lambda: Ga(*args_a, **kw_a))
+        after = np.random.random()
+    finally:
+        Ga.synthesis.eval()
+    assert n_train > n_eval, (n_train, n_eval)                                # the adaptor's layers ran
+    np.random.seed(11)
+    assert after != np.random.random()                                        # ... and the np.random.choice draw was consumed
 
 
 def test_generator_feature_loop(tdgp):

@@ -259,8 +259,8 @@ def test_e2e_full_size(oracle, tdgp, tag):
     ws = oracle.mapping_forward(sd, cfg.to_dict(), inp['z'], inp['c'])
     assert_close(ws, g['ws'], 1e-5, 'ws', 1.0)
     img, depth, inter = oracle.synthesis_forward(sd, cfg.to_dict(), g['ws'], inp['camera'], inp['u_coarse'], inp['u_fine'], 'const', return_intermediates=True)
-    assert_image_parity(img, g, f'oracle {tag} full size img')
-    assert_image_parity(depth, g, f'oracle {tag} full size depth', 'depth')
+    assert_image_parity(img, g, f'oracle {tag} full size img', full_size=True)
+    assert_image_parity(depth, g, f'oracle {tag} full size depth', 'depth', full_size=True)
     pl = inter['planes'].reshape(-1)[g['planes_pick']]
     e_pl = float(np.abs(pl - g['planes_vals']).max() / g['planes_absmax'])
     report_parity(f'oracle {tag} full size tri-planes (4096 sampled texels vs the reference)', range_err=e_pl)
@@ -289,8 +289,8 @@ def test_e2e_full_size(oracle, tdgp, tag):
 def test_e2e_bigger(oracle, tdgp):
     """The hot MLP shape (feat 32, hid 64), 128^2 planes, 96-channel backbone, 48^2 rays x 24 steps."""
     g, img, depth, _ = _e2e(oracle, tdgp, 'e2e_bigger', tdgp.config.config_bigger(), 5)
-    assert_image_parity(img, g, 'oracle e2e_bigger img')
-    assert_image_parity(depth, g, 'oracle e2e_bigger depth', 'depth')
+    assert_image_parity(img, g, 'oracle e2e_bigger img', full_size=True)
+    assert_image_parity(depth, g, 'oracle e2e_bigger depth', 'depth', full_size=True)
 
 
 def test_e2e_tiny_cut_quantile(oracle, tdgp):
