@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libtdgp_hip.so')
 SOURCES = ['core.hip', 'bias_act.hip', 'upfirdn2d.hip', 'modconv.hip', 'conv_grad.hip', 'camera_rays.hip', 'field.hip', 'sampling.hip', 'render_grad.hip', 'render_fused.hip']
-HEADERS = ['common.h', 'modconv_bf16.inc', 'modconv_wino.inc', 'modconv_wino4.inc', 'field_walk2.inc', os.path.join('..', '..', 'include', 'tdgp.h')]
+HEADERS = ['common.h', 'modconv_bf16.inc', 'modconv_wino.inc', 'modconv_wino4.inc', 'modconv_wino4f.inc', 'field_walk2.inc', os.path.join('..', '..', 'include', 'tdgp.h')]
 # -ffp-contract=off: fp32 chains that decide integer rows must round like the reference's eager ops;
 # fused multiply-adds are written explicitly (fmaf_) where wanted.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-fvisibility=hidden',

@@ -2268,6 +2268,7 @@ __global__ __launch_bounds__(256) void z_gather_kernel(const float* __restrict__
 #include "modconv_bf16.inc"
 #include "modconv_wino.inc"
 #include "modconv_wino4.inc"
+#include "modconv_wino4f.inc"
 
 // d[b,o] = rsqrt(sum_c s[b,c]^2 * wsq[c][o] + 1e-8)      (networks_stylegan2.py:62)
 // block (64 out-channels x 16 channel slices): coalesced wsq rows, 16-way split of the Cin loop, LDS tree at the end.
@@ -2634,8 +2635,9 @@ TDGP_API int tdgp_modconv_pack(const float* weight, void* wpack, int Cout, int C
 }
 
 static int g_conv_arith = 0;
+static inline bool arith_wino4() { return g_conv_arith == 0 || g_conv_arith == 4; }
 TDGP_API int tdgp_set_conv_arith(int mode) {
-    TDGP_CHECK(mode >= 0 && mode <= 3, TDGP_EINVAL, "set_conv_arith: mode %d (0 = fp32 MFMA, Winograd F(4x4,3x3) / F(2x2,3x3) where they pay; 1 = split-bf16 MFMA with fp32 accumulation; 2 = fp32 MFMA, direct sums only; 3 = as 0 without F(4x4))", mode);
+    TDGP_CHECK(mode >= 0 && mode <= 4, TDGP_EINVAL, "set_conv_arith: mode %d (0 = fp32 MFMA, Winograd F(4x4,3x3) / F(2x2,3x3) where they pay; 1 = split-bf16 MFMA with fp32 accumulation; 2 = fp32 MFMA, direct sums only; 3 = as 0 without F(4x4); 4 = as 0 with the F(4x4) input transform always as a pass of its own)", mode);
     const int old = g_conv_arith;
     g_conv_arith = mode;
     return old;
@@ -2646,7 +2648,7 @@ TDGP_API int tdgp_set_conv_arith(int mode) {
 // layer's output channels) of this shape on the Winograd F(4x4) kernels under the current arithmetic mode?  The binding asks BEFORE it folds and
 // packs the [4 Cout, Cin, 3, 3] weights (small launches paid the fold, the pack and an exception to learn the answer).
 TDGP_API int tdgp_modconv2d_takes_folded_up2(int B, int Cin, int Cout4, int H, int W) {
-    return (g_conv_arith == 0 && B >= 1 && (Cout4 & 3) == 0 && wino4_shape_ok(B, Cin, Cout4, H, W, 3, 1)) ? 1 : 0;
+    return (arith_wino4() && B >= 1 && (Cout4 & 3) == 0 && wino4_shape_ok(B, Cin, Cout4, H, W, 3, 1)) ? 1 : 0;
 }
 
 TDGP_API int64_t tdgp_modconv2d_workspace_bytes(int B, int Cin, int Cout, int H, int W, int k, int up) {
@@ -2683,7 +2685,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
     // y is [B, Cout / 4, 2H, 2W], noise a 2H x 2W map, bias / dcoef_in replicated per parity by the caller).  Only the F(4x4) kernels write it.
     TDGP_CHECK(out_layout != 2 || (k == 3 && up == 1 && (Cout & 3) == 0 && !skip && (!demodulate || dcoef_in)), TDGP_EINVAL,
                "modconv2d: out_layout 2 (folded x2 layer) needs k=3, up=1, Cout %% 4 == 0, no skip and precomputed demodulation coefficients");
-    TDGP_CHECK(out_layout != 2 || (g_conv_arith == 0 && wino4_shape_ok(B, Cin, Cout, H, W, k, up) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+    TDGP_CHECK(out_layout != 2 || (arith_wino4() && wino4_shape_ok(B, Cin, Cout, H, W, k, up) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                                    (!noise || (((uintptr_t)noise & 15) == 0 && (noise_bstride & 3) == 0))), TDGP_EUNSUPPORTED,
                "modconv2d: out_layout 2 is written by the Winograd F(4x4) kernels only (shape %dx%d, %d -> %d channels, batch %d does not take them)", H, W, Cin, Cout, B);
     TDGP_CHECK((int64_t)B * Cin * H * W < ((int64_t)1 << 30) && (int64_t)B * Cout * (H * up + 1) * (W * up + 1) <= INT32_MAX, TDGP_EINVAL,
@@ -2740,7 +2742,24 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 const size_t lds = (size_t)(2 * 3 * 3 * 64 * 32 + 3 * 10 * 34 * 32 + 5 * 64 * 4 + 2 * Cin * 4);
                 TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3s_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds - 2 * Cin * 4 + 2 * 2048 * 4)););
                 TDGP_LAUNCH("conv_mfma_kernel", conv3s_mfma_kernel, dim3((W >> 5) * cdiv(B * (H + 1), 8), cdiv(Cout, 64)), dim3(256), lds, s, q);
-            } else if (g_conv_arith == 0 && wino4_shape_ok(B, Cin, Cout, H, W, k, up, out_layout == 0) && pi.wino4_floats > 0 && (out_layout == 0 || out_layout == 2) && !skip && ((uintptr_t)x & 15) == 0 &&
+            } else if (g_conv_arith == 0 && TDGP_WINO4F_MAXCIN > 0 && out_layout == 0 && Cin <= TDGP_WINO4F_MAXCIN && (Cin & 15) == 0 && (Cout & 63) == 0 && wino4_txl(H, W) == 4 &&
+                       wino4_shape_ok(B, Cin, Cout, H, W, k, up) && pi.wino4_floats > 0 && (int64_t)B * ((H * W) >> 9) * (Cout >> 6) >= 256 && !skip && ((uintptr_t)x & 15) == 0 &&
+                       ((uintptr_t)y & 15) == 0 && (!noise || (((uintptr_t)noise & 15) == 0 && (noise_bstride & 3) == 0))) {
+                // few input channels (the 256^2 / 512^2 blocks): the input transform runs inside the GEMM kernel, V never leaves the CU (modconv_wino4f.inc)
+                float* vbuf = (float*)((char*)workspace + wl.wino_v);
+                int* ticket = (int*)((char*)vbuf + ((wino4_v_bytes(wino4_sub_batch(B, Cin, Cout, H, W), Cin, H, W) + 255) / 256 * 256));
+                const int cus = tdgp_cu_count(), nxcd = (cus % 8 == 0 && cus >= 64) ? 8 : 1, per = cus / nxcd, nsl = Cout >> 6;
+                int rs = 1;
+                while (rs * 2 <= nsl && (per % (rs * 2)) == 0 && (rs * 2) * 64 + per / (rs * 2) * 32 < rs * 64 + per / rs * 32) rs *= 2;
+                Wino4fParams q;
+                q.x = x; q.styles = styles; q.u = wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats + pi.wino_floats; q.e = e;
+                q.B = B; q.Cin = Cin; q.Cout = Cout; q.H = H; q.W = W; q.u_bytes = (uint32_t)(pi.wino4_floats * 4); q.x_bytes = c.x_bytes; q.st_bytes = c.st_bytes;
+                q.gxn = W / 64; q.gyn = H / 8; q.rs = rs; q.rt = per / rs; q.nxcd = nxcd; q.ticket = ticket;
+                const size_t lds = (size_t)W4F_LDS_FLOATS * 4;
+                TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3_wino4f_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
+                TDGP_CHECK(hipMemsetAsync(ticket, 0, 32, s) == hipSuccess, TDGP_ELAUNCH, "modconv2d: clearing the item counters failed");
+                TDGP_LAUNCH("conv_wino4f_kernel", conv3_wino4f_kernel, dim3((unsigned)(nxcd * per)), dim3(512), lds, s, q);
+            } else if (arith_wino4() && wino4_shape_ok(B, Cin, Cout, H, W, k, up, out_layout == 0) && pi.wino4_floats > 0 && (out_layout == 0 || out_layout == 2) && !skip && ((uintptr_t)x & 15) == 0 &&
                        ((uintptr_t)y & 15) == 0 && (!noise || (((uintptr_t)noise & 15) == 0 && (noise_bstride & 3) == 0))) {
                 float* vbuf = (float*)((char*)workspace + wl.wino_v);
                 // persistent grid; the blocks of an XCD (b, b + 8, ...) take a rectangle of rs slices x rt tile groups per pass: per pass an XCD's L2 then
@@ -2782,7 +2801,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                     else TDGP_LAUNCH("conv_wino4_kernel", (conv3_wino4_kernel<false, pairk>), dim3((unsigned)(nxcd * per)), dim3(pairk ? 512 : W4_NW * 64), lds, s, q);
                     if (ksl) TDGP_LAUNCH("splitk_reduce_kernel", splitk_reduce_kernel, dim3((int)min((int64_t)2048, cdiv64(kslice, 256))), dim3(256), 0, s, partial, 1 << ksl, e);
                 }
-            } else if (k == 3 && (g_conv_arith == 0 || g_conv_arith == 3) && wino_ok(B, Cin, Cout, H, W) && out_layout == 0 && !skip && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 &&
+            } else if (k == 3 && (arith_wino4() || g_conv_arith == 3) && wino_ok(B, Cin, Cout, H, W) && out_layout == 0 && !skip && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0 &&
                        (!noise || (((uintptr_t)noise & 7) == 0 && (noise_bstride & 1) == 0))) {        // 16-byte activation loads, 8-byte noise loads / stores
                 WinoParams q;
                 q.x = x; q.u = wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats; q.styles = styles; q.e = e;

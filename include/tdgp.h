@@ -170,6 +170,9 @@ int     tdgp_conv_transpose2d_x2(const float* x, const void* wpack, const float*
  *       tensor scale).  Every other layer: direct sums;
  *   2 = fp32 MFMA, direct sums in every layer (the summation structure of a plain convolution; results differ from mode 0 in the last
  *       bits only);
+ *   4 = as 0, but the F(4x4) layers with few input channels (Cin <= 128, the 256^2 / 512^2 blocks) keep their input transform as a pass
+ *       of its own instead of inside the GEMM kernel (round 6, modconv_wino4f.inc): the SAME bits as mode 0 (same transform arithmetic,
+ *       same summation order) -- an A/B and test switch;
  *   1 = (stride 1 with W % 32 == 0 and the x2 transposed form, launches of >= 256 tiles with styles present and Cin % 16 == 0) every
  *       fp32 operand split into three bf16 pieces, six piece products per multiply on the bf16 MFMA with fp32 accumulation
  *       (fp32-grade results, <= 4e-6 of the exact layer output; layers outside those conditions keep the fp32 kernels).
