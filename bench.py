@@ -48,7 +48,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf1
 # Fraction of the algorithmic (direct-sum) FLOP a kernel actually executes on the matrix pipe: Winograd F(2x2,3x3) multiplies 16 times
 # per 2x2 outputs where the direct sum multiplies 36 times.  `tflops` stays the algorithmic rate; `tflops_executed` is what
 # the MFMA roofline bounds.
-EXECUTED_FRACTION = {'conv_wino_kernel': 16.0 / 36.0, 'conv_wino4_kernel': 36.0 / 144.0}        # F(2x2): 16 per 4 outputs; F(4x4): 36 per 16 (direct: 9 per output)
+EXECUTED_FRACTION = {'conv_wino_kernel': 16.0 / 36.0, 'conv_wino4_kernel': 36.0 / 144.0, 'conv_wino4f_kernel': 36.0 / 144.0}        # F(2x2): 16 per 4 outputs; F(4x4): 36 per 16 (direct: 9 per output)
 
 
 def winograd_takes(batch, cin, cout, r):
@@ -74,6 +74,13 @@ def winograd4_takes(batch, cin, cout, r, plain=True):
     return plain and batch * per_sample <= (192 << 20) and any((items(batch) << l) >= 256 and nch % (1 << l) == 0 and (nch >> l) >= 16 for l in (1, 2))
 
 
+def winograd4_fused_takes(batch, cin, cout, r):
+    """Mirror of the conv3_wino4f_kernel branch of tdgp_modconv2d (modconv.hip; round 6): the F(4x4) layers with few input channels whose input
+    transform runs inside the GEMM kernel (plain stride-1 layers, Cin <= 128, Cin % 16 == 0, Cout % 64 == 0, 64-pixel-wide tile groups, >= 256 items)."""
+    return (winograd4_takes(batch, cin, cout, r, plain=False) and cin <= 128 and cin % 16 == 0 and cout % 64 == 0 and r % 64 == 0
+            and batch * (r * r // 512) * (cout // 64) >= 256)
+
+
 def algorithmic_flops(cfg, batch=None):
     """Algorithmic FLOP per image of the MFMA kernels: 2 * MAC of every conv launch (stride-1 3x3 layers in
     conv_mfma_kernel -- or, with `batch` given, conv_wino_kernel for the layers the library runs as Winograd at that batch --, the x2
@@ -82,7 +89,7 @@ def algorithmic_flops(cfg, batch=None):
     the bf16 MFMA peak.  -> {kernel label: (flop per image, launches per image batch, peak TFLOP/s)}"""
     ch = cfg.channels
     r16 = cfg.fp16_resolution
-    acc = dict(conv_mfma_kernel=[0, 0], conv_wino_kernel=[0, 0], conv_wino4_kernel=[0, 0], upconv_wino4_kernel=[0, 0], upconv_mfma_kernel=[0, 0], torgb_mfma_kernel=[0, 0], conv_bf16_kernel=[0, 0],
+    acc = dict(conv_mfma_kernel=[0, 0], conv_wino_kernel=[0, 0], conv_wino4_kernel=[0, 0], conv_wino4f_kernel=[0, 0], upconv_wino4_kernel=[0, 0], upconv_mfma_kernel=[0, 0], torgb_mfma_kernel=[0, 0], conv_bf16_kernel=[0, 0],
                upconv_bf16_kernel=[0, 0])
     for i, r in enumerate(cfg.block_resolutions):
         c = ch[r]
@@ -94,8 +101,9 @@ def algorithmic_flops(cfg, batch=None):
             k = 'upconv_bf16_kernel' if bf else ('upconv_wino4_kernel' if folded else 'upconv_mfma_kernel')
             acc[k][0] += 2 * ch[r // 2] * c * 9 * (r // 2) ** 2   # stride-2 transposed conv: 9 taps per INPUT pixel
             acc[k][1] += 1
-        k = 'conv_bf16_kernel' if bf else ('conv_wino4_kernel' if winograd4_takes(batch, c, c, r) else
-                                             ('conv_wino_kernel' if winograd_takes(batch, c, c, r) else 'conv_mfma_kernel'))
+        k = 'conv_bf16_kernel' if bf else ('conv_wino4f_kernel' if winograd4_fused_takes(batch, c, c, r) else
+                                             ('conv_wino4_kernel' if winograd4_takes(batch, c, c, r) else
+                                              ('conv_wino_kernel' if winograd_takes(batch, c, c, r) else 'conv_mfma_kernel')))
         acc[k][0] += 2 * c * c * 9 * r * r                         # conv1
         acc[k][1] += 1
         acc['torgb_mfma_kernel'][0] += 2 * c * cfg.plane_channels * r * r        # ToRGB 1x1

@@ -297,11 +297,17 @@ def test_modconv_winograd_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
     (4, 512, 512, 32, 32, dict(splitk=True)),                            # K split 4 ways: C3's 32^2 layer at batch 4 (64 items unsplit) -- raw sums through the split-K buffer
     (8, 512, 512, 32, 32, dict(splitk=True, noise='per_sample', clamp=0.9)),   # K split 2 ways (batch 8), per-sample noise and clamp applied by the reduction pass
     (8, 256, 200, 32, 32, dict(splitk=True, noise=False)),               # 4 splits of exactly 16 chunks, a ragged last slice
+    (8, 80, 64, 128, 128, {}),                                           # fused input transform (round 6): 20 chunks = five rounds of the unrolled K loop, one 64-channel slice, 256 items
+    (2, 64, 192, 256, 192, dict(noise='per_sample', clamp=0.6)),         # ... three slices (every window transformed three times), H != W, three tile groups per row, clamp
+    (16, 128, 64, 128, 64, dict(styles=False)),                          # ... ONE tile group per row (both halo columns outside the image), unmodulated, 32 chunks
 ])
 def test_modconv_winograd4_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
-    """Winograd F(4x4,3x3) (modconv_wino4.inc: input-transform pass + 36-GEMM kernel, points 0, +-1, 1/2, -2, inf) against the double-accumulating
-    oracle, next to F(2x2) (`set_conv_arith(3)`) and the direct sum (`set_conv_arith(2)`) on the same call; the profiler names which ran.
+    """Winograd F(4x4,3x3) (modconv_wino4.inc: input-transform pass + 36-GEMM kernel, points 0, +-1, 1/2, -2, inf; modconv_wino4f.inc: the layers with
+    Cin <= 128, Cin % 16 == 0, Cout % 64 == 0 on 64-pixel-wide tile groups transform their input INSIDE the GEMM kernel) against the double-accumulating
+    oracle, next to F(2x2) (`set_conv_arith(3)`) and the direct sum (`set_conv_arith(2)`) on the same call; the profiler names which ran.  The fused
+    shapes also run with the separate transform pass (`set_conv_arith(4)`): the two forms must agree bit for bit (same V, same summation order).
     Bound: 1e-5 of the un-clamped output range, the bound of every reduction row (measured per layer in the parity report)."""
+    fused = cin <= 128 and cin % 16 == 0 and cout % 64 == 0 and W % 64 == 0 and H % 8 == 0 and not kw.get('splitk') and B * ((H * W) >> 9) * (cout // 64) >= 256
     rs = np.random.RandomState(cin * 7 + cout + 1)
     x = rs.randn(B, cin, H, W).astype(np.float32)
     x = np.where(x > 0, x, 0.2 * x).astype(np.float32) * np.float32(np.sqrt(2))          # the layers' real input: a leaky-ReLU output (non-zero mean)
@@ -321,7 +327,7 @@ def test_modconv_winograd4_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
     M = tdgp.ops.modconv
     pk = M._packed(T(w))
     out = {}
-    for mode in (0, 3, 2):
+    for mode in (0, 3, 2) + ((4,) if fused else ()):
         prev = tdgp._lib.set_conv_arith(mode)
         tdgp._lib.profile_enable(True)
         try:
@@ -336,7 +342,12 @@ def test_modconv_winograd4_vs_oracle(tdgp, oracle, B, cin, cout, H, W, kw):
             tdgp._lib.profile_enable(False)
             tdgp._lib.set_conv_arith(prev)
         out[mode] = (N(y), names)
-    assert {'conv_wino4_kernel', 'wino4_input_kernel'} <= out[0][1] and 'conv_wino_kernel' not in out[0][1], out[0][1]
+    if fused:
+        assert 'conv_wino4f_kernel' in out[0][1] and not ({'conv_wino4_kernel', 'wino4_input_kernel', 'conv_wino_kernel'} & out[0][1]), out[0][1]
+        assert {'conv_wino4_kernel', 'wino4_input_kernel'} <= out[4][1] and 'conv_wino4f_kernel' not in out[4][1], out[4][1]
+        np.testing.assert_array_equal(out[0][0], out[4][0])              # the transform inside the GEMM kernel == the transform pass + GEMM: every bit
+    else:
+        assert {'conv_wino4_kernel', 'wino4_input_kernel'} <= out[0][1] and not ({'conv_wino_kernel', 'conv_wino4f_kernel'} & out[0][1]), out[0][1]
     assert ('splitk_reduce_kernel' in out[0][1]) == bool(kw.get('splitk')), out[0][1]
     assert 'conv_wino4_kernel' not in out[3][1] and ('conv_wino_kernel' in out[3][1] or cin % 8 != 0 or W < 64), out[3][1]   # (F(2x2): Cin % 8 == 0, >= 256 of its own blocks)
     assert not ({'conv_wino_kernel', 'conv_wino4_kernel'} & out[2][1]), out[2][1]
@@ -383,22 +394,35 @@ def test_modconv_winograd4_sub_batches(tdgp, oracle):
     bias = (0.2 * rs.randn(cout)).astype(np.float32)
     M = tdgp.ops.modconv
     pk = M._packed(T(w))
-    tdgp._lib.profile_enable(True)
-    try:
-        y = M.modconv_forward(x, pk, T(s), noise=noise, bias=T(bias), act='lrelu')
-        torch.cuda.synchronize()
-        rep = tdgp._lib.profile_report()
-    finally:
-        tdgp._lib.profile_enable(False)
-    assert rep['conv_wino4_kernel']['launches'] == 2 and rep['wino4_input_kernel']['launches'] == 2, rep
-    for b in (0, 5, 12, 13, 15):
-        one = M.modconv_forward(x[b:b + 1].contiguous(), pk, T(s[b:b + 1]), noise=noise[b:b + 1].contiguous(), bias=T(bias), act='lrelu')
-        assert torch.equal(one[0], y[b]), b
     oracle.set_threads(min(64, os.cpu_count() or 1))
     xs = N(x[:1, :, :24])
     ref = oracle.modulated_conv2d(xs, w, s[:1], noise=N(noise[:1, :, :24]), up=1, demodulate=True, resample_filter=oracle.setup_filter([1, 3, 3, 1]))
     ref = oracle.bias_act(ref, bias, act='lrelu')[:, :, :16]
-    assert_close(N(y[:1, :, :16]), ref, 1e-5, 'sub-batched F(4x4) layer vs the oracle (rows 0-15 of sample 0)', 1.0)
+    ys = {}
+    # mode 4: the separate transform pass (the sub-batched form this test was written for); mode 0 (round 6): this shape now transforms its input inside
+    # the GEMM kernel -- no V buffer, one launch for the whole batch (2.1 GB of activations through one buffer descriptor)
+    for mode in (4, 0):
+        prev = tdgp._lib.set_conv_arith(mode)
+        tdgp._lib.profile_enable(True)
+        try:
+            y = M.modconv_forward(x, pk, T(s), noise=noise, bias=T(bias), act='lrelu')
+            torch.cuda.synchronize()
+            rep = tdgp._lib.profile_report()
+        finally:
+            tdgp._lib.profile_enable(False)
+        try:
+            if mode == 4:
+                assert rep['conv_wino4_kernel']['launches'] == 2 and rep['wino4_input_kernel']['launches'] == 2 and 'conv_wino4f_kernel' not in rep, rep
+            else:
+                assert rep['conv_wino4f_kernel']['launches'] == 1 and 'wino4_input_kernel' not in rep, rep
+            for b in (0, 5, 12, 13, 15):
+                one = M.modconv_forward(x[b:b + 1].contiguous(), pk, T(s[b:b + 1]), noise=noise[b:b + 1].contiguous(), bias=T(bias), act='lrelu')
+                assert torch.equal(one[0], y[b]), (mode, b)
+        finally:
+            tdgp._lib.set_conv_arith(prev)
+        assert_close(N(y[:1, :, :16]), ref, 1e-5, f'F(4x4) layer 512^2 x 128, conv arith {mode}, vs the oracle (rows 0-15 of sample 0)', 1.0)
+        ys[mode] = y
+    assert torch.equal(ys[0], ys[4])
 
 
 @pytest.mark.parametrize('B,cin,cout,H,kw', [
@@ -1406,7 +1430,9 @@ def test_full_size_c3_at_bench_batches(tdgp, oracle, B):
     w4 = [bench.winograd4_takes(B, cfg.channels[r], cfg.channels[r], r) for r in cfg.block_resolutions]            # mirrors of wino4_shape_ok / wino_ok (modconv.hip)
     w2 = [bench.winograd_takes(B, cfg.channels[r], cfg.channels[r], r) and not f for r, f in zip(cfg.block_resolutions, w4)]
     # (a layer with few channels goes through the F(4x4) kernels in sub-batches: at least one launch per layer)
-    assert launches.get('conv_wino4_kernel', 0) >= sum(w4) == 5 and launches.get('conv_wino_kernel', 0) == sum(w2) == 0, launches
+    w4f = [bench.winograd4_fused_takes(B, cfg.channels[r], cfg.channels[r], r) for r in cfg.block_resolutions]     # ... of the fused-transform branch (round 6): one launch per layer
+    assert launches.get('conv_wino4f_kernel', 0) == sum(w4f) == 2, launches
+    assert launches.get('conv_wino4_kernel', 0) >= sum(w4) - sum(w4f) == 3 and launches.get('conv_wino_kernel', 0) == sum(w2) == 0, launches
     assert launches.get('conv_mfma_kernel', 0) == len(cfg.block_resolutions) - sum(w4), launches                    # the remaining stride-1 3x3 layers: direct sums
     # (1) planes of sample 0 vs the oracle
     oracle.set_threads(min(64, os.cpu_count() or 1))
@@ -1498,7 +1524,8 @@ def test_c4_backbone_at_bench_batch(tdgp, oracle):
     import bench
     w4 = [bench.winograd4_takes(4, cfg.channels[r], cfg.channels[r], r) for r in cfg.block_resolutions]
     w2 = [bench.winograd_takes(4, cfg.channels[r], cfg.channels[r], r) and not f for r, f in zip(cfg.block_resolutions, w4)]
-    assert launches.get('conv_wino4_kernel', 0) >= sum(w4) and launches.get('conv_wino_kernel', 0) == sum(w2), launches
+    w4f = [bench.winograd4_fused_takes(4, cfg.channels[r], cfg.channels[r], r) for r in cfg.block_resolutions]
+    assert launches.get('conv_wino4f_kernel', 0) == sum(w4f) and launches.get('conv_wino4_kernel', 0) >= sum(w4) - sum(w4f) and launches.get('conv_wino_kernel', 0) == sum(w2), launches
     for _ in range(2):
         assert torch.equal(dec(ws[:, :dec.num_ws], noise_mode='const', hwc=True).t, planes.t)
     oracle.set_threads(min(64, os.cpu_count() or 1))

@@ -266,15 +266,17 @@ def test_bench_flop_model_matches_survey(tdgp):
     # at batch 16 the 32^2 ... 512^2 stride-1 layers run as Winograd F(4x4) (conv_wino4_kernel, round 4) and the x2 layers from 32^2 inputs up as
     # four folded parity kernels on the same GEMM (upconv_wino4_kernel); the algorithmic FLOP do not change
     f16 = bench.algorithmic_flops(tdgp.config.config_c3(), batch=16)
-    assert f16['conv_wino4_kernel'][1] == 5 and f16['conv_mfma_kernel'][1] == 3 and 'conv_wino_kernel' not in f16
-    assert abs((f16['conv_wino4_kernel'][0] + f16['conv_mfma_kernel'][0]) / 1e9 - 83.7) < 0.1
+    # (round 6: the two layers with <= 128 channels -- 256^2 x 128, 512^2 x 64 -- run the input transform inside the GEMM kernel: conv_wino4f_kernel)
+    assert f16['conv_wino4_kernel'][1] == 3 and f16['conv_wino4f_kernel'][1] == 2 and f16['conv_mfma_kernel'][1] == 3 and 'conv_wino_kernel' not in f16
+    assert abs((f16['conv_wino4_kernel'][0] + f16['conv_wino4f_kernel'][0] + f16['conv_mfma_kernel'][0]) / 1e9 - 83.7) < 0.1
     assert f16['upconv_wino4_kernel'][1] == 4 and f16['upconv_mfma_kernel'][1] == 3
     assert abs((f16['upconv_wino4_kernel'][0] + f16['upconv_mfma_kernel'][0]) / 1e9 - 35.4) < 0.1
     assert abs(sum(v[0] for v in f16.values()) / 1e9 - 170.4) < 0.3
     f4b = bench.algorithmic_flops(tdgp.config.config_c3(), batch=4)
-    assert f4b['conv_wino4_kernel'][1] == 5 and f4b['conv_mfma_kernel'][1] == 3        # 32^2 at B = 4: too few items for the persistent grid -> its input channels split 4 ways
+    assert f4b['conv_wino4_kernel'][1] + f4b['conv_wino4f_kernel'][1] == 5 and f4b['conv_mfma_kernel'][1] == 3        # 32^2 at B = 4: too few items for the persistent grid -> its input channels split 4 ways
+    assert bench.winograd4_fused_takes(16, 64, 64, 512) and bench.winograd4_fused_takes(4, 128, 128, 256) and not bench.winograd4_fused_takes(16, 256, 256, 128) and not bench.winograd4_fused_takes(16, 72, 64, 512)
     assert bench.winograd4_takes(8, 512, 512, 32) and not bench.winograd4_takes(2, 512, 512, 32) and not bench.winograd4_takes(4, 512, 512, 16)
-    assert bench.EXECUTED_FRACTION['conv_wino4_kernel'] == 0.25 and 'upconv_wino4_kernel' not in bench.EXECUTED_FRACTION    # 36/16 of 9; 4 x 36/16 = the transposed conv's 9
+    assert bench.EXECUTED_FRACTION['conv_wino4_kernel'] == 0.25 and bench.EXECUTED_FRACTION['conv_wino4f_kernel'] == 0.25 and 'upconv_wino4_kernel' not in bench.EXECUTED_FRACTION    # 36/16 of 9; 4 x 36/16 = the transposed conv's 9
     f4 = bench.algorithmic_flops(tdgp.config.config_c4())
     back4 = sum(f4[k][0] for k in ('conv_mfma_kernel', 'upconv_mfma_kernel', 'torgb_mfma_kernel')) / 1e9
     assert abs(back4 - 488.9) < 0.5

@@ -28,7 +28,7 @@ import subprocess
 FETCH_FACTOR = 2.0      # calibrated: profiles/r03_pmc_calibration.md
 
 # device function name -> the label the library's event timing (and bench.py) pools it under
-ALIAS = {'conv3_mfma_kernel': 'conv_mfma_kernel', 'conv3_wino_kernel': 'conv_wino_kernel', 'conv3_wino4_kernel': 'conv_wino4_kernel', 'conv3_bf16_kernel': 'conv_bf16_kernel', 'triplane_walk_kernel': 'triplane_field_kernel', 'triplane_walk2_kernel': 'triplane_field_kernel', 'conv3s_mfma_kernel': 'conv_mfma_kernel', 'upconv3s_mfma_kernel': 'upconv_mfma_kernel'}
+ALIAS = {'conv3_mfma_kernel': 'conv_mfma_kernel', 'conv3_wino_kernel': 'conv_wino_kernel', 'conv3_wino4_kernel': 'conv_wino4_kernel', 'conv3_wino4f_kernel': 'conv_wino4f_kernel', 'conv3_bf16_kernel': 'conv_bf16_kernel', 'triplane_walk_kernel': 'triplane_field_kernel', 'triplane_walk2_kernel': 'triplane_field_kernel', 'conv3s_mfma_kernel': 'conv_mfma_kernel', 'upconv3s_mfma_kernel': 'upconv_mfma_kernel'}
 
 
 def table(path):
