@@ -43,6 +43,7 @@ PEAK_HBM_GBS = 8000.0
 
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
+SPEC_CLOCK_GHZ = 2.4              # MI355X_MICROARCH.md: max clock, the clock the peaks above are quoted at
 
 
 # Fraction of the algorithmic (direct-sum) FLOP a kernel actually executes on the matrix pipe: Winograd F(2x2,3x3) multiplies 16 times
@@ -527,10 +528,19 @@ def main():
                         traffic_note=None if traffic is None else 'memory-side bytes of the L2 per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE counts '
                                      '128-B requests at 64 B: profiles/r03_pmc_calibration.md); Infinity-Cache hits included',
                         pmc_source=pmc_src, flop_per_launch=fl_per_launch, avg_launch_ms=k['avg_ms'], launches_per_step=k['launches_per_step'])
+        # The shader clock the kernel actually sustains (GRBM_GUI_ACTIVE / 8 XCDs / duration, from the same committed counter pass): the chip runs to its
+        # power budget, not to the 2.4 GHz the 157.3 TFLOP/s peak is quoted at.  `frac` stays against the spec peak (the metric's figure);
+        # `frac_at_clock` = the same rate against the peak AT the sustained clock -- the share of the issue slots the kernel's structure leaves unused.
+        if pk.get('sclk_ghz'):
+            roofline.update(sclk_ghz=pk['sclk_ghz'], spec_clock_ghz=SPEC_CLOCK_GHZ, peak_at_clock=round(peak * pk['sclk_ghz'] / SPEC_CLOCK_GHZ, 1),
+                            frac_at_clock=round(achieved / (peak * pk['sclk_ghz'] / SPEC_CLOCK_GHZ), 4),
+                            sclk_note='sclk_ghz is from the committed counter pass (profiles/pmc_latest.json: profiled dispatches clock ~2-3 % lower than un-profiled ones), not measured in this process')
     for k, v in kernels.items():               # the same three figures for every kernel the PMC passes cover
         pk = pmc.get(k)
         if pk and v['avg_ms'] > 0:
             v.update(hbm_gbs=round(pk['hbm_bytes_per_launch'] / (v['avg_ms'] * 1e-3) / 1e9, 1), mfma_busy_pct=pk.get('mfma_busy_pct'))
+            if pk.get('sclk_ghz'):
+                v['sclk_ghz'] = pk['sclk_ghz']
             if 'l2_hit_pct' in pk:
                 v['l2_hit_pct'] = pk['l2_hit_pct']
         if k in flops and v['avg_ms'] > 0:

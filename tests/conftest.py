@@ -216,13 +216,16 @@ def full_golden_case(tdgp, tag):
     return cfg, tdgp.weights.random_state_dict(cfg, seed=seed, exercise_all=True), tdgp.weights.synthetic_inputs(cfg, batch=1, seed=seed + 1)
 
 
+KNOT_ULP_CEILING = 128.0      # hard ceiling of the derived knot-window allowance (assert_inds_mismatches_in_window): beyond it a cdf row is wrong, whatever the strip's noise
+
+
 def _ulps_apart(a, b):
     """Distance in fp32 units in the last place (of the larger magnitude)."""
     a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
     return np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)).astype(np.float64)
 
 
-def assert_inds_mismatches_in_window(inds_a, inds_b, u, cdf_b, cdf_a=None, what='inds', max_ulp=4.0, max_knot_ulp=64.0, samples_a=None, samples_b=None, sample_tol=5e-6):
+def assert_inds_mismatches_in_window(inds_a, inds_b, u, cdf_b, cdf_a=None, what='inds', max_ulp=4.0, max_knot_ulp=None, samples_a=None, samples_b=None, sample_tol=5e-6):
     """SURVEY.md 9.2 protocol for the INT row `inds = searchsorted(cdf, u, right=True)` (tri_plane_renderer.py:282) compared THROUGH THE
     CHAIN (each side ranks the draw against its own cdf, and the two cdfs carry independent fp32 rounding from the MLP sums upstream):
     every draw whose index differs must be EXPLAINED, i.e. sit inside the ambiguity window of a knot.
@@ -230,8 +233,11 @@ def assert_inds_mismatches_in_window(inds_a, inds_b, u, cdf_b, cdf_a=None, what=
     inds = #{k : cdf[k] <= u}.  For a mismatching draw (row r, draw j) with a = inds_a, b = inds_b, the knots k in [min(a,b), max(a,b)) are
     exactly those on which the two sides disagree about `cdf[k] <= u`.  Asserted for each such knot:
       * with both cdfs (`cdf_a` given): u lies in the closed interval spanned by cdf_a[k] and cdf_b[k] -- the flip is CAUSED by the two
-        knot values straddling the draw -- and the two knot values are within `max_knot_ulp` fp32 ulps of each other (the tolerance the
-        cdf rows themselves are held to);
+        knot values straddling the draw -- and the two knot values are within `max_knot_ulp` fp32 ulps of each other.  That allowance is DERIVED
+        from the strip itself, not typed: the distance between the two sides' values of EVERY interior knot of the strip is
+        measured (thousands of knots; the histogram goes into the parity report), and a flipped draw's window may be at most twice the 99.9th
+        percentile of that distribution (never less than SURVEY 9.2's 4 ulp, never more than the hard ceiling KNOT_ULP_CEILING): a flip is explained
+        by the SAME fp32 noise every knot carries, not by an outlier.  An explicit `max_knot_ulp` overrides the derivation;
       * with one cdf: |u - cdf_b[k]| <= `max_ulp` ulps of the knot.
     Anything else (a draw far from every knot landing in another interval) fails.  With `samples_a` / `samples_b` (the fine samples of both sides in DRAW
     order, s-space: depth range 1): the inverse cdf is continuous across a knot, so the two samples of a flipped draw must agree to `sample_tol` (measured <= 1.7e-6 at knot windows of up to 47 ulp; SURVEY 9.2:
@@ -241,6 +247,22 @@ def assert_inds_mismatches_in_window(inds_a, inds_b, u, cdf_b, cdf_a=None, what=
     assert a.shape == b.shape == u.shape and cdf_b.shape[0] == a.shape[0], (a.shape, b.shape, u.shape, cdf_b.shape)
     rows, cols = np.nonzero(a != b)
     worst = 0.0
+    knot_stats = {}
+    if cdf_a is not None:
+        ca, cb = np.asarray(cdf_a, np.float32), np.asarray(cdf_b, np.float32)
+        interior = (cb > 0) & (cb < 1) & (ca > 0) & (ca < 1)              # (the end knots are exactly 0 / 1 on both sides)
+        d_all = _ulps_apart(ca, cb)[interior]
+        if d_all.size:
+            p999 = float(np.quantile(d_all, 0.999))
+            edges = [0, 1, 2, 4, 8, 16, 32, 64, 128, np.inf]
+            hist = np.histogram(d_all, bins=edges)[0]
+            knot_stats = dict(knots=int(d_all.size), knot_ulp_median=float(np.median(d_all)), knot_ulp_p99=float(np.quantile(d_all, 0.99)), knot_ulp_p999=p999,
+                              knot_ulp_max=float(d_all.max()), knot_ulp_hist='|'.join(f'<{e:g}:{int(n)}' for e, n in zip(edges[1:], hist)))
+            if max_knot_ulp is None:
+                max_knot_ulp = min(KNOT_ULP_CEILING, max(4.0, 2.0 * p999))
+                knot_stats['window_bound_ulp'] = max_knot_ulp
+    if max_knot_ulp is None:
+        max_knot_ulp = KNOT_ULP_CEILING
     for r, j in zip(rows, cols):
         lo, hi = sorted((int(a[r, j]), int(b[r, j])))
         for k in range(lo, hi):
@@ -262,7 +284,7 @@ def assert_inds_mismatches_in_window(inds_a, inds_b, u, cdf_b, cdf_a=None, what=
         worst_s = float(ds.max())
         assert worst_s <= sample_tol, f'{what}: a flipped draw moved its fine sample by {worst_s:.3e} (> {sample_tol:.1e}): the inverse cdf is continuous across a knot'
     report_parity(what + ': INT row inds through the chain, every mismatch explained by a knot window', mismatches=int(rows.size), draws=int(a.size),
-                  worst_window_ulp=worst, worst_sample_move=worst_s)
+                  worst_window_ulp=worst, worst_sample_move=worst_s, **knot_stats)
     return int(rows.size), worst
 
 # ------------------------------------------------------------------------------------------------ upfirdn2d backward

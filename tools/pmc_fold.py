@@ -67,18 +67,19 @@ def main():
         base = name.split('<')[0].strip()
         return ALIAS.get(base, base)
 
-    fam = collections.defaultdict(lambda: dict(launches=0, fetch=0.0, write=0.0, mfma=0.0, active=0.0, mlaunches=0, hit=0.0, miss=0.0, req=0.0, rdreq=0.0, rlaunches=0))
+    fam = collections.defaultdict(lambda: dict(launches=0, fetch=0.0, write=0.0, mfma=0.0, active=0.0, mlaunches=0, mdur_us=0.0, hit=0.0, miss=0.0, req=0.0, rdreq=0.0, rlaunches=0))
     for key, fn, counter in (('fetch', 'pmc_FETCH_SIZE.md', 'FETCH_SIZE'), ('write', 'pmc_WRITE_SIZE.md', 'WRITE_SIZE')):
         for name, (calls, _, cs) in table(os.path.join(a.indir, fn)).items():
             f = fam[family(name)]
             f[key] += calls * cs[counter] * 1024.0 * (FETCH_FACTOR if key == 'fetch' else 1.0)
             if key == 'fetch':
                 f['launches'] += calls
-    for name, (calls, _, cs) in table(os.path.join(a.indir, 'pmc_SQ_VALU_MFMA_BUSY_CYCLES.md')).items():
+    for name, (calls, avg_us, cs) in table(os.path.join(a.indir, 'pmc_SQ_VALU_MFMA_BUSY_CYCLES.md')).items():
         f = fam[family(name)]
         f['mfma'] += calls * cs['SQ_VALU_MFMA_BUSY_CYCLES']
         f['active'] += calls * cs['GRBM_GUI_ACTIVE']
         f['mlaunches'] += calls
+        f['mdur_us'] += calls * avg_us          # duration of the same dispatches IN THE SAME PASS (the counter pass runs a little slower than an un-profiled one)
     for name, (calls, _, cs) in table(os.path.join(a.indir, 'pmc_TCC_HIT_sum.md')).items():
         f = fam[family(name)]
         f['hit'] += calls * cs['TCC_HIT_sum']
@@ -107,6 +108,15 @@ def main():
             k['fetch_bytes_per_launch_rdreq128'] = round(f['rdreq'] * 128.0 / f['rlaunches'])      # cross-check of the corrected FETCH_SIZE
         if f['active'] > 0:
             k['mfma_busy_pct'] = round(100.0 * f['mfma'] / (f['active'] / 8.0 * 1024.0), 1)
+            if f['mdur_us'] > 0:
+                # sustained shader clock of the kernel's dispatches: GRBM_GUI_ACTIVE is summed over the 8 XCD instances, each counts the cycles its
+                # graphics pipe was busy = the dispatch's duration in shader clocks (MI355X_MICROARCH.md: DVFS give-back)
+                ghz, avg = f['active'] / 8.0 / (f['mdur_us'] * 1e3), f['mdur_us'] / max(f['mlaunches'], 1)
+                k['pmc_pass_avg_us'] = round(avg, 1)
+                # (GRBM_GUI_ACTIVE also counts the dispatch's ramp-up / drain outside the kernel's own begin / end stamps: a few microseconds, i.e. the
+                #  quotient is only a clock for launches that last hundreds of microseconds -- short kernels read above the 2.4 GHz the part can reach)
+                if avg >= 250.0 and ghz <= 2.45:
+                    k['sclk_ghz'] = round(ghz, 3)
         out['kernels'][name] = k
     json.dump(out, open(a.out, 'w'), indent=1)
     print(json.dumps({k: v for k, v in list(out['kernels'].items())[:8]}, indent=1))
