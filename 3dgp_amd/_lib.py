@@ -47,6 +47,7 @@ _PROTOTYPES = {
     'tdgp_sample_stratified': (c_int, [P, P, P, c_int64, c_int, c_int, c_float, c_float, P]),
     'tdgp_density_activation': (c_int, [P, P, c_int64, c_int, c_float, P]),
     'tdgp_planes_to_hwc': (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    'tdgp_triplane_features': (c_int, [P, P, P, c_int, c_int64, c_int, c_int, c_int, c_float, P]),
     'tdgp_triplane_field': (c_int, [P, P, P, P, P, P, P, P, P, P, c_float, P, P, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                     c_int, P]),
     'tdgp_ray_march': (c_int, [P, P, P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, c_float, c_float, P]),

@@ -60,6 +60,13 @@ class GeneratorConfig:
     tri_plane_res: int = 512
     feat_dim: int = 32
     mlp_hid: int = 64
+    mlp_n_layers: int = 2           # tri_plane.mlp.n_layers (networks_epigraf.py:35-43): 0 = the planes carry rgb + sigma (feat_dim 4); 2 = the fused kernel's form
+    # mapping_kwargs injected by the launcher (train.py:170-172; layers.py:84-93,122-138): camera-conditioned mapping network
+    camera_cond: bool = False
+    camera_raw_scalars: bool = False
+    camera_cond_drop_p: float = 0.0
+    mean_camera_params: Optional[tuple] = None     # (yaw, pitch, roll, ...) used at eval time when no angles are passed
+    has_view_cond: bool = False     # networks_epigraf.py:39: widens the decoder's output to 1 + hid_dim (the reference's forward then only accepts hid_dim == 3)
     ray_marcher_type: str = 'classical'
     num_ray_steps: int = 32
     ray_start: float = 0.75

@@ -581,6 +581,49 @@ __global__ __launch_bounds__(256, TDGP_WALK_WAVES) void triplane_walk_kernel(Fie
 #include "field_walk2.inc"
 
 // NCHW planes [B,3F,H,W] -> [B,3,H,W,F] through an LDS tile of 64 pixels x F channels.
+// The lookup alone: mean over the three planes of the bilinear samples, feats [B,P,F] -- simple_tri_plane_renderer's input to TriPlaneMLP
+// (tri_plane_renderer.py:575-586, networks_epigraf.py:55).  The path of the decoders the fused kernels do not cover (tri_plane.mlp.n_layers != 2,
+// has_view_cond, widths outside its table; round 6): their MLP then runs as eager tensor ops on this output, exactly as the reference's.  Built for
+// correctness, not speed -- thread = (point, 4 channels) -- and written in torch's own evaluation order: per plane nw * a, + ne * b, + sw * c, + se * d
+// (separate multiplies and adds), ((f0 + f1) + f2) / 3.
+__global__ __launch_bounds__(256) void triplane_features_kernel(const float* __restrict__ planes, const float* __restrict__ coords, float* __restrict__ feats,
+                                                                int64_t total, int64_t P, int F, int H, int W, float scale) {
+    const int fq = F >> 2;
+    const float sx = (float)(W - 1) / 2.f, sy = (float)(H - 1) / 2.f;
+    const int64_t plane_elems = (int64_t)H * W * F;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total * fq; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t gp = i / fq;
+        const int c4 = (int)(i - gp * fq) * 4;
+        const int64_t b = gp / P;
+        const float* cp = coords + gp * 3;
+        const float qc[3] = {cp[0] / scale, cp[1] / scale, cp[2] / scale};
+        float4 acc[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            const float u = qc[pl == 2 ? 1 : 0], v = qc[pl == 0 ? 1 : 2];
+            const float ix = (u + 1.0f) * sx, iy = (v + 1.0f) * sy;
+            const float fx = floorf(ix), fy = floorf(iy);
+            const float tw = ix - fx, te = 1.0f - tw, tn = iy - fy, ts = 1.0f - tn;
+            const float cfx = fx < -2.f ? -2.f : (fx > (float)W ? (float)W : fx), cfy = fy < -2.f ? -2.f : (fy > (float)H ? (float)H : fy);
+            const int x0 = (int)cfx, y0 = (int)cfy;
+            const float w4[4] = {ts * te, ts * tw, tn * te, tn * tw};
+            const float* base = planes + (b * 3 + pl) * plane_elems + c4;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = x0 + (k & 1), y = y0 + (k >> 1);
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);                      // zero padding: the tap VALUE is 0, its weight stays (torch's order)
+                if (x >= 0 && x < W && y >= 0 && y < H) t = *(const float4*)(base + ((int64_t)y * W + x) * F);
+                if (k == 0) a = make_float4(t.x * w4[0], t.y * w4[0], t.z * w4[0], t.w * w4[0]);
+                else a = make_float4(a.x + t.x * w4[k], a.y + t.y * w4[k], a.z + t.z * w4[k], a.w + t.w * w4[k]);
+            }
+            acc[pl] = a;
+        }
+        *(float4*)(feats + gp * F + c4) = make_float4(((acc[0].x + acc[1].x) + acc[2].x) / 3.0f, ((acc[0].y + acc[1].y) + acc[2].y) / 3.0f,
+                                                      ((acc[0].z + acc[1].z) + acc[2].z) / 3.0f, ((acc[0].w + acc[1].w) + acc[2].w) / 3.0f);
+    }
+}
+
 __global__ __launch_bounds__(256) void planes_to_hwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int F, int HW, int64_t ntiles,
                                                            int tiles_per_plane) {
     extern __shared__ float tile[];      // [F][65]
@@ -666,6 +709,19 @@ TDGP_API int tdgp_planes_to_hwc(const float* planes_nchw, float* planes_hwc, int
     const int64_t ntiles = (int64_t)B * 3 * tpp;
     TDGP_LAUNCH("planes_to_hwc_kernel", planes_to_hwc_kernel, dim3((int)min((int64_t)65535, ntiles)), dim3(256), F * 65 * sizeof(float), (hipStream_t)stream,
                        planes_nchw, planes_hwc, F, HW, ntiles, tpp);
+    TDGP_LAUNCH_CHECK();
+    return TDGP_OK;
+}
+
+TDGP_API int tdgp_triplane_features(const float* planes_hwc, const float* coords, float* feats, int B, int64_t P, int F, int H, int W, float scale,
+                                    tdgp_stream_t stream) {
+    TDGP_CHECK(planes_hwc && coords && feats, TDGP_EINVAL, "triplane_features: null pointer");
+    TDGP_CHECK(B >= 0 && P >= 0 && H >= 2 && W >= 2 && F >= 4 && (F & 3) == 0, TDGP_EINVAL, "triplane_features: bad shape (feat_dim must be a multiple of 4)");
+    TDGP_CHECK((int64_t)B * P <= INT32_MAX / 4, TDGP_EINVAL, "triplane_features: tensor too large");
+    if (B == 0 || P == 0) return TDGP_OK;
+    const int64_t work = (int64_t)B * P * (F >> 2);
+    TDGP_LAUNCH("triplane_features_kernel", triplane_features_kernel, dim3((unsigned)std::min<int64_t>(65535 * 4, cdiv64(work, 256))), dim3(256), 0, (hipStream_t)stream,
+                planes_hwc, coords, feats, (int64_t)B * P, P, F, H, W, scale);
     TDGP_LAUNCH_CHECK();
     return TDGP_OK;
 }

@@ -97,12 +97,25 @@ class FullyConnectedLayer(torch.nn.Module):
 
 
 class MappingNetwork(torch.nn.Module):
-    """layers.py:66-177 without camera conditioning (`camera_cond` is off in every 3dgp config of the hot path)."""
+    """layers.py:66-177, camera conditioning included (round 6; `camera_cond` is off in every 3dgp config of the hot path --
+    configs/model/base.yaml:26 -- but it is part of the class the checkpoints are made of): with `camera_cond` the yaw / pitch of the camera,
+    wrapped to [-1, 1) turns and Fourier-encoded (`ScalarEncoder1d`, x_multiplier 64; `camera_raw_scalars`: the raw values), are appended
+    to the label `c` before the embedding layer; at eval time with no angles given the stored `mean_camera_params` stand in."""
 
-    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=2, lr_multiplier=0.01, w_avg_beta=0.998):
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=2, lr_multiplier=0.01, w_avg_beta=0.998, camera_cond=False, camera_cond_drop_p=0.0,
+                 camera_raw_scalars=False, mean_camera_params=None):
         super().__init__()
+        if camera_cond:                                                       # layers.py:84-93
+            from .encoders import ScalarEncoder1d
+            self.camera_scalar_enc = (ScalarEncoder1d(coord_dim=2, x_multiplier=0.0, const_emb_dim=0, use_raw=True) if camera_raw_scalars
+                                      else ScalarEncoder1d(coord_dim=2, x_multiplier=64.0, const_emb_dim=0))
+            c_dim = c_dim + self.camera_scalar_enc.get_dim()
+            assert self.camera_scalar_enc.get_dim() > 0
+        else:
+            self.camera_scalar_enc = None
         self.z_dim, self.c_dim, self.w_dim, self.num_ws, self.num_layers = z_dim, c_dim, w_dim, num_ws, num_layers
         self.w_avg_beta = w_avg_beta
+        self.camera_cond_drop_p = camera_cond_drop_p
         embed_features = w_dim if c_dim > 0 else 0
         if c_dim > 0:
             self.embed = FullyConnectedLayer(c_dim, embed_features)
@@ -111,11 +124,25 @@ class MappingNetwork(torch.nn.Module):
             setattr(self, f'fc{i}', FullyConnectedLayer(feats[i], feats[i + 1], activation='lrelu', lr_multiplier=lr_multiplier))
         if num_ws is not None and w_avg_beta is not None:                     # layers.py:119-120
             self.register_buffer('w_avg', torch.zeros([w_dim]))
+        if mean_camera_params is not None:                                    # layers.py:122-125
+            self.register_buffer('mean_camera_params', torch.as_tensor(mean_camera_params, dtype=torch.float32))
+        else:
+            self.mean_camera_params = None
 
     def forward(self, z, c, camera_angles=None, truncation_psi=1, truncation_cutoff=None, update_emas=False):
-        # layers.py:126-137: `camera_angles` only feeds `camera_scalar_enc`, which exists when camera_cond is on.  No 3dgp config
-        # turns it on and this module is never built with it, so -- exactly like the reference with camera_cond off -- the argument
-        # is accepted and ignored (metric_utils.py:310,344 and loss.py:70 always pass it).
+        # layers.py:127-138.  Without camera conditioning `camera_angles` is accepted and ignored, exactly like the reference
+        # (metric_utils.py:310,344 and loss.py:70 always pass it).
+        if self.camera_scalar_enc is not None:
+            if (not self.training) and camera_angles is None:
+                if self.mean_camera_params is None:
+                    raise RuntimeError('MappingNetwork(camera_cond=True): an eval forward without camera_angles needs mean_camera_params')
+                camera_angles = self.mean_camera_params[:3].unsqueeze(0).repeat(len(z), 1)
+            camera_angles = camera_angles[:, [0, 1]]                           # yaw and pitch (roll is always zero)
+            camera_angles = camera_angles.sign() * ((camera_angles.abs() % (2.0 * np.pi)) / (2.0 * np.pi))
+            embs = self.camera_scalar_enc(camera_angles)
+            embs = torch.nn.functional.dropout(embs, p=self.camera_cond_drop_p, training=self.training)
+            c = torch.zeros(len(embs), 0, device=embs.device) if c is None else c
+            c = torch.cat([c, embs], dim=1)
         x = None
         if self.z_dim > 0:
             assert z.shape[1] == self.z_dim, f'Wrong shape: z {tuple(z.shape)}'
@@ -532,7 +559,8 @@ class SynthesisNetwork(torch.nn.Module):
         self.cfg = cfg
         self.img_resolution, self.img_channels = img_resolution, img_channels
         self.tri_plane_decoder = SynthesisBlocksSequence(cfg, out_channels=cfg.feat_dim * 3)
-        self.tri_plane_mlp = _renderer.TriPlaneMLP(cfg.feat_dim, cfg.mlp_hid, out_dim=img_channels, ray_marcher_type=cfg.ray_marcher_type)
+        self.tri_plane_mlp = _renderer.TriPlaneMLP(cfg.feat_dim, cfg.mlp_hid, out_dim=img_channels, ray_marcher_type=cfg.ray_marcher_type, n_layers=cfg.mlp_n_layers,
+                                                   has_view_cond=cfg.has_view_cond)
         self.num_ws = self.tri_plane_decoder.num_ws
         self.test_resolution = img_resolution
         self.train_resolution = cfg.patch_resolution if cfg.patch_resolution is not None else img_resolution
@@ -712,7 +740,7 @@ class Generator(torch.nn.Module):
     """networks_epigraf.py:266-291: forward(z, c, camera_params, camera_angles_cond, truncation_psi, truncation_cutoff,
     update_emas, **synthesis_kwargs)."""
 
-    def __init__(self, cfg: GeneratorConfig, img_resolution=None, img_channels=3):
+    def __init__(self, cfg: GeneratorConfig, img_resolution=None, img_channels=3, mapping_kwargs=None):
         super().__init__()
         self.cfg = cfg
         self.z_dim, self.c_dim, self.w_dim = cfg.z_dim, cfg.c_dim, cfg.w_dim
@@ -720,7 +748,12 @@ class Generator(torch.nn.Module):
         self.img_channels = img_channels
         self.synthesis = SynthesisNetwork(cfg, img_resolution=self.img_resolution, img_channels=img_channels)
         self.num_ws = self.synthesis.num_ws
-        self.mapping = MappingNetwork(z_dim=cfg.z_dim, c_dim=cfg.c_dim, w_dim=cfg.w_dim, num_ws=self.num_ws, num_layers=cfg.map_depth)
+        # mapping_kwargs: what the launcher injects (train.py:170-172: camera_cond, camera_cond_drop_p, camera_raw_scalars, mean_camera_params);
+        # by default taken from the configuration
+        if mapping_kwargs is None and cfg.camera_cond:
+            mapping_kwargs = dict(camera_cond=True, camera_cond_drop_p=cfg.camera_cond_drop_p, camera_raw_scalars=cfg.camera_raw_scalars,
+                                  mean_camera_params=None if cfg.mean_camera_params is None else torch.tensor(cfg.mean_camera_params, dtype=torch.float32))
+        self.mapping = MappingNetwork(z_dim=cfg.z_dim, c_dim=cfg.c_dim, w_dim=cfg.w_dim, num_ws=self.num_ws, num_layers=cfg.map_depth, **(mapping_kwargs or {}))
         self.eval()
 
     def progressive_update(self, cur_kimg):

@@ -3,7 +3,7 @@
 Key names and shapes are the reference's (probed in SURVEY.md section 8a):
   synthesis.tri_plane_decoder.b{r}.{const | conv0|conv1|torgb}.{weight,bias,affine.weight,affine.bias,
       noise_const,noise_strength,resample_filter}
-  synthesis.tri_plane_mlp.model.{0,1}.{weight,bias}
+  synthesis.tri_plane_mlp.model.{0..n-1}.{weight,bias}        (n = tri_plane.mlp.n_layers; none for n = 0)
   mapping.{embed,fc0,fc1}.{weight,bias}, mapping.w_avg
 so a state-dict exported from a reference checkpoint loads unchanged.
 
@@ -50,15 +50,24 @@ def state_dict_spec(cfg: GeneratorConfig):
             layer(pfx + '.conv0', ch[r // 2], cout, r, 3, cfg.use_noise)
         layer(pfx + '.conv1', cout, cout, r, 3, cfg.use_noise)
         layer(pfx + '.torgb', cout, img_c, r, 1, False, synth=False)
-    spec['synthesis.tri_plane_mlp.model.0.weight'] = (cfg.mlp_hid, cfg.feat_dim)
-    spec['synthesis.tri_plane_mlp.model.0.bias'] = (cfg.mlp_hid,)
-    spec['synthesis.tri_plane_mlp.model.1.weight'] = (4, cfg.mlp_hid)
-    spec['synthesis.tri_plane_mlp.model.1.bias'] = (4,)
+    if cfg.mlp_n_layers > 0:               # networks_epigraf.py:35-43 (0 layers: nn.Identity, no parameters)
+        dims = [cfg.feat_dim] + [cfg.mlp_hid] * (cfg.mlp_n_layers - 1) + [1 + (cfg.mlp_hid if cfg.has_view_cond else 3)]
+        for i in range(len(dims) - 1):
+            spec[f'synthesis.tri_plane_mlp.model.{i}.weight'] = (dims[i + 1], dims[i])
+            spec[f'synthesis.tri_plane_mlp.model.{i}.bias'] = (dims[i + 1],)
     spec['mapping.w_avg'] = (cfg.w_dim,)
-    if cfg.c_dim > 0:
-        spec['mapping.embed.weight'] = (cfg.w_dim, cfg.c_dim)
+    c_dim = cfg.c_dim
+    if cfg.camera_cond:                    # layers.py:84-93: yaw / pitch encodings appended to the label
+        enc = 2 * (1 if cfg.camera_raw_scalars else 2 * 6)          # raw: 1 value per angle; Fourier: sin + cos of ceil(log2(64)) = 6 frequencies
+        c_dim += enc
+        if not cfg.camera_raw_scalars:
+            spec['mapping.camera_scalar_enc.fourier_encoder.fourier_coefs'] = (6,)
+        if cfg.mean_camera_params is not None:
+            spec['mapping.mean_camera_params'] = (len(cfg.mean_camera_params),)
+    if c_dim > 0:
+        spec['mapping.embed.weight'] = (cfg.w_dim, c_dim)
         spec['mapping.embed.bias'] = (cfg.w_dim,)
-    feats = [cfg.z_dim + (cfg.w_dim if cfg.c_dim > 0 else 0)] + [cfg.w_dim] * cfg.map_depth
+    feats = [cfg.z_dim + (cfg.w_dim if c_dim > 0 else 0)] + [cfg.w_dim] * cfg.map_depth
     for i in range(cfg.map_depth):
         spec[f'mapping.fc{i}.weight'] = (feats[i + 1], feats[i])
         spec[f'mapping.fc{i}.bias'] = (feats[i + 1],)
@@ -118,6 +127,10 @@ def random_state_dict(cfg: GeneratorConfig, seed=0, exercise_all=False):
             v = resample_filter()
         elif leaf == 'progress_coef':
             v = np.zeros(shape)
+        elif leaf == 'fourier_coefs':                        # construct_log_spaced_freqs(64): 2^k / 64 * pi, k = 0..5 (layers.py:346-358)
+            v = (2.0 ** np.arange(shape[0]) / 2.0 ** shape[0]).astype(np.float32) * np.float32(np.pi)
+        elif leaf == 'mean_camera_params':
+            v = np.asarray(cfg.mean_camera_params, np.float32)
         elif leaf == 'near_plane_offset_raw':
             v = np.full(shape, cfg.depth_adaptor.near_plane_offset_bias + (0.5 * g.randn() if exercise_all else 0.0))
         elif name.startswith('synthesis.camera_adaptor') and leaf == 'weight':
@@ -174,9 +187,7 @@ def config_from_json(d):
     d = dict(d)
     chk = d.pop('checked_options', None)          # written by the exporter: options that change the forward and are not implemented here
     if chk:
-        bad = [k for k in ('use_full_box', 'ray_start_is_auto', 'has_view_cond', 'camera_cond') if chk.get(k)]
-        if chk.get('mlp_n_layers', 2) != 2:
-            bad.append('mlp_n_layers')
+        bad = [k for k in ('use_full_box', 'ray_start_is_auto') if chk.get(k)]
         if not chk.get('fp32_only', True) and chk.get('num_fp16_res', 0) > 0:
             bad.append('num_fp16_res')
         if bad:

@@ -259,6 +259,13 @@ int tdgp_density_activation(const float* sigma, float* out, int64_t n, int flags
 int tdgp_planes_to_hwc(const float* planes_nchw, float* planes_hwc, int B, int F, int H, int W,
                        tdgp_stream_t stream);
 
+/* The lookup alone (round 6): feats [B,P,F] = mean over the three planes of the bilinear samples (align_corners, zero padding) at coords [B,P,3] / scale
+ * -- what simple_tri_plane_renderer hands to TriPlaneMLP (tri_plane_renderer.py:575-586, networks_epigraf.py:55: `x.mean(dim=1)`), in torch's own
+ * evaluation order.  For decoders the fused kernel below does not cover (tri_plane.mlp.n_layers != 2, has_view_cond: networks_epigraf.py:35-43), whose
+ * layers the binding then runs as eager tensor ops like the reference.  planes_hwc [B,3,H,W,F], F % 4 == 0. */
+int tdgp_triplane_features(const float* planes_hwc, const float* coords, float* feats, int B, int64_t P, int F, int H, int W,
+                           float scale, tdgp_stream_t stream);
+
 /* Tri-plane bilinear lookup (align_corners, zero padding) + mean + tiny MLP, fused.
  * planes_hwc: [B,3,H,W,F].  Points are given either as coords [B,P,3] (ray_o = NULL), or as rays:
  * ray_o/ray_d [B,R,3] and t [B,R,S] with P = R*S, point p = ray p/S at depth t[p].  In ray mode `ray_w` > 0 declares that

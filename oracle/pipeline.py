@@ -34,12 +34,31 @@ def num_ws(cfg):
     return n + 1
 
 
-def mapping_forward(sd, cfg, z, c, truncation_psi=1.0, truncation_cutoff=None):
-    """MappingNetwork.forward, layers.py:127-174 (no camera conditioning)."""
+def camera_angle_embeddings(camera_angles, raw_scalars=False, x_multiplier=64.0):
+    """layers.py:132-135 + ScalarEncoder1d / FourierEncoder1d (layers.py:251-340): yaw and pitch wrapped to signed turns, then either raw or
+    sin / cos of (2^k / 64 * pi) * (64 * angle), k = 0..5 -- per angle [raw | sin x 6 | cos x 6], the two angles concatenated."""
+    a = np.asarray(camera_angles, np.float32)[:, [0, 1]]
+    a = (np.sign(a) * (np.mod(np.abs(a), np.float32(2.0 * np.pi)) / np.float32(2.0 * np.pi))).astype(np.float32)
+    if raw_scalars:
+        return a.reshape(len(a), 2)
+    nf = int(np.ceil(np.log2(x_multiplier)))
+    coefs = ((np.float32(2.0) ** np.arange(nf, dtype=np.float32)) / np.float32(2 ** nf)).astype(np.float32) * np.float32(np.pi)
+    raw = coefs[None, None, :] * (a * np.float32(x_multiplier))[:, :, None]
+    return np.concatenate([np.sin(raw), np.cos(raw)], axis=2).astype(np.float32).reshape(len(a), -1)
+
+
+def mapping_forward(sd, cfg, z, c, truncation_psi=1.0, truncation_cutoff=None, camera_angles=None):
+    """MappingNetwork.forward, layers.py:127-174.  With cfg['camera_cond'] (layers.py:84-93,128-138) the camera's yaw / pitch encodings are appended to the
+    label; without angles (eval) `mapping.mean_camera_params` stands in."""
     x = None
+    if cfg.get('camera_cond'):
+        if camera_angles is None:
+            camera_angles = np.repeat(np.asarray(sd['mapping.mean_camera_params'], np.float32)[None, :3], len(z), axis=0)
+        emb = camera_angle_embeddings(camera_angles, raw_scalars=cfg.get('camera_raw_scalars', False))
+        c = emb if (c is None or cfg['c_dim'] == 0) else np.concatenate([np.asarray(c, np.float32), emb], axis=1)
     if cfg['z_dim'] > 0:
         x = O.normalize_2nd_moment(z)
-    if cfg['c_dim'] > 0:
+    if cfg['c_dim'] > 0 or cfg.get('camera_cond'):
         y = O.normalize_2nd_moment(O.fc(c, sd['mapping.embed.weight'], sd['mapping.embed.bias']))
         x = np.concatenate([x, y], axis=1) if x is not None else y
     for i in range(cfg['map_depth']):
@@ -58,6 +77,20 @@ def mapping_forward(sd, cfg, z, c, truncation_psi=1.0, truncation_cutoff=None):
         else:
             ws[:, :cut] = seg - diff * (np.float32(1) - psi)
     return ws
+
+
+def triplane_decode(feats, weights, biases, marcher='classical'):
+    """TriPlaneMLP.forward on the plane-mean features (networks_epigraf.py:46-68) for ANY layer count: FullyConnectedLayer x n (lrelu ... linear; none:
+    nn.Identity), the last value is sigma, the others rgb ('mip': sigmoid * 1.002 - 0.001).  feats [B,P,F] -> (rgb [B,P,3], sigma [B,P,1])."""
+    B, P, F = feats.shape
+    x = np.asarray(feats, np.float32).reshape(B * P, F)
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        x = O.fc(x, w, b, act='lrelu' if i + 1 < len(weights) else 'linear')
+    x = x.reshape(B, P, -1)
+    rgb = x[..., :-1]
+    if marcher == 'mip':
+        rgb = ((1.0 / (1.0 + np.exp(-rgb.astype(np.float64)))).astype(np.float32) * np.float32(1 + 2 * 0.001) - np.float32(0.001)).astype(np.float32)
+    return rgb.astype(np.float32), x[..., -1:].astype(np.float32)
 
 
 def _layer(sd, pfx, x, w, up, noise_mode, f, use_noise, bf16=False, clamp=None):

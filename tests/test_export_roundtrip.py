@@ -21,15 +21,20 @@ def test_export_roundtrip_through_the_reference_pickle():
 
 
 def test_loader_rejects_unsupported_generator_options():
-    """A checkpoint trained with an option that changes the forward and is not implemented here (fp16 blocks with conv_clamp,
-    view conditioning, camera_cond, a deeper tri-plane MLP, use_full_box) must not load silently."""
+    """A checkpoint trained with an option that changes the forward and is not implemented here (fp16 blocks with conv_clamp, use_full_box,
+    ray_start='auto') must not load silently.  Round 6: view conditioning, camera_cond and a tri-plane MLP with n_layers != 2 ARE implemented
+    (configuration fields mlp_n_layers / has_view_cond / camera_cond ...) and load."""
     tdgp = importlib.import_module('3dgp_amd')
     base = tdgp.config.config_tiny().to_dict()
     ok = dict(base, checked_options=dict(use_full_box=False, mlp_n_layers=2, has_view_cond=False, camera_cond=False, fp32_only=True, num_fp16_res=0,
                                          ray_start_is_auto=False))
     assert tdgp.weights.config_from_json(ok).to_dict() == base
-    for bad in (dict(use_full_box=True), dict(mlp_n_layers=3), dict(has_view_cond=True), dict(camera_cond=True), dict(fp32_only=False, num_fp16_res=4),
-                dict(ray_start_is_auto=True)):
+    for fine in (dict(mlp_n_layers=3), dict(has_view_cond=True), dict(camera_cond=True)):
+        d = dict(base, checked_options=dict(ok['checked_options'], **fine))
+        assert tdgp.weights.config_from_json(d).to_dict() == base
+    d = dict(base, mlp_n_layers=3, camera_cond=True, mean_camera_params=[0.0, 1.57, 0.0])
+    assert tdgp.weights.config_from_json(d).mlp_n_layers == 3 and tdgp.weights.config_from_json(d).camera_cond
+    for bad in (dict(use_full_box=True), dict(fp32_only=False, num_fp16_res=4), dict(ray_start_is_auto=True)):
         d = dict(base, checked_options=dict(ok['checked_options'], **bad))
         with pytest.raises(NotImplementedError):
             tdgp.weights.config_from_json(d)

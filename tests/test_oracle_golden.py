@@ -607,3 +607,45 @@ def test_bf16_backbone_and_image(oracle, tdgp):
     img, depth = P.synthesis_forward(sd, c, g['ws'], cam, g['u_coarse'], g['u_fine'], 'const')
     assert_close(img, g['img'], 5e-3, 'img', 1.0)
     assert_close(depth, g['depth'], 2e-3, 'depth', 1.0)
+
+
+# ------------------------------------------------------------------------------------------------ round 6: decoders outside the fused form, camera-conditioned mapping
+MLP_VARIANTS = dict(n3=dict(F=8, hid=16, n=3, view=False, marcher='classical'), n4mip=dict(F=8, hid=16, n=4, view=False, marcher='mip'),
+                    view=dict(F=8, hid=3, n=2, view=True, marcher='classical'), odd=dict(F=12, hid=20, n=2, view=False, marcher='mip'))
+
+
+@pytest.mark.parametrize('tag', sorted(MLP_VARIANTS))
+def test_mlp_variants_oracle(oracle, tag):
+    """TriPlaneMLP with n_layers != 2 / has_view_cond / widths outside the fused kernel's table (networks_epigraf.py:35-43): the oracle's lookup + the
+    n-layer decode against the reference's simple_tri_plane_renderer (tests/golden/mlp_variants.npz)."""
+    from oracle import pipeline
+    g, v = load_golden('mlp_variants'), MLP_VARIANTS[tag]
+    nl = v['n']
+    ws, bs = [g[f'{tag}_w{i}'] for i in range(nl)], [g[f'{tag}_b{i}'] for i in range(nl)]
+    # the lookup: orc_triplane_field's feature output (any 2-layer weights of the right width serve the call)
+    F = v['F']
+    feats = oracle.triplane_field(g[f'{tag}_planes'], g['coords'], np.zeros((16, F), np.float32), np.zeros(16, np.float32), np.zeros((4, 16), np.float32),
+                                  np.zeros(4, np.float32), 0.5, return_feats=True)['feats']
+    rgb, sigma = pipeline.triplane_decode(feats, ws, bs, v['marcher'])
+    assert_close(rgb, g[f'{tag}_rgb'], 2e-6, f'{tag} rgb', max(1.0, float(np.abs(g[f'{tag}_rgb']).max())))
+    assert_close(sigma, g[f'{tag}_sigma'], 2e-6, f'{tag} sigma', max(1.0, float(np.abs(g[f'{tag}_sigma']).max())))
+
+
+@pytest.mark.parametrize('tag', ['four', 'raw'])
+def test_mapping_camera_cond_oracle(oracle, tag):
+    """MappingNetwork(camera_cond=True) (layers.py:84-93,127-138): explicit angles (yaw beyond +-2 pi), the mean-camera stand-in, truncation."""
+    from oracle import pipeline
+    g = load_golden('mapping_cam')
+    sd = {'mapping.' + k.split('::', 1)[1]: v for k, v in g.items() if k.startswith(tag + '::')}
+    c_dim = g[f'{tag}_c'].shape[1]
+    cfg = dict(z_dim=16, c_dim=c_dim, w_dim=24, map_depth=2, camera_cond=True, camera_raw_scalars=(tag == 'raw'))
+    import oracle.pipeline as P
+    nws_was, P.num_ws = P.num_ws, (lambda cfg_: 5)
+    try:
+        ws = pipeline.mapping_forward(sd, cfg, g[f'{tag}_z'], g[f'{tag}_c'], camera_angles=g[f'{tag}_angles'])
+        ws_mean = pipeline.mapping_forward(sd, cfg, g[f'{tag}_z'], g[f'{tag}_c'])
+        ws_psi = pipeline.mapping_forward(sd, cfg, g[f'{tag}_z'], g[f'{tag}_c'], truncation_psi=0.6, camera_angles=g[f'{tag}_angles'])
+    finally:
+        P.num_ws = nws_was
+    for got, key in ((ws, 'ws'), (ws_mean, 'ws_mean'), (ws_psi, 'ws_psi06')):
+        assert_close(got, g[f'{tag}_{key}'], 1e-5, f'{tag} {key}', max(1.0, float(np.abs(g[f"{tag}_{key}"]).max())))

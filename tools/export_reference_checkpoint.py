@@ -33,12 +33,8 @@ def unsupported_options(c, fp16_blocks=(), conv_clamp=None):
     bad = []
     if checked['use_full_box'] or checked['ray_start_is_auto']:
         bad.append("use_full_box / ray_start='auto' (never resolved by the reference renderer either)")
-    if checked['mlp_n_layers'] != 2:
-        bad.append(f"tri_plane.mlp.n_layers={checked['mlp_n_layers']} (the field kernel is the 2-layer TriPlaneMLP)")
-    if checked['has_view_cond']:
-        bad.append('view-direction conditioning of the tri-plane MLP')
-    if checked['camera_cond']:
-        bad.append('camera_cond (camera-conditioned mapping network)')
+    # (round 6: tri_plane.mlp.n_layers != 2, has_view_cond and camera_cond are implemented -- the decoder's eager path / MappingNetwork(camera_cond) --
+    #  and exported as configuration fields below)
     if not checked['fp32_only'] and checked['num_fp16_res'] > 0:
         bad.append(f"fp32_only=false with num_fp16_res={checked['num_fp16_res']} (fp16 blocks + conv_clamp=256: the exported fp32 path has no clamp)")
     return checked, bad
@@ -57,7 +53,12 @@ def cfg_to_json(G):
         raise NotImplementedError('checkpoint uses generator options 3dgp_amd does not implement: ' + '; '.join(bad))
     out = dict(z_dim=int(G.z_dim), w_dim=int(G.w_dim), c_dim=int(G.c_dim), map_depth=int(get(c, 'map_depth', 2)), cbase=int(c.cbase), cmax=int(c.cmax),
                fmaps=float(get(c, 'fmaps', 1.0)), use_noise=bool(get(c, 'use_noise', True)), tri_plane_res=int(c.tri_plane.res), feat_dim=int(c.tri_plane.feat_dim),
-               mlp_hid=int(c.tri_plane.mlp.hid_dim), ray_marcher_type=str(c.ray_marcher_type), num_ray_steps=int(c.num_ray_steps),
+               mlp_hid=int(c.tri_plane.mlp.hid_dim), mlp_n_layers=int(get(c, 'tri_plane.mlp.n_layers', 2)), has_view_cond=bool(get(c, 'has_view_cond', False) or False),
+               camera_cond=getattr(G.mapping, 'camera_scalar_enc', None) is not None,
+               camera_raw_scalars=bool(getattr(getattr(G.mapping, 'camera_scalar_enc', None), 'use_raw', False)),
+               camera_cond_drop_p=float(getattr(G.mapping, 'camera_cond_drop_p', 0.0)),
+               mean_camera_params=None if getattr(G.mapping, 'mean_camera_params', None) is None else [float(v) for v in G.mapping.mean_camera_params.tolist()],
+               ray_marcher_type=str(c.ray_marcher_type), num_ray_steps=int(c.num_ray_steps),
                ray_start=float(c.camera.ray.start), ray_end=float(c.camera.ray.end), cube_scale=float(c.camera.cube_scale), use_inf_depth=bool(c.use_inf_depth),
                last_back=bool(get(c, 'dataset.last_back', False)), white_back=bool(get(c, 'dataset.white_back', False)), density_bias=float(get(c, 'density_bias', 0.0)),
                img_resolution=int(G.img_resolution), max_batch_res=int(get(c, 'max_batch_res', 128)), depth_adaptor=None, camera_adaptor=None)
