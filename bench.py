@@ -190,6 +190,52 @@ def with_host_competitors(n, fn):
             p_.wait()
 
 
+def with_real_siblings(n, batch, fn, timeout_s=120.0):
+    """Run fn() while `n` REAL sibling ranks -- separate Python processes, each with its own HIP context, allocator, streams and launch thread, running
+    C3 forwards of `batch` items on THIS GPU (tools/one_gpu_ranks.py load) -- are active: what the launch thread of one rank sees next to live siblings,
+    as far as one GPU can show it (the spinning dummies of with_host_competitors model busy cores only).  The siblings share the
+    device, so GPU times measured inside fn() are not this process's alone: only host-side figures are taken from it.  Children are started and ended
+    by PID; returns (fn's result or None, info)."""
+    import select
+    import subprocess
+    procs, info = [], dict(siblings=n, sibling_batch=batch)
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r + 1), WORLD_SIZE='1', HSA_ENABLE_IPC_MODE_LEGACY='0', TDGP_ONE_GPU_CONFIG=os.environ.get('TDGP_ONE_GPU_CONFIG', 'c3'))
+            env.pop('MASTER_PORT', None)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, 'tools', 'one_gpu_ranks.py'), 'load', str(batch)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                          text=True, env=env))
+        deadline = time.time() + timeout_s
+        for p_ in procs:                             # wait for every sibling's `ready`
+            ok = False
+            while time.time() < deadline and p_.poll() is None:
+                if select.select([p_.stdout], [], [], 1.0)[0]:
+                    if 'ready' in p_.stdout.readline():
+                        ok = True
+                        break
+            if not ok:
+                info['error'] = 'a sibling did not come up'
+                return None, info
+        time.sleep(0.5)
+        t0 = time.time()
+        out = fn()
+        info['measured_for_s'] = round(time.time() - t0, 2)
+        info['siblings_alive'] = sum(p_.poll() is None for p_ in procs)
+        return out, info
+    except Exception as e:                            # noqa: BLE001  (a probe must never take the bench line down)
+        info['error'] = repr(e)[:200]
+        return None, info
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+        for p_ in procs:
+            try:
+                p_.wait(timeout=30)
+            except Exception:                         # noqa: BLE001
+                pass
+
+
 def parity_statement(config):
     """What `-m gpu` asserts for this configuration and the figures the last committed GPU test run met (profiles/parity_latest.json =
     gpurun_out/parity_report.json of that run; tests/conftest.py:assert_image_parity defines every figure)."""
@@ -303,6 +349,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cmax', type=int, default=0, help='override the backbone width (cbase = 64 x cmax): `--config c5 --cmax 1024` is the bf16 configuration as BASELINE.md section 3 sizes it')
     ap.add_argument('--no-host-probe', action='store_true', help='skip the host-side launch-cost probe (host_launch_ms / launch_bound_margin)')
+    ap.add_argument('--no-real-siblings', action='store_true', help='host probe without the 3 real sibling processes on the same GPU (host_launch.batch_4.*_real_siblings)')
     ap.add_argument('--depth-adaptor', action='store_true', help='also run the DepthAdaptor inside G.forward (SURVEY 8f rank 1; off = the 8a hot path)')
     ap.add_argument('--profile-steps', type=int, default=3)
     ap.add_argument('--chunk', type=int, default=-1, help='samples per pass through the high-resolution blocks + renderer (Infinity-Cache-sized working set); '
@@ -459,6 +506,15 @@ def main():
             w48, _ = with_host_competitors(7, lambda: host_launch_probe(e4))
             host_probe['batch_4'] = dict(host_launch_ms=round(w4, 3), gpu_step_ms=round(g4, 3), launch_bound_margin=round(g4 / max(w4, 1e-6), 2),
                                          host_launch_ms_7_competitors=round(w48, 3), launch_bound_margin_7_competitors=round(g4 / max(w48, 1e-6), 2))
+            if not args.no_real_siblings:
+                # next to 3 REAL sibling ranks on this very GPU (own HIP contexts, allocators, launch threads; C3 forwards at the reference's FID batch of 4):
+                # only the HOST figure is meaningful -- the device is shared
+                r4, sib = with_real_siblings(3, 4, lambda: host_launch_probe(e4, steps=6))
+                if r4 is not None:
+                    host_probe['batch_4'].update(host_launch_ms_3_real_siblings=round(r4[0], 3), host_cpu_ms_3_real_siblings=round(r4[1], 3),
+                                                 launch_bound_margin_3_real_siblings=round(g4 / max(r4[0], 1e-6), 2))
+                host_probe['real_siblings'] = dict(sib, note='3 sibling processes (tools/one_gpu_ranks.py load) with their own HIP contexts running C3 forwards of 4 items on the same '
+                                                   'GPU while this process enqueues its batch-4 forwards; margin = this process\'s un-shared GPU step time / that enqueue time')
             del xb4, e4
         else:
             # every rank must take the same launch mode: the smallest margin over the ranks decides
