@@ -129,13 +129,17 @@ def check_wino4_kernel(body):
     # 2. the pair form's K loop
     waits = [k for k, (_, c) in enumerate(code) if re.match(r'^s_waitcnt vmcnt\(4\)$', c)]
     summary = dict(m0_writes=m0_writes, pair_loops=len(waits))
+    k_loops = 0
     for w in waits:
         lab = next((code[k][1][:-1] for k in range(w, -1, -1) if code[k][1].endswith(':')), None)
         back = [k for k in range(w, len(code)) if re.match(r'^s_c?branch\w* ' + re.escape(lab or '?') + '$', code[k][1])]
         if lab is None or not back:
-            raise IsaListingError('conv3_wino4_kernel: the block of `s_waitcnt vmcnt(4)` is not the latch of a loop in this listing')
+            continue                                # (a compiler-placed vmcnt(4) in straight-line code -- e.g. the output stage's noise loads: not the K loop)
         k0 = next(k for k in range(w, -1, -1) if code[k][1] == lab + ':')
         loop = [c for _, c in code[k0:back[-1] + 1] if not c.endswith(':')]
+        if not any(c.startswith('v_mfma') for c in loop):
+            continue                                # a loop without matrix instructions is not the K loop either
+        k_loops += 1
         vmem = [c for c in loop if re.match(r'^(buffer_|global_|flat_|scratch_)', c)]
         notlds = [c for c in vmem if not (c.startswith('buffer_load_dwordx4') and c.endswith(' lds'))]
         for c in notlds:
@@ -149,6 +153,7 @@ def check_wino4_kernel(body):
         if vwaits != ['s_waitcnt vmcnt(4)']:
             bad.append(('the K loop must hold exactly one vector-memory wait, the hand-written vmcnt(4)', ' | '.join(vwaits)))
         summary.update(loop_instructions=len(loop), lds_direct_sites=len(vmem) - len(notlds), mfma=sum(c.startswith('v_mfma') for c in loop))
+    summary['pair_loops'] = k_loops
     return summary, bad
 
 
