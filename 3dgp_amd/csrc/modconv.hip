@@ -2763,6 +2763,7 @@ TDGP_API int tdgp_modconv2d(const float* x, const void* wpack, const float* styl
                 Wino4fParams q;
                 q.x = x; q.styles = styles; q.u = wp + pi.wp_floats + pi.wsq_floats + pi.wsplit_floats + pi.wbf_floats + pi.wino_floats; q.e = e;
                 q.B = B; q.Cin = Cin; q.Cout = Cout; q.H = H; q.W = W; q.u_bytes = (uint32_t)(pi.wino4_floats * 4); q.x_bytes = c.x_bytes; q.st_bytes = c.st_bytes;
+                q.nz_bytes = noise ? (uint32_t)(((noise_bstride ? (int64_t)(B - 1) * noise_bstride : 0) + (int64_t)H * W) * 4) : 0u;
                 q.gxn = W / 64; q.gyn = H / 8; q.rs = rs; q.rt = per / rs; q.nxcd = nxcd; q.ticket = ticket;
                 const size_t lds = (size_t)W4F_LDS_FLOATS * 4;
                 TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)conv3_wino4f_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds););
