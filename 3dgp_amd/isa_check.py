@@ -168,3 +168,103 @@ def check_wino4_asm(asm_text):
         end = next((j for j in range(i, len(lines)) if lines[j].strip().startswith('.amdhsa_kernel')), len(lines))
         out[m.group(1)] = check_wino4_kernel(lines[i:end])
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# conv3_wino4f_kernel (csrc/modconv_wino4f.inc, round 6): EVERY vector-memory read of the item loop is hand-issued -- U pieces, window rows, halo quads,
+# styles and noise patch as LDS-direct loads, the ticket as a returning atomic whose result register is only read after the K loop --, and the only waits are
+# the hand-written `s_waitcnt vmcnt(0)` (item top, chunk ends).  The compiler's own wait counts do not know any of them, so the properties are checked here:
+#   1. m0 only by `s_mov_b32 m0, <sgpr>` + `s_nop 0` + an LDS-direct buffer load (dwordx4 or dword);
+#   2. no scratch access anywhere (a spill reload is a vector-memory load + `vmcnt(0)`: it would wait for the requests in flight);
+#   3. the K loop (the loop holding the 144 MFMAs): its vector-memory instructions are LDS-direct loads only, its vector-memory waits `vmcnt(0)` only;
+#   4. the destination of a `global_atomic_add` is not read before the next `s_waitcnt vmcnt(0)`;
+#   5. from the K loop's last MFMA to the item-end barrier the only vector-memory loads are LDS-direct ones and the only `vmcnt` waits those that follow an
+#      atomic (the ticket retry path) -- the output stage waits for nothing the next item requested.
+# ------------------------------------------------------------------------------------------------------------------------------------
+def check_wino4f_kernel(body):
+    code = [(i, ln.split(';')[0].strip()) for i, ln in enumerate(body)]
+    code = [c for _, c in code if c and (not c.startswith('.') or re.match(r'^\.LBB\d+_\d+:', c))]
+    ins = [c for c in code if not c.endswith(':')]
+    bad = []
+    lds_direct = lambda c: re.match(r'^buffer_load_dword(x4)? ', c) and c.endswith(' lds')      # noqa: E731
+    m0_writes = 0
+    for k, c in enumerate(ins):
+        if not re.search(r'\bm0\b', c):
+            continue
+        if not re.match(r'^s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi|ttmp\d+)$', c):
+            bad.append(('m0 is touched by an instruction other than the hand-written `s_mov_b32 m0, <sgpr>`', c))
+            continue
+        m0_writes += 1
+        nxt = ins[k + 1:k + 3]
+        if len(nxt) < 2 or nxt[0] != 's_nop 0' or not lds_direct(nxt[1]):
+            bad.append(('`s_mov_b32 m0` is not followed by `s_nop 0` + an LDS-direct buffer load', c + ' | ' + ' | '.join(nxt)))
+    for c in ins:
+        if c.startswith('scratch_'):
+            bad.append(('scratch access (a spill: its reload waits with vmcnt(0) for every LDS-direct load in flight)', c))
+            break
+    mf = [k for k, c in enumerate(code) if c.startswith('v_mfma')]
+    if len(mf) != 144:
+        raise IsaListingError(f'conv3_wino4f_kernel: expected 144 MFMAs (4 chunks x 36), found {len(mf)}')
+    # the K loop: the nearest label in front of the first MFMA that a branch behind the last MFMA jumps back to
+    k0 = back = None
+    for k in range(mf[0], -1, -1):
+        if code[k].endswith(':'):
+            bk = [j for j in range(mf[-1], len(code)) if re.match(r'^s_c?branch\w* ' + re.escape(code[k][:-1]) + '$', code[j])]
+            if bk:
+                k0, back = k, bk[0]
+                break
+    if k0 is None:
+        raise IsaListingError('conv3_wino4f_kernel: K loop not found (no back edge behind the last MFMA to a label in front of the first)')
+    loop = [c for c in code[k0:back + 1] if not c.endswith(':')]
+    vmem = [c for c in loop if re.match(r'^(buffer_|global_|flat_|scratch_)', c)]
+    for c in vmem:
+        if not lds_direct(c):
+            bad.append(('a vector-memory instruction other than an LDS-direct load inside the K loop', c))
+    for c in loop:
+        if c.startswith('s_waitcnt') and 'vmcnt' in c and c != 's_waitcnt vmcnt(0)':
+            bad.append(('a vector-memory wait other than the hand-written vmcnt(0) inside the K loop', c))
+    # 4. atomics
+    atomics = 0
+    for k, c in enumerate(ins):
+        m = re.match(r'^global_atomic_add (v\d+),', c)
+        if not m:
+            continue
+        atomics += 1
+        for c2 in ins[k + 1:]:
+            if c2 == 's_waitcnt vmcnt(0)':
+                break
+            if re.search(r'\b' + m.group(1) + r'\b', c2):
+                bad.append((f'{m.group(1)}, the destination of a returning atomic, is touched before the next vmcnt(0)', c2))
+                break
+    # 5. behind the K loop, up to the item loop's closing branch.  Not scanned: the block a branch IN FRONT of the K loop jumps to behind it -- the
+    #    zero-chunk path around the loop (never taken: Cin >= 16), where the compiler may wait for the bias load it placed in front of the loop
+    item_back = next((k for k in range(len(code) - 1, back, -1) if re.match(r'^s_c?branch\w* \.LBB\d+_\d+$', code[k])), len(code) - 1)
+    around = {code[k].split()[-1] for k in range(k0) if re.match(r'^s_c?branch\w* \.LBB\d+_\d+$', code[k])}
+    tail, skip = [], False
+    for c in code[back + 1:item_back]:
+        if c.endswith(':'):
+            skip = c[:-1] in around
+            continue
+        if not skip:
+            tail.append(c)
+    for k, c in enumerate(tail):
+        if re.match(r'^(buffer_load|global_load|flat_load)', c) and not lds_direct(c):
+            bad.append(('a vector-memory load of the compiler\'s behind the K loop (its wait would also wait for the next item\'s requests)', c))
+        if c.startswith('s_waitcnt') and 'vmcnt' in c:
+            prev = tail[max(0, k - 4):k]
+            if not any(x.startswith('global_atomic_add') for x in prev):
+                bad.append(('a vector-memory wait behind the K loop that does not belong to the ticket retry path', c))
+    return dict(m0_writes=m0_writes, mfma=len(mf), loop_instructions=len(loop), lds_direct_sites=len(vmem), atomics=atomics, stores_behind_loop=sum(c.startswith('global_store') for c in tail)), bad
+
+
+def check_wino4f_asm(asm_text):
+    """conv3_wino4f_kernel in a modconv.hip assembly listing.  -> {mangled name: (summary, violations)}"""
+    lines = asm_text.splitlines()
+    out = {}
+    for i, ln in enumerate(lines):
+        m = re.match(r'^(_Z\S*conv3_wino4f_kernel\S*):', ln)
+        if not m:
+            continue
+        end = next((j for j in range(i, len(lines)) if lines[j].strip().startswith('.amdhsa_kernel')), len(lines))
+        out[m.group(1)] = check_wino4f_kernel(lines[i:end])
+    return out

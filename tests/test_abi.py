@@ -146,9 +146,15 @@ def test_wino4_isa_check_runs_in_the_build(tdgp):
     asm = os.path.join(build.CSRC, 'build', 'modconv.s')
     if not os.path.exists(asm):
         subprocess.check_call([build._hipcc()] + build.FLAGS + ['-S', '--cuda-device-only', '-o', asm, os.path.join(build.CSRC, 'modconv.hip')], stderr=subprocess.DEVNULL)
-    res = build.verify_modconv_isa(asm)
+    res_all = build.verify_modconv_isa(asm)
+    res = {k: v for k, v in res_all.items() if 'wino4f' not in k}
     assert len(res) == 2 and all(not bad for _, bad in res.values())
     assert all(s['lds_direct_sites'] == 8 and s['mfma'] == 36 and s['m0_writes'] > 0 for s, _ in res.values())
+    # conv3_wino4f_kernel (round 6): every vector-memory read of its item loop is hand-issued; no spill, nothing of the compiler's to wait for behind the K loop
+    resf = {k: v for k, v in res_all.items() if 'wino4f' in k}
+    assert len(resf) == 1 and all(not bad for _, bad in resf.values())
+    sf = next(iter(resf.values()))[0]
+    assert sf['mfma'] == 144 and sf['lds_direct_sites'] >= 40 and sf['atomics'] >= 2 and sf['stores_behind_loop'] >= 16, sf
     lines = open(asm).read().splitlines()
     i0 = next(i for i, ln in enumerate(lines) if re.match(r'^_ZN\S*conv3_wino4_kernelILb1ELb1E\S*:', ln))
     i1 = next(j for j in range(i0, len(lines)) if lines[j].strip().startswith('.amdhsa_kernel'))
@@ -165,6 +171,22 @@ def test_wino4_isa_check_runs_in_the_build(tdgp):
     b3 = [ln for i, ln in enumerate(body) if not (i > w and ' lds' in ln and i < w + 120)]      # drop the first LDS-direct sites of the loop
     _, bad = isa.check_wino4_kernel(b3)
     assert bad
+    # the fused kernel: a spill reload, a compiler-side load behind the K loop, a touched atomic destination are each caught
+    f0 = next(i for i, ln in enumerate(lines) if re.match(r'^_Z\S*conv3_wino4f_kernel\S*:', ln))
+    f1 = next(j for j in range(f0, len(lines)) if lines[j].strip().startswith('.amdhsa_kernel'))
+    fbody = lines[f0:f1]
+    last_mfma = max(i for i, ln in enumerate(fbody) if 'v_mfma' in ln)
+    first_store = next(i for i in range(last_mfma, len(fbody)) if 'global_store_dwordx4' in fbody[i])
+    at = next(i for i, ln in enumerate(fbody) if re.search(r'global_atomic_add v\d+, v\d+, v\d+, s\[', ln) and 's_waitcnt vmcnt(0)' not in ''.join(fbody[i:i + 6]))
+    dst = re.search(r'global_atomic_add (v\d+),', fbody[at]).group(1)
+    for pos, inject, needle in ((first_store, '\tscratch_load_dword v1, off, off offset:4', 'scratch access'),
+                                (first_store, '\tglobal_load_dword v1, v[2:3], off', 'behind the K loop'),
+                                (first_store, '\ts_waitcnt vmcnt(2)', 'wait behind the K loop'),
+                                (at + 1, f'\tv_mov_b32_e32 v1, {dst}', 'destination of a returning atomic')):
+        b2 = list(fbody)
+        b2.insert(pos, inject)
+        _, bad = isa.check_wino4f_kernel(b2)
+        assert bad and any(needle in why for why, _ in bad), (inject, bad[:2])
     # a listing without loop annotations is reported as unreadable, not as an IndexError
     with pytest.raises(isa.IsaListingError):
         isa.check_kernel(['_Zfoo:', '\ts_endpgm'], 8)

@@ -21,10 +21,11 @@ for (Ci, Co, R, b) in [(64, 64, 512, 16), (128, 128, 256, 16)]:
     for _ in range(3):
         y = M.modconv_forward(x, pk, s, noise=nz, bias=bias, act='lrelu')
     torch.cuda.synchronize()
-    t = y.flatten()[:256 * 8].view(torch.int32).reshape(256, 8).cpu().double()
-    items = t[:, 5]
-    names = ['prologue (wait, transform, 2 barriers)', 'K loop', 'ticket + begin_item', 'output stage', 'item-end barrier']
-    tot = t[:, :5].sum(1)
+    t = y.flatten()[:256 * 16].view(torch.int32).reshape(256, 16).cpu().double()
+    items = t[:, 11]
+    names = ['prologue: 2nd barrier', 'K loop', 'begin_item', 'output stage', 'item-end barrier', 'prologue: ticket draw, bias / demod loads', 'prologue: wait for the requests',
+             'prologue: 1st barrier', 'prologue: transform', 'ticket hand-over (2 barriers) + its arithmetic']
+    tot = t[:, :10].sum(1)
     print(f'Cin={Ci} Cout={Co} R={R} B={b}: items/block {items.min():.0f}..{items.max():.0f}, cycles/block {tot.mean():.0f} (s_memtime ticks)')
     for i, n in enumerate(names):
         print(f'   {n:42s} {t[:, i].sum() / items.sum():9.0f} ticks/item  {100 * t[:, i].sum() / tot.sum():5.1f} %')
