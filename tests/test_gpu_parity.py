@@ -430,6 +430,7 @@ def test_modconv_winograd4_sub_batches(tdgp, oracle):
     (16, 64, 64, 64, dict(clamp=0.9, noise='per_sample')),   # the fewest channels; clamp; one noise map per sample
     (4, 512, 256, 64, {}),                                   # the longest reduction (C3's 64^2 -> 128^2 layer, C4's at half the channels)
     (32, 132, 70, 32, dict(noise=False)),                    # 33 chunks, Cout' = 280 (a ragged last slice), 32-pixel-wide tile groups, no noise; 320 items
+    (43, 64, 64, 24, dict(W=64, noise='per_sample')),        # 129 tile groups: the last PAIR has one group only -- its second half parks (round 6: noise rows in the free V stage) and stores nothing; H != W
 ])
 def test_modconv_up2_folded_vs_oracle(tdgp, oracle, B, cin, cout, H, kw):
     """The x2 layers with the FIR folded into four 3x3 parity kernels on the Winograd F(4x4) path (ops/modconv.py: fold_up2_table,
@@ -437,14 +438,15 @@ def test_modconv_up2_folded_vs_oracle(tdgp, oracle, B, cin, cout, H, kw):
     convolution + FIR kernels on the same call.  Bound: 1e-5 of the un-clamped output range, as for every reduction row."""
     rs = np.random.RandomState(cin * 5 + cout)
     mc = tdgp.ops.modconv
-    x = rs.randn(B, cin, H, H).astype(np.float32)
+    W = kw.get('W', H)
+    x = rs.randn(B, cin, H, W).astype(np.float32)
     x = np.where(x > 0, x, 0.2 * x).astype(np.float32) * np.float32(np.sqrt(2))
     w = rs.randn(cout, cin, 3, 3).astype(np.float32)
     s = (1 + 0.5 * rs.randn(B, cin)).astype(np.float32)
     bias = (0.2 * rs.randn(cout)).astype(np.float32)
-    noise = (0.3 * rs.randn(2 * H, 2 * H)).astype(np.float32) if kw.get('noise', True) else None
+    noise = (0.3 * rs.randn(2 * H, 2 * W)).astype(np.float32) if kw.get('noise', True) else None
     if kw.get('noise') == 'per_sample':
-        noise = (0.3 * rs.randn(B, 1, 2 * H, 2 * H)).astype(np.float32)
+        noise = (0.3 * rs.randn(B, 1, 2 * H, 2 * W)).astype(np.float32)
     clamp = kw.get('clamp')
     f = oracle.setup_filter([1, 3, 3, 1])
     oracle.set_threads(min(64, os.cpu_count() or 1))
