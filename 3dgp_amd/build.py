@@ -79,6 +79,7 @@ def verify_modconv_isa(asm_path):
     """isa_check.check_wino4_asm + check_wino4f_asm over the assembly of modconv.hip (hand-issued LDS-direct loads of conv3_wino4_kernel and conv3_wino4f_kernel)."""
     res = dict(_verify_isa(asm_path, 'conv3_wino4_kernel', 'check_wino4_asm'))
     res.update(_verify_isa(asm_path, 'conv3_wino4f_kernel', 'check_wino4f_asm'))
+    res.update(_verify_isa(asm_path, 'torgb_mfma_kernel (FAST)', 'check_torgb_asm'))
     return res
 
 

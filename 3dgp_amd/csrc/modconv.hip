@@ -117,6 +117,24 @@ __device__ __forceinline__ SkipTaps skip_taps(int h2, int w2, int oy, int ox, co
     t.w11 = (vr1 && vc1) ? fir[(ky0 + 2) * 4 + kx0 + 2] : 0.f;
     return t;
 }
+// The same taps with the FIR weights picked by SELECTS among 16 values held in scalar registers (a plain struct of named floats, each made opaque by the caller:
+// `fir[ky0 * 4 + kx0 ..]` with per-lane parities is a vector-memory load per weight -- and so is any select the compiler can fold back into an indexed load --, which a
+// pipeline of hand-counted waits cannot hold: rgb_output_skip_pipelined).
+struct FirRegs { float f0, f1, f2, f3, f4, f5, f6, f7, f8, f9, f10, f11, f12, f13, f14, f15; };
+__device__ __forceinline__ SkipTaps skip_taps_sel(int h2, int w2, int oy, int ox, const FirRegs& r) {
+    SkipTaps t;
+    const int r0 = (oy - 1) >> 1, c0 = (ox - 1) >> 1;
+    const bool ky = oy & 1, kx = ox & 1;
+    const bool vr0 = r0 >= 0, vr1 = r0 + 1 < h2, vc0 = c0 >= 0, vc1 = c0 + 1 < w2;
+    const int ra = vr0 ? r0 : 0, rb = vr1 ? r0 + 1 : h2 - 1, ca = vc0 ? c0 : 0, cb = vc1 ? c0 + 1 : w2 - 1;
+    t.i00 = ra * w2 + ca; t.i01 = ra * w2 + cb; t.i10 = rb * w2 + ca; t.i11 = rb * w2 + cb;
+    auto pick = [&](float a, float b, float c, float d) { return ky ? (kx ? d : c) : (kx ? b : a); };      // fir[base], [base + 1], [base + 4], [base + 5]
+    t.w00 = (vr0 && vc0) ? pick(r.f0, r.f1, r.f4, r.f5) : 0.f;
+    t.w01 = (vr0 && vc1) ? pick(r.f2, r.f3, r.f6, r.f7) : 0.f;
+    t.w10 = (vr1 && vc0) ? pick(r.f8, r.f9, r.f12, r.f13) : 0.f;
+    t.w11 = (vr1 && vc1) ? pick(r.f10, r.f11, r.f14, r.f15) : 0.f;
+    return t;
+}
 __device__ __forceinline__ float skip_eval(const float* __restrict__ img, const SkipTaps& t, int stride) {
     const float a = img[(int64_t)t.i00 * stride], b = img[(int64_t)t.i01 * stride], c = img[(int64_t)t.i10 * stride], d = img[(int64_t)t.i11 * stride];
     return fmaf_(t.w11, d, fmaf_(t.w10, c, fmaf_(t.w01, b, t.w00 * a)));
@@ -1811,6 +1829,123 @@ __device__ __forceinline__ void rgb_output_tile(const EpiParams& e, const float*
   }
 }
 
+// The skip form of the stage above as a PIPELINE over the MT channel tiles x 2 half tiles (round 6).  On this ISA stores count in vmcnt and complete
+// out of order with loads, so a batch of tap loads issued BEHIND the previous batch's stores is answered with a wait that also waits for those stores to be
+// acknowledged: the stage ran as MT x (tap round trip + store round trip), 24 k cycles per 128-pixel tile against 6 k of multiply (and twice as many, smaller
+// batches were 13 % slower still: round 3).  Here a batch is ONE pass (4 tap loads, one store) and the loads of batches b + 1, b + 2 are issued BEFORE batch b's
+// store -- three register sets of 4 taps, 48 registers where the 4-pass form held 64 --, so the wait for a batch never has a store to wait for and every tap round
+// trip but the first runs under two batches of arithmetic and stores.  Same taps, same fma chains, same bits.
+typedef float rgb_f32x4 __attribute__((ext_vector_type(4)));
+template <int MT, bool PLAIN>
+__device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, const float* __restrict__ bias_lds, float* ct, f32x16 (&acc)[MT], int64_t pix0, int64_t P, int lw, int lhw) {
+    const int l = lane_id(), cg = l & 7, pr = l >> 3, l32 = l & 31, half = l >> 5;
+    const int planes = e.Cout / e.out_feat, h2 = e.Hout / 2, w2 = e.Wout / 2;
+    const float lim = e.clamp >= 0.f ? e.clamp : __builtin_inff();
+    // The tap loads are issued BY HAND (as the field kernel's): written as C++ loads the compiler answered the loop-carried register set with `vmcnt(0)` in front of
+    // every use (ISA of the first build) -- its wait counts cannot see across the back edge what is still in flight.  The waits are hand-counted: when batch b is
+    // finished the wave has, in issue order, the 8 loads of b, the 2 stores of b - 1, the 8 loads of b + 1 in flight; loads complete in order among themselves, stores
+    // at any time, so `vmcnt(8)` -- at most the 8 loads of b + 1 left -- guarantees b's taps (if the two stores are slow it also waits for two loads of b + 1; it never
+    // waits for a store to be acknowledged when the loads are there).  The last batch has nothing behind it: `vmcnt(0)`.
+    // the FIR taps as 16 scalar registers: left in memory the compiler folds the parity selects back into one indexed load per weight
+    FirRegs fr = {e.fir[0], e.fir[1], e.fir[2], e.fir[3], e.fir[4], e.fir[5], e.fir[6], e.fir[7], e.fir[8], e.fir[9], e.fir[10], e.fir[11], e.fir[12], e.fir[13], e.fir[14], e.fir[15]};
+    asm volatile("" : "+s"(fr.f0), "+s"(fr.f1), "+s"(fr.f2), "+s"(fr.f3), "+s"(fr.f4), "+s"(fr.f5), "+s"(fr.f6), "+s"(fr.f7));
+    asm volatile("" : "+s"(fr.f8), "+s"(fr.f9), "+s"(fr.f10), "+s"(fr.f11), "+s"(fr.f12), "+s"(fr.f13), "+s"(fr.f14), "+s"(fr.f15));
+    constexpr int NSET = 3, NB = 4 * MT;            // a batch = one pass (8 pixels x 32 channels per wave): 4 tap loads, one store; three register sets = two batches of look-ahead
+    rgb_f32x4 tA[NSET][4];
+    // (pixel geometry, tap indices and weights are RECOMPUTED where the batch is finished -- two dozen scalar-ish vector instructions per pass -- instead of
+    //  carried beside the taps: registers the kernel does not have)
+    struct Geo { int addr; bool ok; SkipTaps tp; const float* sp; };
+    auto geo = [&](int tile, int pass) {
+        Geo g;
+        const int o = tile * 32 + 4 * cg;
+        const bool okc = o < e.Cout;
+        const int oc = okc ? o : 0;
+        const int pl = oc / e.out_feat, f = oc - pl * e.out_feat;
+        const int px = pass * 8 + pr;
+        const int pix = (int)pix0 + 4 * px;                                      // B*H*W < 2^31 - 512 (host check)
+        const bool ok = pix < (int)P;
+        const int pc = ok ? pix : 0;
+        const int b = pc >> lhw, inner = pc & ((1 << lhw) - 1), oy = inner >> lw, ox = inner & ((1 << lw) - 1);
+        g.ok = ok && okc;
+        const int plane = b * planes + pl;
+        g.addr = ((plane * e.Hout + oy) * e.Wout + ox) * e.out_feat + f;
+        g.tp = skip_taps_sel(h2, w2, oy, ox, fr);
+        g.sp = e.skip + (int64_t)plane * h2 * w2 * e.out_feat + f;
+        return g;
+    };
+    auto ld = [&](rgb_f32x4& dst, const float* ptr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory"); };
+    auto issue = [&](int bi) {
+        const Geo g = geo(bi >> 2, bi & 3);
+        rgb_f32x4 (&t)[4] = tA[bi % NSET];
+        ld(t[0], g.sp + (int64_t)g.tp.i00 * e.out_feat); ld(t[1], g.sp + (int64_t)g.tp.i01 * e.out_feat);
+        ld(t[2], g.sp + (int64_t)g.tp.i10 * e.out_feat); ld(t[3], g.sp + (int64_t)g.tp.i11 * e.out_feat);
+    };
+    auto finish = [&](int bi) {
+        const int tile = bi >> 2, pass = bi & 3;
+        const int o = tile * 32 + 4 * cg;
+        const int oc = o < e.Cout ? o : 0;
+        const float4 bias4 = *(const float4*)(bias_lds + oc);
+        const rgb_f32x2 b01 = {bias4.x, bias4.y}, b23 = {bias4.z, bias4.w};
+        int tl = tile, ps = pass;
+        asm volatile("" : "+s"(tl), "+s"(ps));                                   // (opaque: the geometry is recomputed here, not kept from issue())
+        const Geo g = geo(tl, ps);
+        const float4 c4 = *(const float4*)&ct[(pass * 8 + pr) * CT_LD + 4 * cg];
+        // in flight, in issue order: this batch's 4 loads, <= 2 stores, the 4 + 4 loads of the two batches ahead (fewer at the end)
+        if (bi + 2 < NB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (bi + 1 < NB) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        rgb_f32x2 r01, r23;
+        if (!PLAIN) {                               // conv -> (bf16) -> + bias -> * gain -> clamp -> (bf16), then the skip (networks_stylegan2.py:170-171, 265-269)
+            float qv[4] = {c4.x, c4.y, c4.z, c4.w};
+            const float bq[4] = {bias4.x, bias4.y, bias4.z, bias4.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float t = qv[i];
+                if (e.round_bf16) t = (float)(__bf16)t;
+                t = (t + (e.round_bf16 ? (float)(__bf16)bq[i] : bq[i])) * e.gain;
+                t = t < -lim ? -lim : (t > lim ? lim : t);
+                qv[i] = e.round_bf16 ? (float)(__bf16)t : t;
+            }
+            r01 = (rgb_f32x2){qv[0], qv[1]}; r23 = (rgb_f32x2){qv[2], qv[3]};
+        } else {
+            r01 = (rgb_f32x2){c4.x, c4.y} + b01; r23 = (rgb_f32x2){c4.z, c4.w} + b23;
+        }
+        const SkipTaps& tp = g.tp;
+        const rgb_f32x2 w00 = {tp.w00, tp.w00}, w01 = {tp.w01, tp.w01}, w10 = {tp.w10, tp.w10}, w11 = {tp.w11, tp.w11};
+        const rgb_f32x4 ta = tA[bi % NSET][0], tb = tA[bi % NSET][1], tc = tA[bi % NSET][2], td = tA[bi % NSET][3];
+        const rgb_f32x2 a01 = {ta[0], ta[1]}, a23 = {ta[2], ta[3]}, bb01 = {tb[0], tb[1]}, bb23 = {tb[2], tb[3]};
+        const rgb_f32x2 cc01 = {tc[0], tc[1]}, cc23 = {tc[2], tc[3]}, d01 = {td[0], td[1]}, d23 = {td[2], td[3]};
+        r01 = r01 + __builtin_elementwise_fma(w11, d01, __builtin_elementwise_fma(w10, cc01, __builtin_elementwise_fma(w01, bb01, w00 * a01)));
+        r23 = r23 + __builtin_elementwise_fma(w11, d23, __builtin_elementwise_fma(w10, cc23, __builtin_elementwise_fma(w01, bb23, w00 * a23)));
+        if (g.ok) *(float4*)(e.y + g.addr) = make_float4(r01.x, r01.y, r23.x, r23.y);
+    };
+    issue(0);
+    issue(1);
+#pragma unroll
+    for (int bi = 0; bi < NB; bi++) {
+        if ((bi & 3) == 0) {
+            // this channel tile's accumulators -> the wave's pixel-major LDS tile (wave-private: a wave barrier orders it against the previous tile's reads)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int k = bi >> 2;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                *(float4*)&ct[l32 * CT_LD + 8 * r4 + 4 * half] = make_float4(acc[k][4 * r4], acc[k][4 * r4 + 1], acc[k][4 * r4 + 2], acc[k][4 * r4 + 3]);
+                acc[k][4 * r4] = 0.f; acc[k][4 * r4 + 1] = 0.f; acc[k][4 * r4 + 2] = 0.f; acc[k][4 * r4 + 3] = 0.f;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);          // (nothing of one batch moves into another: hoisted address arithmetic of later batches is what spilled the first build)
+        if (bi + 2 < NB) issue(bi + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(bi);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---- ToRGB: 1x1 modulated conv without demodulation, Cout <= 96, channel-last plane output with the fused x2 skip ---------
 // (networks_stylegan2.py:252-273).  12 kFLOP against 736 B per pixel at 64 channels: the layer sits on the ridge between the
 // matrix cores and HBM, so the kernel is built to keep both busy -- one block = 128 consecutive pixels (1x1: no halo, tiles
@@ -2021,6 +2156,12 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
             }
         }
         const int64_t pix0 = t * BN + wv;
+#ifndef TDGP_RGB_PIPELINED
+#define TDGP_RGB_PIPELINED 1           // 0: the stage per channel tile (rounds 2-6; A/B builds, same bits)
+#endif
+        if (TDGP_RGB_PIPELINED && FAST && has_skip) {
+            rgb_output_skip_pipelined<MT, true>(p.e, side, ct, acc, pix0, p.P, p.lw, p.lhw);
+        } else
 #pragma unroll 1
         for (int tile = 0; tile < MT; tile++) {
 #pragma unroll
@@ -2036,8 +2177,12 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             constexpr int G = 4;
-            if (has_skip) rgb_output_tile<true, FAST, !LANE_GEOM, G>(p.e, side, ct, tile * 32, pb, poy, pox, pok, pix0, p.P, p.lw, p.lhw);
-            else rgb_output_tile<false, FAST, !LANE_GEOM, G>(p.e, side, ct, tile * 32, pb, poy, pox, pok, pix0, p.P, p.lw, p.lhw);
+            if constexpr (!(TDGP_RGB_PIPELINED && FAST)) {
+                if (has_skip) rgb_output_tile<true, FAST, !LANE_GEOM, G>(p.e, side, ct, tile * 32, pb, poy, pox, pok, pix0, p.P, p.lw, p.lhw);
+                else rgb_output_tile<false, FAST, !LANE_GEOM, G>(p.e, side, ct, tile * 32, pb, poy, pox, pok, pix0, p.P, p.lw, p.lhw);
+            } else {
+                rgb_output_tile<false, FAST, !LANE_GEOM, G>(p.e, side, ct, tile * 32, pb, poy, pox, pok, pix0, p.P, p.lw, p.lhw);      // (FAST with a skip took the pipelined stage)
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }

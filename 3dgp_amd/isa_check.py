@@ -268,3 +268,83 @@ def check_wino4f_asm(asm_text):
         end = next((j for j in range(i, len(lines)) if lines[j].strip().startswith('.amdhsa_kernel')), len(lines))
         out[m.group(1)] = check_wino4f_kernel(lines[i:end])
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# torgb_mfma_kernel<.., FAST = true> (csrc/modconv.hip: rgb_output_skip_pipelined, round 6): the skip taps are hand-issued `global_load_dwordx4` in batches of 4
+# with two batches of look-ahead, the waits hand-counted `vmcnt(8)` (.. `vmcnt(4)`, `vmcnt(0)` for the last two batches): the count holds only if, in program
+# order, every batch is exactly 4 tap loads + at most one store and NOTHING else of vector memory stands between two of those waits (a compiler-side load -- e.g.
+# the FIR weight fetched by a per-lane index -- would be counted by the hardware and not by the hand).  Checked per kernel:
+#   the waits `vmcnt(8)` form one run of 4 MT - 2, followed by one `vmcnt(4)` and one `vmcnt(0)`; between two consecutive waits of the run: 4 `global_load_dwordx4`,
+#   1 `global_store_dwordx4`, no other buffer_ / global_ / flat_ / scratch_ instruction; no scratch access in the kernel.
+# ------------------------------------------------------------------------------------------------------------------------------------
+def check_torgb_kernel(body, mt):
+    # (hand-written statements stand between `;;#ASMSTART` / `;;#ASMEND` in the listing: a compiler-placed `vmcnt(8)` elsewhere in the kernel is not one of the counted waits)
+    code, hand, in_asm = [], [], False
+    for ln in body:
+        t = ln.strip()
+        if t.startswith(';;#ASMSTART'):
+            in_asm = True
+            continue
+        if t.startswith(';;#ASMEND'):
+            in_asm = False
+            continue
+        c = ln.split(';')[0].strip()
+        if c and not c.startswith('.') and not c.endswith(':'):
+            code.append(c)
+            hand.append(in_asm)
+    bad = []
+    if any(c.startswith('scratch_') for c in code):
+        bad.append(('scratch access in a ToRGB kernel with hand-counted tap waits', next(c for c in code if c.startswith('scratch_'))))
+    w8 = [k for k, c in enumerate(code) if c == 's_waitcnt vmcnt(8)' and hand[k]]
+    if len(w8) != 4 * mt - 2:
+        bad.append((f'expected {4 * mt - 2} hand-counted vmcnt(8) waits (4 MT batches, the last two wait with 4 and 0), found {len(w8)}', ''))
+        return dict(batches=len(w8)), bad
+    tail = code[w8[-1] + 1:]
+    ends = [c for c in tail if c.startswith('s_waitcnt') and 'vmcnt' in c][:2]
+    if ends != ['s_waitcnt vmcnt(4)', 's_waitcnt vmcnt(0)']:
+        bad.append(('the last two batches must wait with vmcnt(4) and vmcnt(0)', ' | '.join(ends)))
+    for a, b in zip(w8[:-1], w8[1:]):
+        seg = [c for c in code[a + 1:b] if re.match(r'^(buffer_|global_|flat_|scratch_)', c)]
+        loads = [c for c in seg if c.startswith('global_load_dwordx4')]
+        stores = [c for c in seg if c.startswith('global_store_dwordx4')]
+        other = [c for c in seg if c not in loads and c not in stores]
+        if len(loads) != 4 or len(stores) != 1 or other:
+            bad.append((f'between two hand-counted waits: {len(loads)} tap loads (4), {len(stores)} stores (1), other vector-memory instructions: {other[:2]}', ''))
+            break
+    # the registers a tap load of batch i writes are touched by nothing before the i-th hand-written wait (the compiler knows neither the load nor the wait: a copy or a
+    # reuse in between would read / clobber data still in flight)
+    hw = [k for k, c in enumerate(code) if hand[k] and c.startswith('s_waitcnt') and 'vmcnt' in c]
+    hl = [k for k, c in enumerate(code) if hand[k] and c.startswith('global_load_dwordx4')]
+    touched = 0
+    for n, k in enumerate(hl):
+        m = re.match(r'^global_load_dwordx4 v\[(\d+):(\d+)\]', code[k])
+        if not m or n // 4 >= len(hw):
+            bad.append(('a hand-issued tap load the checker cannot place', code[k]))
+            break
+        regs = set(range(int(m.group(1)), int(m.group(2)) + 1))
+        for c in code[k + 1:hw[n // 4]]:
+            ops = c.split(None, 1)[1] if ' ' in c else ''
+            used = set()
+            for tok in re.findall(r'v\[(\d+):(\d+)\]|\bv(\d+)\b', ops):
+                used |= set(range(int(tok[0]), int(tok[1]) + 1)) if tok[0] else {int(tok[2])}
+            if used & regs and not (hand[code.index(c)] and c.startswith('global_load_dwordx4') and c == code[k]):
+                touched += 1
+                bad.append((f'registers of a tap load in flight are touched before its wait ({code[k].split(",")[0]})', c))
+                break
+        if touched:
+            break
+    return dict(batches=len(w8) + 2, tap_loads=len(hl), hand_waits=len(hw)), bad
+
+
+def check_torgb_asm(asm_text):
+    """Every FAST fp32 instantiation of torgb_mfma_kernel in a modconv.hip listing.  -> {mangled name: (summary, violations)}"""
+    lines = asm_text.splitlines()
+    out = {}
+    for i, ln in enumerate(lines):
+        m = re.match(r'^(_ZN\S*torgb_mfma_kernelILi(\d)ELb[01]ELb1ELb0E\S*):', ln)
+        if not m:
+            continue
+        end = next((j for j in range(i, len(lines)) if lines[j].strip().startswith('.amdhsa_kernel')), len(lines))
+        out[m.group(1)] = check_torgb_kernel(lines[i:end], int(m.group(2)))
+    return out

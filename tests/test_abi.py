@@ -147,7 +147,11 @@ def test_wino4_isa_check_runs_in_the_build(tdgp):
     if not os.path.exists(asm):
         subprocess.check_call([build._hipcc()] + build.FLAGS + ['-S', '--cuda-device-only', '-o', asm, os.path.join(build.CSRC, 'modconv.hip')], stderr=subprocess.DEVNULL)
     res_all = build.verify_modconv_isa(asm)
-    res = {k: v for k, v in res_all.items() if 'wino4f' not in k}
+    res = {k: v for k, v in res_all.items() if 'wino4f' not in k and 'torgb' not in k}
+    # torgb_mfma_kernel<.., FAST> (round 6): hand-issued skip taps in batches of 4 under hand-counted waits
+    rest = {k: v for k, v in res_all.items() if 'torgb' in k}
+    assert len(rest) == 6 and all(not bad for _, bad in rest.values()), {k[-40:]: bad[:1] for k, (_, bad) in rest.items() if bad}
+    assert all(s_['tap_loads'] == 4 * s_['batches'] == 4 * s_['hand_waits'] for s_, _ in rest.values())
     assert len(res) == 2 and all(not bad for _, bad in res.values())
     assert all(s['lds_direct_sites'] == 8 and s['mfma'] == 36 and s['m0_writes'] > 0 for s, _ in res.values())
     # conv3_wino4f_kernel (round 6): every vector-memory read of its item loop is hand-issued; no spill, nothing of the compiler's to wait for behind the K loop
@@ -186,6 +190,19 @@ def test_wino4_isa_check_runs_in_the_build(tdgp):
         b2 = list(fbody)
         b2.insert(pos, inject)
         _, bad = isa.check_wino4f_kernel(b2)
+        assert bad and any(needle in why for why, _ in bad), (inject, bad[:2])
+    # ToRGB: a compiler-side load between two hand-counted waits, and a copy of a tap register still in flight, are each caught
+    t0 = next(i for i, ln in enumerate(lines) if re.match(r'^_ZN\S*torgb_mfma_kernelILi3ELb1ELb1ELb0E\S*:', ln))
+    t1 = next(j for j in range(t0, len(lines)) if lines[j].strip().startswith('.amdhsa_kernel'))
+    tbody = lines[t0:t1]
+    w8 = [i for i, ln in enumerate(tbody) if ln.strip() == 's_waitcnt vmcnt(8)' and tbody[i - 1].strip().startswith(';;#ASMSTART')]
+    hl = [i for i, ln in enumerate(tbody) if ln.strip().startswith('global_load_dwordx4') and tbody[i - 1].strip().startswith(';;#ASMSTART')]
+    dst = re.search(r'global_load_dwordx4 v\[(\d+):', tbody[hl[8]]).group(1)
+    for pos, inject, needle in ((w8[3] + 2, '\tglobal_load_dword v1, v[2:3], off', 'between two hand-counted waits'),
+                                (hl[8] + 2, f'\tv_mov_b32_e32 v1, v{dst}', 'in flight')):
+        b2 = list(tbody)
+        b2.insert(pos, inject)
+        _, bad = isa.check_torgb_kernel(b2, 3)
         assert bad and any(needle in why for why, _ in bad), (inject, bad[:2])
     # a listing without loop annotations is reported as unreadable, not as an IndexError
     with pytest.raises(isa.IsaListingError):
