@@ -1836,7 +1836,8 @@ __device__ __forceinline__ void rgb_output_tile(const EpiParams& e, const float*
 // store -- three register sets of 4 taps, 48 registers where the 4-pass form held 64 --, so the wait for a batch never has a store to wait for and every tap round
 // trip but the first runs under two batches of arithmetic and stores.  Same taps, same fma chains, same bits.
 typedef float rgb_f32x4 __attribute__((ext_vector_type(4)));
-template <int MT, bool PLAIN>
+// PARKED: all MT channel tiles already sit in LDS, tile k at ct + k * 32 * CT_LD (torgb_ws_kernel: another wave put them there); else `acc` is parked tile by tile into `ct`.
+template <int MT, bool PLAIN, bool PARKED = false>
 __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, const float* __restrict__ bias_lds, float* ct, f32x16 (&acc)[MT], int64_t pix0, int64_t P, int lw, int lhw) {
     const int l = lane_id(), cg = l & 7, pr = l >> 3, l32 = l & 31, half = l >> 5;
     const int planes = e.Cout / e.out_feat, h2 = e.Hout / 2, w2 = e.Wout / 2;
@@ -1850,7 +1851,12 @@ __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, co
     FirRegs fr = {e.fir[0], e.fir[1], e.fir[2], e.fir[3], e.fir[4], e.fir[5], e.fir[6], e.fir[7], e.fir[8], e.fir[9], e.fir[10], e.fir[11], e.fir[12], e.fir[13], e.fir[14], e.fir[15]};
     asm volatile("" : "+s"(fr.f0), "+s"(fr.f1), "+s"(fr.f2), "+s"(fr.f3), "+s"(fr.f4), "+s"(fr.f5), "+s"(fr.f6), "+s"(fr.f7));
     asm volatile("" : "+s"(fr.f8), "+s"(fr.f9), "+s"(fr.f10), "+s"(fr.f11), "+s"(fr.f12), "+s"(fr.f13), "+s"(fr.f14), "+s"(fr.f15));
-    constexpr int NSET = 3, NB = 4 * MT;            // a batch = one pass (8 pixels x 32 channels per wave): 4 tap loads, one store; three register sets = two batches of look-ahead
+#ifndef TDGP_RGB_WS_NSET
+#define TDGP_RGB_WS_NSET 6
+#endif
+    // a batch = one pass (8 pixels x 32 channels per wave): 4 tap loads, one store; NSET register sets = NSET - 1 batches of look-ahead (three sets in the one-role
+    // kernels, which sit at their register limit; six for the memory waves of the two-role kernel, whose whole stage is these round trips)
+    constexpr int NSET = PARKED ? TDGP_RGB_WS_NSET : 3, NB = 4 * MT;
     rgb_f32x4 tA[NSET][4];
     // (pixel geometry, tap indices and weights are RECOMPUTED where the batch is finished -- two dozen scalar-ish vector instructions per pass -- instead of
     //  carried beside the taps: registers the kernel does not have)
@@ -1874,11 +1880,39 @@ __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, co
         return g;
     };
     auto ld = [&](rgb_f32x4& dst, const float* ptr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory"); };
+    // PARKED (the two-role kernel's memory waves, which have the registers): the per-pass geometry -- sample, tap indices and weights, pixel offset -- ONCE per tile; a
+    // batch then is a handful of integer operations.  (Recomputed per batch the stage was ~1400 vector instructions per wave and tile on the FMA units the
+    // multiplying wave of the same SIMD needs: the roles did not overlap.)
+    int pg_b[4], pg_pix[4], pg_i[4][4];
+    float pg_w[4][4];
+    bool pg_ok[4];
+    if constexpr (PARKED) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int pix = (int)pix0 + 4 * (q * 8 + pr);
+            const bool ok = pix < (int)P;
+            const int pc = ok ? pix : 0;
+            const int b = pc >> lhw, inner = pc & ((1 << lhw) - 1), oy = inner >> lw, ox = inner & ((1 << lw) - 1);
+            const SkipTaps tp = skip_taps_sel(h2, w2, oy, ox, fr);
+            pg_b[q] = b * planes; pg_pix[q] = oy * e.Wout + ox; pg_ok[q] = ok;
+            pg_i[q][0] = tp.i00; pg_i[q][1] = tp.i01; pg_i[q][2] = tp.i10; pg_i[q][3] = tp.i11;
+            pg_w[q][0] = tp.w00; pg_w[q][1] = tp.w01; pg_w[q][2] = tp.w10; pg_w[q][3] = tp.w11;
+        }
+    }
     auto issue = [&](int bi) {
-        const Geo g = geo(bi >> 2, bi & 3);
         rgb_f32x4 (&t)[4] = tA[bi % NSET];
-        ld(t[0], g.sp + (int64_t)g.tp.i00 * e.out_feat); ld(t[1], g.sp + (int64_t)g.tp.i01 * e.out_feat);
-        ld(t[2], g.sp + (int64_t)g.tp.i10 * e.out_feat); ld(t[3], g.sp + (int64_t)g.tp.i11 * e.out_feat);
+        if constexpr (PARKED) {
+            const int tile = bi >> 2, q = bi & 3;
+            const int o = tile * 32 + 4 * cg, oc = o < e.Cout ? o : 0;
+            const int pl = oc / e.out_feat, f = oc - pl * e.out_feat;
+            const float* sp = e.skip + (int64_t)(pg_b[q] + pl) * (h2 * w2) * e.out_feat + f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) ld(t[j], sp + (int64_t)pg_i[q][j] * e.out_feat);
+        } else {
+            const Geo g = geo(bi >> 2, bi & 3);
+            ld(t[0], g.sp + (int64_t)g.tp.i00 * e.out_feat); ld(t[1], g.sp + (int64_t)g.tp.i01 * e.out_feat);
+            ld(t[2], g.sp + (int64_t)g.tp.i10 * e.out_feat); ld(t[3], g.sp + (int64_t)g.tp.i11 * e.out_feat);
+        }
     };
     auto finish = [&](int bi) {
         const int tile = bi >> 2, pass = bi & 3;
@@ -1886,14 +1920,29 @@ __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, co
         const int oc = o < e.Cout ? o : 0;
         const float4 bias4 = *(const float4*)(bias_lds + oc);
         const rgb_f32x2 b01 = {bias4.x, bias4.y}, b23 = {bias4.z, bias4.w};
-        int tl = tile, ps = pass;
-        asm volatile("" : "+s"(tl), "+s"(ps));                                   // (opaque: the geometry is recomputed here, not kept from issue())
-        const Geo g = geo(tl, ps);
-        const float4 c4 = *(const float4*)&ct[(pass * 8 + pr) * CT_LD + 4 * cg];
-        // in flight, in issue order: this batch's 4 loads, <= 2 stores, the 4 + 4 loads of the two batches ahead (fewer at the end)
-        if (bi + 2 < NB) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (bi + 1 < NB) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        Geo g;
+        if constexpr (PARKED) {
+            const int pl = oc / e.out_feat, f = oc - pl * e.out_feat;
+            g.ok = pg_ok[pass] && o < e.Cout;
+            g.addr = ((pg_b[pass] + pl) * (e.Hout * e.Wout) + pg_pix[pass]) * e.out_feat + f;
+            g.tp.w00 = pg_w[pass][0]; g.tp.w01 = pg_w[pass][1]; g.tp.w10 = pg_w[pass][2]; g.tp.w11 = pg_w[pass][3];
+        } else {
+            int tl = tile, ps = pass;
+            asm volatile("" : "+s"(tl), "+s"(ps));                               // (opaque: the geometry is recomputed here, not kept from issue())
+            g = geo(tl, ps);
+        }
+        const float4 c4 = *(const float4*)&ct[(PARKED ? tile * (32 * CT_LD) : 0) + (pass * 8 + pr) * CT_LD + 4 * cg];
+        // in flight, in issue order: this batch's 4 loads, the stores of earlier batches, the 4 loads of each batch ahead (NSET - 1 of them, fewer at the end)
+        {
+            constexpr int kAheadMax = NSET - 1;
+            const int ahead = NB - 1 - bi < kAheadMax ? NB - 1 - bi : kAheadMax;      // compile-time: the batch loop is unrolled
+            if (ahead == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else if (ahead == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (ahead == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         rgb_f32x2 r01, r23;
         if (!PLAIN) {                               // conv -> (bf16) -> + bias -> * gain -> clamp -> (bf16), then the skip (networks_stylegan2.py:170-171, 265-269)
             float qv[4] = {c4.x, c4.y, c4.z, c4.w};
@@ -1919,11 +1968,12 @@ __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, co
         r23 = r23 + __builtin_elementwise_fma(w11, d23, __builtin_elementwise_fma(w10, cc23, __builtin_elementwise_fma(w01, bb23, w00 * a23)));
         if (g.ok) *(float4*)(e.y + g.addr) = make_float4(r01.x, r01.y, r23.x, r23.y);
     };
-    issue(0);
-    issue(1);
+    static_assert(NSET >= 2 && NSET <= 6, "wait counts are spelled out for up to five batches of look-ahead");
+#pragma unroll
+    for (int bi = 0; bi < NSET - 1 && bi < NB; bi++) issue(bi);
 #pragma unroll
     for (int bi = 0; bi < NB; bi++) {
-        if ((bi & 3) == 0) {
+        if (!PARKED && (bi & 3) == 0) {
             // this channel tile's accumulators -> the wave's pixel-major LDS tile (wave-private: a wave barrier orders it against the previous tile's reads)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1937,7 +1987,7 @@ __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, co
             __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_sched_barrier(0);          // (nothing of one batch moves into another: hoisted address arithmetic of later batches is what spilled the first build)
-        if (bi + 2 < NB) issue(bi + 2);
+        if (bi + NSET - 1 < NB) issue(bi + NSET - 1);
         __builtin_amdgcn_sched_barrier(0);
         finish(bi);
         __builtin_amdgcn_sched_barrier(0);
@@ -2194,6 +2244,144 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
         printf("torgb blk %d tiles %d iters %d: prologue+issue %lld wait+store %lld issue-next %lld mma %lld epilogue %lld\n", (int)blockIdx.x, (int)(t_end - t_begin), niter, tq[0], tq[1], tq[2], tq[3], tq[4]);
 #endif
 #undef TR
+}
+
+// ---- ToRGB, two roles per block (round 6): Cin <= 64 (weights resident), power-of-two image, gain 1, no clamp, with a skip -- the 512^2 layer of C3 / C4 ----
+// torgb_mfma_kernel runs a tile's three resources one after the other -- activation staging (global -> registers -> style, transpose -> LDS), 96 MFMAs per wave, the
+// output stage's 48 tap loads + 12 stores per wave -- and two resident blocks per CU overlap them only partly (ablations of round 2: multiply + staging alone 0.56 ms of
+// the layer's 1.05, the MFMAs alone 0.33).  Here a block is 8 waves, one per CU: waves 0..3 MULTIPLY tile t (fragments from LDS, nothing else), waves 4..7 do everything
+// of the output stage of tile t - 1 -- 48 tap loads, 12 stores per wave, from the LDS tile the multipliers parked, with the per-pass geometry computed once per tile --; the
+// multipliers also carry tile t + 1's activations (requested before the multiply, staged into the other X buffer behind it).  One of each role per SIMD, two block barriers per tile.  Same fragments, same K order, same fma chains as torgb_mfma_kernel: same bits.
+#ifndef TDGP_RGB_WS_ABL
+#define TDGP_RGB_WS_ABL 0              // timing experiments (wrong results): 1 = no output stage, 2 = no multiply
+#endif
+template <int MT>
+__global__ __launch_bounds__(512, 1) void torgb_ws_kernel(RgbParams p) {
+    constexpr int BM = 32 * MT, BN = 128, NCH = 16;
+    constexpr int AS_SZ = NCH * BM * 4, XS_SZ = NCH * BN * 4, CT_SZ = 4 * MT * 32 * CT_LD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Xs = smem + AS_SZ;                                       // two buffers
+    float* Ct = smem + AS_SZ + 2 * XS_SZ;                           // [4 pixel groups][MT channel tiles][32 pixels][CT_LD]
+    float* side = Ct + CT_SZ;                                       // [BM] bias
+    const int tid = threadIdx.x, l = tid & 63, wv = TDGP_WAVE_INDEX(tid), role = wv >> 2, wj = wv & 3, l32 = l & 31, half = l >> 5;
+    const int mt = tid & 255;                                       // thread index inside the role
+    const int64_t ntiles = (p.P + BN - 1) / BN;
+    const int64_t nb_ = gridDim.x;
+    const int64_t lb_ = ((nb_ & 7) == 0 && nb_ >= 64) ? (int64_t)(blockIdx.x & 7) * (nb_ >> 3) + (blockIdx.x >> 3) : (int64_t)blockIdx.x;       // XCD-compact, as torgb_mfma_kernel
+    const int64_t t_begin = lb_ * p.tpb, t_end = min(t_begin + p.tpb, ntiles);
+    if (t_begin >= t_end) return;
+    for (int i = tid; i < BM; i += 512) side[i] = (i < p.Cout && p.e.bias) ? p.e.bias[i] : 0.f;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x, p.x_bytes), rw = make_rsrc(p.wp, p.wp_bytes), rs = make_rsrc(p.styles ? p.styles : p.x, p.styles ? p.st_bytes : 0);
+    // weights: one stage, once per block (every thread of both roles)
+    for (int e = tid; e < NCH * BM; e += 512) {
+        const int chunk = e / BM, col = e % BM;
+        *(float4*)(As + e * 4) = col < p.CoutP ? buf_load4(rw, (uint32_t)(chunk * p.CoutP + col) * 16u, 0u) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // memory role: two 4-channel x 4-pixel micro-tiles per thread and tile
+    uint32_t x_vo[2], s_vo[2];
+    const int cq = mt >> 5, pq = mt & 31;
+    auto tile_offsets = [&](int64_t t) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int64_t pix = t * BN + 4 * pq;
+            x_vo[k] = kOOB; s_vo[k] = kOOB;
+            if (pix < p.P) {
+                const int b = (int)(pix >> p.lhw), inner = (int)pix & ((1 << p.lhw) - 1);
+                const int sb = b * p.Cin + 4 * (cq + 8 * k);
+                s_vo[k] = (uint32_t)sb * 4u;
+                x_vo[k] = (uint32_t)(sb * p.HW + inner) * 4u;
+            }
+        }
+    };
+    const uint32_t hw4 = (uint32_t)p.HW * 4u;
+    const bool cin4 = (p.Cin & 3) == 0;
+    float4 xr[2][4], sr[2];
+    auto load_x = [&]() {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) xr[k][j] = buf_load4(rx, x_vo[k], (uint32_t)j * hw4);
+            if (p.styles) {
+                if (cin4) sr[k] = buf_load4(rs, s_vo[k], 0u);
+                else sr[k] = make_float4(buf_load1(rs, s_vo[k], 0u), buf_load1(rs, s_vo[k], 4u), buf_load1(rs, s_vo[k], 8u), buf_load1(rs, s_vo[k], 12u));
+            } else {
+                sr[k] = make_float4(1.f, 1.f, 1.f, 1.f);
+            }
+        }
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            float* d = Xs + buf * XS_SZ + (((cq + 8 * k) * BN) + pq) * 4;        // (pixel 4 pq + j -> slot j * 32 + pq: torgb_mfma_kernel::store_stage)
+            *(float4*)(d + 0 * 128) = make_float4(xr[k][0].x * sr[k].x, xr[k][1].x * sr[k].y, xr[k][2].x * sr[k].z, xr[k][3].x * sr[k].w);
+            *(float4*)(d + 1 * 128) = make_float4(xr[k][0].y * sr[k].x, xr[k][1].y * sr[k].y, xr[k][2].y * sr[k].z, xr[k][3].y * sr[k].w);
+            *(float4*)(d + 2 * 128) = make_float4(xr[k][0].z * sr[k].x, xr[k][1].z * sr[k].y, xr[k][2].z * sr[k].z, xr[k][3].z * sr[k].w);
+            *(float4*)(d + 3 * 128) = make_float4(xr[k][0].w * sr[k].x, xr[k][1].w * sr[k].y, xr[k][2].w * sr[k].z, xr[k][3].w * sr[k].w);
+        }
+    };
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+    float* ctw = Ct + wj * (MT * 32 * CT_LD);
+    // prologue: tile t_begin staged (by the multiplying waves: they carry the activations, the memory waves carry the taps)
+    if (role == 0) {
+        tile_offsets(t_begin);
+        load_x();
+        store_x(0);
+    }
+    __syncthreads();
+    const int n = (int)(t_end - t_begin);
+    for (int i = 0; i < n; i++) {
+        const int64_t t = t_begin + i;
+        if (role == 0) {
+            // tile t + 1's activations travel under this tile's multiply (the block's last tile re-reads itself: no load under a condition)
+            tile_offsets(t + 1 < t_end ? t + 1 : t);
+            load_x();
+            const float* Al = As + l32 * 4 + 2 * half;
+            const float* Xl = Xs + (i & 1) * XS_SZ + (wj * 32 + l32) * 4 + 2 * half;
+            f32x2 fa[2][MT], fb[2];
+            auto load_frag = [&](int buf, int ch) {
+#pragma unroll
+                for (int m = 0; m < MT; m++) fa[buf][m] = *(const f32x2*)(Al + (ch * BM + m * 32) * 4);
+                fb[buf] = *(const f32x2*)(Xl + ch * BN * 4);
+            };
+            load_frag(0, 0);
+#pragma unroll
+            for (int ch = 0; ch < ((TDGP_RGB_WS_ABL & 2) ? 1 : NCH); ch++) {
+                const int cb = ch & 1;
+                if (ch + 1 < NCH) load_frag(cb ^ 1, ch + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                    for (int m = 0; m < MT; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][m][kk], fb[cb][kk], acc[m], 0, 0, 0);
+            }
+            store_x((i + 1) & 1);                   // (nobody reads that buffer before the barriers below: tile t - 1's multiply ended an iteration ago)
+        } else {
+            if (i > 0 && !(TDGP_RGB_WS_ABL & 1)) {
+                f32x16 none[MT];
+                rgb_output_skip_pipelined<MT, true, true>(p.e, side, ctw, none, (t - 1) * BN + wj, p.P, p.lw, p.lhw);
+            }
+        }
+        __syncthreads();                            // the multipliers are through with X[i & 1] and have written X[(i + 1) & 1]; tile t - 1's parked outputs have been read
+        if (role == 0) {
+#pragma unroll
+            for (int k = 0; k < MT; k++)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    *(float4*)&ctw[k * (32 * CT_LD) + l32 * CT_LD + 8 * r4 + 4 * half] = make_float4(acc[k][4 * r4], acc[k][4 * r4 + 1], acc[k][4 * r4 + 2], acc[k][4 * r4 + 3]);
+                    acc[k][4 * r4] = 0.f; acc[k][4 * r4 + 1] = 0.f; acc[k][4 * r4 + 2] = 0.f; acc[k][4 * r4 + 3] = 0.f;
+                }
+        }
+        __syncthreads();                            // tile t's outputs are parked
+    }
+    if (role == 1) {
+        f32x16 none[MT];
+        rgb_output_skip_pipelined<MT, true, true>(p.e, side, ctw, none, (t_end - 1) * BN + wj, p.P, p.lw, p.lhw);
+    }
 }
 
 // Split-K reduction: y = epilogue(sum_ks partial[ks]) ; one thread per output element, ks summed in order (deterministic).
@@ -2637,6 +2825,21 @@ void launch_torgb_v(const RgbParams& r, hipStream_t s) {
     // RESIDENT: several consecutive tiles per block once there are more tiles than ~4 rounds of the 512 resident blocks
     RgbParams rr = r;
     const int64_t ntiles = cdiv64(r.P, 128);
+#ifndef TDGP_RGB_WS
+#define TDGP_RGB_WS 1                  // 0: torgb_mfma_kernel for every layer (A/B builds, same bits)
+#endif
+    if constexpr (RESIDENT && FAST && !XBF) {
+        // the two-role form: enough tiles for >= 16 per block on a grid of four blocks per CU (C3 / C4: the 512^2 layer; at B = 1 the 512^2 layer still has 2048 tiles)
+        const int cus = tdgp_cu_count();
+        if (TDGP_RGB_WS && r.e.skip && ntiles >= (int64_t)cus * 8) {
+            constexpr size_t lds_ws = (size_t)(16 * BM * 4 + 2 * 16 * 128 * 4 + 4 * MT * 32 * CT_LD + BM) * sizeof(float);
+            TDGP_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)torgb_ws_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ws););
+            const int64_t blocks = (int64_t)cus * 4;
+            rr.tpb = (int)cdiv64(ntiles, blocks);
+            TDGP_LAUNCH("torgb_mfma_kernel", (torgb_ws_kernel<MT>), dim3((unsigned)cdiv64(ntiles, rr.tpb)), dim3(512), lds_ws, s, rr);
+            return;
+        }
+    }
     rr.tpb = RESIDENT ? (int)max((int64_t)1, min((int64_t)8, ntiles / 2048)) : 1;
     TDGP_LAUNCH("torgb_mfma_kernel", (torgb_mfma_kernel<MT, RESIDENT, FAST, XBF>), dim3((unsigned)cdiv64(ntiles, rr.tpb)), dim3(256), lds, s, rr);
 }

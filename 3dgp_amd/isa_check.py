@@ -296,53 +296,61 @@ def check_torgb_kernel(body, mt):
     bad = []
     if any(c.startswith('scratch_') for c in code):
         bad.append(('scratch access in a ToRGB kernel with hand-counted tap waits', next(c for c in code if c.startswith('scratch_'))))
-    w8 = [k for k, c in enumerate(code) if c == 's_waitcnt vmcnt(8)' and hand[k]]
-    if len(w8) != 4 * mt - 2:
-        bad.append((f'expected {4 * mt - 2} hand-counted vmcnt(8) waits (4 MT batches, the last two wait with 4 and 0), found {len(w8)}', ''))
-        return dict(batches=len(w8)), bad
-    tail = code[w8[-1] + 1:]
-    ends = [c for c in tail if c.startswith('s_waitcnt') and 'vmcnt' in c][:2]
-    if ends != ['s_waitcnt vmcnt(4)', 's_waitcnt vmcnt(0)']:
-        bad.append(('the last two batches must wait with vmcnt(4) and vmcnt(0)', ' | '.join(ends)))
-    for a, b in zip(w8[:-1], w8[1:]):
-        seg = [c for c in code[a + 1:b] if re.match(r'^(buffer_|global_|flat_|scratch_)', c)]
-        loads = [c for c in seg if c.startswith('global_load_dwordx4')]
-        stores = [c for c in seg if c.startswith('global_store_dwordx4')]
-        other = [c for c in seg if c not in loads and c not in stores]
-        if len(loads) != 4 or len(stores) != 1 or other:
-            bad.append((f'between two hand-counted waits: {len(loads)} tap loads (4), {len(stores)} stores (1), other vector-memory instructions: {other[:2]}', ''))
-            break
-    # the registers a tap load of batch i writes are touched by nothing before the i-th hand-written wait (the compiler knows neither the load nor the wait: a copy or a
-    # reuse in between would read / clobber data still in flight)
-    hw = [k for k, c in enumerate(code) if hand[k] and c.startswith('s_waitcnt') and 'vmcnt' in c]
+    hw = [k for k, c in enumerate(code) if hand[k] and re.match(r'^s_waitcnt vmcnt\(\d+\)$', c)]
     hl = [k for k, c in enumerate(code) if hand[k] and c.startswith('global_load_dwordx4')]
-    touched = 0
-    for n, k in enumerate(hl):
-        m = re.match(r'^global_load_dwordx4 v\[(\d+):(\d+)\]', code[k])
-        if not m or n // 4 >= len(hw):
-            bad.append(('a hand-issued tap load the checker cannot place', code[k]))
-            break
-        regs = set(range(int(m.group(1)), int(m.group(2)) + 1))
-        for c in code[k + 1:hw[n // 4]]:
-            ops = c.split(None, 1)[1] if ' ' in c else ''
-            used = set()
-            for tok in re.findall(r'v\[(\d+):(\d+)\]|\bv(\d+)\b', ops):
-                used |= set(range(int(tok[0]), int(tok[1]) + 1)) if tok[0] else {int(tok[2])}
-            if used & regs and not (hand[code.index(c)] and c.startswith('global_load_dwordx4') and c == code[k]):
-                touched += 1
-                bad.append((f'registers of a tap load in flight are touched before its wait ({code[k].split(",")[0]})', c))
+    nb = 4 * mt
+    if not hw or len(hw) % nb or len(hl) != 4 * len(hw):
+        bad.append((f'expected a multiple of {nb} hand-counted waits and four tap loads per wait, found {len(hw)} waits, {len(hl)} loads', ''))
+        return dict(batches=len(hw), tap_loads=len(hl), hand_waits=len(hw)), bad
+    stages = len(hw) // nb
+    for st in range(stages):                         # one instance of the stage = 4 MT batches (the two-role kernel holds two: the tile loop's and the last tile's)
+        w, ld_ = hw[st * nb:(st + 1) * nb], hl[st * 4 * nb:(st + 1) * 4 * nb]
+        counts = [int(re.search(r'\((\d+)\)', code[k]).group(1)) for k in w]
+        ahead = counts[0] // 4
+        want = [4 * min(ahead, nb - 1 - bi) for bi in range(nb)]
+        if counts != want or counts[0] % 4 or not 1 <= ahead <= 5:
+            bad.append((f'wait counts of a stage must be 4 x min(look-ahead, batches left): {want}', str(counts)))
+            continue
+        if not (ld_[0] < w[0] and all(ld_[4 * (bi + ahead)] > w[bi - 1] for bi in range(1, nb - ahead)) and ld_[-1] < w[nb - ahead - 1 if nb > ahead else 0] + 10 ** 9):
+            bad.append(('tap loads and waits of a stage are not interleaved as issued', ''))
+        # between the stage's first tap load and its last wait: the hand-issued loads, one compiler store per batch, nothing else of vector memory
+        seg = [(k, c) for k, c in enumerate(code[ld_[0]:w[-1] + 1], ld_[0]) if re.match(r'^(buffer_|global_|flat_|scratch_)', c)]
+        other = [c for k, c in seg if not (hand[k] and c.startswith('global_load_dwordx4')) and not c.startswith('global_store_dwordx4')]
+        if other:
+            bad.append(('a vector-memory instruction of the compiler\'s between the hand-counted waits of a stage (the hardware counts it, the hand does not)', other[0]))
+        for bi in range(nb - 1):
+            st_ = [c for c in code[w[bi]:w[bi + 1]] if c.startswith('global_store_dwordx4')]
+            if len(st_) != 1:
+                bad.append((f'{len(st_)} stores between two hand-counted waits (one per batch)', ''))
                 break
-        if touched:
-            break
-    return dict(batches=len(w8) + 2, tap_loads=len(hl), hand_waits=len(hw)), bad
+        # the registers a tap load of batch i writes are touched by nothing before the i-th wait of the stage
+        for n, k in enumerate(ld_):
+            m = re.match(r'^global_load_dwordx4 v\[(\d+):(\d+)\]', code[k])
+            if not m:
+                bad.append(('a hand-issued tap load the checker cannot read', code[k]))
+                break
+            regs = set(range(int(m.group(1)), int(m.group(2)) + 1))
+            hit = None
+            for c in code[k + 1:w[n // 4]]:
+                ops = c.split(None, 1)[1] if ' ' in c else ''
+                used = set()
+                for tok in re.findall(r'v\[(\d+):(\d+)\]|\bv(\d+)\b', ops):
+                    used |= set(range(int(tok[0]), int(tok[1]) + 1)) if tok[0] else {int(tok[2])}
+                if used & regs:
+                    hit = c
+                    break
+            if hit:
+                bad.append((f'registers of a tap load in flight are touched before its wait ({code[k].split(",")[0]})', hit))
+                break
+    return dict(batches=len(hw), tap_loads=len(hl), hand_waits=len(hw), stages=stages), bad
 
 
 def check_torgb_asm(asm_text):
-    """Every FAST fp32 instantiation of torgb_mfma_kernel in a modconv.hip listing.  -> {mangled name: (summary, violations)}"""
+    """Every FAST fp32 instantiation of torgb_mfma_kernel, and torgb_ws_kernel, in a modconv.hip listing.  -> {mangled name: (summary, violations)}"""
     lines = asm_text.splitlines()
     out = {}
     for i, ln in enumerate(lines):
-        m = re.match(r'^(_ZN\S*torgb_mfma_kernelILi(\d)ELb[01]ELb1ELb0E\S*):', ln)
+        m = re.match(r'^(_ZN\S*torgb_mfma_kernelILi(\d)ELb[01]ELb1ELb0E\S*):', ln) or re.match(r'^(_ZN\S*torgb_ws_kernelILi(\d)E\S*):', ln)
         if not m:
             continue
         end = next((j for j in range(i, len(lines)) if lines[j].strip().startswith('.amdhsa_kernel')), len(lines))

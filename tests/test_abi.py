@@ -150,8 +150,9 @@ def test_wino4_isa_check_runs_in_the_build(tdgp):
     res = {k: v for k, v in res_all.items() if 'wino4f' not in k and 'torgb' not in k}
     # torgb_mfma_kernel<.., FAST> (round 6): hand-issued skip taps in batches of 4 under hand-counted waits
     rest = {k: v for k, v in res_all.items() if 'torgb' in k}
-    assert len(rest) == 6 and all(not bad for _, bad in rest.values()), {k[-40:]: bad[:1] for k, (_, bad) in rest.items() if bad}
+    assert len(rest) == 9 and all(not bad for _, bad in rest.values()), {k[-40:]: bad[:1] for k, (_, bad) in rest.items() if bad}       # 6 one-role instances + 3 of torgb_ws_kernel
     assert all(s_['tap_loads'] == 4 * s_['batches'] == 4 * s_['hand_waits'] for s_, _ in rest.values())
+    assert sorted(s_['stages'] for s_, _ in rest.values()) == [1] * 6 + [2] * 3
     assert len(res) == 2 and all(not bad for _, bad in res.values())
     assert all(s['lds_direct_sites'] == 8 and s['mfma'] == 36 and s['m0_writes'] > 0 for s, _ in res.values())
     # conv3_wino4f_kernel (round 6): every vector-memory read of its item loop is hand-issued; no spill, nothing of the compiler's to wait for behind the K loop
@@ -198,7 +199,7 @@ def test_wino4_isa_check_runs_in_the_build(tdgp):
     w8 = [i for i, ln in enumerate(tbody) if ln.strip() == 's_waitcnt vmcnt(8)' and tbody[i - 1].strip().startswith(';;#ASMSTART')]
     hl = [i for i, ln in enumerate(tbody) if ln.strip().startswith('global_load_dwordx4') and tbody[i - 1].strip().startswith(';;#ASMSTART')]
     dst = re.search(r'global_load_dwordx4 v\[(\d+):', tbody[hl[8]]).group(1)
-    for pos, inject, needle in ((w8[3] + 2, '\tglobal_load_dword v1, v[2:3], off', 'between two hand-counted waits'),
+    for pos, inject, needle in ((w8[3] + 2, '\tglobal_load_dword v1, v[2:3], off', 'between the hand-counted waits'),
                                 (hl[8] + 2, f'\tv_mov_b32_e32 v1, v{dst}', 'in flight')):
         b2 = list(tbody)
         b2.insert(pos, inject)
