@@ -1837,7 +1837,10 @@ __device__ __forceinline__ void rgb_output_tile(const EpiParams& e, const float*
 // trip but the first runs under two batches of arithmetic and stores.  Same taps, same fma chains, same bits.
 typedef float rgb_f32x4 __attribute__((ext_vector_type(4)));
 // PARKED: all MT channel tiles already sit in LDS, tile k at ct + k * 32 * CT_LD (torgb_ws_kernel: another wave put them there); else `acc` is parked tile by tile into `ct`.
-template <int MT, bool PLAIN, bool PARKED = false>
+#ifndef TDGP_RGB_NSET_STREAMED
+#define TDGP_RGB_NSET_STREAMED 5       // register sets of taps in the one-role kernels that stream their weights (they have registers to spare; A/B builds)
+#endif
+template <int MT, bool PLAIN, bool PARKED = false, int NSET1 = 3>
 __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, const float* __restrict__ bias_lds, float* ct, f32x16 (&acc)[MT], int64_t pix0, int64_t P, int lw, int lhw) {
     const int l = lane_id(), cg = l & 7, pr = l >> 3, l32 = l & 31, half = l >> 5;
     const int planes = e.Cout / e.out_feat, h2 = e.Hout / 2, w2 = e.Wout / 2;
@@ -1856,7 +1859,7 @@ __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, co
 #endif
     // a batch = one pass (8 pixels x 32 channels per wave): 4 tap loads, one store; NSET register sets = NSET - 1 batches of look-ahead (three sets in the one-role
     // kernels, which sit at their register limit; six for the memory waves of the two-role kernel, whose whole stage is these round trips)
-    constexpr int NSET = PARKED ? TDGP_RGB_WS_NSET : 3, NB = 4 * MT;
+    constexpr int NSET = PARKED ? TDGP_RGB_WS_NSET : NSET1, NB = 4 * MT;
     rgb_f32x4 tA[NSET][4];
     // (pixel geometry, tap indices and weights are RECOMPUTED where the batch is finished -- two dozen scalar-ish vector instructions per pass -- instead of
     //  carried beside the taps: registers the kernel does not have)
@@ -2210,7 +2213,7 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
 #define TDGP_RGB_PIPELINED 1           // 0: the stage per channel tile (rounds 2-6; A/B builds, same bits)
 #endif
         if (TDGP_RGB_PIPELINED && FAST && has_skip) {
-            rgb_output_skip_pipelined<MT, true>(p.e, side, ct, acc, pix0, p.P, p.lw, p.lhw);
+            rgb_output_skip_pipelined<MT, true, false, RESIDENT ? 3 : TDGP_RGB_NSET_STREAMED>(p.e, side, ct, acc, pix0, p.P, p.lw, p.lhw);
         } else
 #pragma unroll 1
         for (int tile = 0; tile < MT; tile++) {
