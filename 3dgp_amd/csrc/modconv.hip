@@ -1837,10 +1837,13 @@ __device__ __forceinline__ void rgb_output_tile(const EpiParams& e, const float*
 // trip but the first runs under two batches of arithmetic and stores.  Same taps, same fma chains, same bits.
 typedef float rgb_f32x4 __attribute__((ext_vector_type(4)));
 // PARKED: all MT channel tiles already sit in LDS, tile k at ct + k * 32 * CT_LD (torgb_ws_kernel: another wave put them there); else `acc` is parked tile by tile into `ct`.
+#ifndef TDGP_RGB_PRE_STREAMED
+#define TDGP_RGB_PRE_STREAMED 1        // per-pass geometry once per tile in the streamed one-role kernels too (A/B builds)
+#endif
 #ifndef TDGP_RGB_NSET_STREAMED
 #define TDGP_RGB_NSET_STREAMED 5       // register sets of taps in the one-role kernels that stream their weights (they have registers to spare; A/B builds)
 #endif
-template <int MT, bool PLAIN, bool PARKED = false, int NSET1 = 3>
+template <int MT, bool PLAIN, bool PARKED = false, int NSET1 = 3, bool PRE1 = false>
 __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, const float* __restrict__ bias_lds, float* ct, f32x16 (&acc)[MT], int64_t pix0, int64_t P, int lw, int lhw) {
     const int l = lane_id(), cg = l & 7, pr = l >> 3, l32 = l & 31, half = l >> 5;
     const int planes = e.Cout / e.out_feat, h2 = e.Hout / 2, w2 = e.Wout / 2;
@@ -1886,10 +1889,11 @@ __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, co
     // PARKED (the two-role kernel's memory waves, which have the registers): the per-pass geometry -- sample, tap indices and weights, pixel offset -- ONCE per tile; a
     // batch then is a handful of integer operations.  (Recomputed per batch the stage was ~1400 vector instructions per wave and tile on the FMA units the
     // multiplying wave of the same SIMD needs: the roles did not overlap.)
+    constexpr bool PRE = PARKED || PRE1;            // (PRE1: the one-role kernels that stream their weights have the registers too)
     int pg_b[4], pg_pix[4], pg_i[4][4];
     float pg_w[4][4];
     bool pg_ok[4];
-    if constexpr (PARKED) {
+    if constexpr (PRE) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int pix = (int)pix0 + 4 * (q * 8 + pr);
@@ -1904,7 +1908,7 @@ __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, co
     }
     auto issue = [&](int bi) {
         rgb_f32x4 (&t)[4] = tA[bi % NSET];
-        if constexpr (PARKED) {
+        if constexpr (PRE) {
             const int tile = bi >> 2, q = bi & 3;
             const int o = tile * 32 + 4 * cg, oc = o < e.Cout ? o : 0;
             const int pl = oc / e.out_feat, f = oc - pl * e.out_feat;
@@ -1924,7 +1928,7 @@ __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, co
         const float4 bias4 = *(const float4*)(bias_lds + oc);
         const rgb_f32x2 b01 = {bias4.x, bias4.y}, b23 = {bias4.z, bias4.w};
         Geo g;
-        if constexpr (PARKED) {
+        if constexpr (PRE) {
             const int pl = oc / e.out_feat, f = oc - pl * e.out_feat;
             g.ok = pg_ok[pass] && o < e.Cout;
             g.addr = ((pg_b[pass] + pl) * (e.Hout * e.Wout) + pg_pix[pass]) * e.out_feat + f;
@@ -2213,7 +2217,7 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
 #define TDGP_RGB_PIPELINED 1           // 0: the stage per channel tile (rounds 2-6; A/B builds, same bits)
 #endif
         if (TDGP_RGB_PIPELINED && FAST && has_skip) {
-            rgb_output_skip_pipelined<MT, true, false, RESIDENT ? 3 : TDGP_RGB_NSET_STREAMED>(p.e, side, ct, acc, pix0, p.P, p.lw, p.lhw);
+            rgb_output_skip_pipelined<MT, true, false, RESIDENT ? 3 : TDGP_RGB_NSET_STREAMED, !RESIDENT && TDGP_RGB_PRE_STREAMED>(p.e, side, ct, acc, pix0, p.P, p.lw, p.lhw);
         } else
 #pragma unroll 1
         for (int tile = 0; tile < MT; tile++) {
