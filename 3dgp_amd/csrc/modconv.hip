@@ -1843,7 +1843,8 @@ typedef float rgb_f32x4 __attribute__((ext_vector_type(4)));
 #ifndef TDGP_RGB_NSET_STREAMED
 #define TDGP_RGB_NSET_STREAMED 5       // register sets of taps in the one-role kernels that stream their weights (they have registers to spare; A/B builds)
 #endif
-template <int MT, bool PLAIN, bool PARKED = false, int NSET1 = 3, bool PRE1 = false>
+// B0, B1 (PARKED only): the batches [B0, B1) of the tile's 4 MT -- the two roles of torgb_ws_kernel share a tile's stage.
+template <int MT, bool PLAIN, bool PARKED = false, int NSET1 = 3, bool PRE1 = false, int B0 = 0, int B1 = 4 * MT>
 __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, const float* __restrict__ bias_lds, float* ct, f32x16 (&acc)[MT], int64_t pix0, int64_t P, int lw, int lhw) {
     const int l = lane_id(), cg = l & 7, pr = l >> 3, l32 = l & 31, half = l >> 5;
     const int planes = e.Cout / e.out_feat, h2 = e.Hout / 2, w2 = e.Wout / 2;
@@ -1862,7 +1863,8 @@ __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, co
 #endif
     // a batch = one pass (8 pixels x 32 channels per wave): 4 tap loads, one store; NSET register sets = NSET - 1 batches of look-ahead (three sets in the one-role
     // kernels, which sit at their register limit; six for the memory waves of the two-role kernel, whose whole stage is these round trips)
-    constexpr int NSET = PARKED ? TDGP_RGB_WS_NSET : NSET1, NB = 4 * MT;
+    constexpr int NSET = PARKED ? (B1 - B0 < TDGP_RGB_WS_NSET ? (B1 - B0 > 1 ? B1 - B0 : 2) : TDGP_RGB_WS_NSET) : NSET1, NB = B1;
+    static_assert(PARKED || (B0 == 0 && B1 == 4 * MT), "a batch sub-range needs the parked form");
     rgb_f32x4 tA[NSET][4];
     // (pixel geometry, tap indices and weights are RECOMPUTED where the batch is finished -- two dozen scalar-ish vector instructions per pass -- instead of
     //  carried beside the taps: registers the kernel does not have)
@@ -1977,9 +1979,9 @@ __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, co
     };
     static_assert(NSET >= 2 && NSET <= 6, "wait counts are spelled out for up to five batches of look-ahead");
 #pragma unroll
-    for (int bi = 0; bi < NSET - 1 && bi < NB; bi++) issue(bi);
+    for (int bi = B0; bi < B0 + NSET - 1 && bi < NB; bi++) issue(bi);
 #pragma unroll
-    for (int bi = 0; bi < NB; bi++) {
+    for (int bi = B0; bi < NB; bi++) {
         if (!PARKED && (bi & 3) == 0) {
             // this channel tile's accumulators -> the wave's pixel-major LDS tile (wave-private: a wave barrier orders it against the previous tile's reads)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2259,6 +2261,9 @@ __global__ __launch_bounds__(256, 2) void torgb_mfma_kernel(RgbParams p) {
 // the layer's 1.05, the MFMAs alone 0.33).  Here a block is 8 waves, one per CU: waves 0..3 MULTIPLY tile t (fragments from LDS, nothing else), waves 4..7 do everything
 // of the output stage of tile t - 1 -- 48 tap loads, 12 stores per wave, from the LDS tile the multipliers parked, with the per-pass geometry computed once per tile --; the
 // multipliers also carry tile t + 1's activations (requested before the multiply, staged into the other X buffer behind it).  One of each role per SIMD, two block barriers per tile.  Same fragments, same K order, same fma chains as torgb_mfma_kernel: same bits.
+#ifndef TDGP_RGB_WS_SHARE
+#define TDGP_RGB_WS_SHARE 0            // batches of a tile's output stage (of 4 MT) the MULTIPLYING waves take, in front of their multiply.  Measured (512^2, B = 16): 0 -> 1.00-1.01 ms, 2 -> 1.03-1.04, 3 -> 1.05-1.06: the memory waves keep all of it
+#endif
 #ifndef TDGP_RGB_WS_ABL
 #define TDGP_RGB_WS_ABL 0              // timing experiments (wrong results): 1 = no output stage, 2 = no multiply
 #endif
@@ -2343,7 +2348,13 @@ __global__ __launch_bounds__(512, 1) void torgb_ws_kernel(RgbParams p) {
     const int n = (int)(t_end - t_begin);
     for (int i = 0; i < n; i++) {
         const int64_t t = t_begin + i;
+        constexpr int NBT = 4 * MT, SPLIT = NBT - (TDGP_RGB_WS_SHARE < MT ? TDGP_RGB_WS_SHARE : MT);       // (at most a quarter of the batches)
         if (role == 0) {
+            // the last batches of tile t - 1's output stage (the memory waves' 0.76 ms against the multipliers' 0.58: the multipliers wait at the barrier otherwise)
+            if (SPLIT < NBT && i > 0 && !(TDGP_RGB_WS_ABL & 1)) {
+                f32x16 none[MT];
+                rgb_output_skip_pipelined<MT, true, true, 3, false, SPLIT, NBT>(p.e, side, ctw, none, (t - 1) * BN + wj, p.P, p.lw, p.lhw);
+            }
             // tile t + 1's activations travel under this tile's multiply (the block's last tile re-reads itself: no load under a condition)
             tile_offsets(t + 1 < t_end ? t + 1 : t);
             load_x();
@@ -2370,7 +2381,7 @@ __global__ __launch_bounds__(512, 1) void torgb_ws_kernel(RgbParams p) {
         } else {
             if (i > 0 && !(TDGP_RGB_WS_ABL & 1)) {
                 f32x16 none[MT];
-                rgb_output_skip_pipelined<MT, true, true>(p.e, side, ctw, none, (t - 1) * BN + wj, p.P, p.lw, p.lhw);
+                rgb_output_skip_pipelined<MT, true, true, 3, false, 0, SPLIT>(p.e, side, ctw, none, (t - 1) * BN + wj, p.P, p.lw, p.lhw);
             }
         }
         __syncthreads();                            // the multipliers are through with X[i & 1] and have written X[(i + 1) & 1]; tile t - 1's parked outputs have been read
@@ -2385,9 +2396,11 @@ __global__ __launch_bounds__(512, 1) void torgb_ws_kernel(RgbParams p) {
         }
         __syncthreads();                            // tile t's outputs are parked
     }
-    if (role == 1) {
+    {
+        constexpr int NBT = 4 * MT, SPLIT = NBT - (TDGP_RGB_WS_SHARE < MT ? TDGP_RGB_WS_SHARE : MT);       // (at most a quarter of the batches)
         f32x16 none[MT];
-        rgb_output_skip_pipelined<MT, true, true>(p.e, side, ctw, none, (t_end - 1) * BN + wj, p.P, p.lw, p.lhw);
+        if (role == 1) rgb_output_skip_pipelined<MT, true, true, 3, false, 0, SPLIT>(p.e, side, ctw, none, (t_end - 1) * BN + wj, p.P, p.lw, p.lhw);
+        else if (SPLIT < NBT) rgb_output_skip_pipelined<MT, true, true, 3, false, SPLIT, NBT>(p.e, side, ctw, none, (t_end - 1) * BN + wj, p.P, p.lw, p.lhw);
     }
 }
 

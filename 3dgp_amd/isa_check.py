@@ -271,12 +271,12 @@ def check_wino4f_asm(asm_text):
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------
-# torgb_mfma_kernel<.., FAST = true> (csrc/modconv.hip: rgb_output_skip_pipelined, round 6): the skip taps are hand-issued `global_load_dwordx4` in batches of 4
-# with two batches of look-ahead, the waits hand-counted `vmcnt(8)` (.. `vmcnt(4)`, `vmcnt(0)` for the last two batches): the count holds only if, in program
-# order, every batch is exactly 4 tap loads + at most one store and NOTHING else of vector memory stands between two of those waits (a compiler-side load -- e.g.
-# the FIR weight fetched by a per-lane index -- would be counted by the hardware and not by the hand).  Checked per kernel:
-#   the waits `vmcnt(8)` form one run of 4 MT - 2, followed by one `vmcnt(4)` and one `vmcnt(0)`; between two consecutive waits of the run: 4 `global_load_dwordx4`,
-#   1 `global_store_dwordx4`, no other buffer_ / global_ / flat_ / scratch_ instruction; no scratch access in the kernel.
+# torgb_mfma_kernel<.., FAST = true> / torgb_ws_kernel (csrc/modconv.hip: rgb_output_skip_pipelined, round 6): the skip taps are hand-issued `global_load_dwordx4`
+# in batches of 4 with A batches of look-ahead (A = 2 .. 5), the waits hand-counted `vmcnt(4 A)` (.. fewer for the last A batches, `vmcnt(0)` for the last): the count
+# holds only if, in program order, every batch is exactly 4 tap loads + one store and NOTHING else of vector memory stands between the waits of a stage (a compiler-side
+# load -- e.g. the FIR weight fetched by a per-lane index -- would be counted by the hardware and not by the hand).  Checked per kernel, per stage instance (the
+# batches up to a hand-written `vmcnt(0)`): wait counts = 4 x min(A, batches left); four hand loads per wait, interleaved as issued; one `global_store_dwordx4` per
+# batch; no other buffer_ / global_ / flat_ / scratch_ instruction inside; the registers of a load in flight untouched before its wait; no scratch access in the kernel.
 # ------------------------------------------------------------------------------------------------------------------------------------
 def check_torgb_kernel(body, mt):
     # (hand-written statements stand between `;;#ASMSTART` / `;;#ASMEND` in the listing: a compiler-placed `vmcnt(8)` elsewhere in the kernel is not one of the counted waits)
@@ -298,17 +298,21 @@ def check_torgb_kernel(body, mt):
         bad.append(('scratch access in a ToRGB kernel with hand-counted tap waits', next(c for c in code if c.startswith('scratch_'))))
     hw = [k for k, c in enumerate(code) if hand[k] and re.match(r'^s_waitcnt vmcnt\(\d+\)$', c)]
     hl = [k for k, c in enumerate(code) if hand[k] and c.startswith('global_load_dwordx4')]
-    nb = 4 * mt
-    if not hw or len(hw) % nb or len(hl) != 4 * len(hw):
-        bad.append((f'expected a multiple of {nb} hand-counted waits and four tap loads per wait, found {len(hw)} waits, {len(hl)} loads', ''))
+    # one instance of the stage = the batches up to a hand-written `vmcnt(0)` (the one-role kernels hold one of 4 MT batches; the two-role kernel four: the tile loop's
+    # and the last tile's, each shared between the memory waves and the multiplying waves)
+    ends = [n for n, k in enumerate(hw) if code[k] == 's_waitcnt vmcnt(0)']
+    if not hw or not ends or ends[-1] != len(hw) - 1 or len(hl) != 4 * len(hw) or len(hw) % (4 * mt):
+        bad.append((f'expected stages of hand-counted waits ending in vmcnt(0), 4 MT batches per tile and four tap loads per wait; found {len(hw)} waits, {len(hl)} loads', ''))
         return dict(batches=len(hw), tap_loads=len(hl), hand_waits=len(hw)), bad
-    stages = len(hw) // nb
-    for st in range(stages):                         # one instance of the stage = 4 MT batches (the two-role kernel holds two: the tile loop's and the last tile's)
-        w, ld_ = hw[st * nb:(st + 1) * nb], hl[st * 4 * nb:(st + 1) * 4 * nb]
+    bounds = [0] + [n + 1 for n in ends]
+    stages = len(ends)
+    for st in range(stages):
+        nb = bounds[st + 1] - bounds[st]
+        w, ld_ = hw[bounds[st]:bounds[st + 1]], hl[4 * bounds[st]:4 * bounds[st + 1]]
         counts = [int(re.search(r'\((\d+)\)', code[k]).group(1)) for k in w]
         ahead = counts[0] // 4
         want = [4 * min(ahead, nb - 1 - bi) for bi in range(nb)]
-        if counts != want or counts[0] % 4 or not 1 <= ahead <= 5:
+        if counts != want or counts[0] % 4 or not (1 <= ahead <= 5 or (ahead == 0 and nb == 1)):
             bad.append((f'wait counts of a stage must be 4 x min(look-ahead, batches left): {want}', str(counts)))
             continue
         if not (ld_[0] < w[0] and all(ld_[4 * (bi + ahead)] > w[bi - 1] for bi in range(1, nb - ahead)) and ld_[-1] < w[nb - ahead - 1 if nb > ahead else 0] + 10 ** 9):
