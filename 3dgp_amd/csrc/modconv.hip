@@ -1851,9 +1851,10 @@ __device__ __forceinline__ void rgb_output_skip_pipelined(const EpiParams& e, co
     const float lim = e.clamp >= 0.f ? e.clamp : __builtin_inff();
     // The tap loads are issued BY HAND (as the field kernel's): written as C++ loads the compiler answered the loop-carried register set with `vmcnt(0)` in front of
     // every use (ISA of the first build) -- its wait counts cannot see across the back edge what is still in flight.  The waits are hand-counted: when batch b is
-    // finished the wave has, in issue order, the 8 loads of b, the 2 stores of b - 1, the 8 loads of b + 1 in flight; loads complete in order among themselves, stores
-    // at any time, so `vmcnt(8)` -- at most the 8 loads of b + 1 left -- guarantees b's taps (if the two stores are slow it also waits for two loads of b + 1; it never
-    // waits for a store to be acknowledged when the loads are there).  The last batch has nothing behind it: `vmcnt(0)`.
+    // finished the wave has, in issue order, the 4 loads of b, the stores of earlier batches, and the 4 A loads of the A batches ahead (A = NSET - 1) in flight; loads
+    // complete in order among themselves, stores at any time, so `vmcnt(4 A)` -- at most the loads of the batches ahead left -- guarantees b's taps (with slow stores it
+    // also waits for a few loads of the next batch; it never waits for a store to be acknowledged when the loads are there).  The last A batches wait with fewer, the last
+    // with `vmcnt(0)`.  3dgp_amd/isa_check.py: check_torgb_asm holds the generated code to exactly this pattern.
     // the FIR taps as 16 scalar registers: left in memory the compiler folds the parity selects back into one indexed load per weight
     FirRegs fr = {e.fir[0], e.fir[1], e.fir[2], e.fir[3], e.fir[4], e.fir[5], e.fir[6], e.fir[7], e.fir[8], e.fir[9], e.fir[10], e.fir[11], e.fir[12], e.fir[13], e.fir[14], e.fir[15]};
     asm volatile("" : "+s"(fr.f0), "+s"(fr.f1), "+s"(fr.f2), "+s"(fr.f3), "+s"(fr.f4), "+s"(fr.f5), "+s"(fr.f6), "+s"(fr.f7));
